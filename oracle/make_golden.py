@@ -1,0 +1,131 @@
+"""Generate tests/golden/*.npz from the REAL reference (stub-imported) -- container only.
+
+TEST INFRASTRUCTURE ONLY. Run from the repo root:
+
+    TORCHDYNAMO_DISABLE=1 python -m oracle.make_golden
+
+Every vector is produced by /root/reference's own code (CultionetLitModel.forward,
+calc_loss, autograd) on PyTorch-CPU fp32 with key-seeded weights
+(oracle.towerunet_oracle.seeded_state_dict) and seeded inputs (seeded_batch), so
+the GPU box can rebuild identical weights/inputs without a weight file. The
+fixtures hold inputs' seeds and expected outputs only (data, no source).
+"""
+from __future__ import annotations
+
+import os
+import sys
+
+import numpy as np
+import torch
+
+from . import refimport
+from . import towerunet_oracle as O
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+def _ref_model(ns, hidden, in_channels=3, in_time=12, **kw):
+    m = ns.CultionetLitModel(in_channels=in_channels, in_time=in_time, hidden_channels=hidden, dropout=0.0, **kw)
+    m.load_state_dict(O.seeded_state_dict(m.state_dict()))
+    return m
+
+
+def _train_case(ns, hidden, B, H, W, with_mask, seed=7, stages=False, loss_name="TanimotoComplementLoss", **kw):
+    m = _ref_model(ns, hidden, loss_name=loss_name, **kw)
+    m.train()
+    x, y, bdist = O.seeded_batch(B, height=H, width=W, seed=seed, with_mask=with_mask)
+    batch = ns.Data(x=x, y=y, bdist=bdist, lon=torch.zeros(B), lat=torch.zeros(B))
+    rec = {}
+    hooks = []
+    if stages:
+        tu = m.cultionet_model.mask_model
+
+        def grab(name):
+            def fn(mod, inp, out):
+                if isinstance(out, dict):
+                    for k, v in out.items():
+                        rec[f"stage.{k}"] = v.detach().numpy().copy()
+                else:
+                    rec[f"stage.{name}"] = out.detach().numpy().copy()
+            return fn
+
+        for name in ("pre_unet", "encoder", "decoder", "tower_fusion"):
+            hooks.append(getattr(tu, name).register_forward_hook(grab(name)))
+    pred = m(batch)
+    loss, rep = m.calc_loss(batch, pred)
+    loss.backward()
+    for h in hooks:
+        h.remove()
+    out = dict(rec)
+    for k in ("distance", "edge", "crop"):
+        out[k] = pred[k].detach().numpy()
+    out["loss"] = np.float64(loss.item())
+    for k, v in rep.items():
+        out[k] = np.float64(v.item())
+    names, norms = [], []
+    for n, p in m.named_parameters():
+        names.append(n.replace("cultionet_TowerUNet.mask_model.", ""))
+        norms.append(float(p.grad.double().norm()))
+    out["grad_names"] = np.array(names)
+    out["grad_norms"] = np.array(norms, dtype=np.float64)
+    out["margin"] = np.float64(min(float((pred[k] - 0.5).abs().min()) for k in ("distance", "edge", "crop")))
+    # running statistics after one train-mode forward (BN momentum path)
+    sd = m.state_dict()
+    k0 = "cultionet_TowerUNet.mask_model.tower_fusion.tower_a.res_conv.res_modules.0.block.0.seq.1."
+    out["bn_running_mean"] = sd[k0 + "running_mean"].numpy().copy()
+    out["bn_running_var"] = sd[k0 + "running_var"].numpy().copy()
+    out["meta"] = np.array([hidden, B, H, W, int(with_mask), seed])
+    return out
+
+
+def _eval_case(ns, hidden, B, C, T, H, W, seed=11, crop=64):
+    m = _ref_model(ns, hidden, in_channels=C, in_time=T)
+    m.eval()
+    x, y, bdist = O.seeded_batch(B, channels=C, time=T, height=H, width=W, seed=seed)
+    batch = ns.Data(x=x, y=y, bdist=bdist, lon=torch.zeros(B), lat=torch.zeros(B))
+    with torch.no_grad():
+        pred = m(batch)
+    out = {"meta": np.array([hidden, B, C, T, H, W, seed])}
+    for k in ("distance", "edge", "crop"):
+        p = pred[k]
+        out[f"{k}_sum"] = np.float64(p.double().sum().item())
+        out[f"{k}_crop"] = p[:, :, :crop, :crop].numpy().copy() if crop else p.numpy().copy()
+        out[f"{k}_rowsum"] = p.double().sum(dim=(0, 1, 3)).numpy()
+    return out
+
+
+def main():
+    assert refimport.available(), "/root/reference is required to generate fixtures"
+    torch.set_float32_matmul_precision("highest")
+    torch.set_num_threads(8)
+    ns = refimport.import_reference()
+    os.makedirs(OUT, exist_ok=True)
+
+    def save(name, d):
+        path = os.path.join(OUT, name)
+        np.savez_compressed(path, **d)
+        print(name, os.path.getsize(path) // 1024, "KiB", "loss" in d and d["loss"])
+
+    # (i) small model with per-stage activations, train mode (odd sizes: 28->14->7->4)
+    save("train_h8_b2_28.npz", _train_case(ns, 8, 2, 28, 28, False, stages=True))
+    save("train_h8_b2_28_masked.npz", _train_case(ns, 8, 2, 28, 28, True, stages=False))
+    # other selectable losses (args.yml:436-442)
+    save("train_h8_b2_28_tanimoto.npz", _train_case(ns, 8, 2, 28, 28, True, loss_name="TanimotoDistLoss"))
+    save("train_h8_b2_28_combined.npz", _train_case(ns, 8, 2, 28, 28, True, loss_name="TanimotoCombined"))
+    # attention_weights=None variant (tests/test_train.py default)
+    save("train_h8_b2_28_noattn.npz", _train_case(ns, 8, 2, 28, 28, False, attention_weights=None))
+    # true dilated convs (dilations entry >= 3)
+    save("train_h8_b2_28_dil3.npz", _train_case(ns, 8, 2, 28, 28, False, dilations=[1, 3]))
+    # (ii) BASELINE configs[0] / configs[1] shapes at hidden 32
+    save("train_h32_b1_100.npz", _train_case(ns, 32, 1, 100, 100, False))
+    save("train_h32_b1_100_masked.npz", _train_case(ns, 32, 1, 100, 100, True))
+    if "--no-big" not in sys.argv:
+        save("train_h32_b8_100.npz", _train_case(ns, 32, 8, 100, 100, False))
+        # (iv) configs[4]: large-tile eval forward
+        save("eval_h32_b1_4x25x256.npz", _eval_case(ns, 32, 1, 4, 25, 256, 256))
+    # eval-mode (running stats) small case, whole outputs
+    save("eval_h8_b2_28.npz", _eval_case(ns, 8, 2, 3, 12, 28, 28, crop=0))
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,114 @@
+"""Stub-import the real reference hot path from /root/reference (THIS CONTAINER ONLY).
+
+TEST INFRASTRUCTURE ONLY. /root/reference does not exist on the GPU box, so
+nothing that runs there may import this module; it is used by
+``oracle/make_golden.py`` and by the ``not gpu`` oracle-vs-reference tests
+(which skip when /root/reference is absent).
+
+Recipe:
+  1. register an empty ``cultionet`` package whose ``__path__`` points at the
+     reference sources, so ``cultionet/__init__.py`` (which needs lightning) is
+     skipped;
+  2. stub the third-party modules that are absent here: ``cv2``, ``lightning``,
+     ``torchmetrics``, ``cultionet.data`` (10-line ``Data``) and ``natten``
+     (``oracle.na2d_ref``);
+  3. disable dynamo so ``torch.compile`` at nunet.py:141 is a no-op.
+No reference source is copied: the modules are executed from where they lie.
+"""
+from __future__ import annotations
+
+import os
+import sys
+import types
+
+REF_SRC = "/root/reference/src/cultionet"
+
+
+def available() -> bool:
+    return os.path.isdir(REF_SRC)
+
+
+def import_reference():
+    """Returns a namespace with TowerUNet, CultionetLitModel, losses, Data."""
+    if "cultionet" in sys.modules and getattr(sys.modules["cultionet"], "_oracle_stub", False):
+        return _namespace()
+    os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
+    import torch
+    import torch.nn as nn
+
+    from . import na2d_ref
+
+    pkg = types.ModuleType("cultionet")
+    pkg.__path__ = [REF_SRC]
+    pkg._oracle_stub = True
+    sys.modules["cultionet"] = pkg
+
+    sys.modules.setdefault("cv2", types.ModuleType("cv2"))
+
+    # lightning stub
+    lightning = types.ModuleType("lightning")
+
+    class LightningModule(nn.Module):
+        def save_hyperparameters(self, *a, **k):
+            pass
+
+        def log(self, *a, **k):
+            pass
+
+        def log_dict(self, *a, **k):
+            pass
+
+    lightning.LightningModule = LightningModule
+    sys.modules["lightning"] = lightning
+
+    tm = types.ModuleType("torchmetrics")
+
+    class _Metric(nn.Module):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    for name in ("MeanAbsoluteError", "MeanSquaredError", "FBetaScore", "MatthewsCorrCoef"):
+        setattr(tm, name, _Metric)
+    sys.modules["torchmetrics"] = tm
+
+    # natten stub -> our restatement (the only non-torch arithmetic on the path)
+    natten = types.ModuleType("natten")
+    natten.NeighborhoodAttention2D = na2d_ref.NeighborhoodAttention2D
+    nf = types.ModuleType("natten.functional")
+    nf.na2d = na2d_ref.na2d
+    nf.na2d_qk = na2d_ref.na2d_qk
+    nf.na2d_av = na2d_ref.na2d_av
+    natten.functional = nf
+    sys.modules["natten"] = natten
+    sys.modules["natten.functional"] = nf
+
+    # cultionet.data stub: the in-memory contract of data/data.py:51-139
+    data_mod = types.ModuleType("cultionet.data")
+
+    class Data:
+        def __init__(self, x, y=None, **kwargs):
+            self.x = x
+            self.y = y
+            for k, v in kwargs.items():
+                setattr(self, k, v)
+
+        @property
+        def num_samples(self):
+            return self.x.shape[0]
+
+    data_mod.Data = Data
+    sys.modules["cultionet.data"] = data_mod
+    return _namespace()
+
+
+def _namespace():
+    import importlib
+
+    ns = types.SimpleNamespace()
+    ns.nunet = importlib.import_module("cultionet.models.nunet")
+    ns.lightning = importlib.import_module("cultionet.models.lightning")
+    ns.losses = importlib.import_module("cultionet.losses")
+    ns.Data = sys.modules["cultionet.data"].Data
+    ns.TowerUNet = ns.nunet.TowerUNet
+    ns.CultionetLitModel = ns.lightning.CultionetLitModel
+    return ns
