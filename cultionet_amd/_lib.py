@@ -1,0 +1,101 @@
+"""ctypes binding of libcultionet_hip.so (the C ABI declared in include/cultionet_hip.h).
+
+The product path has NO fallback: if the shared library is missing or a symbol is absent,
+importing / calling raises immediately (build it with ``make -C cultionet_amd/csrc`` or
+``python -c "import __graft_entry__ as g; g.build()"``).
+"""
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_double, c_float, c_int, c_long, c_void_p
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libcultionet_hip.so")
+
+P = c_void_p  # device pointers are passed as integers (tensor.data_ptr())
+I, L, F = c_int, c_long, c_float
+
+# name -> argtypes (restype is always int); mirrors include/cultionet_hip.h one to one
+SIGNATURES = {
+    "cn_version": [],
+    "cn_conv_kpad": [I],
+    "cn_conv_npad": [I],
+    "cn_pack_weights_f32": [P, P, I, I, I, L, L, L, P],
+    "cn_conv2d_fwd_f32": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
+    "cn_conv2d_bwd_data_f32": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
+    "cn_conv2d_bwd_weight_f32": [P, L, P, L, P, I, I, I, I, I, I, I, I, I, I, P],
+    "cn_conv_transpose2d_fwd_f32": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, P],
+    "cn_conv_transpose2d_bwd_data_f32": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, I, P],
+    "cn_conv_transpose2d_bwd_weight_f32": [P, L, P, L, P, I, I, I, I, I, I, I, I, I, P],
+    "cn_channel_sum_f32": [P, L, I, I, I, P, I, P],
+    "cn_bn_workspace_doubles": [I],
+    "cn_bn_act_fwd_f32": [P, L, P, P, P, P, P, L, P, L, P, P, P, I, I, I, I, F, F, I, P],
+    "cn_bn_act_bwd_f32": [P, L, P, L, P, P, P, P, P, L, P, P, P, P, I, I, I, I, I, I, I, P],
+    "cn_layernorm_c_fwd_f32": [P, L, P, P, P, L, P, L, P, P, I, I, I, F, P],
+    "cn_layernorm_c_bwd_f32": [P, L, P, L, P, P, P, P, L, P, P, I, I, I, I, P],
+    "cn_na2d_fwd_f32": [P, L, P, L, P, I, I, I, I, I, I, I, P],
+    "cn_na2d_bwd_f32": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, P],
+    "cn_bilinear_fwd_f32": [P, L, P, L, I, I, I, I, I, I, P],
+    "cn_bilinear_bwd_f32": [P, L, P, L, I, I, I, I, I, I, I, P],
+    "cn_copy_f32": [P, L, P, L, I, L, I, P],
+    "cn_add_f32": [P, L, P, L, P, L, I, L, P],
+    "cn_fill_f32": [P, L, F, P],
+    "cn_final_combine_fwd_f32": [P, P, P, P, P, P, P, I, I, F, P],
+    "cn_final_combine_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, F, P],
+    "cn_tanimoto_fwd_f32": [P, L, P, P, P, I, I, I, I, I, L, I, F, I, P, P, P, F, P, P],
+    "cn_tanimoto_bwd_f32": [P, L, P, P, P, I, I, I, I, I, L, P, F, P, L, I, P],
+    "cn_grad_sumsq_f32": [P, L, P, P],
+    "cn_adamw_step_f32": [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P],
+    "cn_pack_timeconv_f32": [P, P, I, I, I, I, I, P],
+    "cn_fold_timeconv_grad_f32": [P, P, I, I, I, I, P],
+}
+
+ERRORS = {-1: "CN_ERR_ARG (invalid argument / unsupported shape)", -2: "CN_ERR_LAUNCH (HIP launch failed)",
+          -3: "CN_ERR_LDS (tile does not fit the LDS budget)"}
+
+
+class HipLibraryMissing(RuntimeError):
+    pass
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def load() -> ctypes.CDLL:
+    """Load (once) and type the shared library. Raises HipLibraryMissing -- never falls back."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipLibraryMissing(
+            f"{LIB_PATH} not found: the cultionet_amd HIP extension is not built. "
+            "Run `make -C cultionet_amd/csrc` (needs hipcc); there is no CPU fallback."
+        )
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:  # pragma: no cover
+            raise HipLibraryMissing(f"symbol {name} missing from {LIB_PATH}; rebuild the extension") from e
+        fn.argtypes = argtypes
+        fn.restype = c_int
+    _lib = lib
+    return lib
+
+
+def call(name: str, *args) -> int:
+    """Call an entry point that returns a status code; raise on error."""
+    rc = getattr(load(), name)(*args)
+    if rc != 0:
+        raise HipKernelError(f"{name} failed: {ERRORS.get(rc, rc)}")
+    return rc
+
+
+def query(name: str, *args) -> int:
+    """Call an entry point that returns a value (cn_version, cn_conv_kpad, ...)."""
+    return getattr(load(), name)(*args)

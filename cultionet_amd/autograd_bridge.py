@@ -1,0 +1,77 @@
+"""torch.autograd <-> engine bridge: lets ``loss.backward()`` of a Lightning fit loop drive the HIP tape.
+
+The engine has its own reverse-mode tape (cultionet_amd.engine). For callers that live in torch.autograd
+(lightning.Trainer.fit -> training_step -> loss.backward(), torch DDP hooks, torch optimizers) the whole
+TowerUNet is presented as ONE autograd.Function: forward runs the engine forward and keeps the tape,
+backward seeds the three output gradients, replays the tape and hands the parameter gradients back to
+autograd (views of one clone of the flat gradient buffer, so DDP hooks fire as usual).
+"""
+from __future__ import annotations
+
+import typing as T
+
+import torch
+
+from . import engine as E
+from .enums import InferenceNames
+
+_KEYS = (InferenceNames.DISTANCE, InferenceNames.EDGE, InferenceNames.CROP)
+
+
+class _TowerUNetFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, model, x, *params):
+        store = model.param_store()
+        with E.using_store(store), E.recording(True) as tape:
+            outs = model.forward_vars(model.input_var(x))
+        ctx.model, ctx.tape, ctx.outs, ctx.store = model, tape, outs, store
+        ctx.n_params = len(params)
+        return tuple(outs[k].t for k in _KEYS)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        store = ctx.store
+        store.zero_grad()
+        for k, g in zip(_KEYS, grads):
+            ctx.outs[k].grad = g.contiguous() if g is not None else None
+        with E.using_store(store):
+            ctx.tape.backward()
+        flat = store.flat_grad.clone()
+        pg = tuple(flat[o:o + p.numel()].view(p.shape) for p, o in zip(store.params, store.offsets))
+        ctx.tape = ctx.outs = None
+        return (None, None) + pg
+
+
+def run_towerunet(model, x: torch.Tensor) -> T.Dict[str, torch.Tensor]:
+    store = model.param_store()
+    if torch.is_grad_enabled() and any(p.requires_grad for p in store.params):
+        d, e, c = _TowerUNetFn.apply(model, x, *store.params)
+        return {_KEYS[0]: d, _KEYS[1]: e, _KEYS[2]: c}
+    with E.using_store(store), E.recording(False):
+        outs = model.forward_vars(model.input_var(x))
+    return {k: outs[k].t for k in _KEYS}
+
+
+class _TanimotoFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, kw):
+        with E.recording(True) as tape:
+            pv = E.Var(pred.contiguous(), True)
+            loss = E.tanimoto_loss(pv, **kw)
+        ctx.tape, ctx.pv = tape, pv
+        return loss.view(())
+
+    @staticmethod
+    def backward(ctx, g):
+        ctx.tape.backward()
+        dp = ctx.pv.grad
+        ctx.tape = ctx.pv = None
+        return dp * g, None
+
+
+def tanimoto_autograd(pred: torch.Tensor, **kw) -> torch.Tensor:
+    """Tanimoto loss (HIP kernels) as a differentiable torch scalar."""
+    if torch.is_grad_enabled() and pred.requires_grad:
+        return _TanimotoFn.apply(pred, kw)
+    with E.recording(False):
+        return E.tanimoto_loss(E.Var(pred.contiguous(), False), **kw).view(())

@@ -1,0 +1,221 @@
+"""Convolution blocks of the TowerUNet hot path, executed by HIP kernels through cultionet_amd.engine.
+
+Host-side mirror of /root/reference/src/cultionet/nn/modules/convolution.py: same class names, constructor
+arguments, sub-module attribute names (=> identical state-dict keys) and error behaviour. torch.nn
+layers are used as *parameter containers only* (so initialisation and checkpoints are those of the
+reference); every forward runs engine ops on ``Var`` buffers:
+
+  * Conv2d -> BatchNorm2d -> SiLU is two engine ops (implicit-GEMM conv, fused BN+SiLU(+residual));
+  * the ResUNet-a sum ``skip(x) + sum_d branch_d(x)`` is fused into the last BN+SiLU of each branch;
+  * ``+ LayerNorm(NA(LayerNorm(skip)))`` keeps tensors NCHW: the two LayerNorms normalise over the
+    channel stride, qkv / proj run as 1x1 convs and the residual add is fused into the second LayerNorm.
+"""
+from __future__ import annotations
+
+import typing as T
+
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from .enums import AttentionTypes, ResBlockTypes
+
+
+class SetActivation(nn.Module):
+    """nn/modules/activations.py:5-24. Only SiLU (default everywhere upstream) has a fused kernel."""
+
+    def __init__(self, activation_type: str):
+        super().__init__()
+        if activation_type != "SiLU":
+            raise NotImplementedError(f"activation {activation_type!r}: only 'SiLU' has a HIP kernel")
+        self.activation = nn.SiLU()
+
+
+class _Marker(nn.Module):
+    """Parameter-free placeholder keeping nn.Sequential indices equal to the reference's."""
+
+
+class ConvTranspose2d(nn.Module):
+    """convolution.py:45-68: nn.ConvTranspose2d(k, stride, padding) then bilinear resize iff size differs."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, stride: int = 2, padding: int = 1):
+        super().__init__()
+        self.stride, self.padding = stride, padding
+        self.up_conv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding)
+
+    def forward(self, x: E.Var, size) -> E.Var:
+        y = E.conv_transpose2d(x, self.up_conv, self.stride, self.padding)
+        return E.resize_bilinear(y, tuple(size))
+
+
+class ConvBlock2d(nn.Module):
+    """convolution.py:71-120 (batchnorm_first=False): Conv2d(bias=False) -> BatchNorm2d -> [SiLU]."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int, padding: int = 0, dilation: int = 1,
+                 stride: int = 1, add_activation: bool = True, activation_type: str = "SiLU",
+                 batchnorm_first: bool = False):
+        super().__init__()
+        if batchnorm_first:
+            raise NotImplementedError("batchnorm_first=True is not on the HIP path yet (SURVEY.md 8f rank 1)")
+        self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.act = E.ACT_SILU if add_activation else E.ACT_NONE
+        layers = [
+            nn.Conv2d(in_channels, out_channels, kernel_size, padding=padding, dilation=dilation, stride=stride,
+                      bias=False),
+            nn.BatchNorm2d(out_channels),
+        ]
+        if add_activation:
+            layers.append(SetActivation(activation_type))
+        self.seq = nn.Sequential(*layers)
+
+    def forward(self, x: E.Var, residual: T.Optional[E.Var] = None) -> E.Var:
+        y = E.conv2d(x, self.seq[0], self.stride, self.padding, self.dilation)
+        return E.bn_act(y, self.seq[1], self.act, residual=residual, training=self.training)
+
+
+class ResConvBlock2d(nn.Module):
+    """convolution.py:123-176. Block 0: dilation 1; blocks 1..n-1: pad = dil = max(1, d-1)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, dilation: int = 1,
+                 activation_type: str = "SiLU", num_blocks: int = 2, batchnorm_first: bool = False):
+        super().__init__()
+        assert num_blocks > 0, "There must be at least one block."
+        layers = [ConvBlock2d(in_channels, out_channels, kernel_size, padding=0 if kernel_size == 1 else kernel_size // 2,
+                              dilation=1, activation_type=activation_type, batchnorm_first=batchnorm_first)]
+        for _ in range(num_blocks - 1):
+            d = 1 if kernel_size == 1 else max(1, dilation - 1)
+            layers.append(ConvBlock2d(out_channels, out_channels, kernel_size, padding=0 if kernel_size == 1 else d,
+                                      dilation=d, activation_type=activation_type, batchnorm_first=batchnorm_first))
+        self.block = nn.ModuleList(layers)
+
+    def forward(self, x: E.Var, residual: T.Optional[E.Var] = None) -> E.Var:
+        last = len(self.block) - 1
+        for i, layer in enumerate(self.block):
+            x = layer(x, residual if i == last else None)
+        return x
+
+
+class NeighborhoodAttention2D(nn.Module):
+    """natten.NeighborhoodAttention2D(dim, heads, k, dilation, qkv_bias=True, rel_pos_bias=False) parameters
+    (``qkv``, ``proj`` Linear layers, names as in natten 0.17.1) driving the HIP NA kernel on NCHW buffers."""
+
+    def __init__(self, dim: int, num_heads: int, kernel_size: int, dilation: int = 1, rel_pos_bias: bool = False,
+                 qkv_bias: bool = True, attn_drop: float = 0.0, proj_drop: float = 0.0):
+        super().__init__()
+        if rel_pos_bias:
+            raise NotImplementedError("rel_pos_bias is not used by cultionet")
+        if attn_drop or proj_drop:
+            raise NotImplementedError("NA dropout > 0 has no HIP kernel yet (dropout=0 path only)")
+        self.num_heads, self.kernel_size, self.dilation = num_heads, kernel_size, dilation
+        self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
+        self.proj = nn.Linear(dim, dim)
+
+    def forward(self, x: E.Var) -> E.Var:
+        qkv = E.conv2d(x, _as_conv(self.qkv))
+        o = E.na2d(qkv, self.num_heads, self.kernel_size, self.dilation)
+        return E.conv2d(o, _as_conv(self.proj))
+
+
+class _LinearAsConv:
+    """View of an nn.Linear as a 1x1 conv for engine.conv2d (weight [out][in] -> [out][in][1][1])."""
+
+    __slots__ = ("lin", "__dict__")
+
+    def __init__(self, lin: nn.Linear):
+        self.lin = lin
+
+    @property
+    def weight(self):
+        return self.lin.weight
+
+    @property
+    def bias(self):
+        return self.lin.bias
+
+
+def _as_conv(lin: nn.Linear):
+    v = lin.__dict__.get("_cn_conv_view")
+    if v is None:
+        v = _LinearAsConv(lin)
+        lin.__dict__["_cn_conv_view"] = v
+    return v
+
+
+class ResidualAConv(nn.Module):
+    """convolution.py:250-395: out = skip(x) + sum_d ResConvBlock2d_d(x) [+ LN(NA(LN(skip(x))))]."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, num_blocks: int = 2,
+                 dilations: T.Optional[T.List[int]] = None, attention_weights: T.Optional[str] = None,
+                 activation_type: str = "SiLU", batchnorm_first: bool = False, natten_num_heads: int = 8,
+                 natten_kernel_size: int = 3, natten_dilation: int = 1, natten_attn_drop: float = 0.0,
+                 natten_proj_drop: float = 0.0):
+        super().__init__()
+        if dilations is None:
+            dilations = [1, 2]
+        self.attention_weights = attention_weights
+        self.skip = nn.Conv2d(in_channels, out_channels, kernel_size=1, padding=0) if in_channels != out_channels \
+            else nn.Identity()
+        if self.attention_weights is not None:
+            assert self.attention_weights in [AttentionTypes.NATTEN, AttentionTypes.SPATIAL_CHANNEL], \
+                "The attention method is not supported."
+            if self.attention_weights != AttentionTypes.NATTEN:
+                raise NotImplementedError("attention_weights='spatial_channel' is not on the HIP path yet")
+            self.attention_conv = nn.Sequential(
+                _Marker(),
+                nn.LayerNorm(out_channels),
+                NeighborhoodAttention2D(out_channels, natten_num_heads, natten_kernel_size, natten_dilation,
+                                        attn_drop=natten_attn_drop, proj_drop=natten_proj_drop),
+                nn.LayerNorm(out_channels),
+                _Marker(),
+            )
+        self.res_modules = nn.ModuleList([
+            ResConvBlock2d(in_channels, out_channels, kernel_size, dilation=d, activation_type=activation_type,
+                           num_blocks=num_blocks, batchnorm_first=batchnorm_first) for d in dilations
+        ])
+
+    def forward(self, x: E.Var) -> E.Var:
+        out = E.conv2d(x, self.skip) if isinstance(self.skip, nn.Conv2d) else x
+        skip = out
+        for layer in self.res_modules:
+            out = layer(x, residual=out)  # out + SiLU(BN(conv(...))) fused in the last block
+        if self.attention_weights is not None:
+            a = E.layer_norm_c(skip, self.attention_conv[1])
+            a = self.attention_conv[2](a)
+            out = E.layer_norm_c(a, self.attention_conv[3], residual=out)
+        return out
+
+
+class PoolResidualConv(nn.Module):
+    """convolution.py:398-513: [stride-2 ConvBlock2d without activation] -> ResidualAConv -> Dropout2d."""
+
+    def __init__(self, in_channels: int, out_channels: int, dropout: float = 0.0, kernel_size: int = 3,
+                 num_blocks: int = 2, attention_weights: T.Optional[str] = None, activation_type: str = "SiLU",
+                 res_block_type: str = ResBlockTypes.RESA, dilations: T.Sequence[int] = None, pool_first: bool = True,
+                 pool_by_max: bool = False, batchnorm_first: bool = False, natten_num_heads: int = 8,
+                 natten_kernel_size: int = 3, natten_dilation: int = 1, natten_attn_drop: float = 0.0,
+                 natten_proj_drop: float = 0.0):
+        super().__init__()
+        assert res_block_type in (ResBlockTypes.RES, ResBlockTypes.RESA)
+        if res_block_type != ResBlockTypes.RESA:
+            raise NotImplementedError("res_block_type='res' is not on the HIP path yet")
+        if pool_by_max:
+            raise NotImplementedError("pool_by_max=True is not on the HIP path yet")
+        if dropout:
+            raise NotImplementedError("dropout > 0 has no HIP kernel yet (parity runs use dropout=0)")
+        self.pool_first, self.pool_by_max = pool_first, pool_by_max
+        if self.pool_first:
+            self.pool_conv = ConvBlock2d(in_channels, out_channels, kernel_size=3, padding=1, stride=2,
+                                         add_activation=False, batchnorm_first=False)
+            in_channels = out_channels
+        self.res_conv = ResidualAConv(in_channels, out_channels, kernel_size=kernel_size, dilations=dilations,
+                                      num_blocks=num_blocks, attention_weights=attention_weights,
+                                      activation_type=activation_type, batchnorm_first=batchnorm_first,
+                                      natten_num_heads=natten_num_heads, natten_kernel_size=natten_kernel_size,
+                                      natten_dilation=natten_dilation, natten_attn_drop=natten_attn_drop,
+                                      natten_proj_drop=natten_proj_drop)
+        self.dropout_layer = nn.Dropout2d(p=dropout)
+
+    def forward(self, x: E.Var) -> E.Var:
+        if self.pool_first:
+            x = self.pool_conv(x)
+        return self.res_conv(x)

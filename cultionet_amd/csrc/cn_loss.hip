@@ -1,0 +1,192 @@
+// Tanimoto loss family (forward sums, per-sample coefficients, elementwise backward) and the
+// label preparation of get_true_labels, fused. HBM-bound single-pass reductions (gfx950).
+//
+// Reference: TanimotoComplementLoss / TanimotoDistLoss / CombinedLoss / LossPreprocessing
+// (/root/reference/src/cultionet/losses/losses.py:9-340), get_true_labels + calc_loss
+// (/root/reference/src/cultionet/models/lightning.py:161-354).
+//
+// Per sample five running sums suffice (Sy, Syh, Syyh, Syy, Syhyh over C*H*W after masking);
+// the complement terms follow algebraically with N = C*H*W because masked pixels are zeroed
+// BEFORE the complement (they enter it as (1,1) pairs).
+#include "cn_common.h"
+
+// target modes
+#define TGT_FLOAT 0   // target_f [B][C][HW] float (regression: bdist)
+#define TGT_EQ 1      // labels [B][HW] int64: t = (y == klass)            (true_edge)
+#define TGT_RANGE 2   // labels: t = (0 < y < klass)                       (true_crop)
+#define TGT_ONEHOT 3  // labels: t[c] = (y == c)                           (LossPreprocessing one-hot, C > 1)
+// mask modes
+#define MSK_NONE 0
+#define MSK_LABEL 1   // m = (labels != -1)   (get_true_labels; identity when no -1 is present)
+#define MSK_I64 2     // explicit int64 mask [B][HW]
+#define MSK_F32 3     // explicit float mask [B][HW]
+
+__device__ __forceinline__ float ls_target(int mode, const float* tf, const long long* lab, long b, int c, int C,
+                                           long HW, long p, int klass) {
+  if (mode == TGT_FLOAT) return tf[(b * C + c) * HW + p];
+  const long long y = lab[b * HW + p];
+  if (mode == TGT_EQ) return y == klass ? 1.f : 0.f;
+  if (mode == TGT_RANGE) return (y > 0 && y < klass) ? 1.f : 0.f;
+  return y == c ? 1.f : 0.f;
+}
+
+__device__ __forceinline__ float ls_mask(int mode, const long long* lab, const void* mk, long b, long HW, long p) {
+  if (mode == MSK_NONE) return 1.f;
+  if (mode == MSK_LABEL) return lab[b * HW + p] != -1 ? 1.f : 0.f;
+  if (mode == MSK_I64) return (float)((const long long*)mk)[b * HW + p];
+  return ((const float*)mk)[b * HW + p];
+}
+
+// sums[b][5] (double, atomically accumulated: zero first)
+__global__ __launch_bounds__(256) void cn_tanimoto_sums_kernel(const float* __restrict__ pred, long pbs,
+                                                              const float* __restrict__ tf,
+                                                              const long long* __restrict__ lab,
+                                                              const void* __restrict__ mk, int tmode, int mmode,
+                                                              int klass, int C, long HW, double* __restrict__ sums) {
+  __shared__ double scratch[4];
+  const long b = blockIdx.y;
+  const long n = (long)C * HW;
+  double a[5] = {0, 0, 0, 0, 0};
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i / HW);
+    const long p = i - c * HW;
+    const float m = ls_mask(mmode, lab, mk, b, HW, p);
+    const float yh = pred[b * pbs + i] * m;
+    const float y = ls_target(tmode, tf, lab, b, c, C, HW, p, klass) * m;
+    a[0] += y;
+    a[1] += yh;
+    a[2] += (double)y * yh;
+    a[3] += (double)y * y;
+    a[4] += (double)yh * yh;
+  }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const double r = cn_block_sum<double, 256>(a[k], scratch);
+    if (threadIdx.x == 0) atomicAdd(sums + b * 5 + k, r);
+  }
+}
+
+// loss kinds
+#define LOSS_COMPLEMENT 0  // TanimotoComplementLoss (depth 5)
+#define LOSS_DIST 1        // TanimotoDistLoss
+#define LOSS_COMBINED 2    // mean of the two
+
+// f(tpl, sq) and its partials for the two distance definitions
+__device__ __forceinline__ void tnm_complement(double tpl, double sq, double smooth, int depth, double& f,
+                                               double& dtpl, double& dsq) {
+  double den = 0.0, dden_tpl = 0.0, dden_sq = 0.0;
+  for (int d = 0; d < depth; ++d) {
+    const double a = (double)(1 << d), bb = -(2.0 * a - 1.0);
+    const double q = a * sq + bb * tpl + smooth;
+    den += 1.0 / q;
+    dden_tpl += -bb / (q * q);
+    dden_sq += -a / (q * q);
+  }
+  const double num = tpl + smooth, scale = 1.0 / depth;
+  f = 1.0 - num * den * scale;
+  dtpl = -(den + num * dden_tpl) * scale;
+  dsq = -(num * dden_sq) * scale;
+}
+
+__device__ __forceinline__ void tnm_dist(double tpl, double sq, double smooth, double& f, double& dtpl, double& dsq) {
+  const double num = tpl + smooth, den = sq - tpl + smooth;
+  f = 1.0 - num / den;
+  dtpl = -(1.0 / den + num / (den * den));
+  dsq = num / (den * den);
+}
+
+// One thread per sample: loss_b and coefficients coef[b][4] = {A, Bq, Ac, Bc} so that
+//   dL/dyhat_m = A*y + 2*Bq*yh - Ac*(1-y) - 2*Bc*(1-yh)      (all per sample, already /B and *0.5)
+// loss_out[0] = mean_b loss_b ; loss_b_out[b] optional.
+__global__ void cn_tanimoto_finalize_kernel(const double* __restrict__ sums, int B, double N, int kind, float smooth,
+                                            int depth, float* __restrict__ loss_out, float* __restrict__ coef,
+                                            float weight, float* __restrict__ total_out) {
+  __shared__ double scratch[4];
+  double lsum = 0.0;
+  for (int b = threadIdx.x; b < B; b += 256) {
+    const double Sy = sums[b * 5 + 0], Syh = sums[b * 5 + 1], tpl = sums[b * 5 + 2];
+    const double sq = sums[b * 5 + 3] + sums[b * 5 + 4];
+    const double tplc = N - Sy - Syh + tpl;                       // sum (1-y)(1-yh)
+    const double sqc = 2.0 * N - 2.0 * Sy - 2.0 * Syh + sq;       // sum (1-y)^2 + (1-yh)^2
+    double f1 = 0, a1 = 0, b1 = 0, f2 = 0, a2 = 0, b2 = 0, w = 1.0;
+    if (kind == LOSS_COMPLEMENT || kind == LOSS_COMBINED) {
+      double f, da, db;
+      tnm_complement(tpl, sq, smooth, depth, f, da, db); f1 += f; a1 += da; b1 += db;
+      tnm_complement(tplc, sqc, smooth, depth, f, da, db); f2 += f; a2 += da; b2 += db;
+    }
+    if (kind == LOSS_DIST || kind == LOSS_COMBINED) {
+      double f, da, db;
+      tnm_dist(tpl, sq, smooth, f, da, db); f1 += f; a1 += da; b1 += db;
+      tnm_dist(tplc, sqc, smooth, f, da, db); f2 += f; a2 += da; b2 += db;
+    }
+    if (kind == LOSS_COMBINED) w = 0.5;
+    const double lb = 0.5 * (f1 + f2) * w;
+    lsum += lb;
+    const double sc = 0.5 * w / B;
+    coef[b * 4 + 0] = (float)(a1 * sc);
+    coef[b * 4 + 1] = (float)(b1 * sc);
+    coef[b * 4 + 2] = (float)(a2 * sc);
+    coef[b * 4 + 3] = (float)(b2 * sc);
+  }
+  lsum = cn_block_sum<double, 256>(lsum, scratch);
+  if (threadIdx.x == 0) {
+    loss_out[0] = (float)(lsum / B);
+    if (total_out != nullptr) total_out[0] += weight * (float)(lsum / B);
+  }
+}
+
+// dpred[b][i] (+)= upstream * m * (A*y + 2*Bq*yh - Ac*(1-y) - 2*Bc*(1-yh)),  yh,y masked
+__global__ __launch_bounds__(256) void cn_tanimoto_bwd_kernel(const float* __restrict__ pred, long pbs,
+                                                             const float* __restrict__ tf,
+                                                             const long long* __restrict__ lab,
+                                                             const void* __restrict__ mk, int tmode, int mmode,
+                                                             int klass, int C, long HW, const float* __restrict__ coef,
+                                                             float upstream, float* __restrict__ dpred, long dbs,
+                                                             int accumulate) {
+  const long b = blockIdx.y;
+  const long n = (long)C * HW;
+  const float A = coef[b * 4 + 0], Bq = coef[b * 4 + 1], Ac = coef[b * 4 + 2], Bc = coef[b * 4 + 3];
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i / HW);
+    const long p = i - c * HW;
+    const float m = ls_mask(mmode, lab, mk, b, HW, p);
+    const float yh = pred[b * pbs + i] * m;
+    const float y = ls_target(tmode, tf, lab, b, c, C, HW, p, klass) * m;
+    float g = upstream * m * (A * y + 2.f * Bq * yh - Ac * (1.f - y) - 2.f * Bc * (1.f - yh));
+    if (accumulate) g += dpred[b * dbs + i];
+    dpred[b * dbs + i] = g;
+  }
+}
+
+static dim3 loss_grid(int B, long n) {
+  long bx = (n + 1023) / 1024;
+  if (bx > 64) bx = 64;
+  if (bx < 1) bx = 1;
+  return dim3((unsigned)bx, B);
+}
+
+// Forward: loss_out[0] = mean over batch; coef [B][4] kept for backward; sums: [B][5] doubles (scratch).
+extern "C" int cn_tanimoto_fwd_f32(const float* pred, long pbs, const float* target_f, const long long* labels,
+                                   const void* mask, int target_mode, int mask_mode, int klass, int B, int C, long HW,
+                                   int loss_kind, float smooth, int depth, double* sums, float* coef, float* loss_out,
+                                   float weight, float* total_out /*nullable: += weight*loss*/, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || B > 65535) return CN_ERR_ARG;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 5 * B, stream) != hipSuccess) return CN_ERR_LAUNCH;
+  hipLaunchKernelGGL(cn_tanimoto_sums_kernel, loss_grid(B, (long)C * HW), dim3(256), 0, stream, pred, pbs, target_f,
+                     labels, mask, target_mode, mask_mode, klass, C, HW, sums);
+  hipLaunchKernelGGL(cn_tanimoto_finalize_kernel, dim3(1), dim3(256), 0, stream, sums, B, (double)C * HW, loss_kind,
+                     smooth, depth, loss_out, coef, weight, total_out);
+  return cn_check_launch();
+}
+
+extern "C" int cn_tanimoto_bwd_f32(const float* pred, long pbs, const float* target_f, const long long* labels,
+                                   const void* mask, int target_mode, int mask_mode, int klass, int B, int C, long HW,
+                                   const float* coef, float upstream, float* dpred, long dbs, int accumulate,
+                                   void* stream_) {
+  if (B <= 0 || B > 65535) return CN_ERR_ARG;
+  hipLaunchKernelGGL(cn_tanimoto_bwd_kernel, loss_grid(B, (long)C * HW), dim3(256), 0, (hipStream_t)stream_, pred, pbs,
+                     target_f, labels, mask, target_mode, mask_mode, klass, C, HW, coef, upstream, dpred, dbs,
+                     accumulate);
+  return cn_check_launch();
+}

@@ -1,0 +1,242 @@
+// Neighborhood attention core (q.k over a clamped/dilated KxK window -> softmax -> .v) on NCHW
+// planes, forward and backward. HBM/L2-bound; one lane per (pixel, head).
+//
+// Restates natten 0.17.1's unfused NA2D (na2d_qk -> softmax -> na2d_av, no rel-pos bias,
+// non-causal) used at /root/reference/src/cultionet/nn/modules/convolution.py:341-350.
+// The surrounding qkv / proj Linear layers run as 1x1 convolutions on the MFMA kernel
+// (cn_conv.hip), so q,k,v arrive as channel blocks of one [B, 3C, H, W] tensor:
+// channel of (which, head, d) = which*C + head*D + d  (== natten's reshape(B,H,W,3,heads,D)).
+#include "cn_common.h"
+
+#define NA_K 3
+#define NA_KK 9
+
+// natten get_window_start (K = 3, n = 1)
+__device__ __forceinline__ int na_window_start(int i, int len, int dil) {
+  if (dil <= 1) return max(i - 1, 0) + ((i + 1 >= len) ? (len - i - 2) : 0);
+  const int ni = i - dil;
+  if (ni < 0) return i % dil;
+  if (i + dil >= len) {
+    const int imodd = i % dil;
+    const int a = (len / dil) * dil;
+    const int b = len - a;
+    if (imodd < b) return len - b + imodd - 2 * dil;
+    return a + imodd - NA_K * dil;
+  }
+  return ni;
+}
+
+// qkv [B][3C][H][W] (batch stride qbs); out [B][C][H][W]; attn [B][heads][9][H][W] (saved probs).
+template <int D>
+__global__ __launch_bounds__(256) void cn_na2d_fwd_kernel(const float* __restrict__ qkv, long qbs,
+                                                         float* __restrict__ out, long obs,
+                                                         float* __restrict__ attn, int B, int C, int heads, int H,
+                                                         int W, int dil, float scale) {
+  const int HW = H * W;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int y = p / W, x = p - y * W;
+  const int sy = na_window_start(y, H, dil), sx = na_window_start(x, W, dil);
+  const float* qp = qkv + b * qbs + (long)(h * D) * HW;
+  const float* kp = qp + (long)C * HW;
+  const float* vp = kp + (long)C * HW;
+  float q[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) q[d] = qp[(long)d * HW + p] * scale;
+  float lg[NA_KK];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int i = 0; i < NA_K; ++i)
+#pragma unroll
+    for (int j = 0; j < NA_K; ++j) {
+      const int kpix = (sy + i * dil) * W + sx + j * dil;
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) s += q[d] * kp[(long)d * HW + kpix];
+      lg[i * NA_K + j] = s;
+      mx = fmaxf(mx, s);
+    }
+  float den = 0.f;
+#pragma unroll
+  for (int t = 0; t < NA_KK; ++t) {
+    lg[t] = expf(lg[t] - mx);
+    den += lg[t];
+  }
+  const float inv = 1.0f / den;
+  float* ap = attn + ((long)(b * heads + h) * NA_KK) * HW + p;
+#pragma unroll
+  for (int t = 0; t < NA_KK; ++t) {
+    lg[t] *= inv;
+    if (attn) ap[(long)t * HW] = lg[t];
+  }
+  float o[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NA_K; ++i)
+#pragma unroll
+    for (int j = 0; j < NA_K; ++j) {
+      const int kpix = (sy + i * dil) * W + sx + j * dil;
+      const float pr = lg[i * NA_K + j];
+#pragma unroll
+      for (int d = 0; d < D; ++d) o[d] += pr * vp[(long)d * HW + kpix];
+    }
+  float* op = out + b * obs + (long)(h * D) * HW + p;
+#pragma unroll
+  for (int d = 0; d < D; ++d) op[(long)d * HW] = o[d];
+}
+
+// Backward, query side: dP = dOut.v ; dS = P*(dP - sum P dP) ; dq = scale * sum dS*k ; saves dS.
+template <int D>
+__global__ __launch_bounds__(256) void cn_na2d_bwd_q_kernel(const float* __restrict__ qkv, long qbs,
+                                                           const float* __restrict__ dout, long dobs,
+                                                           const float* __restrict__ attn,
+                                                           float* __restrict__ dattn, float* __restrict__ dqkv,
+                                                           long dqbs, int B, int C, int heads, int H, int W, int dil,
+                                                           float scale) {
+  const int HW = H * W;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int y = p / W, x = p - y * W;
+  const int sy = na_window_start(y, H, dil), sx = na_window_start(x, W, dil);
+  const float* kp = qkv + b * qbs + (long)(C + h * D) * HW;
+  const float* vp = kp + (long)C * HW;
+  const float* dop = dout + b * dobs + (long)(h * D) * HW + p;
+  float go[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) go[d] = dop[(long)d * HW];
+  const float* ap = attn + ((long)(b * heads + h) * NA_KK) * HW + p;
+  float pr[NA_KK], dp[NA_KK];
+  float dot = 0.f;
+#pragma unroll
+  for (int i = 0; i < NA_K; ++i)
+#pragma unroll
+    for (int j = 0; j < NA_K; ++j) {
+      const int t = i * NA_K + j;
+      const int kpix = (sy + i * dil) * W + sx + j * dil;
+      float s = 0.f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) s += go[d] * vp[(long)d * HW + kpix];
+      pr[t] = ap[(long)t * HW];
+      dp[t] = s;
+      dot += pr[t] * s;
+    }
+  float* dap = dattn + ((long)(b * heads + h) * NA_KK) * HW + p;
+#pragma unroll
+  for (int t = 0; t < NA_KK; ++t) {
+    dp[t] = pr[t] * (dp[t] - dot);  // dS
+    dap[(long)t * HW] = dp[t];
+  }
+  float dq[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) dq[d] = 0.f;
+#pragma unroll
+  for (int i = 0; i < NA_K; ++i)
+#pragma unroll
+    for (int j = 0; j < NA_K; ++j) {
+      const int kpix = (sy + i * dil) * W + sx + j * dil;
+      const float ds = dp[i * NA_K + j];
+#pragma unroll
+      for (int d = 0; d < D; ++d) dq[d] += ds * kp[(long)d * HW + kpix];
+    }
+  float* dqp = dqkv + b * dqbs + (long)(h * D) * HW + p;
+#pragma unroll
+  for (int d = 0; d < D; ++d) dqp[(long)d * HW] = dq[d] * scale;
+}
+
+// Backward, key side (gather form, deterministic): for key pixel (y,x) visit every query whose
+// window contains it: dk = scale * sum dS[q,t]*q[q] ; dv = sum P[q,t]*dOut[q].
+template <int D>
+__global__ __launch_bounds__(256) void cn_na2d_bwd_kv_kernel(const float* __restrict__ qkv, long qbs,
+                                                            const float* __restrict__ dout, long dobs,
+                                                            const float* __restrict__ attn,
+                                                            const float* __restrict__ dattn,
+                                                            float* __restrict__ dqkv, long dqbs, int B, int C,
+                                                            int heads, int H, int W, int dil, float scale) {
+  const int HW = H * W;
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= HW) return;
+  const int h = blockIdx.y, b = blockIdx.z;
+  const int y = p / W, x = p - y * W;
+  const float* qp = qkv + b * qbs + (long)(h * D) * HW;
+  const float* dop = dout + b * dobs + (long)(h * D) * HW;
+  const float* ap = attn + ((long)(b * heads + h) * NA_KK) * HW;
+  const float* dap = dattn + ((long)(b * heads + h) * NA_KK) * HW;
+  float dk[D], dv[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    dk[d] = 0.f;
+    dv[d] = 0.f;
+  }
+  for (int my = -2; my <= 2; ++my) {
+    const int qy = y + my * dil;
+    if (qy < 0 || qy >= H) continue;
+    const int offy = y - na_window_start(qy, H, dil);
+    if (offy < 0 || offy > 2 * dil) continue;  // same residue class => divisible by dil
+    const int i = offy / dil;
+    for (int mx = -2; mx <= 2; ++mx) {
+      const int qx = x + mx * dil;
+      if (qx < 0 || qx >= W) continue;
+      const int offx = x - na_window_start(qx, W, dil);
+      if (offx < 0 || offx > 2 * dil) continue;
+      const int t = i * NA_K + offx / dil;
+      const int qpix = qy * W + qx;
+      const float ds = dap[(long)t * HW + qpix];
+      const float pr = ap[(long)t * HW + qpix];
+#pragma unroll
+      for (int d = 0; d < D; ++d) {
+        dk[d] += ds * qp[(long)d * HW + qpix];
+        dv[d] += pr * dop[(long)d * HW + qpix];
+      }
+    }
+  }
+  float* dkp = dqkv + b * dqbs + (long)(C + h * D) * HW + p;
+  float* dvp = dkp + (long)C * HW;
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    dkp[(long)d * HW] = dk[d] * scale;
+    dvp[(long)d * HW] = dv[d];
+  }
+}
+
+#define NA_DISPATCH(D_, KERNEL, ...)                                                                          \
+  switch (D_) {                                                                                               \
+    case 2: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(256), 0, stream, __VA_ARGS__); break;                 \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(256), 0, stream, __VA_ARGS__); break;                 \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), grid, dim3(256), 0, stream, __VA_ARGS__); break;                 \
+    case 16: hipLaunchKernelGGL((KERNEL<16>), grid, dim3(256), 0, stream, __VA_ARGS__); break;               \
+    case 32: hipLaunchKernelGGL((KERNEL<32>), grid, dim3(256), 0, stream, __VA_ARGS__); break;               \
+    case 64: hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, stream, __VA_ARGS__); break;               \
+    default: return CN_ERR_ARG;                                                                               \
+  }
+
+// kernel_size must be 3 (every NATTEN_PARAMS entry used by TowerUNet: unet_parts.py:19-40).
+extern "C" int cn_na2d_fwd_f32(const float* qkv, long qbs, float* out, long obs, float* attn, int B, int C,
+                               int heads, int H, int W, int kernel_size, int dilation, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (kernel_size != NA_K || heads <= 0 || C % heads != 0) return CN_ERR_ARG;
+  if (kernel_size * dilation > H || kernel_size * dilation > W) return CN_ERR_ARG;
+  const int D = C / heads;
+  const float scale = 1.0f / sqrtf((float)D);
+  dim3 grid((H * W + 255) / 256, heads, B);
+  NA_DISPATCH(D, cn_na2d_fwd_kernel, qkv, qbs, out, obs, attn, B, C, heads, H, W, dilation, scale);
+  return cn_check_launch();
+}
+
+// dqkv [B][3C][H][W] is fully overwritten (dq, dk, dv); dattn is scratch of attn's size.
+extern "C" int cn_na2d_bwd_f32(const float* qkv, long qbs, const float* dout, long dobs, const float* attn,
+                               float* dattn, float* dqkv, long dqbs, int B, int C, int heads, int H, int W,
+                               int kernel_size, int dilation, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (kernel_size != NA_K || heads <= 0 || C % heads != 0) return CN_ERR_ARG;
+  const int D = C / heads;
+  const float scale = 1.0f / sqrtf((float)D);
+  dim3 grid((H * W + 255) / 256, heads, B);
+  NA_DISPATCH(D, cn_na2d_bwd_q_kernel, qkv, qbs, dout, dobs, attn, dattn, dqkv, dqbs, B, C, heads, H, W, dilation,
+              scale);
+  NA_DISPATCH(D, cn_na2d_bwd_kv_kernel, qkv, qbs, dout, dobs, attn, dattn, dqkv, dqbs, B, C, heads, H, W, dilation,
+              scale);
+  return cn_check_launch();
+}

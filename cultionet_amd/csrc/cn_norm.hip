@@ -1,0 +1,373 @@
+// BatchNorm (train / eval) with fused SiLU + residual add, LayerNorm over the channel axis
+// of NCHW tensors, and per-channel sums. HBM-bound streaming kernels (gfx950).
+//
+// Reference ops: nn.BatchNorm2d / BatchNorm3d + SiLU inside ConvBlock2d
+// (/root/reference/src/cultionet/nn/modules/convolution.py:71-120, models/nunet.py:18-57),
+// nn.LayerNorm over channels in NHWC (nunet.py:93-97, convolution.py:338-353).
+// Here tensors stay NCHW: a LayerNorm "row" is the C values of one pixel (stride L),
+// lanes walk consecutive pixels so every access is coalesced.
+#include "cn_common.h"
+
+#define BN_SPLIT_MAX 64
+
+// ---------------------------------------------------------------------------
+// BatchNorm statistics: x viewed as [B][C][L] (batch stride xbs). Partial sums in fp64.
+// part[c][split][2] = {sum, sumsq} over this block's share.
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cn_bn_partial_kernel(const float* __restrict__ x, long xbs, int B, int C,
+                                                           int L, int splits, double* __restrict__ part) {
+  __shared__ double scratch[4];
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const int per = (L + splits - 1) / splits;
+  const int beg = sp * per;
+  const int end = (beg + per < L) ? beg + per : L;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float* xp = x + b * xbs + (long)c * L;
+    for (int l = beg + threadIdx.x; l < end; l += 256) {
+      const float v = xp[l];
+      s += v;
+      ss += (double)v * v;
+    }
+  }
+  s = cn_block_sum<double, 256>(s, scratch);
+  ss = cn_block_sum<double, 256>(ss, scratch);
+  if (threadIdx.x == 0) {
+    part[((long)c * splits + sp) * 2 + 0] = s;
+    part[((long)c * splits + sp) * 2 + 1] = ss;
+  }
+}
+
+// Finalize: mean / rstd (biased variance), running-stat update (momentum, unbiased variance).
+__global__ void cn_bn_finalize_kernel(const double* __restrict__ part, int C, int splits, double count, float eps,
+                                      float momentum, float* __restrict__ mean, float* __restrict__ rstd,
+                                      float* __restrict__ running_mean, float* __restrict__ running_var) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0, ss = 0.0;
+  for (int i = 0; i < splits; ++i) {
+    s += part[((long)c * splits + i) * 2 + 0];
+    ss += part[((long)c * splits + i) * 2 + 1];
+  }
+  const double m = s / count;
+  double var = ss / count - m * m;
+  if (var < 0.0) var = 0.0;
+  mean[c] = (float)m;
+  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean != nullptr) {
+    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// Eval mode: mean/rstd from running statistics.
+__global__ void cn_bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
+                                        int C, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  mean[c] = running_mean[c];
+  rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+}
+
+// y = act(gamma * (x - mean) * rstd + beta) (+ residual). act: 0 none, 1 SiLU.
+__global__ __launch_bounds__(256) void cn_bn_apply_kernel(const float* __restrict__ x, long xbs,
+                                                         const float* __restrict__ mean,
+                                                         const float* __restrict__ rstd,
+                                                         const float* __restrict__ gamma,
+                                                         const float* __restrict__ beta,
+                                                         const float* __restrict__ res, long rbs,
+                                                         float* __restrict__ y, long ybs, int B, int C, int L, int act) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float m = mean[c], sc = gamma[c] * rstd[c], be = beta[c];
+  const long r0 = (long)c * L;
+  const float* xp = x + b * xbs + r0;
+  const float* rp = res ? res + b * rbs + r0 : nullptr;
+  float* yp = y + b * ybs + r0;
+  for (int l = blockIdx.x * 256 + threadIdx.x; l < L; l += gridDim.x * 256) {
+    float z = (xp[l] - m) * sc + be;
+    if (act == 1) z = cn_silu(z);
+    if (rp) z += rp[l];
+    yp[l] = z;
+  }
+}
+
+// Backward pass 1: per-channel partial sums of dz and dz*xhat, dz = dy * act'(z).
+__global__ __launch_bounds__(256) void cn_bn_bwd_partial_kernel(const float* __restrict__ x, long xbs,
+                                                               const float* __restrict__ dy, long dybs,
+                                                               const float* __restrict__ mean,
+                                                               const float* __restrict__ rstd,
+                                                               const float* __restrict__ gamma,
+                                                               const float* __restrict__ beta, int B, int C, int L,
+                                                               int act, int splits, double* __restrict__ part) {
+  __shared__ double scratch[4];
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const int per = (L + splits - 1) / splits;
+  const int beg = sp * per;
+  const int end = (beg + per < L) ? beg + per : L;
+  const float m = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float* xp = x + b * xbs + (long)c * L;
+    const float* dp = dy + b * dybs + (long)c * L;
+    for (int l = beg + threadIdx.x; l < end; l += 256) {
+      const float xh = (xp[l] - m) * rs;
+      float dz = dp[l];
+      if (act == 1) dz *= cn_silu_grad(ga * xh + be);
+      s1 += dz;
+      s2 += (double)dz * xh;
+    }
+  }
+  s1 = cn_block_sum<double, 256>(s1, scratch);
+  s2 = cn_block_sum<double, 256>(s2, scratch);
+  if (threadIdx.x == 0) {
+    part[((long)c * splits + sp) * 2 + 0] = s1;
+    part[((long)c * splits + sp) * 2 + 1] = s2;
+  }
+}
+
+// Reduce the partials; dgamma/dbeta (+)=; coef[c] = {s1/N, s2/N} for the apply pass.
+__global__ void cn_bn_bwd_finalize_kernel(const double* __restrict__ part, int C, int splits, double count,
+                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                          float* __restrict__ coef, int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < splits; ++i) {
+    s1 += part[((long)c * splits + i) * 2 + 0];
+    s2 += part[((long)c * splits + i) * 2 + 1];
+  }
+  if (accumulate) {
+    dgamma[c] += (float)s2;
+    dbeta[c] += (float)s1;
+  } else {
+    dgamma[c] = (float)s2;
+    dbeta[c] = (float)s1;
+  }
+  coef[2 * c + 0] = (float)(s1 / count);
+  coef[2 * c + 1] = (float)(s2 / count);
+}
+
+// Backward pass 2: dx (+)= gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat))   [train]
+//                  dx (+)= gamma*rstd*dz                                        [eval: coef == nullptr]
+__global__ __launch_bounds__(256) void cn_bn_bwd_apply_kernel(const float* __restrict__ x, long xbs,
+                                                             const float* __restrict__ dy, long dybs,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ coef,
+                                                             float* __restrict__ dx, long dxbs, int B, int C, int L,
+                                                             int act, int accumulate) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float m = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+  const float c1 = coef ? coef[2 * c] : 0.f, c2 = coef ? coef[2 * c + 1] : 0.f;
+  const long r0 = (long)c * L;
+  const float* xp = x + b * xbs + r0;
+  const float* dp = dy + b * dybs + r0;
+  float* dxp = dx + b * dxbs + r0;
+  for (int l = blockIdx.x * 256 + threadIdx.x; l < L; l += gridDim.x * 256) {
+    const float xh = (xp[l] - m) * rs;
+    float dz = dp[l];
+    if (act == 1) dz *= cn_silu_grad(ga * xh + be);
+    float g = (dz - c1 - xh * c2) * (ga * rs);
+    if (accumulate) g += dxp[l];
+    dxp[l] = g;
+  }
+}
+
+static int bn_splits(int C, long L) {
+  int s = (1024 + C - 1) / C;
+  const long maxs = (L + 511) / 512;
+  if (s > maxs) s = (int)maxs;
+  if (s > BN_SPLIT_MAX) s = BN_SPLIT_MAX;
+  if (s < 1) s = 1;
+  return s;
+}
+
+static dim3 plane_grid(int B, int C, int L) {
+  int bx = (L + 1023) / 1024;  // ~4 elements per thread
+  if (bx < 1) bx = 1;
+  return dim3(bx, C, B);
+}
+
+extern "C" int cn_bn_workspace_doubles(int C) { return C * BN_SPLIT_MAX * 2; }
+
+// Forward. x,y viewed as [B][C][L] (L = H*W for BatchNorm2d, T*H*W for BatchNorm3d).
+// training != 0: batch statistics (saved to mean/rstd [C]) and running stats updated in place.
+// ws: workspace of cn_bn_workspace_doubles(C) doubles.
+extern "C" int cn_bn_act_fwd_f32(const float* x, long xbs, const float* gamma, const float* beta,
+                                 float* running_mean, float* running_var, const float* res, long rbs, float* y,
+                                 long ybs, float* mean, float* rstd, double* ws, int B, int C, int L, int training,
+                                 float momentum, float eps, int act, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
+  if (training) {
+    const int splits = bn_splits(C, L);
+    hipLaunchKernelGGL(cn_bn_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, B, C, L, splits, ws);
+    hipLaunchKernelGGL(cn_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, ws, C, splits,
+                       (double)B * L, eps, momentum, mean, rstd, running_mean, running_var);
+  } else {
+    hipLaunchKernelGGL(cn_bn_eval_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, running_mean,
+                       running_var, C, eps, mean, rstd);
+  }
+  hipLaunchKernelGGL(cn_bn_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, x, xbs, mean,
+                     rstd, gamma, beta, res, rbs, y, ybs, B, C, L, act);
+  return cn_check_launch();
+}
+
+// Backward. dgamma/dbeta (+)= per accumulate_params; dx (+)= per accumulate_dx.
+// coef: scratch [2*C] floats; ws as in forward.
+extern "C" int cn_bn_act_bwd_f32(const float* x, long xbs, const float* dy, long dybs, const float* mean,
+                                 const float* rstd, const float* gamma, const float* beta, float* dx, long dxbs,
+                                 float* dgamma, float* dbeta, float* coef, double* ws, int B, int C, int L,
+                                 int training, int act, int accumulate_dx, int accumulate_params, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
+  const int splits = bn_splits(C, L);
+  hipLaunchKernelGGL(cn_bn_bwd_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, dy, dybs, mean, rstd,
+                     gamma, beta, B, C, L, act, splits, ws);
+  hipLaunchKernelGGL(cn_bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, ws, C, splits,
+                     (double)B * L, dgamma, dbeta, coef, accumulate_params);
+  if (dx != nullptr)
+    hipLaunchKernelGGL(cn_bn_bwd_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, x, xbs,
+                       dy, dybs, mean, rstd, gamma, beta, training ? coef : (const float*)nullptr, dx, dxbs, B, C,
+                       L, act, accumulate_dx);
+  return cn_check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// Per-channel sum over [B][C][L] (bias gradients): out[c] (+)= sum x[b,c,l]
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cn_channel_sum_kernel(const float* __restrict__ x, long xbs, int B, int C,
+                                                            int L, float* __restrict__ out, int accumulate) {
+  __shared__ double scratch[4];
+  const int c = blockIdx.x;
+  double s = 0.0;
+  for (int b = 0; b < B; ++b) {
+    const float* xp = x + b * xbs + (long)c * L;
+    for (int l = threadIdx.x; l < L; l += 256) s += xp[l];
+  }
+  s = cn_block_sum<double, 256>(s, scratch);
+  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+extern "C" int cn_channel_sum_f32(const float* x, long xbs, int B, int C, int L, float* out, int accumulate,
+                                  void* stream) {
+  if (C <= 0) return CN_OK;
+  hipLaunchKernelGGL(cn_channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, xbs, B, C, L, out,
+                     accumulate);
+  return cn_check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// LayerNorm over C for NCHW tensors: one lane per pixel, values strided by L.
+//   y = (x - mu) * rstd * w[c] + b[c] (+ residual);  mu/rstd saved per pixel [B][L].
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cn_ln_fwd_kernel(const float* __restrict__ x, long xbs,
+                                                       const float* __restrict__ w, const float* __restrict__ bvec,
+                                                       const float* __restrict__ res, long rbs,
+                                                       float* __restrict__ y, long ybs, float* __restrict__ mu,
+                                                       float* __restrict__ rstd, int B, int C, int L, float eps) {
+  const long p = blockIdx.x * 256L + threadIdx.x;
+  if (p >= (long)B * L) return;
+  const long b = p / L, l = p - b * L;
+  const float* xp = x + b * xbs + l;
+  float s = 0.f;
+  for (int c = 0; c < C; ++c) s += xp[(long)c * L];
+  const float m = s / C;
+  float v = 0.f;
+  for (int c = 0; c < C; ++c) {
+    const float d = xp[(long)c * L] - m;
+    v += d * d;
+  }
+  const float rs = 1.0f / sqrtf(v / C + eps);
+  mu[p] = m;
+  rstd[p] = rs;
+  float* yp = y + b * ybs + l;
+  const float* rp = res ? res + b * rbs + l : nullptr;
+  for (int c = 0; c < C; ++c) {
+    float o = (xp[(long)c * L] - m) * rs * w[c] + bvec[c];
+    if (rp) o += rp[(long)c * L];
+    yp[(long)c * L] = o;
+  }
+}
+
+// dx (+)= rstd * (g - mean_c(g) - xhat * mean_c(g*xhat)), g = dy*w; dw/db via block partials + atomics.
+template <int MAXC>
+__global__ __launch_bounds__(256) void cn_ln_bwd_kernel(const float* __restrict__ x, long xbs,
+                                                       const float* __restrict__ dy, long dybs,
+                                                       const float* __restrict__ w, const float* __restrict__ mu,
+                                                       const float* __restrict__ rstd, float* __restrict__ dx,
+                                                       long dxbs, float* __restrict__ dw, float* __restrict__ db,
+                                                       int B, int C, int L, int accumulate_dx) {
+  __shared__ float red[2][4][MAXC];
+  const long p = blockIdx.x * 256L + threadIdx.x;
+  const bool ok = p < (long)B * L;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  long b = 0, l = 0;
+  float m = 0.f, rs = 0.f;
+  if (ok) {
+    b = p / L;
+    l = p - b * L;
+    m = mu[p];
+    rs = rstd[p];
+  }
+  const float* xp = x + b * xbs + l;
+  const float* dp = dy + b * dybs + l;
+  float s1 = 0.f, s2 = 0.f;
+  for (int c = 0; c < C; ++c) {
+    float g = 0.f, xh = 0.f, d = 0.f;
+    if (ok) {
+      d = dp[(long)c * L];
+      xh = (xp[(long)c * L] - m) * rs;
+      g = d * w[c];
+    }
+    s1 += g;
+    s2 += g * xh;
+    // per-channel parameter gradients: wave reduce, then one LDS slot per wave
+    const float dwv = cn_wave_sum(d * xh);
+    const float dbv = cn_wave_sum(d);
+    if (lane == 0) {
+      red[0][wid][c] = dwv;
+      red[1][wid][c] = dbv;
+    }
+  }
+  if (ok) {
+    const float a1 = s1 / C, a2 = s2 / C;
+    float* dxp = dx + b * dxbs + l;
+    for (int c = 0; c < C; ++c) {
+      const float xh = (xp[(long)c * L] - m) * rs;
+      float g = rs * (dp[(long)c * L] * w[c] - a1 - xh * a2);
+      if (accumulate_dx) g += dxp[(long)c * L];
+      dxp[(long)c * L] = g;
+    }
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dw + c, red[0][0][c] + red[0][1][c] + red[0][2][c] + red[0][3][c]);
+    atomicAdd(db + c, red[1][0][c] + red[1][1][c] + red[1][2][c] + red[1][3][c]);
+  }
+}
+
+extern "C" int cn_layernorm_c_fwd_f32(const float* x, long xbs, const float* w, const float* b, const float* res,
+                                      long rbs, float* y, long ybs, float* mu, float* rstd, int B, int C, int L,
+                                      float eps, void* stream) {
+  const long P = (long)B * L;
+  if (P <= 0) return CN_OK;
+  hipLaunchKernelGGL(cn_ln_fwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, xbs,
+                     w, b, res, rbs, y, ybs, mu, rstd, B, C, L, eps);
+  return cn_check_launch();
+}
+
+// dw/db are accumulated with atomics: zero them first for a fresh gradient.
+extern "C" int cn_layernorm_c_bwd_f32(const float* x, long xbs, const float* dy, long dybs, const float* w,
+                                      const float* mu, const float* rstd, float* dx, long dxbs, float* dw,
+                                      float* db, int B, int C, int L, int accumulate_dx, void* stream) {
+  const long P = (long)B * L;
+  if (P <= 0) return CN_OK;
+  if (C > 512) return CN_ERR_ARG;
+  hipLaunchKernelGGL((cn_ln_bwd_kernel<512>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+                     x, xbs, dy, dybs, w, mu, rstd, dx, dxbs, dw, db, B, C, L, accumulate_dx);
+  return cn_check_launch();
+}

@@ -1,0 +1,279 @@
+// Streaming kernels: bilinear resize (align_corners=True), slice copy / add, the fused
+// final-combine heads and label preparation. All HBM-bound (gfx950).
+//
+// Reference ops: F.interpolate(mode="bilinear", align_corners=True) in check_upsample
+// (/root/reference/src/cultionet/nn/functional.py:72-81), torch.cat in TowerUNetBlock /
+// TowerUNetFinal (nn/modules/unet_parts.py:281-309,700-760), TowerUNetFinalCombine + SigmoidCrisp
+// (unet_parts.py:43-193).
+#include "cn_common.h"
+
+// ---------------------------------------------------------------------------
+// Bilinear resize, align_corners=True. Planes = B*C, both tensors [B][C][H][W] with batch strides.
+// src index math follows ATen's area_pixel_compute_source_index (fp32).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ void bl_src(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
+  const float src = scale * o;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = src - i0;
+}
+
+__global__ __launch_bounds__(256) void cn_bilinear_fwd_kernel(const float* __restrict__ x, long xbs,
+                                                             float* __restrict__ y, long ybs, int C, int Hi, int Wi,
+                                                             int Ho, int Wo, float sh, float sw) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= Ho * Wo) return;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int oy = p / Wo, ox = p - oy * Wo;
+  int y0, y1, x0, x1;
+  float ly, lx;
+  bl_src(oy, sh, Hi, y0, y1, ly);
+  bl_src(ox, sw, Wi, x0, x1, lx);
+  const float* xp = x + b * xbs + (long)c * Hi * Wi;
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const float v = hy * (hx * xp[y0 * Wi + x0] + lx * xp[y0 * Wi + x1]) +
+                  ly * (hx * xp[y1 * Wi + x0] + lx * xp[y1 * Wi + x1]);
+  y[b * ybs + (long)c * Ho * Wo + p] = v;
+}
+
+// Adjoint in gather form: every input pixel sums the output pixels that read it (deterministic).
+__global__ __launch_bounds__(256) void cn_bilinear_bwd_kernel(const float* __restrict__ dy, long dybs,
+                                                             float* __restrict__ dx, long dxbs, int C, int Hi,
+                                                             int Wi, int Ho, int Wo, float sh, float sw,
+                                                             float inv_sh, float inv_sw, int accumulate) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= Hi * Wi) return;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int iy = p / Wi, ix = p - iy * Wi;
+  // candidate outputs: src in (iy-1, iy+1)  ->  o in ((iy-1)/s, (iy+1)/s), widened by one for rounding
+  int oy_lo = (int)floorf((iy - 1) * inv_sh) - 1, oy_hi = (int)ceilf((iy + 1) * inv_sh) + 1;
+  int ox_lo = (int)floorf((ix - 1) * inv_sw) - 1, ox_hi = (int)ceilf((ix + 1) * inv_sw) + 1;
+  if (sh == 0.f) { oy_lo = 0; oy_hi = Ho - 1; }
+  if (sw == 0.f) { ox_lo = 0; ox_hi = Wo - 1; }
+  oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, Ho - 1);
+  ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, Wo - 1);
+  const float* dp = dy + b * dybs + (long)c * Ho * Wo;
+  float acc = 0.f;
+  for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+    int y0, y1; float ly;
+    bl_src(oy, sh, Hi, y0, y1, ly);
+    float wy = 0.f;
+    if (y0 == iy) wy += 1.f - ly;
+    if (y1 == iy) wy += ly;
+    if (wy == 0.f) continue;
+    for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+      int x0, x1; float lx;
+      bl_src(ox, sw, Wi, x0, x1, lx);
+      float wx = 0.f;
+      if (x0 == ix) wx += 1.f - lx;
+      if (x1 == ix) wx += lx;
+      if (wx != 0.f) acc += wy * wx * dp[oy * Wo + ox];
+    }
+  }
+  float* o = dx + b * dxbs + (long)c * Hi * Wi + p;
+  *o = accumulate ? *o + acc : acc;
+}
+
+static inline float bl_scale(int in_size, int out_size) {
+  return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+}
+
+extern "C" int cn_bilinear_fwd_f32(const float* x, long xbs, float* y, long ybs, int B, int C, int Hi, int Wi, int Ho,
+                                   int Wo, void* stream) {
+  if (B <= 0 || C <= 0) return CN_OK;
+  dim3 grid((Ho * Wo + 255) / 256, C, B);
+  hipLaunchKernelGGL(cn_bilinear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, xbs, y, ybs, C, Hi, Wi, Ho,
+                     Wo, bl_scale(Hi, Ho), bl_scale(Wi, Wo));
+  return cn_check_launch();
+}
+
+extern "C" int cn_bilinear_bwd_f32(const float* dy, long dybs, float* dx, long dxbs, int B, int C, int Hi, int Wi,
+                                   int Ho, int Wo, int accumulate, void* stream) {
+  if (B <= 0 || C <= 0) return CN_OK;
+  const float sh = bl_scale(Hi, Ho), sw = bl_scale(Wi, Wo);
+  dim3 grid((Hi * Wi + 255) / 256, C, B);
+  hipLaunchKernelGGL(cn_bilinear_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dybs, dx, dxbs, C, Hi, Wi,
+                     Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, accumulate);
+  return cn_check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// Strided-batch copy / add:  dst[b][i] (+)= src[b][i], i < n  (channel slices of NCHW tensors)
+// ---------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cn_copy_kernel(const float* __restrict__ src, long sbs,
+                                                     float* __restrict__ dst, long dbs, long n, int accumulate) {
+  const int b = blockIdx.y;
+  const float* s = src + b * sbs;
+  float* d = dst + b * dbs;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    d[i] = accumulate ? d[i] + s[i] : s[i];
+  }
+}
+
+extern "C" int cn_copy_f32(const float* src, long sbs, float* dst, long dbs, int B, long n, int accumulate,
+                           void* stream) {
+  if (B <= 0 || n <= 0) return CN_OK;
+  long bx = (n + 1023) / 1024;
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(cn_copy_kernel, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, src, sbs, dst, dbs, n,
+                     accumulate);
+  return cn_check_launch();
+}
+
+// dst[b][i] = a[b][i] + c[b][i]
+__global__ __launch_bounds__(256) void cn_add_kernel(const float* __restrict__ a, long abs_, const float* __restrict__ c,
+                                                    long cbs, float* __restrict__ dst, long dbs, long n) {
+  const int b = blockIdx.y;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    dst[b * dbs + i] = a[b * abs_ + i] + c[b * cbs + i];
+}
+
+extern "C" int cn_add_f32(const float* a, long abs_, const float* c, long cbs, float* dst, long dbs, int B, long n,
+                          void* stream) {
+  if (B <= 0 || n <= 0) return CN_OK;
+  long bx = (n + 1023) / 1024;
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(cn_add_kernel, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, a, abs_, c, cbs, dst,
+                     dbs, n);
+  return cn_check_launch();
+}
+
+__global__ void cn_fill_kernel(float* __restrict__ p, long n, float v) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) p[i] = v;
+}
+
+extern "C" int cn_fill_f32(float* p, long n, float v, void* stream) {
+  if (n <= 0) return CN_OK;
+  long bx = (n + 1023) / 1024;
+  if (bx > 2048) bx = 2048;
+  hipLaunchKernelGGL(cn_fill_kernel, dim3((unsigned)bx), dim3(256), 0, (hipStream_t)stream, p, n, v);
+  return cn_check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// TowerUNetFinalCombine (unet_parts.py:101-193), fused:
+//   s_k   = sum_t (1/gamma[k][t]) * h_t[:, k]          k = 0 dist, 1 edge, 2 crop; t = towers a,b,c
+//   z_k   = w[k] * s_k + bias[k]                        (the 1x1 Conv2d(1,1))
+//   out_k = sigmoid(z_k)                                (dist, crop)
+//   out_1 = sigmoid(z_1 / (smooth + sigmoid(crisp)))    (edge: SigmoidCrisp)
+// h_t: [B][3][HW] tower outputs (channel = task). params: HOST array of 16 DEVICE pointers to the
+// scalar parameters: [3k+t] gamma[k][t], [9+k] w[k], [12+k] bias[k], [15] crisp gamma.
+// ---------------------------------------------------------------------------
+struct CnPtr16 { const float* p[16]; };
+struct CnMutPtr16 { float* p[16]; };
+
+__global__ __launch_bounds__(256) void cn_final_combine_fwd_kernel(const float* __restrict__ ha,
+                                                                  const float* __restrict__ hb,
+                                                                  const float* __restrict__ hc,
+                                                                  const CnPtr16 pp,
+                                                                  float* __restrict__ dist, float* __restrict__ edge,
+                                                                  float* __restrict__ crop, int B, int HW,
+                                                                  float smooth) {
+  float prm[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) prm[k] = *pp.p[k];
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= (long)B * HW) return;
+  const long b = i / HW, p = i - b * HW;
+  const float crisp = 1.0f / (smooth + cn_sigmoid(prm[15]));
+  float* outs[3] = {dist, edge, crop};
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    const long off = (b * 3 + k) * HW + p;
+    const float s = (1.0f / prm[3 * k + 0]) * ha[off] + (1.0f / prm[3 * k + 1]) * hb[off] + (1.0f / prm[3 * k + 2]) * hc[off];
+    float z = prm[9 + k] * s + prm[12 + k];
+    if (k == 1) z *= crisp;
+    outs[k][i] = cn_sigmoid(z);
+  }
+}
+
+// Backward: dh_t (written); dparams: 16 device pointers, atomically accumulated into.
+__global__ __launch_bounds__(256) void cn_final_combine_bwd_kernel(
+    const float* __restrict__ ha, const float* __restrict__ hb, const float* __restrict__ hc,
+    const CnPtr16 pp, const float* __restrict__ dist, const float* __restrict__ edge,
+    const float* __restrict__ crop, const float* __restrict__ ddist, const float* __restrict__ dedge,
+    const float* __restrict__ dcrop, float* __restrict__ dha, float* __restrict__ dhb, float* __restrict__ dhc,
+    const CnMutPtr16 dpp, int B, int HW, float smooth) {
+  __shared__ float scratch[4];
+  float prm[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) prm[k] = *pp.p[k];
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  const bool ok = i < (long)B * HW;
+  const long b = ok ? i / HW : 0, p = ok ? i - b * HW : 0;
+  const float sg = cn_sigmoid(prm[15]);
+  const float crisp = 1.0f / (smooth + sg);
+  const float* outs[3] = {dist, edge, crop};
+  const float* douts[3] = {ddist, dedge, dcrop};
+  float dcrisp = 0.f;
+#pragma unroll
+  for (int k = 0; k < 3; ++k) {
+    float g1 = 0.f, g2 = 0.f, g3 = 0.f, gw = 0.f, gb = 0.f;
+    if (ok) {
+      const long off = (b * 3 + k) * HW + p;
+      const float ia = 1.0f / prm[3 * k + 0], ib = 1.0f / prm[3 * k + 1], ic = 1.0f / prm[3 * k + 2];
+      const float va = ha[off], vb = hb[off], vc = hc[off];
+      const float s = va * ia + vb * ib + vc * ic;
+      const float o = outs[k][i];
+      float dz = douts[k][i] * o * (1.f - o);  // wrt sigmoid argument
+      if (k == 1) {
+        const float zlin = prm[9 + k] * s + prm[12 + k];
+        dcrisp += dz * zlin;
+        dz *= crisp;
+      }
+      const float ds = dz * prm[9 + k];
+      gw = dz * s;
+      gb = dz;
+      dha[off] = ds * ia;
+      dhb[off] = ds * ib;
+      dhc[off] = ds * ic;
+      g1 = -ds * va * ia * ia;
+      g2 = -ds * vb * ib * ib;
+      g3 = -ds * vc * ic * ic;
+    }
+    g1 = cn_block_sum<float, 256>(g1, scratch);
+    g2 = cn_block_sum<float, 256>(g2, scratch);
+    g3 = cn_block_sum<float, 256>(g3, scratch);
+    gw = cn_block_sum<float, 256>(gw, scratch);
+    gb = cn_block_sum<float, 256>(gb, scratch);
+    if (threadIdx.x == 0) {
+      atomicAdd(dpp.p[3 * k + 0], g1);
+      atomicAdd(dpp.p[3 * k + 1], g2);
+      atomicAdd(dpp.p[3 * k + 2], g3);
+      atomicAdd(dpp.p[9 + k], gw);
+      atomicAdd(dpp.p[12 + k], gb);
+    }
+  }
+  dcrisp = cn_block_sum<float, 256>(dcrisp, scratch);
+  // d/dgamma [1/(smooth + sigmoid(gamma))] = -sg(1-sg) * crisp^2
+  if (threadIdx.x == 0) atomicAdd(dpp.p[15], dcrisp * (-sg * (1.f - sg) * crisp * crisp));
+}
+
+extern "C" int cn_final_combine_fwd_f32(const float* ha, const float* hb, const float* hc,
+                                        const float* const* params, float* dist, float* edge, float* crop, int B,
+                                        int HW, float smooth, void* stream) {
+  const long n = (long)B * HW;
+  if (n <= 0) return CN_OK;
+  CnPtr16 pp;
+  for (int k = 0; k < 16; ++k) pp.p[k] = params[k];
+  hipLaunchKernelGGL(cn_final_combine_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, ha, hb, hc, pp, dist, edge, crop, B, HW, smooth);
+  return cn_check_launch();
+}
+
+extern "C" int cn_final_combine_bwd_f32(const float* ha, const float* hb, const float* hc,
+                                        const float* const* params, const float* dist, const float* edge,
+                                        const float* crop, const float* ddist, const float* dedge,
+                                        const float* dcrop, float* dha, float* dhb, float* dhc,
+                                        float* const* dparams, int B, int HW, float smooth, void* stream) {
+  const long n = (long)B * HW;
+  if (n <= 0) return CN_OK;
+  CnPtr16 pp;
+  CnMutPtr16 dpp;
+  for (int k = 0; k < 16; ++k) { pp.p[k] = params[k]; dpp.p[k] = dparams[k]; }
+  hipLaunchKernelGGL(cn_final_combine_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, ha, hb, hc, pp, dist, edge, crop, ddist, dedge, dcrop, dha, dhb, dhc,
+                     dpp, B, HW, smooth);
+  return cn_check_launch();
+}

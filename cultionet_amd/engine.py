@@ -1,0 +1,722 @@
+"""Execution engine of cultionet_amd: a reverse-mode tape whose every node is a HIP kernel launch.
+
+PyTorch is used for device memory (caching allocator), streams and parameter containers only;
+all arithmetic runs in libcultionet_hip.so through the C ABI (cultionet_amd._lib). There is no
+CPU path: calling any op without the HIP library or with CPU tensors raises.
+
+Design (MI355X-first, not torch.autograd):
+  * ``Var`` = a device buffer (+ its gradient buffer). Buffers are NCHW fp32; a Var may be a channel
+    slice of a bigger buffer (batch stride != C*H*W), which every kernel supports natively.
+  * forward ops append a closure to the tape; ``Tape.backward()`` walks it in reverse. Gradient
+    buffers are written with beta=0 by the first producer and accumulated in-kernel (beta=1) by
+    later ones, or aliased when an op is the identity on its gradient (residual adds, concat
+    slices): no separate add/copy kernels.
+  * parameters live in ONE flat fp32 buffer and so do their gradients (``ParamStore``): the optimizer
+    is one fused launch and data-parallel all-reduce buckets are plain slices of the flat gradient.
+"""
+from __future__ import annotations
+
+import threading
+import typing as T
+
+import torch
+
+from . import _lib
+
+_state = threading.local()
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _check(t: torch.Tensor) -> torch.Tensor:
+    if not t.is_cuda:
+        raise RuntimeError("cultionet_amd ops need device tensors (MI355X); there is no CPU fallback")
+    if t.dtype != torch.float32:
+        raise RuntimeError(f"fp32 tensor expected, got {t.dtype}")
+    return t
+
+
+def bstride(t: torch.Tensor) -> int:
+    """Batch stride of an NCHW(-like) buffer whose inner dims are dense."""
+    return t.stride(0) if t.shape[0] > 1 else int(t[0].numel())
+
+
+def _dense_inner(t: torch.Tensor) -> bool:
+    exp = 1
+    for d in range(t.dim() - 1, 0, -1):
+        if t.shape[d] != 1 and t.stride(d) != exp:
+            return False
+        exp *= t.shape[d]
+    return True
+
+
+class Var:
+    """A device buffer and (during training) its gradient buffer."""
+
+    __slots__ = ("t", "grad", "req")
+
+    def __init__(self, t: torch.Tensor, req: bool = False):
+        self.t = t
+        self.grad: T.Optional[torch.Tensor] = None
+        self.req = req
+
+    @property
+    def shape(self):
+        return self.t.shape
+
+
+class Tape:
+    def __init__(self, enabled: bool):
+        self.enabled = enabled
+        self.nodes: T.List[T.Callable[[], None]] = []
+
+    def add(self, fn: T.Callable[[], None]) -> None:
+        if self.enabled:
+            self.nodes.append(fn)
+
+    def backward(self) -> None:
+        nodes, self.nodes = self.nodes, []
+        while nodes:
+            nodes.pop()()
+
+
+def current_tape() -> Tape:
+    tp = getattr(_state, "tape", None)
+    if tp is None:
+        tp = Tape(False)
+        _state.tape = tp
+    return tp
+
+
+class recording:
+    """Context manager: run forward ops under a fresh tape (enabled or not)."""
+
+    def __init__(self, enabled: bool = True):
+        self.tape = Tape(enabled)
+
+    def __enter__(self) -> Tape:
+        self.prev = getattr(_state, "tape", None)
+        _state.tape = self.tape
+        return self.tape
+
+    def __exit__(self, *exc):
+        _state.tape = self.prev
+        return False
+
+
+# ---------------------------------------------------------------------------
+# gradient plumbing
+# ---------------------------------------------------------------------------
+
+def grad_buffer(v: Var) -> T.Tuple[torch.Tensor, int]:
+    """(buffer, accumulate flag) to write/accumulate v's gradient into."""
+    if v.grad is None:
+        v.grad = torch.empty(v.t.shape, dtype=torch.float32, device=v.t.device)
+        return v.grad, 0
+    return v.grad, 1
+
+
+def give_grad(v: Var, g: torch.Tensor) -> None:
+    """v.grad (+)= g where the op is the identity on the gradient: alias when first, else add in place."""
+    if not v.req:
+        return
+    if v.grad is None:
+        v.grad = g
+        return
+    B = g.shape[0]
+    n = g[0].numel()
+    _lib.call("cn_copy_f32", g.data_ptr(), bstride(g), v.grad.data_ptr(), bstride(v.grad), B, n, 1, _stream())
+
+
+# ---------------------------------------------------------------------------
+# flat parameter store
+# ---------------------------------------------------------------------------
+
+class ParamStore:
+    """All parameters of a module in one flat fp32 buffer; gradients likewise.
+
+    ``param.data`` becomes a view of ``flat`` (checkpoints / state_dict keep working); gradients are
+    accumulated by the kernels into ``flat_grad``, on which the fused AdamW step and the RCCL
+    all-reduce operate directly (``attach_grads`` exposes them as ``param.grad`` views).
+    """
+
+    def __init__(self, module: torch.nn.Module):
+        params = [p for p in module.parameters()]
+        if not params:
+            raise ValueError("module has no parameters")
+        dev = params[0].device
+        if dev.type != "cuda":
+            raise RuntimeError("ParamStore needs the module on the GPU (call .to('cuda') first)")
+        self.params = params
+        offs, n = [], 0
+        for p in params:
+            offs.append(n)
+            n += (p.numel() + 3) // 4 * 4  # 16-byte aligned slices
+        self.numel = n
+        self.offsets = offs
+        self.flat = torch.zeros(n, dtype=torch.float32, device=dev)
+        self.flat_grad = torch.zeros(n, dtype=torch.float32, device=dev)
+        with torch.no_grad():
+            for p, o in zip(params, offs):
+                view = self.flat[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data)
+                p.data = view
+        self.version = 0  # bumped whenever parameter values change (invalidates packed weights)
+        self._base = self.flat.data_ptr()
+
+    def owns(self, module: torch.nn.Module) -> bool:
+        lo, hi = self._base, self._base + self.numel * 4
+        first, last = self.params[0], self.params[-1]
+        return lo <= first.data_ptr() < hi and lo <= last.data_ptr() < hi
+
+    def grad_of(self, p: torch.Tensor) -> torch.Tensor:
+        """Gradient slice matching a parameter (or any dense view of one) inside the flat buffer."""
+        o = (p.data_ptr() - self._base) // 4
+        if o < 0 or o + p.numel() > self.numel:
+            raise RuntimeError("tensor is not part of this ParamStore (was the module moved or re-created?)")
+        return self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def attach_grads(self) -> None:
+        """Point every ``param.grad`` at its slice of the flat gradient (for torch optimizers)."""
+        for p, o in zip(self.params, self.offsets):
+            p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
+
+    def zero_grad(self) -> None:
+        _lib.call("cn_fill_f32", self.flat_grad.data_ptr(), self.numel, 0.0, _stream())
+
+    def bump(self) -> None:
+        self.version += 1
+
+
+def current_store() -> ParamStore:
+    st = getattr(_state, "store", None)
+    if st is None:
+        raise RuntimeError("no active ParamStore (ops on parameters must run inside a model forward)")
+    return st
+
+
+class using_store:
+    def __init__(self, store: ParamStore):
+        self.store = store
+
+    def __enter__(self):
+        self.prev = getattr(_state, "store", None)
+        _state.store = self.store
+        return self.store
+
+    def __exit__(self, *exc):
+        _state.store = self.prev
+        return False
+
+
+def pgrad(p: torch.nn.Parameter) -> torch.Tensor:
+    return current_store().grad_of(p)
+
+
+# ---------------------------------------------------------------------------
+# packed weights cache (re-packed when the store version changes)
+# ---------------------------------------------------------------------------
+
+class PackedWeight:
+    """Packed copies of one weight tensor for the implicit-GEMM kernels (forward / bwd-data)."""
+
+    __slots__ = ("fwd", "bwd", "version")
+
+    def __init__(self):
+        self.fwd = None
+        self.bwd = None
+        self.version = -1
+
+
+def _pack(w: torch.Tensor, T_: int, K: int, N: int, sk: int, sn: int, st: int) -> torch.Tensor:
+    kp = _lib.query("cn_conv_kpad", K)
+    np_ = _lib.query("cn_conv_npad", N)
+    out = torch.empty(T_ * kp * np_, dtype=torch.float32, device=w.device)
+    _lib.call("cn_pack_weights_f32", w.data_ptr(), out.data_ptr(), T_, K, N, sk, sn, st, _stream())
+    return out
+
+
+def packed_conv(mod, need_bwd: bool) -> PackedWeight:
+    """Packed weights of an nn.Conv2d / nn.Linear-like module (weight [Cout][Cin][KH][KW])."""
+    pw = mod.__dict__.get("_cn_packed")
+    if pw is None:
+        pw = PackedWeight()
+        mod.__dict__["_cn_packed"] = pw
+    ver = current_store().version
+    if pw.version != ver:
+        pw.fwd = pw.bwd = None
+        pw.version = ver
+    w = mod.weight
+    cout, cin = w.shape[0], w.shape[1]
+    taps = int(w[0, 0].numel()) if w.dim() > 2 else 1
+    if pw.fwd is None:
+        pw.fwd = _pack(w, taps, cin, cout, taps, cin * taps, 1)
+    if need_bwd and pw.bwd is None:
+        pw.bwd = _pack(w, taps, cout, cin, cin * taps, taps, 1)
+    return pw
+
+
+def packed_convT(mod, need_bwd: bool) -> PackedWeight:
+    """Packed weights of an nn.ConvTranspose2d (weight [Cin][Cout][KH][KW])."""
+    pw = mod.__dict__.get("_cn_packed")
+    if pw is None:
+        pw = PackedWeight()
+        mod.__dict__["_cn_packed"] = pw
+    ver = current_store().version
+    if pw.version != ver:
+        pw.fwd = pw.bwd = None
+        pw.version = ver
+    w = mod.weight
+    cin, cout = w.shape[0], w.shape[1]
+    taps = int(w[0, 0].numel())
+    if pw.fwd is None:
+        pw.fwd = _pack(w, taps, cin, cout, cout * taps, taps, 1)
+    if need_bwd and pw.bwd is None:
+        pw.bwd = _pack(w, taps, cout, cin, taps, cout * taps, 1)
+    return pw
+
+
+# ---------------------------------------------------------------------------
+# ops
+# ---------------------------------------------------------------------------
+
+def _new(shape, like: torch.Tensor) -> torch.Tensor:
+    return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def conv2d(x: Var, mod, stride: int = 1, padding: int = 0, dilation: int = 1, out: T.Optional[torch.Tensor] = None) -> Var:
+    """nn.Conv2d forward (+ tape node for bwd-data, bwd-weight, bias grad)."""
+    tape = current_tape()
+    xt = _check(x.t)
+    B, Cin, H, W = xt.shape
+    w = mod.weight
+    Cout = w.shape[0]
+    KH, KW = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+    Ho = (H + 2 * padding - dilation * (KH - 1) - 1) // stride + 1
+    Wo = (W + 2 * padding - dilation * (KW - 1) - 1) // stride + 1
+    pw = packed_conv(mod, tape.enabled and x.req)
+    y = out if out is not None else _new((B, Cout, Ho, Wo), xt)
+    bias = mod.bias
+    _lib.call("cn_conv2d_fwd_f32", xt.data_ptr(), bstride(xt), pw.fwd.data_ptr(),
+              bias.data_ptr() if bias is not None else None, y.data_ptr(), bstride(y), B, Cin, H, W, Cout, KH, KW,
+              stride, padding, dilation, 0, _stream())
+    yv = Var(y, tape.enabled)
+    if tape.enabled:
+        store = current_store()
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            s = _stream()
+            _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
+                      store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, s)
+            if bias is not None:
+                _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Ho * Wo,
+                          store.grad_of(bias).data_ptr(), 1, s)
+            if x.req:
+                dx, acc = grad_buffer(x)
+                _lib.call("cn_conv2d_bwd_data_f32", dy.data_ptr(), bstride(dy), pw.bwd.data_ptr(), dx.data_ptr(),
+                          bstride(dx), B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, acc, s)
+            yv.grad = None
+
+        tape.add(bwd)
+    return yv
+
+
+def conv_transpose2d(x: Var, mod, stride: int, padding: int) -> Var:
+    """nn.ConvTranspose2d forward (k x k, stride s, padding p, with bias)."""
+    tape = current_tape()
+    xt = _check(x.t)
+    B, Cin, H, W = xt.shape
+    w = mod.weight
+    Cout, KH, KW = w.shape[1], w.shape[2], w.shape[3]
+    Ho = (H - 1) * stride - 2 * padding + KH
+    Wo = (W - 1) * stride - 2 * padding + KW
+    pw = packed_convT(mod, tape.enabled and x.req)
+    y = _new((B, Cout, Ho, Wo), xt)
+    bias = mod.bias
+    _lib.call("cn_conv_transpose2d_fwd_f32", xt.data_ptr(), bstride(xt), pw.fwd.data_ptr(),
+              bias.data_ptr() if bias is not None else None, y.data_ptr(), bstride(y), B, Cin, H, W, Cout, KH, KW,
+              stride, padding, 0, _stream())
+    yv = Var(y, tape.enabled)
+    if tape.enabled:
+        store = current_store()
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            s = _stream()
+            _lib.call("cn_conv_transpose2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
+                      store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, s)
+            if bias is not None:
+                _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Ho * Wo,
+                          store.grad_of(bias).data_ptr(), 1, s)
+            if x.req:
+                dx, acc = grad_buffer(x)
+                _lib.call("cn_conv_transpose2d_bwd_data_f32", dy.data_ptr(), bstride(dy), pw.bwd.data_ptr(),
+                          dx.data_ptr(), bstride(dx), B, Cin, H, W, Cout, KH, KW, stride, padding, acc, s)
+            yv.grad = None
+
+        tape.add(bwd)
+    return yv
+
+
+def time_conv(x: Var, mod, tin: int) -> Var:
+    """nn.Conv3d(kernel (k,1,1), bias=False) on x viewed as [B, Cin*Tin, H, W] -> [B, Cout*Tout, H, W]."""
+    tape = current_tape()
+    xt = _check(x.t)
+    B, CT, H, W = xt.shape
+    w = mod.weight  # [Cout, Cin, k, 1, 1]
+    Cout, Cin, k = w.shape[0], w.shape[1], w.shape[2]
+    assert CT == Cin * tin
+    tout = tin - k + 1
+    ver = current_store().version
+    pw = mod.__dict__.get("_cn_packed")
+    if pw is None or pw.version != ver:
+        pw = PackedWeight()
+        pw.version = ver
+        mod.__dict__["_cn_packed"] = pw
+    if pw.fwd is None:
+        n = _lib.query("cn_conv_kpad", Cin * tin) * _lib.query("cn_conv_npad", Cout * tout)
+        pw.fwd = _new((n,), xt)
+        _lib.call("cn_pack_timeconv_f32", w.data_ptr(), pw.fwd.data_ptr(), Cout, Cin, tin, k, 0, _stream())
+    if tape.enabled and x.req and pw.bwd is None:
+        n = _lib.query("cn_conv_kpad", Cout * tout) * _lib.query("cn_conv_npad", Cin * tin)
+        pw.bwd = _new((n,), xt)
+        _lib.call("cn_pack_timeconv_f32", w.data_ptr(), pw.bwd.data_ptr(), Cout, Cin, tin, k, 1, _stream())
+    y = _new((B, Cout * tout, H, W), xt)
+    _lib.call("cn_conv2d_fwd_f32", xt.data_ptr(), bstride(xt), pw.fwd.data_ptr(), None, y.data_ptr(), bstride(y), B,
+              CT, H, W, Cout * tout, 1, 1, 1, 0, 1, 0, _stream())
+    yv = Var(y, tape.enabled)
+    if tape.enabled:
+        store = current_store()
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            s = _stream()
+            dwexp = torch.zeros(Cout * tout * CT, dtype=torch.float32, device=xt.device)
+            _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
+                      dwexp.data_ptr(), B, CT, H, W, Cout * tout, 1, 1, 1, 0, 1, s)
+            _lib.call("cn_fold_timeconv_grad_f32", dwexp.data_ptr(), store.grad_of(w).data_ptr(), Cout, Cin, tin, k, s)
+            if x.req:
+                dx, acc = grad_buffer(x)
+                _lib.call("cn_conv2d_bwd_data_f32", dy.data_ptr(), bstride(dy), pw.bwd.data_ptr(), dx.data_ptr(),
+                          bstride(dx), B, CT, H, W, Cout * tout, 1, 1, 1, 0, 1, acc, s)
+            yv.grad = None
+
+        tape.add(bwd)
+    return yv
+
+
+ACT_NONE, ACT_SILU = 0, 1
+
+
+def bn_act(x: Var, bn, act: int, residual: T.Optional[Var] = None, channels: T.Optional[int] = None,
+           training: bool = True) -> Var:
+    """y = act(batch_norm(x)) (+ residual). x viewed as [B][C][L] with C = ``channels`` (BatchNorm3d: L = T*H*W)."""
+    tape = current_tape()
+    xt = _check(x.t)
+    B = xt.shape[0]
+    C = channels if channels is not None else xt.shape[1]
+    L = int(xt[0].numel()) // C
+    dev = xt.device
+    y = _new(xt.shape, xt)
+    mean = _new((C,), xt)
+    rstd = _new((C,), xt)
+    ws = torch.empty(_lib.query("cn_bn_workspace_doubles", C), dtype=torch.float64, device=dev)
+    rt = residual.t if residual is not None else None
+    mom = bn.momentum if bn.momentum is not None else 0.1
+    use_batch = training or (bn.running_mean is None)
+    _lib.call("cn_bn_act_fwd_f32", xt.data_ptr(), bstride(xt), bn.weight.data_ptr(), bn.bias.data_ptr(),
+              bn.running_mean.data_ptr() if bn.running_mean is not None else None,
+              bn.running_var.data_ptr() if bn.running_var is not None else None,
+              rt.data_ptr() if rt is not None else None, bstride(rt) if rt is not None else 0, y.data_ptr(),
+              bstride(y), mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), B, C, L, 1 if use_batch else 0, float(mom),
+              float(bn.eps), act, _stream())
+    req = tape.enabled
+    yv = Var(y, req)
+    if tape.enabled:
+        store = current_store()
+        gamma, beta = bn.weight, bn.bias
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            s = _stream()
+            if residual is not None:
+                give_grad(residual, dy)
+            coef = _new((2 * C,), xt)
+            if x.req:
+                dx, acc = grad_buffer(x)
+                dxp, dxbs = dx.data_ptr(), bstride(dx)
+            else:
+                dxp, dxbs, acc = None, 0, 0
+            _lib.call("cn_bn_act_bwd_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy), mean.data_ptr(),
+                      rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dxp, dxbs, store.grad_of(gamma).data_ptr(),
+                      store.grad_of(beta).data_ptr(), coef.data_ptr(), ws.data_ptr(), B, C, L, 1 if use_batch else 0,
+                      act, acc, 1, s)
+            yv.grad = None
+
+        tape.add(bwd)
+    return yv
+
+
+def layer_norm_c(x: Var, ln, residual: T.Optional[Var] = None) -> Var:
+    """nn.LayerNorm over the channel axis of an NCHW buffer (+ residual)."""
+    tape = current_tape()
+    xt = _check(x.t)
+    B, C = xt.shape[0], xt.shape[1]
+    L = int(xt[0, 0].numel())
+    y = _new(xt.shape, xt)
+    mu = _new((B, L), xt)
+    rstd = _new((B, L), xt)
+    rt = residual.t if residual is not None else None
+    _lib.call("cn_layernorm_c_fwd_f32", xt.data_ptr(), bstride(xt), ln.weight.data_ptr(), ln.bias.data_ptr(),
+              rt.data_ptr() if rt is not None else None, bstride(rt) if rt is not None else 0, y.data_ptr(),
+              bstride(y), mu.data_ptr(), rstd.data_ptr(), B, C, L, float(ln.eps), _stream())
+    yv = Var(y, tape.enabled)
+    if tape.enabled:
+        store = current_store()
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            if residual is not None:
+                give_grad(residual, dy)
+            dx, acc = grad_buffer(x)
+            _lib.call("cn_layernorm_c_bwd_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
+                      ln.weight.data_ptr(), mu.data_ptr(), rstd.data_ptr(), dx.data_ptr(), bstride(dx),
+                      store.grad_of(ln.weight).data_ptr(), store.grad_of(ln.bias).data_ptr(), B, C, L, acc, _stream())
+            yv.grad = None
+
+        tape.add(bwd)
+    return yv
+
+
+def na2d(qkv: Var, heads: int, kernel_size: int, dilation: int) -> Var:
+    """Neighborhood attention core on a [B, 3C, H, W] qkv buffer -> [B, C, H, W]."""
+    tape = current_tape()
+    qt = _check(qkv.t)
+    B, C3, H, W = qt.shape
+    C = C3 // 3
+    out = _new((B, C, H, W), qt)
+    attn = _new((B, heads, kernel_size * kernel_size, H, W), qt)
+    _lib.call("cn_na2d_fwd_f32", qt.data_ptr(), bstride(qt), out.data_ptr(), bstride(out), attn.data_ptr(), B, C,
+              heads, H, W, kernel_size, dilation, _stream())
+    ov = Var(out, tape.enabled)
+    if tape.enabled:
+
+        def bwd():
+            do = ov.grad
+            if do is None:
+                return
+            dattn = torch.empty_like(attn)
+            if qkv.grad is None:
+                dq = _new(qt.shape, qt)
+                _lib.call("cn_na2d_bwd_f32", qt.data_ptr(), bstride(qt), do.data_ptr(), bstride(do), attn.data_ptr(),
+                          dattn.data_ptr(), dq.data_ptr(), bstride(dq), B, C, heads, H, W, kernel_size, dilation,
+                          _stream())
+                qkv.grad = dq
+            else:  # pragma: no cover - qkv has a single consumer in TowerUNet
+                dq = _new(qt.shape, qt)
+                _lib.call("cn_na2d_bwd_f32", qt.data_ptr(), bstride(qt), do.data_ptr(), bstride(do), attn.data_ptr(),
+                          dattn.data_ptr(), dq.data_ptr(), bstride(dq), B, C, heads, H, W, kernel_size, dilation,
+                          _stream())
+                give_grad(qkv, dq)
+            ov.grad = None
+
+        tape.add(bwd)
+    return ov
+
+
+def resize_bilinear(x: Var, size: T.Tuple[int, int], out: T.Optional[torch.Tensor] = None) -> Var:
+    """F.interpolate(mode='bilinear', align_corners=True); identity when the size already matches."""
+    tape = current_tape()
+    xt = _check(x.t)
+    B, C, Hi, Wi = xt.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    if (Hi, Wi) == (Ho, Wo) and out is None:
+        return x
+    y = out if out is not None else _new((B, C, Ho, Wo), xt)
+    _lib.call("cn_bilinear_fwd_f32", xt.data_ptr(), bstride(xt), y.data_ptr(), bstride(y), B, C, Hi, Wi, Ho, Wo,
+              _stream())
+    yv = Var(y, tape.enabled and x.req)
+    if tape.enabled and x.req:
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            dx, acc = grad_buffer(x)
+            _lib.call("cn_bilinear_bwd_f32", dy.data_ptr(), bstride(dy), dx.data_ptr(), bstride(dx), B, C, Hi, Wi, Ho,
+                      Wo, acc, _stream())
+            yv.grad = None
+
+        tape.add(bwd)
+    return yv
+
+
+def cat_channels(parts: T.Sequence[Var]) -> Var:
+    """torch.cat(dim=1). Backward hands each input a channel-slice VIEW of the gradient (no copies)."""
+    tape = current_tape()
+    t0 = _check(parts[0].t)
+    B, H, W = t0.shape[0], t0.shape[2], t0.shape[3]
+    Ctot = sum(p.t.shape[1] for p in parts)
+    y = _new((B, Ctot, H, W), t0)
+    off = 0
+    for p in parts:
+        c = p.t.shape[1]
+        dst = y[:, off:off + c]
+        _lib.call("cn_copy_f32", p.t.data_ptr(), bstride(p.t), dst.data_ptr(), bstride(y), B, c * H * W, 0, _stream())
+        off += c
+    yv = Var(y, tape.enabled)
+    if tape.enabled:
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            o = 0
+            for p in parts:
+                c = p.t.shape[1]
+                give_grad(p, dy[:, o:o + c])
+                o += c
+            yv.grad = None
+
+        tape.add(bwd)
+    return yv
+
+
+def add(a: Var, b: Var) -> Var:
+    tape = current_tape()
+    at, bt = _check(a.t), _check(b.t)
+    B = at.shape[0]
+    n = int(at[0].numel())
+    y = _new(at.shape, at)
+    _lib.call("cn_add_f32", at.data_ptr(), bstride(at), bt.data_ptr(), bstride(bt), y.data_ptr(), bstride(y), B, n,
+              _stream())
+    yv = Var(y, tape.enabled)
+    if tape.enabled:
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            give_grad(a, dy)
+            if b.req:
+                if b.grad is None:  # never let two Vars alias one gradient buffer
+                    cp = _new(dy.shape, dy)
+                    _lib.call("cn_copy_f32", dy.data_ptr(), bstride(dy), cp.data_ptr(), bstride(cp), B, n, 0, _stream())
+                    b.grad = cp
+                else:
+                    give_grad(b, dy)
+            yv.grad = None
+
+        tape.add(bwd)
+    return yv
+
+
+def _ptr_table(ptrs: T.Sequence[int]):
+    import ctypes
+
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+def final_combine(ha: Var, hb: Var, hc: Var, params: T.Sequence[torch.nn.Parameter], smooth: float) -> T.Tuple[Var, Var, Var]:
+    """Fused TowerUNetFinalCombine. ``params``: 16 scalar parameters in the layout of cn_final_combine_fwd_f32."""
+    tape = current_tape()
+    a, b, c = _check(ha.t), _check(hb.t), _check(hc.t)
+    B, _, H, W = a.shape
+    HW = H * W
+    for t in (a, b, c):
+        if not t.is_contiguous():
+            raise RuntimeError("final_combine expects dense [B,3,H,W] tower outputs")
+    ptab = _ptr_table([p.data_ptr() for p in params])
+    dist, edge, crop = (_new((B, 1, H, W), a) for _ in range(3))
+    _lib.call("cn_final_combine_fwd_f32", a.data_ptr(), b.data_ptr(), c.data_ptr(), ptab, dist.data_ptr(),
+              edge.data_ptr(), crop.data_ptr(), B, HW, float(smooth), _stream())
+    outs = tuple(Var(t, tape.enabled) for t in (dist, edge, crop))
+    if tape.enabled:
+        store = current_store()
+
+        def bwd():
+            zeros = None
+            gs = []
+            for v in outs:
+                if v.grad is None:
+                    if zeros is None:
+                        zeros = _new(dist.shape, dist)
+                        _lib.call("cn_fill_f32", zeros.data_ptr(), zeros.numel(), 0.0, _stream())
+                    gs.append(zeros)
+                else:
+                    gs.append(v.grad)
+            das = []
+            for v in (ha, hb, hc):
+                if v.grad is not None:
+                    raise RuntimeError("final_combine inputs must have a single consumer")
+                v.grad = _new(v.t.shape, v.t)
+                das.append(v.grad)
+            dtab = _ptr_table([store.grad_of(p).data_ptr() for p in params])
+            _lib.call("cn_final_combine_bwd_f32", a.data_ptr(), b.data_ptr(), c.data_ptr(), ptab, dist.data_ptr(),
+                      edge.data_ptr(), crop.data_ptr(), gs[0].data_ptr(), gs[1].data_ptr(), gs[2].data_ptr(),
+                      das[0].data_ptr(), das[1].data_ptr(), das[2].data_ptr(), dtab, B, HW, float(smooth), _stream())
+            for v in outs:
+                v.grad = None
+
+        tape.add(bwd)
+    return outs
+
+
+# loss kinds / target modes of cn_tanimoto_*
+LOSS_KINDS = {"TanimotoComplementLoss": 0, "TanimotoDistLoss": 1, "TanimotoCombined": 2}
+TGT_FLOAT, TGT_EQ, TGT_RANGE, TGT_ONEHOT = 0, 1, 2, 3
+MSK_NONE, MSK_LABEL, MSK_I64, MSK_F32 = 0, 1, 2, 3
+
+
+def tanimoto_loss(pred: Var, *, target_f: T.Optional[torch.Tensor] = None, labels: T.Optional[torch.Tensor] = None,
+                  mask: T.Optional[torch.Tensor] = None, target_mode: int, mask_mode: int, klass: int = 0,
+                  loss_kind: int = 0, weight: float = 1.0, smooth: float = 1e-5, depth: int = 5,
+                  total: T.Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Batch-mean Tanimoto loss of ``pred`` [B,C,H,W]; returns a 1-element device tensor.
+
+    The tape node writes ``weight * dL/dpred`` into pred's gradient; ``total`` (1-element device
+    tensor), when given, is incremented by ``weight * loss`` on the device.
+    """
+    tape = current_tape()
+    pt = _check(pred.t)
+    B, C = pt.shape[0], pt.shape[1]
+    HW = int(pt[0, 0].numel())
+    dev = pt.device
+    if labels is not None and labels.dtype != torch.int64:
+        raise RuntimeError("labels must be int64")
+    if target_f is not None:
+        _check(target_f)
+        if not target_f.is_contiguous():
+            raise RuntimeError("float target must be contiguous")
+    sums = torch.empty(5 * B, dtype=torch.float64, device=dev)
+    coef = torch.empty(4 * B, dtype=torch.float32, device=dev)
+    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    tf = target_f.data_ptr() if target_f is not None else None
+    lb = labels.data_ptr() if labels is not None else None
+    mk = mask.data_ptr() if mask is not None else None
+    _lib.call("cn_tanimoto_fwd_f32", pt.data_ptr(), bstride(pt), tf, lb, mk, target_mode, mask_mode, klass, B, C, HW,
+              loss_kind, smooth, depth, sums.data_ptr(), coef.data_ptr(), loss.data_ptr(), float(weight),
+              total.data_ptr() if total is not None else None, _stream())
+    if tape.enabled and pred.req:
+
+        def bwd():
+            dp, acc = grad_buffer(pred)
+            _lib.call("cn_tanimoto_bwd_f32", pt.data_ptr(), bstride(pt), tf, lb, mk, target_mode, mask_mode, klass, B,
+                      C, HW, coef.data_ptr(), float(weight), dp.data_ptr(), bstride(dp), acc, _stream())
+            _keep = (target_f, labels, mask)  # noqa: F841  keep inputs alive until backward has run
+
+        tape.add(bwd)
+    return loss

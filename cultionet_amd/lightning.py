@@ -1,0 +1,354 @@
+"""CultionetLitModel on the HIP engine.
+
+Host-side mirror of /root/reference/src/cultionet/models/lightning.py for the hot path: the constructor
+keeps the reference's 24 keyword arguments (lightning.py:822-847), the model lives under the attribute
+``f"{model_name}_{model_type}"`` (state-dict prefix ``cultionet_TowerUNet.mask_model.``), and
+``forward / predict_step / get_true_labels / calc_loss / training_step / configure_optimizers`` keep their
+signatures and return types, so ``cultionet.fit`` / ``predict_lightning`` can drive it unchanged.
+
+Two ways to train:
+  * **drop-in** (lightning.Trainer): ``training_step`` returns a torch scalar whose ``backward()`` replays
+    the HIP tape through cultionet_amd.autograd_bridge; torch optimizers / DDP work as usual.
+  * **native** (``HipTrainer``, used by bench.py): forward + Tanimoto + backward + global-norm clip + fused
+    AdamW entirely in HIP kernels on flat parameter/gradient buffers, RCCL all-reduce of the flat gradient
+    overlapped with the backward tape (cultionet_amd.ddp).
+"""
+from __future__ import annotations
+
+import typing as T
+from pathlib import Path
+
+import torch
+
+from . import engine as E
+from .cultionet import CultioNet
+from .data import Data
+from .enums import (AttentionTypes, InferenceNames, LearningRateSchedulers, LossTypes, ModelTypes, ResBlockTypes,
+                    ValidationNames)
+from .losses import CombinedLoss, TanimotoComplementLoss, TanimotoDistLoss
+
+try:  # the real LightningModule when lightning is installed (it is not in the build image)
+    from lightning import LightningModule as _Base  # type: ignore
+except Exception:  # pragma: no cover - exercised in the build image
+    class _Base(torch.nn.Module):
+        """Minimal stand-in providing the LightningModule methods this file uses."""
+
+        def __init__(self):
+            super().__init__()
+            self.hparams: T.Dict[str, T.Any] = {}
+            self.trainer = None
+
+        def save_hyperparameters(self, *args, **kwargs):
+            import inspect
+
+            frame = inspect.currentframe().f_back
+            av = inspect.getargvalues(frame)
+            self.hparams = {k: av.locals[k] for k in av.args if k != "self"}
+
+        def log(self, *args, **kwargs):
+            pass
+
+        def log_dict(self, *args, **kwargs):
+            pass
+
+        @classmethod
+        def load_from_checkpoint(cls, checkpoint_path, map_location=None, **kwargs):
+            ckpt = torch.load(str(checkpoint_path), map_location=map_location or "cpu", weights_only=False)
+            hp = dict(ckpt.get("hyper_parameters", {}))
+            hp.update(kwargs)
+            model = cls(**hp)
+            model.load_state_dict(ckpt["state_dict"])
+            return model
+
+
+# lightning.py:38-92 restricted to the losses selectable from the CLI (args.yml:436-442)
+LOSS_DICT = {
+    LossTypes.TANIMOTO_COMPLEMENT: {
+        "classification": TanimotoComplementLoss(),
+        "regression": TanimotoComplementLoss(transform_logits=False, one_hot_targets=False),
+    },
+    LossTypes.TANIMOTO: {
+        "classification": TanimotoDistLoss(),
+        "regression": TanimotoDistLoss(transform_logits=False, one_hot_targets=False),
+    },
+    LossTypes.TANIMOTO_COMBINED: {
+        "classification": CombinedLoss(losses=[TanimotoDistLoss(), TanimotoComplementLoss()]),
+        "regression": CombinedLoss(losses=[TanimotoDistLoss(transform_logits=False, one_hot_targets=False),
+                                           TanimotoComplementLoss(transform_logits=False, one_hot_targets=False)]),
+    },
+}
+
+
+class LightningModuleMixin(_Base):
+    def __init__(self):
+        super().__init__()
+
+    def __call__(self, *args, **kwargs):
+        return self.forward(*args, **kwargs)
+
+    def forward(self, batch: Data, batch_idx: int = None) -> T.Dict[str, torch.Tensor]:
+        """distance / edge / crop probabilities, each (B, 1, H, W); crop_type, classes_l2, classes_l3 = None."""
+        return self.cultionet_model(batch)
+
+    @property
+    def cultionet_model(self) -> CultioNet:
+        return getattr(self, self.model_attr)
+
+    def predict_step(self, batch: Data, batch_idx: int = None) -> T.Dict[str, torch.Tensor]:
+        return self.forward(batch, batch_idx=batch_idx)
+
+    @torch.no_grad()
+    def get_true_labels(self, batch: Data, crop_type: torch.Tensor = None) -> T.Dict[str, T.Optional[torch.Tensor]]:
+        """lightning.py:161-207. Kept for API compatibility (validation code reads these tensors); the training
+        loss does not call it: the HIP loss kernel derives edge / crop / mask from ``batch.y`` on the fly."""
+        y = batch.y
+        ec = self.edge_class
+        true_edge = (y == ec).long()
+        true_crop = ((y > 0) & (y < ec)).long()
+        mask = None
+        if y.min() == -1:
+            mask = (y != -1).long().unsqueeze(1)
+        return {
+            ValidationNames.TRUE_EDGE: true_edge,
+            ValidationNames.TRUE_CROP: true_crop,
+            ValidationNames.TRUE_CROP_AND_EDGE: (y > 0).long(),
+            ValidationNames.TRUE_CROP_OR_EDGE: torch.where((y > 0) & (y < ec), 1, torch.where(y == ec, 2, 0)).long(),
+            ValidationNames.TRUE_CROP_TYPE: torch.where(y == ec, 0, y).long() if crop_type is not None else None,
+            ValidationNames.MASK: mask,
+        }
+
+    def _loss_terms(self, batch: Data):
+        """(prediction key, kernel kwargs) of the three main losses of calc_loss (lightning.py:307-339).
+
+        The weak-supervision mask ``y != -1`` is always applied in-kernel: when no -1 is present it is the
+        identity, which removes the reference's device->host sync (``batch.y.min() == -1``, lightning.py:194).
+        """
+        y = batch.y
+        if y.dtype != torch.int64:
+            y = y.long()
+        y = y.contiguous()
+        ec = int(self.edge_class)
+        return (
+            (InferenceNames.DISTANCE, dict(target_f=batch.bdist.contiguous(), labels=y, target_mode=E.TGT_FLOAT,
+                                           mask_mode=E.MSK_LABEL)),
+            (InferenceNames.EDGE, dict(labels=y, target_mode=E.TGT_EQ, mask_mode=E.MSK_LABEL, klass=ec)),
+            (InferenceNames.CROP, dict(labels=y, target_mode=E.TGT_RANGE, mask_mode=E.MSK_LABEL, klass=ec)),
+        )
+
+    def calc_loss(self, batch: T.Union[Data, T.List], predictions: T.Dict[str, torch.Tensor]):
+        """lightning.py:209-354: (dist + edge + crop) / 3 and the report dict {dloss, eloss, closs}."""
+        from .autograd_bridge import tanimoto_autograd
+
+        kind = E.LOSS_KINDS[str(self.loss_name)]
+        terms = []
+        for key, kw in self._loss_terms(batch):
+            terms.append(tanimoto_autograd(predictions[key], loss_kind=kind, **kw))
+        loss = (terms[0] + terms[1] + terms[2]) / 3.0
+        return loss, {"dloss": terms[0], "eloss": terms[1], "closs": terms[2]}
+
+    def training_step(self, batch: Data, batch_idx: int = None):
+        predictions = self(batch)
+        loss, _ = self.calc_loss(batch, predictions)
+        self.log("loss", loss, on_step=False, on_epoch=True, prog_bar=True, batch_size=batch.num_samples)
+        return loss
+
+    def validation_step(self, batch: Data, batch_idx: int = None) -> dict:
+        with torch.no_grad():
+            predictions = self(batch)
+            loss, report = self.calc_loss(batch, predictions)
+        metrics = {"vloss": loss, **{f"v{k}": v for k, v in report.items()}}
+        self.log_dict(metrics, on_step=False, on_epoch=True, prog_bar=True)
+        return metrics
+
+    def test_step(self, batch: Data, batch_idx: int = None) -> dict:
+        with torch.no_grad():
+            predictions = self(batch)
+            loss, report = self.calc_loss(batch, predictions)
+        metrics = {"tloss": loss, **{f"t{k}": v for k, v in report.items()}}
+        self.log_dict(metrics, on_step=False, on_epoch=True, prog_bar=True)
+        return metrics
+
+    def configure_scorer(self):
+        """lightning.py:562-577 (torchmetrics scorers; validation bookkeeping is out of scope)."""
+        try:
+            import torchmetrics  # type: ignore
+
+            self.mae_scorer = torchmetrics.MeanAbsoluteError()
+            self.mse_scorer = torchmetrics.MeanSquaredError()
+            self.f_beta_scorer = torchmetrics.FBetaScore(task="multiclass", num_classes=2, beta=2.0)
+            self.mcc_scorer = torchmetrics.MatthewsCorrCoef(task="multiclass", num_classes=2)
+        except Exception:
+            self.mae_scorer = self.mse_scorer = self.f_beta_scorer = self.mcc_scorer = None
+
+    def configure_loss(self):
+        """lightning.py:589-609."""
+        if str(self.loss_name) not in [str(k) for k in LOSS_DICT]:
+            raise NameError(f"loss {self.loss_name!r} has no HIP kernel; choose one of {[str(k) for k in LOSS_DICT]}")
+        entry = {str(k): v for k, v in LOSS_DICT.items()}[str(self.loss_name)]
+        self.reg_loss = entry.get("regression")
+        self.cls_loss = entry.get("classification")
+
+    def configure_optimizers(self):
+        """lightning.py:611-683."""
+        from torch.optim import lr_scheduler as sched
+
+        params_list = list(self.cultionet_model.parameters())
+        interval = "epoch"
+        if self.optimizer == "Adam":
+            optimizer = torch.optim.Adam(params_list, lr=self.learning_rate, eps=self.eps)
+        elif self.optimizer == "AdamW":
+            optimizer = torch.optim.AdamW(params_list, lr=self.learning_rate, weight_decay=self.weight_decay,
+                                          eps=self.eps, betas=(0.9, 0.98))
+        elif self.optimizer == "RAdam":
+            optimizer = torch.optim.RAdam(params_list, lr=self.learning_rate, weight_decay=self.weight_decay,
+                                          decoupled_weight_decay=True, eps=self.eps, betas=(0.9, 0.99))
+        elif self.optimizer == "SGD":
+            optimizer = torch.optim.SGD(params_list, lr=self.learning_rate, weight_decay=self.weight_decay,
+                                        momentum=0.9)
+        else:
+            raise NameError("Choose either 'AdamW' or 'SGD'.")
+
+        if self.lr_scheduler == LearningRateSchedulers.COSINE_ANNEALING_LR:
+            model_lr_scheduler = sched.CosineAnnealingLR(optimizer, T_max=20, eta_min=1e-5, last_epoch=-1)
+        elif self.lr_scheduler == LearningRateSchedulers.EXPONENTIAL_LR:
+            model_lr_scheduler = sched.ExponentialLR(optimizer, gamma=0.5)
+        elif self.lr_scheduler == LearningRateSchedulers.ONE_CYCLE_LR:
+            model_lr_scheduler = sched.OneCycleLR(optimizer, max_lr=self.learning_rate,
+                                                  epochs=self.trainer.max_epochs,
+                                                  steps_per_epoch=self.trainer.estimated_stepping_batches)
+            interval = "step"
+        elif self.lr_scheduler == LearningRateSchedulers.STEP_LR:
+            model_lr_scheduler = sched.StepLR(optimizer, step_size=self.steplr_step_size, gamma=0.5)
+        else:
+            raise NameError("The learning rate scheduler is not implemented in Cultionet.")
+
+        return {
+            "optimizer": optimizer,
+            "lr_scheduler": {"scheduler": model_lr_scheduler, "name": "lr_sch", "monitor": "val_score",
+                             "interval": interval, "frequency": 1},
+        }
+
+
+class CultionetLitModel(LightningModuleMixin):
+    def __init__(
+        self,
+        in_channels: int,
+        in_time: int,
+        hidden_channels: int = 64,
+        model_type: str = ModelTypes.TOWERUNET,
+        dropout: float = 0.2,
+        activation_type: str = "SiLU",
+        dilations: T.Union[int, T.Sequence[int]] = None,
+        res_block_type: str = ResBlockTypes.RESA,
+        attention_weights: str = AttentionTypes.NATTEN,
+        optimizer: str = "AdamW",
+        loss_name: str = LossTypes.TANIMOTO_COMPLEMENT,
+        learning_rate: float = 0.01,
+        lr_scheduler: str = LearningRateSchedulers.ONE_CYCLE_LR,
+        steplr_step_size: int = 5,
+        weight_decay: float = 1e-3,
+        eps: float = 1e-4,
+        ckpt_name: str = "last",
+        model_name: str = "cultionet",
+        pool_by_max: bool = False,
+        batchnorm_first: bool = False,
+        class_counts: T.Optional[torch.Tensor] = None,
+        edge_class: T.Optional[int] = None,
+        scale_pos_weight: bool = False,
+        save_batch_val_metrics: bool = False,
+    ):
+        super().__init__()
+        self.save_hyperparameters()
+        self.optimizer = optimizer
+        self.loss_name = loss_name
+        self.learning_rate = learning_rate
+        self.lr_scheduler = lr_scheduler
+        self.steplr_step_size = steplr_step_size
+        self.weight_decay = weight_decay
+        self.eps = eps
+        self.ckpt_name = ckpt_name
+        self.model_name = model_name
+        self.in_time = in_time
+        self.class_counts = class_counts
+        self.scale_pos_weight = scale_pos_weight
+        self.save_batch_val_metrics = save_batch_val_metrics
+        self.edge_class = edge_class if edge_class is not None else 2
+        self.model_attr = f"{model_name}_{model_type}"
+        setattr(self, self.model_attr, CultioNet(
+            in_channels=in_channels, in_time=in_time, hidden_channels=hidden_channels, model_type=model_type,
+            dropout=dropout, activation_type=activation_type, dilations=dilations, res_block_type=res_block_type,
+            attention_weights=attention_weights, pool_by_max=pool_by_max, batchnorm_first=batchnorm_first))
+        self.configure_loss()
+        self.configure_scorer()
+
+    @property
+    def is_transfer_model(self) -> bool:
+        return False
+
+
+class HipTrainer:
+    """Native training step: every FLOP and byte of forward + loss + backward + clip + AdamW in HIP kernels.
+
+    Semantics of lightning.Trainer(gradient_clip_val=1.0) + AdamW(lr, wd, eps, betas=(0.9, 0.98)) as configured
+    by the reference (model.py:84,168-186; lightning.py:622-629); the LR schedule is supplied by the caller
+    (``lr_fn(step) -> lr``; constant by default). With ``world_size > 1`` the flat gradient is all-reduced over
+    RCCL in buckets overlapped with the backward tape (see cultionet_amd.ddp).
+    """
+
+    def __init__(self, lit: CultionetLitModel, gradient_clip_val: T.Optional[float] = 1.0,
+                 lr_fn: T.Optional[T.Callable[[int], float]] = None, comm=None):
+        self.lit = lit
+        self.model = lit.cultionet_model.mask_model
+        self.store = self.model.param_store()
+        dev = self.store.flat.device
+        self.exp_avg = torch.zeros_like(self.store.flat)
+        self.exp_avg_sq = torch.zeros_like(self.store.flat)
+        self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+        self.total = torch.zeros(1, dtype=torch.float32, device=dev)
+        self.clip = gradient_clip_val
+        self.lr_fn = lr_fn or (lambda step: lit.learning_rate)
+        self.step_count = 0
+        self.comm = comm
+        if lit.optimizer != "AdamW":
+            raise NotImplementedError("the fused HIP optimizer implements AdamW (the reference default)")
+
+    def forward_backward(self, batch: Data) -> torch.Tensor:
+        """Forward + loss + backward; leaves d(loss)/d(params) in store.flat_grad. Returns the loss (1-elem tensor)."""
+        from . import _lib
+
+        lit, store = self.lit, self.store
+        kind = E.LOSS_KINDS[str(lit.loss_name)]
+        s = E._stream()
+        _lib.call("cn_fill_f32", self.total.data_ptr(), 1, 0.0, s)
+        with E.using_store(store), E.recording(True) as tape:
+            outs = self.model.forward_vars(self.model.input_var(batch.x))
+            for key, kw in lit._loss_terms(batch):
+                E.tanimoto_loss(outs[key], loss_kind=kind, weight=1.0 / 3.0, total=self.total, **kw)
+            store.zero_grad()
+            if self.comm is not None:
+                self.comm.backward(tape, store)
+            else:
+                tape.backward()
+        return self.total
+
+    def optimizer_step(self) -> None:
+        from . import _lib
+
+        lit, store = self.lit, self.store
+        self.step_count += 1
+        s = E._stream()
+        scale = 1.0 / self.comm.world_size if self.comm is not None else 1.0
+        sumsq = None
+        if self.clip is not None:
+            _lib.call("cn_grad_sumsq_f32", store.flat_grad.data_ptr(), store.numel, self.sumsq.data_ptr(), s)
+            sumsq = self.sumsq.data_ptr()
+        _lib.call("cn_adamw_step_f32", store.flat.data_ptr(), store.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
+                  self.exp_avg_sq.data_ptr(), store.numel, float(self.lr_fn(self.step_count)), 0.9, 0.98,
+                  float(lit.eps), float(lit.weight_decay), self.step_count, scale, sumsq,
+                  float(self.clip) if self.clip is not None else 0.0, s)
+        store.bump()
+
+    def training_step(self, batch: Data) -> torch.Tensor:
+        loss = self.forward_backward(batch)
+        self.optimizer_step()
+        return loss

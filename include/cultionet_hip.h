@@ -1,0 +1,154 @@
+/* cultionet_hip.h -- C ABI of libcultionet_hip.so (hand-written HIP kernels for gfx950 / MI355X).
+ *
+ * The reference (jgrss/cultionet @ 2024_10_08) has no native code; every op on its TowerUNet hot
+ * path runs in ATen/oneDNN/cuDNN or libnatten underneath torch.nn modules. This library is the
+ * drop-in for those ops: each entry point names the reference call site it replaces
+ * (paths relative to /root/reference/src/cultionet).
+ *
+ * Conventions
+ *   - plain C, `extern "C"`, no torch types; all tensors are dense fp32 NCHW device pointers;
+ *     `*bs` arguments are BATCH strides in elements (channel stride is always H*W), so channel
+ *     slices of a concat buffer can be read/written in place;
+ *   - the CALLER owns every buffer (kernels never allocate); `stream` is a hipStream_t;
+ *   - returns 0 on success, <0 on error (CN_ERR_*); no exceptions cross the ABI; re-entrant,
+ *     no global state;
+ *   - `accumulate != 0` means `out += result` instead of `out = result`;
+ *   - entry points documented "zero first" combine partial results with f32 atomics.
+ */
+#ifndef CULTIONET_HIP_H
+#define CULTIONET_HIP_H
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CN_OK 0
+#define CN_ERR_ARG (-1)
+#define CN_ERR_LAUNCH (-2)
+#define CN_ERR_LDS (-3)
+
+int cn_version(void);
+
+/* ---- packed weights for the implicit-GEMM kernels -------------------------------------------
+ * wp[t][k][n] = w[k*sk + n*sn + t*st] zero-padded to [T][cn_conv_kpad(K)][cn_conv_npad(N)].
+ *   Conv2d weight [Cout][Cin][KH][KW]:   forward  K=Cin N=Cout sk=KH*KW      sn=Cin*KH*KW st=1
+ *                                        bwd-data K=Cout N=Cin sk=Cin*KH*KW  sn=KH*KW     st=1
+ *   ConvTranspose2d weight [Cin][Cout][KH][KW]: forward K=Cin N=Cout sk=Cout*KH*KW sn=KH*KW st=1
+ *                                        bwd-data K=Cout N=Cin sk=KH*KW      sn=Cout*KH*KW st=1
+ *   Linear weight [out][in] == Conv2d 1x1. */
+int cn_conv_kpad(int k_in);
+int cn_conv_npad(int n_out);
+int cn_pack_weights_f32(const float* w, float* wp, int T, int K, int N, long sk, long sn, long st, void* stream);
+
+/* ---- torch.nn.Conv2d (nn/modules/convolution.py:71-120,250-395; unet_parts.py:196-224) ------
+ * also nn.Linear of NeighborhoodAttention2D.qkv / .proj (convolution.py:341-350) as 1x1 convs,
+ * and the two nn.Conv3d of models/nunet.py:18-57 (kernel (k,1,1)) after a [B,C*T,H,W] view. */
+int cn_conv2d_fwd_f32(const float* x, long xbs, const float* wp, const float* bias /*nullable*/, float* y, long ybs,
+                      int B, int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, int dil,
+                      int accumulate, void* stream);
+int cn_conv2d_bwd_data_f32(const float* dy, long dybs, const float* wp_t, float* dx, long dxbs, int B, int Cin,
+                           int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, int dil, int accumulate,
+                           void* stream);
+/* dw [Cout][Cin][KH][KW] += ...  (zero first) */
+int cn_conv2d_bwd_weight_f32(const float* x, long xbs, const float* dy, long dybs, float* dw, int B, int Cin, int Hin,
+                             int Win, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream);
+
+/* ---- nn.Conv3d(kernel (k,1,1), no bias) of PreTimeReduction (models/nunet.py:18-57) ----------
+ * run as a 1x1 conv over the [B, C*T, H, W] view with a banded weight matrix.
+ * w [Cout][Cin][k]; transposed=0 packs for forward (K=Cin*Tin, N=Cout*Tout), !=0 for bwd-data.
+ * fold: dw[co][ci][dt] += sum_t' dWexp[(co,t')][(ci,t'+dt)], dWexp dense [Cout*Tout][Cin*Tin]. */
+int cn_pack_timeconv_f32(const float* w, float* wp, int Cout, int Cin, int Tin, int k, int transposed, void* stream);
+int cn_fold_timeconv_grad_f32(const float* dwexp, float* dw, int Cout, int Cin, int Tin, int k, void* stream);
+
+/* ---- torch.nn.ConvTranspose2d(k=3, stride s, padding 1) (convolution.py:45-68) --------------- */
+int cn_conv_transpose2d_fwd_f32(const float* x, long xbs, const float* wp, const float* bias, float* y, long ybs,
+                                int B, int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride, int pad,
+                                int accumulate, void* stream);
+int cn_conv_transpose2d_bwd_data_f32(const float* dy, long dybs, const float* wp_t, float* dx, long dxbs, int B,
+                                     int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride, int pad,
+                                     int accumulate, void* stream);
+/* dw [Cin][Cout][KH][KW] += ...  (zero first) */
+int cn_conv_transpose2d_bwd_weight_f32(const float* x, long xbs, const float* dy, long dybs, float* dw, int B, int Cin,
+                                       int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, void* stream);
+
+/* bias gradients: out[c] (+)= sum_{b,l} x[b][c][l] */
+int cn_channel_sum_f32(const float* x, long xbs, int B, int C, int L, float* out, int accumulate, void* stream);
+
+/* ---- nn.BatchNorm2d / BatchNorm3d (+ SiLU, + residual add) (convolution.py:71-120, nunet.py:18-57)
+ * tensors viewed as [B][C][L]; act: 0 none, 1 SiLU; y = act(bn(x)) (+ res).
+ * training: batch stats saved to mean/rstd[C], running stats updated (momentum, unbiased var).
+ * ws: cn_bn_workspace_doubles(C) doubles; coef: 2*C floats scratch. */
+int cn_bn_workspace_doubles(int C);
+int cn_bn_act_fwd_f32(const float* x, long xbs, const float* gamma, const float* beta, float* running_mean,
+                      float* running_var, const float* res /*nullable*/, long rbs, float* y, long ybs, float* mean,
+                      float* rstd, double* ws, int B, int C, int L, int training, float momentum, float eps, int act,
+                      void* stream);
+int cn_bn_act_bwd_f32(const float* x, long xbs, const float* dy, long dybs, const float* mean, const float* rstd,
+                      const float* gamma, const float* beta, float* dx /*nullable*/, long dxbs, float* dgamma,
+                      float* dbeta, float* coef, double* ws, int B, int C, int L, int training, int act,
+                      int accumulate_dx, int accumulate_params, void* stream);
+
+/* ---- nn.LayerNorm over channels, tensors kept NCHW (nunet.py:93-97, convolution.py:338-353) --
+ * mu/rstd: [B][L] saved statistics. dw/db: zero first. */
+int cn_layernorm_c_fwd_f32(const float* x, long xbs, const float* w, const float* b, const float* res /*nullable*/,
+                           long rbs, float* y, long ybs, float* mu, float* rstd, int B, int C, int L, float eps,
+                           void* stream);
+int cn_layernorm_c_bwd_f32(const float* x, long xbs, const float* dy, long dybs, const float* w, const float* mu,
+                           const float* rstd, float* dx, long dxbs, float* dw, float* db, int B, int C, int L,
+                           int accumulate_dx, void* stream);
+
+/* ---- natten.NeighborhoodAttention2D core (convolution.py:341-350; natten 0.17.1 na2d_qk ->
+ * softmax -> na2d_av, kernel 3, dilation d, no rpb). qkv [B][3C][H][W] with channel
+ * (which*C + head*D + d); attn [B][heads][9][H][W] saved probabilities; dattn same-size scratch. */
+int cn_na2d_fwd_f32(const float* qkv, long qbs, float* out, long obs, float* attn, int B, int C, int heads, int H,
+                    int W, int kernel_size, int dilation, void* stream);
+int cn_na2d_bwd_f32(const float* qkv, long qbs, const float* dout, long dobs, const float* attn, float* dattn,
+                    float* dqkv, long dqbs, int B, int C, int heads, int H, int W, int kernel_size, int dilation,
+                    void* stream);
+
+/* ---- F.interpolate(mode="bilinear", align_corners=True) (nn/functional.py:72-81) ------------ */
+int cn_bilinear_fwd_f32(const float* x, long xbs, float* y, long ybs, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                        void* stream);
+int cn_bilinear_bwd_f32(const float* dy, long dybs, float* dx, long dxbs, int B, int C, int Hi, int Wi, int Ho,
+                        int Wo, int accumulate, void* stream);
+
+/* ---- torch.cat / residual adds / fills on channel slices ------------------------------------ */
+int cn_copy_f32(const float* src, long sbs, float* dst, long dbs, int B, long n, int accumulate, void* stream);
+int cn_add_f32(const float* a, long abs_, const float* c, long cbs, float* dst, long dbs, int B, long n, void* stream);
+int cn_fill_f32(float* p, long n, float v, void* stream);
+
+/* ---- TowerUNetFinalCombine + SigmoidCrisp (nn/modules/unet_parts.py:43-193), fused ----------
+ * h*: [B][3][HW] fuse_conv outputs of towers a,b,c (channel = dist, edge, crop).
+ * params: HOST array of 16 DEVICE pointers to scalars: [3k+t] gamma of task k tower t, [9+k] 1x1
+ * weight, [12+k] bias, [15] crisp gamma. dparams: 16 device pointers, atomically accumulated into. */
+int cn_final_combine_fwd_f32(const float* ha, const float* hb, const float* hc, const float* const* params,
+                             float* dist, float* edge, float* crop, int B, int HW, float smooth, void* stream);
+int cn_final_combine_bwd_f32(const float* ha, const float* hb, const float* hc, const float* const* params,
+                             const float* dist, const float* edge, const float* crop, const float* ddist,
+                             const float* dedge, const float* dcrop, float* dha, float* dhb, float* dhc,
+                             float* const* dparams, int B, int HW, float smooth, void* stream);
+
+/* ---- Tanimoto losses + get_true_labels (losses/losses.py:9-340, models/lightning.py:161-354) -
+ * target_mode: 0 float target [B][C][HW]; 1 labels==klass; 2 0<labels<klass; 3 one-hot(labels)
+ * mask_mode:   0 none; 1 labels != -1; 2 int64 mask [B][HW]; 3 float mask [B][HW]
+ * loss_kind:   0 TanimotoComplementLoss; 1 TanimotoDistLoss; 2 TanimotoCombined
+ * sums: 5*B doubles scratch; coef: 4*B floats (kept for backward); loss_out: 1 float (batch mean). */
+int cn_tanimoto_fwd_f32(const float* pred, long pbs, const float* target_f, const long long* labels, const void* mask,
+                        int target_mode, int mask_mode, int klass, int B, int C, long HW, int loss_kind, float smooth,
+                        int depth, double* sums, float* coef, float* loss_out, float weight,
+                        float* total_out /*nullable: total_out[0] += weight*loss*/, void* stream);
+int cn_tanimoto_bwd_f32(const float* pred, long pbs, const float* target_f, const long long* labels, const void* mask,
+                        int target_mode, int mask_mode, int klass, int B, int C, long HW, const float* coef,
+                        float upstream, float* dpred, long dbs, int accumulate, void* stream);
+
+/* ---- torch.optim.AdamW + clip_grad_norm_ (models/lightning.py:622-629, model.py:84,173) ------
+ * one flat buffer each for params, grads, exp_avg, exp_avg_sq. sumsq nullable (no clipping). */
+int cn_grad_sumsq_f32(const float* g, long n, double* out, void* stream);
+int cn_adamw_step_f32(float* p, const float* g, float* m, float* v, long n, float lr, float beta1, float beta2,
+                      float eps, float weight_decay, int step, float grad_scale, const double* sumsq, float max_norm,
+                      void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* CULTIONET_HIP_H */

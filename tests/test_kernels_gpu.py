@@ -1,0 +1,420 @@
+"""Per-kernel parity: every HIP entry point (through the C ABI, via cultionet_amd.engine) against the
+same op in plain PyTorch fp32 on the CPU, forward and backward, on seeded inputs.
+
+Tolerances (fp32): outputs 2e-5 * scale where scale = max|ref| (the MFMA path is an fp32 fma chain
+with a different summation order than oneDNN); gradients 1e-4 * scale.
+"""
+import math
+
+import pytest
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _close(a, b, tol, what=""):
+    a = a.detach().cpu().double()
+    b = b.detach().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = max(1.0, float(b.abs().max()))
+    err = float((a - b).abs().max())
+    assert err <= tol * scale, f"{what}: max err {err:.3e} > {tol * scale:.3e} (scale {scale:.3e})"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _engine_run(mod, fn, inputs, dy, req=None):
+    """Run fn(*Vars) under the tape with module `mod` on the GPU; returns y, input grads, param grads."""
+    from cultionet_amd import engine as E
+
+    dev = _dev()
+    mod = mod.to(dev)
+    store = E.ParamStore(mod)
+    store.zero_grad()
+    with E.using_store(store), E.recording(True) as tape:
+        xs = [E.Var(t.to(dev).contiguous(), True if req is None else req[i]) for i, t in enumerate(inputs)]
+        y = fn(*xs)
+        y.grad = dy.to(dev).contiguous()
+        tape.backward()
+    torch.cuda.synchronize()
+    pg = {n: store.grad_of(p).cpu() for n, p in mod.named_parameters()}
+    return y.t.cpu(), [x.grad.cpu() if x.grad is not None else None for x in xs], pg
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, dil, bias
+    (2, 16, 20, 20, 32, 3, 1, 1, 1, False),
+    (2, 32, 25, 25, 64, 3, 1, 1, 1, False),
+    (1, 72, 13, 13, 128, 3, 1, 1, 1, False),
+    (2, 8, 28, 28, 16, 3, 2, 1, 1, False),    # pool conv (stride 2)
+    (1, 16, 25, 25, 32, 3, 2, 1, 1, False),   # odd size stride 2 -> 13
+    (2, 40, 14, 14, 128, 1, 1, 0, 1, True),   # 1x1 skip with bias
+    (2, 128, 13, 13, 256, 1, 1, 0, 1, False),
+    (2, 32, 28, 28, 3, 3, 1, 1, 1, False),    # head 128->3 style
+    (2, 3, 28, 28, 1, 3, 1, 1, 1, True),      # head 3->1 with bias
+    (2, 3, 28, 28, 3, 3, 1, 1, 1, False),     # fuse conv
+    (2, 16, 28, 28, 16, 3, 1, 2, 2, False),   # true dilated conv
+    (1, 130, 9, 11, 140, 3, 1, 1, 1, True),   # ragged channels, non-square
+    (3, 24, 100, 100, 32, 3, 1, 1, 1, False), # BASELINE spatial size
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d(case):
+    from cultionet_amd import engine as E
+
+    B, Cin, H, W, Cout, k, s, p, d, bias = case
+    conv = nn.Conv2d(Cin, Cout, k, stride=s, padding=p, dilation=d, bias=bias)
+    x = _rand(B, Cin, H, W, seed=1)
+    xr = x.clone().requires_grad_(True)
+    yr = conv(xr)
+    dy = _rand(*yr.shape, seed=2)
+    yr.backward(dy)
+    ref_w, ref_b = conv.weight.grad.clone(), (conv.bias.grad.clone() if bias else None)
+    y, (dx,), pg = _engine_run(conv, lambda v: E.conv2d(v, conv, s, p, d), [x], dy)
+    _close(y, yr, 2e-5, "y")
+    _close(dx, xr.grad, 1e-4, "dx")
+    _close(pg["weight"], ref_w, 1e-4, "dw")
+    if bias:
+        _close(pg["bias"], ref_b, 1e-4, "db")
+
+
+CONVT_CASES = [
+    # B, Cin, H, W, Cout, stride
+    (2, 16, 13, 13, 16, 2),
+    (2, 32, 25, 25, 32, 2),
+    (1, 24, 14, 14, 24, 2),
+    (2, 16, 7, 7, 16, 4),     # final_c: stride 4 (some outputs receive only bias)
+    (1, 128, 25, 25, 128, 2),
+    (2, 40, 50, 50, 40, 2),
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv_transpose2d(case):
+    from cultionet_amd import engine as E
+
+    B, Cin, H, W, Cout, s = case
+    conv = nn.ConvTranspose2d(Cin, Cout, 3, stride=s, padding=1)
+    x = _rand(B, Cin, H, W, seed=3)
+    xr = x.clone().requires_grad_(True)
+    yr = conv(xr)
+    dy = _rand(*yr.shape, seed=4)
+    yr.backward(dy)
+    ref_w, ref_b = conv.weight.grad.clone(), conv.bias.grad.clone()
+    y, (dx,), pg = _engine_run(conv, lambda v: E.conv_transpose2d(v, conv, s, 1), [x], dy)
+    _close(y, yr, 2e-5, "y")
+    _close(dx, xr.grad, 1e-4, "dx")
+    _close(pg["weight"], ref_w, 1e-4, "dw")
+    _close(pg["bias"], ref_b, 1e-4, "db")
+
+
+@pytest.mark.parametrize("k", [3, 5])
+def test_time_conv(k):
+    """nn.Conv3d(kernel (k,1,1)) of PreTimeReduction as a banded 1x1 contraction."""
+    from cultionet_amd import engine as E
+
+    B, C, Tn, H, W, Cout = 2, 3, 12, 20, 20, 3
+    conv = nn.Conv3d(C, Cout, (k, 1, 1), bias=False)
+    x = _rand(B, C, Tn, H, W, seed=5)
+    xr = x.clone().requires_grad_(True)
+    yr = conv(xr)
+    dy = _rand(*yr.shape, seed=6)
+    yr.backward(dy)
+    ref_w = conv.weight.grad.clone()
+    y, (dx,), pg = _engine_run(conv, lambda v: E.time_conv(v, conv, Tn), [x.reshape(B, C * Tn, H, W)],
+                               dy.reshape(B, -1, H, W))
+    _close(y.reshape(yr.shape), yr, 2e-5, "y")
+    _close(dx.reshape(x.shape), xr.grad, 1e-4, "dx")
+    _close(pg["weight"], ref_w, 1e-4, "dw")
+
+
+@pytest.mark.parametrize("shape,act,res,train", [
+    ((4, 32, 25, 25), 1, True, True),
+    ((2, 128, 13, 13), 1, False, True),
+    ((3, 16, 50, 50), 0, False, True),
+    ((2, 3, 28, 28), 1, True, True),
+    ((2, 32, 25, 25), 1, True, False),
+    ((2, 64, 100, 100), 1, True, True),
+])
+def test_bn_act(shape, act, res, train):
+    from cultionet_amd import engine as E
+
+    C = shape[1]
+    bn = nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.1 * _rand(C, seed=7))
+        bn.bias.copy_(0.1 * _rand(C, seed=8))
+        bn.running_mean.copy_(0.1 * _rand(C, seed=9))
+        bn.running_var.copy_(torch.rand(C, generator=torch.Generator().manual_seed(10)) + 0.5)
+    bn.train(train)
+    x = _rand(*shape, seed=11) * 2 + 0.5
+    r = _rand(*shape, seed=12)
+    xr, rr = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    import copy
+
+    bn_ref = copy.deepcopy(bn)
+    z = bn_ref(xr)
+    if act:
+        z = F.silu(z)
+    yr = z + rr if res else z
+    dy = _rand(*shape, seed=13)
+    yr.backward(dy)
+
+    def fn(xv, rv):
+        return E.bn_act(xv, bn, act, residual=rv if res else None, training=train)
+
+    y, (dx, dr), pg = _engine_run(bn, fn, [x, r], dy)
+    _close(y, yr, 2e-5, "y")
+    _close(dx, xr.grad, 1e-4, "dx")
+    if res:
+        _close(dr, rr.grad, 1e-6, "dres")
+    _close(pg["weight"], bn_ref.weight.grad, 1e-4, "dgamma")
+    _close(pg["bias"], bn_ref.bias.grad, 1e-4, "dbeta")
+    _close(bn.running_mean, bn_ref.running_mean, 1e-5, "running_mean")
+    _close(bn.running_var, bn_ref.running_var, 1e-5, "running_var")
+
+
+def test_bn3d_view():
+    """BatchNorm3d over [B, C, T, H, W] run on the [B, C*T, H, W] view (channels=C)."""
+    from cultionet_amd import engine as E
+
+    B, C, Tn, H, W = 2, 3, 10, 20, 20
+    bn = nn.BatchNorm3d(C)
+    x = _rand(B, C, Tn, H, W, seed=14)
+    xr = x.clone().requires_grad_(True)
+    import copy
+
+    bn_ref = copy.deepcopy(bn)
+    yr = F.silu(bn_ref(xr))
+    dy = _rand(*yr.shape, seed=15)
+    yr.backward(dy)
+    y, (dx,), pg = _engine_run(bn, lambda v: E.bn_act(v, bn, 1, channels=C), [x.reshape(B, C * Tn, H, W)],
+                               dy.reshape(B, C * Tn, H, W))
+    _close(y.reshape(yr.shape), yr, 2e-5, "y")
+    _close(dx.reshape(x.shape), xr.grad, 1e-4, "dx")
+    _close(pg["weight"], bn_ref.weight.grad, 1e-4, "dgamma")
+
+
+@pytest.mark.parametrize("shape,res", [((2, 32, 20, 20), False), ((2, 128, 25, 25), True), ((1, 8, 28, 28), True)])
+def test_layer_norm_c(shape, res):
+    from cultionet_amd import engine as E
+
+    C = shape[1]
+    ln = nn.LayerNorm(C)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.1 * _rand(C, seed=16))
+        ln.bias.copy_(0.1 * _rand(C, seed=17))
+    x, r = _rand(*shape, seed=18) * 3, _rand(*shape, seed=19)
+    xr, rr = x.clone().requires_grad_(True), r.clone().requires_grad_(True)
+    import copy
+
+    ln_ref = copy.deepcopy(ln)
+    yr = ln_ref(xr.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+    if res:
+        yr = yr + rr
+    dy = _rand(*shape, seed=20)
+    yr.backward(dy)
+    y, (dx, dr), pg = _engine_run(ln, lambda xv, rv: E.layer_norm_c(xv, ln, rv if res else None), [x, r], dy)
+    _close(y, yr, 2e-5, "y")
+    _close(dx, xr.grad, 1e-4, "dx")
+    _close(pg["weight"], ln_ref.weight.grad, 1e-4, "dw")
+    _close(pg["bias"], ln_ref.bias.grad, 1e-4, "db")
+
+
+@pytest.mark.parametrize("B,C,heads,H,W,dil", [(2, 32, 4, 14, 14, 1), (1, 32, 4, 28, 28, 2), (2, 128, 8, 25, 25, 1),
+                                               (1, 128, 4, 50, 50, 2), (1, 16, 8, 7, 9, 2)])
+def test_na2d(B, C, heads, H, W, dil):
+    from cultionet_amd import engine as E
+    from oracle import na2d_ref as N
+
+    D = C // heads
+    qkv = _rand(B, 3 * C, H, W, seed=21)
+    qr = qkv.clone().requires_grad_(True)
+    t = qr.reshape(B, 3, heads, D, H, W).permute(1, 0, 2, 4, 5, 3)  # [3,B,h,H,W,D]
+    q, k, v = t[0] * (D ** -0.5), t[1], t[2]
+    o = N.na2d_av(N.na2d_qk(q, k, 3, dil).softmax(-1), v, 3, dil)  # [B,h,H,W,D]
+    yr = o.permute(0, 1, 4, 2, 3).reshape(B, C, H, W)
+    dy = _rand(B, C, H, W, seed=22)
+    yr.backward(dy)
+    y, (dq,), _ = _engine_run(nn.Linear(1, 1), lambda v_: E.na2d(v_, heads, 3, dil), [qkv], dy)
+    _close(y, yr, 2e-5, "out")
+    _close(dq, qr.grad, 1e-4, "dqkv")
+
+
+@pytest.mark.parametrize("B,C,Hi,Wi,Ho,Wo", [(2, 8, 13, 13, 14, 14), (1, 16, 49, 49, 50, 50), (2, 4, 99, 99, 100, 100),
+                                             (2, 4, 97, 97, 100, 100), (1, 3, 27, 25, 28, 28)])
+def test_bilinear(B, C, Hi, Wi, Ho, Wo):
+    from cultionet_amd import engine as E
+
+    x = _rand(B, C, Hi, Wi, seed=23)
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=(Ho, Wo), mode="bilinear", align_corners=True)
+    dy = _rand(*yr.shape, seed=24)
+    yr.backward(dy)
+    y, (dx,), _ = _engine_run(nn.Linear(1, 1), lambda v: E.resize_bilinear(v, (Ho, Wo)), [x], dy)
+    _close(y, yr, 1e-6, "y")
+    _close(dx, xr.grad, 1e-5, "dx")
+
+
+def test_cat_and_slices():
+    from cultionet_amd import engine as E
+
+    a, b, c = _rand(2, 5, 9, 9, seed=25), _rand(2, 7, 9, 9, seed=26), _rand(2, 3, 9, 9, seed=27)
+    dy = _rand(2, 15, 9, 9, seed=28)
+    y, grads, _ = _engine_run(nn.Linear(1, 1), lambda x, y_, z: E.cat_channels([x, y_, z]), [a, b, c], dy)
+    _close(y, torch.cat([a, b, c], 1), 0, "cat")
+    _close(grads[0], dy[:, :5], 0, "da")
+    _close(grads[1], dy[:, 5:12], 0, "db")
+    _close(grads[2], dy[:, 12:], 0, "dc")
+
+
+def test_final_combine():
+    from cultionet_amd import engine as E
+    from oracle import towerunet_oracle as O
+
+    B, H, W = 2, 20, 20
+    fc = O.TowerUNetFinalCombine()
+    with torch.no_grad():
+        for i, p in enumerate(fc.parameters()):
+            p.copy_(torch.rand(p.shape, generator=torch.Generator().manual_seed(30 + i)) * 0.5 + 0.75)
+    hs = [_rand(B, 3, H, W, seed=40 + i) for i in range(3)]
+    hr = [h.clone().requires_grad_(True) for h in hs]
+    outs = fc(*[torch.chunk(h, 3, dim=1) for h in hr])
+    dys = [_rand(B, 1, H, W, seed=50 + i) for i in range(3)]
+    loss = sum((outs[k] * d).sum() for k, d in zip(("distance", "edge", "crop"), dys))
+    loss.backward()
+
+    from cultionet_amd.unet_parts import final_combine_params
+
+    dev = _dev()
+    fc_dev = fc.to(dev)
+    store = E.ParamStore(fc_dev)
+    store.zero_grad()
+    with E.using_store(store), E.recording(True) as tape:
+        vs = [E.Var(h.to(dev), True) for h in hs]
+        o = E.final_combine(vs[0], vs[1], vs[2], final_combine_params(fc_dev), 1e-2)
+        for v, d in zip(o, dys):
+            v.grad = d.to(dev)
+        tape.backward()
+    torch.cuda.synchronize()
+    for v, k in zip(o, ("distance", "edge", "crop")):
+        _close(v.t, outs[k], 2e-6, k)
+    for v, h in zip(vs, hr):
+        _close(v.grad, h.grad, 1e-5, "dh")
+    fc_cpu = O.TowerUNetFinalCombine()
+    for (n, p), (_, pr) in zip(fc_dev.named_parameters(), fc.named_parameters()):
+        pass
+    # parameter grads (fc was moved in place: its .grad tensors hold the CPU reference values)
+    ref = {n: p.grad for n, p in fc.named_parameters()}
+    for n, p in fc_dev.named_parameters():
+        _close(store.grad_of(p), ref[n] if ref[n] is not None else torch.zeros_like(p), 1e-4, n)
+
+
+def _loss_inputs():
+    import numpy as np
+
+    rng = np.random.default_rng(100)
+    B, H, W = 2, 20, 20
+    rng.uniform(low=-3, high=3, size=(B, 2, H, W))
+    crop_prob = torch.from_numpy(rng.dirichlet((0.5, 0.5), size=(B * H * W))).float()
+    crop_prob = crop_prob.reshape(B, H, W, 2).permute(0, 3, 1, 2).contiguous()
+    rng.random((B, 1, H, W))
+    dist = torch.from_numpy(rng.random((B, 1, H, W))).float()
+    targets = torch.from_numpy(rng.integers(low=0, high=2, size=(B, H, W))).long()
+    rng.integers(low=0, high=1, size=(B, H, W))
+    dist_t = torch.from_numpy(rng.random((B, H, W))).float()
+    mask = torch.from_numpy(rng.integers(low=0, high=2, size=(B, 1, H, W))).long()
+    return crop_prob, dist, targets, dist_t, mask
+
+
+def test_tanimoto_known_answers_and_grads():
+    """/root/reference/tests/test_loss.py:109-145 known answers (3 decimals) + gradients vs the oracle."""
+    from cultionet_amd import engine as E
+    from oracle import towerunet_oracle as O
+
+    dev = _dev()
+    crop_prob, dist, targets, dist_t, mask = _loss_inputs()
+    cases = [
+        ("TanimotoDistLoss", crop_prob, dict(labels=targets, target_mode=E.TGT_ONEHOT), None, 0.611, O.tanimoto_dist_loss, True),
+        ("TanimotoDistLoss", crop_prob, dict(labels=targets, target_mode=E.TGT_ONEHOT), mask, 0.431, O.tanimoto_dist_loss, True),
+        ("TanimotoComplementLoss", crop_prob, dict(labels=targets, target_mode=E.TGT_ONEHOT), None, 0.824, O.tanimoto_complement_loss, True),
+        ("TanimotoComplementLoss", crop_prob, dict(labels=targets, target_mode=E.TGT_ONEHOT), mask, 0.692, O.tanimoto_complement_loss, True),
+        ("TanimotoCombined", crop_prob, dict(labels=targets, target_mode=E.TGT_ONEHOT), None, 0.717, O.tanimoto_combined_loss, True),
+        ("TanimotoCombined", crop_prob, dict(labels=targets, target_mode=E.TGT_ONEHOT), mask, 0.561, O.tanimoto_combined_loss, True),
+        ("TanimotoDistLoss", dist, dict(target_f=dist_t, target_mode=E.TGT_FLOAT), None, 0.417, O.tanimoto_dist_loss, False),
+        ("TanimotoComplementLoss", dist, dict(target_f=dist_t, target_mode=E.TGT_FLOAT), None, 0.704, O.tanimoto_complement_loss, False),
+    ]
+    for kind, pred, tk, mk, expect, ofn, onehot in cases:
+        pr = pred.clone().requires_grad_(True)
+        tgt = tk.get("labels") if "labels" in tk else tk["target_f"]
+        lr = ofn(pr, tgt, mk, one_hot_targets=onehot)
+        lr.backward()
+        with E.recording(True) as tape:
+            pv = E.Var(pred.to(dev), True)
+            kw = {k: (v.to(dev) if torch.is_tensor(v) else v) for k, v in tk.items()}
+            loss = E.tanimoto_loss(pv, mask=mk.to(dev) if mk is not None else None,
+                                   mask_mode=E.MSK_I64 if mk is not None else E.MSK_NONE,
+                                   loss_kind=E.LOSS_KINDS[kind], **kw)
+            tape.backward()
+        torch.cuda.synchronize()
+        assert round(float(loss.item()), 3) == expect, (kind, float(loss.item()), expect)
+        assert abs(float(loss.item()) - float(lr.item())) < 2e-6
+        _close(pv.grad, pr.grad, 1e-5, kind + " grad")
+
+
+def test_label_modes():
+    """get_true_labels fused into the loss kernel (lightning.py:161-207)."""
+    from cultionet_amd import engine as E
+    from oracle import towerunet_oracle as O
+
+    dev = _dev()
+    g = torch.Generator().manual_seed(60)
+    B, H, W = 3, 25, 25
+    y = torch.randint(-1, 3, (B, H, W), generator=g)
+    pred = torch.rand(B, 1, H, W, generator=g)
+    te, tc, mask = O.true_labels(y, 2)
+    for mode, tgt in ((E.TGT_EQ, te), (E.TGT_RANGE, tc)):
+        pr = pred.clone().requires_grad_(True)
+        lr = O.tanimoto_complement_loss(pr, tgt, mask)
+        lr.backward()
+        with E.recording(True) as tape:
+            pv = E.Var(pred.to(dev), True)
+            loss = E.tanimoto_loss(pv, labels=y.to(dev), target_mode=mode, mask_mode=E.MSK_LABEL, klass=2)
+            tape.backward()
+        assert abs(float(loss.item()) - float(lr.item())) < 2e-6
+        _close(pv.grad, pr.grad, 1e-5, "grad")
+
+
+def test_adamw_and_clip():
+    from cultionet_amd import _lib
+    from cultionet_amd import engine as E
+
+    dev = _dev()
+    n = 10007
+    p0, g0 = _rand(n, seed=70), _rand(n, seed=71) * 3
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.AdamW([pr], lr=0.01, weight_decay=1e-3, eps=1e-4, betas=(0.9, 0.98))
+    p, m, v = p0.to(dev), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
+    for step in range(1, 4):
+        g = g0 * step
+        pr.grad = g.clone()
+        torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        gd = g.to(dev)
+        _lib.call("cn_grad_sumsq_f32", gd.data_ptr(), n, sumsq.data_ptr(), E._stream())
+        _lib.call("cn_adamw_step_f32", p.data_ptr(), gd.data_ptr(), m.data_ptr(), v.data_ptr(), n, 0.01, 0.9, 0.98,
+                  1e-4, 1e-3, step, 1.0, sumsq.data_ptr(), 1.0, E._stream())
+        torch.cuda.synchronize()
+        _close(p, pr, 1e-6, f"step {step}")

@@ -1,0 +1,174 @@
+"""End-to-end parity of the HIP TowerUNet path against the golden vectors of the REAL reference
+(tests/golden, produced by oracle/make_golden.py) and against the CPU oracle on the same seeded inputs.
+
+Tolerance (BASELINE.json north_star): 1e-4 fp32 on the probability maps and on the loss; `> 0.5` masks must
+be identical wherever the reference's margin |p - 0.5| exceeds the tolerance.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+TOL = 1e-4
+KEYS = ("distance", "edge", "crop")
+
+
+def _setup(g, **kw):
+    from cultionet_amd.data import Data
+    from cultionet_amd.selfcheck import build_pair
+    from oracle import towerunet_oracle as O
+
+    hidden, B, H, W, with_mask, seed = (int(v) for v in g["meta"])
+    lit, ref = build_pair(hidden=hidden, device="cuda:0", **kw)
+    x, y, bdist = O.seeded_batch(B, height=H, width=W, seed=seed, with_mask=bool(with_mask))
+    batch = Data(x=x.cuda(), y=y.cuda(), bdist=bdist.cuda(), lon=torch.zeros(B).cuda(), lat=torch.zeros(B).cuda())
+    return lit, ref, batch
+
+
+def _check_outputs(pred, g):
+    for k in KEYS:
+        p = pred[k].detach().cpu().numpy()
+        err = np.abs(p - g[k]).max()
+        assert err <= TOL, f"{k}: max |diff| {err:.3e}"
+        safe = np.abs(g[k] - 0.5) > TOL
+        assert np.array_equal((p > 0.5)[safe], (g[k] > 0.5)[safe]), f"{k}: >0.5 mask differs"
+
+
+@pytest.mark.parametrize("name,kw", [
+    ("train_h8_b2_28", {}),
+    ("train_h8_b2_28_masked", {}),
+    ("train_h8_b2_28_tanimoto", {"loss_name": "TanimotoDistLoss"}),
+    ("train_h8_b2_28_combined", {"loss_name": "TanimotoCombined"}),
+    ("train_h8_b2_28_noattn", {"attention_weights": None}),
+    ("train_h8_b2_28_dil3", {"dilations": [1, 3]}),
+    ("train_h32_b1_100", {}),
+    ("train_h32_b1_100_masked", {}),
+    ("train_h32_b8_100", {}),
+])
+def test_native_train_step_matches_reference(golden_dir, name, kw):
+    from cultionet_amd.lightning import HipTrainer
+
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    lit, ref, batch = _setup(g, **kw)
+    lit.train()
+    trainer = HipTrainer(lit)
+    with torch.no_grad():
+        pass
+    loss = trainer.forward_backward(batch)
+    torch.cuda.synchronize()
+    assert abs(float(loss.item()) - float(g["loss"])) <= TOL, (float(loss.item()), float(g["loss"]))
+    model = lit.cultionet_model.mask_model
+    norms = {n: float(trainer.store.grad_of(p).double().norm()) for n, p in model.named_parameters()}
+    bad = []
+    for n, refn in zip(g["grad_names"], g["grad_norms"]):
+        if abs(norms[str(n)] - refn) > 2e-3 * max(1e-3, abs(refn)) + 1e-6:
+            bad.append((str(n), norms[str(n)], float(refn)))
+    assert not bad, bad[:8]
+    sd = model.state_dict()
+    k0 = "tower_fusion.tower_a.res_conv.res_modules.0.block.0.seq.1."
+    assert np.abs(sd[k0 + "running_mean"].cpu().numpy() - g["bn_running_mean"]).max() <= 1e-5
+    assert np.abs(sd[k0 + "running_var"].cpu().numpy() - g["bn_running_var"]).max() <= 1e-5
+    assert int(sd[k0 + "num_batches_tracked"]) == 1
+
+
+@pytest.mark.parametrize("name,kw", [("train_h8_b2_28", {}), ("train_h32_b1_100_masked", {})])
+def test_dropin_forward_calc_loss_backward(golden_dir, name, kw):
+    """The LightningModule surface: forward(Data) -> calc_loss -> loss.backward() through torch.autograd."""
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    lit, ref, batch = _setup(g, **kw)
+    lit.train()
+    pred = lit(batch)
+    assert pred["crop_type"] is None and pred["classes_l2"] is None and pred["classes_l3"] is None
+    _check_outputs(pred, g)
+    loss, rep = lit.calc_loss(batch, pred)
+    assert abs(float(loss) - float(g["loss"])) <= TOL
+    for k in ("dloss", "eloss", "closs"):
+        assert abs(float(rep[k]) - float(g[k])) <= TOL
+    loss.backward()
+    model = lit.cultionet_model.mask_model
+    for n, refn in zip(g["grad_names"], g["grad_norms"]):
+        p = dict(model.named_parameters())[str(n)]
+        assert p.grad is not None, n
+        assert abs(float(p.grad.double().norm()) - refn) <= 2e-3 * max(1e-3, abs(refn)) + 1e-6, n
+
+
+def test_stage_activations(golden_dir):
+    """Per-stage activations of the small model (embeddings, encoder, decoder, towers)."""
+    from cultionet_amd import engine as E
+
+    g = np.load(os.path.join(golden_dir, "train_h8_b2_28.npz"))
+    lit, ref, batch = _setup(g)
+    lit.train()
+    model = lit.cultionet_model.mask_model
+    store = model.param_store()
+    with E.using_store(store), E.recording(False):
+        emb = model.pre_unet(model.input_var(batch.x))
+        enc = model.encoder(emb)
+        dec = model.decoder(enc)
+        tow = model.tower_fusion(encoded=enc, decoded=dec)
+    got = {"pre_unet": emb, **enc, **dec, **tow}
+    for key in g.files:
+        if key.startswith("stage."):
+            s = key[len("stage."):]
+            err = np.abs(got[s].t.cpu().numpy() - g[key]).max()
+            scale = max(1.0, float(np.abs(g[key]).max()))
+            assert err <= 1e-4 * scale, (s, err)
+
+
+def test_eval_mode(golden_dir):
+    g = np.load(os.path.join(golden_dir, "eval_h8_b2_28.npz"))
+    from cultionet_amd.selfcheck import build_pair
+    from oracle import towerunet_oracle as O
+
+    hidden, B, C, Tn, H, W, seed = (int(v) for v in g["meta"])
+    lit, _ = build_pair(hidden=hidden, in_channels=C, in_time=Tn)
+    lit.eval()
+    x, _, _ = O.seeded_batch(B, channels=C, time=Tn, height=H, width=W, seed=seed)
+    with torch.no_grad():
+        pred = lit.cultionet_model.mask_model(x.cuda())
+    for k in KEYS:
+        assert np.abs(pred[k].cpu().numpy() - g[f"{k}_crop"]).max() <= TOL
+
+
+def test_large_tile_eval(golden_dir):
+    """BASELINE configs[4]: [1,4,25,256,256] eval forward, checked by checksums + a 64x64 crop."""
+    g = np.load(os.path.join(golden_dir, "eval_h32_b1_4x25x256.npz"))
+    from cultionet_amd.selfcheck import build_pair
+    from oracle import towerunet_oracle as O
+
+    hidden, B, C, Tn, H, W, seed = (int(v) for v in g["meta"])
+    lit, _ = build_pair(hidden=hidden, in_channels=C, in_time=Tn)
+    lit.eval()
+    x, _, _ = O.seeded_batch(B, channels=C, time=Tn, height=H, width=W, seed=seed)
+    with torch.no_grad():
+        pred = lit.cultionet_model.mask_model(x.cuda())
+    for k in KEYS:
+        p = pred[k].cpu()
+        assert np.abs(p[:, :, :64, :64].numpy() - g[f"{k}_crop"]).max() <= TOL
+        assert np.abs(p.double().sum(dim=(0, 1, 3)).numpy() - g[f"{k}_rowsum"]).max() <= TOL * W
+
+
+def test_adamw_step_matches_oracle(golden_dir):
+    """One full native step (clip 1.0 + AdamW) vs torch on the CPU oracle: parameter deltas."""
+    from cultionet_amd.lightning import HipTrainer
+    from oracle import towerunet_oracle as O
+
+    g = np.load(os.path.join(golden_dir, "train_h8_b2_28_masked.npz"))
+    lit, ref, batch = _setup(g)
+    lit.train()
+    ref.train()
+    opt = torch.optim.AdamW(ref.parameters(), lr=0.01, weight_decay=1e-3, eps=1e-4, betas=(0.9, 0.98))
+    pred = ref(batch.x.cpu())
+    loss, _ = O.calc_loss(pred, batch.y.cpu(), batch.bdist.cpu())
+    loss.backward()
+    torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+    opt.step()
+    trainer = HipTrainer(lit)
+    trainer.training_step(batch)
+    torch.cuda.synchronize()
+    model = lit.cultionet_model.mask_model
+    for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
+        assert (p.detach().cpu() - pr.detach()).abs().max() <= 2e-4, n
