@@ -49,6 +49,8 @@ SIGNATURES = {
     "cn_adamw_step_f32": [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P],
     "cn_pack_timeconv_f32": [P, P, I, I, I, I, I, P],
     "cn_fold_timeconv_grad_f32": [P, P, I, I, I, I, P],
+    "cn_profile_begin": [],
+    "cn_profile_end": [P],
 }
 
 ERRORS = {-1: "CN_ERR_ARG (invalid argument / unsupported shape)", -2: "CN_ERR_LAUNCH (HIP launch failed)",

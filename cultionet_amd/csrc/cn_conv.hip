@@ -17,9 +17,10 @@
 // along W of NCHW. fp32 MFMA is bit-for-bit an fp32 fma chain (no TF32 on gfx950).
 #include "cn_common.h"
 #include "cn_conv_geom.h"
+#include "cn_profile.h"
 
 #define KC 8
-#define NI 8  // max staged plane = NI*256 floats per channel
+#define NI 12  // max staged plane = NI*256 floats per channel
 
 template <int WAVES_N, int TN>
 __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const float* __restrict__ x,
@@ -215,7 +216,9 @@ static int cn_launch_igemm(const float* x, const float* wp, const float* bias, f
     attr_set = true;
   }
   dim3 grid(g.B * g.tiles_per_img, (g.Cout + NT - 1) / NT);
+  cn_prof_before(stream);
   hipLaunchKernelGGL((cn_conv_igemm_kernel<WAVES_N, TN>), grid, dim3(256), lds, stream, x, wp, bias, y, g);
+  cn_prof_after(stream, NT == 128 ? 0 : 1, 2.0 * g.B * Mimg * (double)g.Cout * g.Cin * g.ntaps);
   return cn_check_launch();
 }
 

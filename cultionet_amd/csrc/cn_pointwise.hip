@@ -12,7 +12,8 @@
 // src index math follows ATen's area_pixel_compute_source_index (fp32).
 // ---------------------------------------------------------------------------
 __device__ __forceinline__ void bl_src(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
-  const float src = scale * o;
+#pragma clang fp contract(off)  // ATen rounds scale*o before subtracting floor(): an fma here shifts lambda by ~1e-6
+  const float src = scale * (float)o;
   i0 = (int)src;
   if (i0 > in_size - 1) i0 = in_size - 1;
   i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);

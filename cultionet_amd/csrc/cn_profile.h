@@ -1,0 +1,10 @@
+// Optional per-launch timing of the contraction kernels with HIP events on the launch stream
+// (diagnostics for bench.py's roofline figure; off by default, zero cost when off).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#define CN_PROF_KINDS 4  // 0 igemm<NT=128>  1 igemm<NT<=64>  2 wgrad<T=9>  3 wgrad<T=1>
+
+bool cn_prof_on();
+void cn_prof_before(hipStream_t stream);
+void cn_prof_after(hipStream_t stream, int kind, double flops);

@@ -12,6 +12,7 @@
 // Reference op: autograd of torch.nn.Conv2d / ConvTranspose2d used by
 // /root/reference/src/cultionet/nn/modules/convolution.py:45-120.
 #include "cn_common.h"
+#include "cn_profile.h"
 
 #define WG_MAX_TAPS 9
 #define WG_BC 32   // b-channels per block
@@ -218,7 +219,9 @@ static int cn_wgrad_launch_t(const float* S, const float* Bg, float* dW, CnWgrad
                               160 * 1024);
     attr_set = true;
   }
+  cn_prof_before(stream);
   hipLaunchKernelGGL((cn_wgrad_kernel<T>), dim3(gx, gy, splits), dim3(256), lds, stream, S, Bg, dW, g);
+  cn_prof_after(stream, T == 9 ? 2 : 3, 2.0 * g.N * g.Hs * g.Ws * (double)g.A * g.Bc * g.T);
   return cn_check_launch();
 }
 

@@ -71,10 +71,16 @@ class Tape:
     def __init__(self, enabled: bool):
         self.enabled = enabled
         self.nodes: T.List[T.Callable[[], None]] = []
+        self.marks: T.Dict[int, int] = {}  # flat offset of a parameter -> index of the node that uses it
 
-    def add(self, fn: T.Callable[[], None]) -> None:
+    def add(self, fn: T.Callable[[], None], params: T.Sequence[T.Optional[torch.Tensor]] = ()) -> None:
         if self.enabled:
             self.nodes.append(fn)
+            if params:
+                base = current_store()._base
+                for p in params:
+                    if p is not None:
+                        self.marks[(p.data_ptr() - base) // 4] = len(self.nodes) - 1
 
     def backward(self) -> None:
         nodes, self.nodes = self.nodes, []
@@ -322,7 +328,7 @@ def conv2d(x: Var, mod, stride: int = 1, padding: int = 0, dilation: int = 1, ou
                           bstride(dx), B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, acc, s)
             yv.grad = None
 
-        tape.add(bwd)
+        tape.add(bwd, (w, bias))
     return yv
 
 
@@ -361,7 +367,7 @@ def conv_transpose2d(x: Var, mod, stride: int, padding: int) -> Var:
                           dx.data_ptr(), bstride(dx), B, Cin, H, W, Cout, KH, KW, stride, padding, acc, s)
             yv.grad = None
 
-        tape.add(bwd)
+        tape.add(bwd, (w, bias))
     return yv
 
 
@@ -410,7 +416,7 @@ def time_conv(x: Var, mod, tin: int) -> Var:
                           bstride(dx), B, CT, H, W, Cout * tout, 1, 1, 1, 0, 1, acc, s)
             yv.grad = None
 
-        tape.add(bwd)
+        tape.add(bwd, (w,))
     return yv
 
 
@@ -464,7 +470,7 @@ def bn_act(x: Var, bn, act: int, residual: T.Optional[Var] = None, channels: T.O
                       act, acc, 1, s)
             yv.grad = None
 
-        tape.add(bwd)
+        tape.add(bwd, (gamma, beta))
     return yv
 
 
@@ -497,7 +503,7 @@ def layer_norm_c(x: Var, ln, residual: T.Optional[Var] = None) -> Var:
                       store.grad_of(ln.weight).data_ptr(), store.grad_of(ln.bias).data_ptr(), B, C, L, acc, _stream())
             yv.grad = None
 
-        tape.add(bwd)
+        tape.add(bwd, (ln.weight, ln.bias))
     return yv
 
 
@@ -671,7 +677,7 @@ def final_combine(ha: Var, hb: Var, hc: Var, params: T.Sequence[torch.nn.Paramet
             for v in outs:
                 v.grad = None
 
-        tape.add(bwd)
+        tape.add(bwd, tuple(params))
     return outs
 
 

@@ -148,6 +148,14 @@ int cn_adamw_step_f32(float* p, const float* g, float* m, float* v, long n, floa
                       float eps, float weight_decay, int step, float grad_scale, const double* sumsq, float max_norm,
                       void* stream);
 
+/* ---- diagnostics: per-launch HIP-event timing of the contraction kernels (bench.py roofline) ---
+ * begin() starts recording event pairs around every implicit-GEMM / weight-gradient launch on the
+ * launch stream; end() synchronises them and fills out[4][3] = {milliseconds, algorithmic flops,
+ * launches} for kinds {igemm NT=128, igemm NT<=64, wgrad 3x3, wgrad 1x1}. Process-global, off by
+ * default, not thread-safe. */
+int cn_profile_begin(void);
+int cn_profile_end(double* out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -78,9 +78,27 @@ def _train_case(ns, hidden, B, H, W, with_mask, seed=7, stages=False, loss_name=
     return out
 
 
+def calibrate_bn(model, forward):
+    """Make the BatchNorm running statistics those of one train-mode pass (momentum 1.0), as a trained
+    checkpoint's would be; with the raw key-seeded running stats eval-mode activations are not
+    normalised and the forward is numerically chaotic (any two fp32 implementations diverge)."""
+    bns = [m for m in model.modules() if isinstance(m, torch.nn.modules.batchnorm._BatchNorm)]
+    old = [m.momentum for m in bns]
+    for m in bns:
+        m.momentum = 1.0
+    model.train()
+    with torch.no_grad():
+        forward()
+    for m, mo in zip(bns, old):
+        m.momentum = mo
+    model.eval()
+
+
 def _eval_case(ns, hidden, B, C, T, H, W, seed=11, crop=64):
     m = _ref_model(ns, hidden, in_channels=C, in_time=T)
-    m.eval()
+    xc, yc, bc = O.seeded_batch(B, channels=C, time=T, height=H, width=W, seed=seed + 1000)
+    cal = ns.Data(x=xc, y=yc, bdist=bc, lon=torch.zeros(B), lat=torch.zeros(B))
+    calibrate_bn(m, lambda: m(cal))
     x, y, bdist = O.seeded_batch(B, channels=C, time=T, height=H, width=W, seed=seed)
     batch = ns.Data(x=x, y=y, bdist=bdist, lon=torch.zeros(B), lat=torch.zeros(B))
     with torch.no_grad():
@@ -106,6 +124,10 @@ def main():
         np.savez_compressed(path, **d)
         print(name, os.path.getsize(path) // 1024, "KiB", "loss" in d and d["loss"])
 
+    if "--eval-only" in sys.argv:
+        save("eval_h32_b1_4x25x256.npz", _eval_case(ns, 32, 1, 4, 25, 256, 256))
+        save("eval_h8_b2_28.npz", _eval_case(ns, 8, 2, 3, 12, 28, 28, crop=0))
+        return
     # (i) small model with per-stage activations, train mode (odd sizes: 28->14->7->4)
     save("train_h8_b2_28.npz", _train_case(ns, 8, 2, 28, 28, False, stages=True))
     save("train_h8_b2_28_masked.npz", _train_case(ns, 8, 2, 28, 28, True, stages=False))

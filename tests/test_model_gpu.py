@@ -124,11 +124,15 @@ def test_eval_mode(golden_dir):
     from oracle import towerunet_oracle as O
 
     hidden, B, C, Tn, H, W, seed = (int(v) for v in g["meta"])
+    from oracle.make_golden import calibrate_bn
+
     lit, _ = build_pair(hidden=hidden, in_channels=C, in_time=Tn)
-    lit.eval()
+    model = lit.cultionet_model.mask_model
+    xc, _, _ = O.seeded_batch(B, channels=C, time=Tn, height=H, width=W, seed=seed + 1000)
+    calibrate_bn(model, lambda: model(xc.cuda()))
     x, _, _ = O.seeded_batch(B, channels=C, time=Tn, height=H, width=W, seed=seed)
     with torch.no_grad():
-        pred = lit.cultionet_model.mask_model(x.cuda())
+        pred = model(x.cuda())
     for k in KEYS:
         assert np.abs(pred[k].cpu().numpy() - g[f"{k}_crop"]).max() <= TOL
 
@@ -140,11 +144,15 @@ def test_large_tile_eval(golden_dir):
     from oracle import towerunet_oracle as O
 
     hidden, B, C, Tn, H, W, seed = (int(v) for v in g["meta"])
+    from oracle.make_golden import calibrate_bn
+
     lit, _ = build_pair(hidden=hidden, in_channels=C, in_time=Tn)
-    lit.eval()
+    model = lit.cultionet_model.mask_model
+    xc, _, _ = O.seeded_batch(B, channels=C, time=Tn, height=H, width=W, seed=seed + 1000)
+    calibrate_bn(model, lambda: model(xc.cuda()))
     x, _, _ = O.seeded_batch(B, channels=C, time=Tn, height=H, width=W, seed=seed)
     with torch.no_grad():
-        pred = lit.cultionet_model.mask_model(x.cuda())
+        pred = model(x.cuda())
     for k in KEYS:
         p = pred[k].cpu()
         assert np.abs(p[:, :, :64, :64].numpy() - g[f"{k}_crop"]).max() <= TOL

@@ -69,9 +69,12 @@ def test_oracle_train_matches_reference_vectors(golden_dir, name, kw, loss_name)
 def test_oracle_eval_matches_reference_vectors(golden_dir):
     g = np.load(os.path.join(golden_dir, "eval_h8_b2_28.npz"))
     hidden, B, C, T, H, W, seed = (int(v) for v in g["meta"])
+    from oracle.make_golden import calibrate_bn
+
     m = O.TowerUNet(C, T, hidden_channels=hidden)
     m.load_state_dict(O.seeded_state_dict(m.state_dict()))
-    m.eval()
+    xc, _, _ = O.seeded_batch(B, channels=C, time=T, height=H, width=W, seed=seed + 1000)
+    calibrate_bn(m, lambda: m(xc))
     x, _, _ = O.seeded_batch(B, channels=C, time=T, height=H, width=W, seed=seed)
     with torch.no_grad():
         pred = m(x)
