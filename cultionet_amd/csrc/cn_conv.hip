@@ -20,9 +20,11 @@
 #include "cn_profile.h"
 
 #define KC 8
-#define NI 12  // max staged plane = NI*256 floats per channel
 
-template <int WAVES_N, int TN>
+// Software-pipelined implicit GEMM.
+//   NI_T: halo plane capacity = NI_T*256 floats per channel (register prefetch uses NI_T*KC VGPRs)
+// grid = (tiles over all classes and images, N tiles, K splits)
+template <int WAVES_N, int TN, int NI_T>
 __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const float* __restrict__ x,
                                                            const float* __restrict__ wp,
                                                            const float* __restrict__ bias,
@@ -30,29 +32,48 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const float* __restr
   constexpr int WAVES_M = 4 / WAVES_N;
   constexpr int MT = WAVES_M * 64;
   constexpr int NT = WAVES_N * TN * 32;
+  constexpr int WI = (CN_MAX_TAPS * KC * (NT / 4) + 255) / 256;  // float4 weight loads per thread per chunk
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* in_lds = smem;                 // [KC][plane]
-  float* w_lds = smem + g.w_lds_off;    // [ntaps*KC][NT]
+  float* in_lds = smem;               // [KC][plane]
+  float* w_lds = smem + g.w_lds_off;  // [ntaps*KC][NT]
+  int* tap_lds = reinterpret_cast<int*>(smem + g.tap_lds_off);  // [0..8] LDS tap offsets, [9..17] packed tap ids
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
-  const int b = blockIdx.x / g.tiles_per_img;
-  const int m0 = (blockIdx.x - b * g.tiles_per_img) * MT;
+
+  // ---- which class / image / tile
+  int ci_ = 0;
+#pragma unroll 1
+  for (int c = 1; c < g.ncls; ++c)
+    if ((int)blockIdx.x >= g.cls[c].block_begin) ci_ = c;
+  const int Hg = g.cls[ci_].Hg, Wg = g.cls[ci_].Wg, ntaps = g.cls[ci_].ntaps;
+  const int pitch = g.cls[ci_].pitch, plane = g.cls[ci_].plane;
+  const int min_dy = g.cls[ci_].min_dy, min_dx = g.cls[ci_].min_dx;
+  const int oy0 = g.cls[ci_].oy0, ox0 = g.cls[ci_].ox0;
+  const int tiles_per_img = g.cls[ci_].tiles_per_img;
+  const int tile = blockIdx.x - g.cls[ci_].block_begin;
+  const int b = tile / tiles_per_img;
+  const int m0 = (tile - b * tiles_per_img) * MT;
+  if (tid < ntaps) {
+    tap_lds[tid] = (g.cls[ci_].dy[tid] - min_dy) * pitch + (g.cls[ci_].dx[tid] - min_dx);
+    tap_lds[CN_MAX_TAPS + tid] = g.cls[ci_].wt[tid];
+  }
+  __syncthreads();
   const int n0 = blockIdx.y * NT;
-  const int Mimg = g.Hg * g.Wg;
-  const int gy0 = m0 / g.Wg;
-  const int iy_base = gy0 * g.is + g.min_dy;
+  const int Mimg = Hg * Wg;
+  const int gy0 = m0 / Wg;
+  const int iy_base = gy0 * g.is + min_dy;
   const int HWin = g.Hin * g.Win;
 
   // per-thread decode of the staged halo plane (same for every K-chunk)
-  int goff[NI];
+  int goff[NI_T];
 #pragma unroll
-  for (int i = 0; i < NI; ++i) {
+  for (int i = 0; i < NI_T; ++i) {
     const int e = tid + i * 256;
-    if (e < g.plane) {
-      const int r = e / g.pitch, c = e - r * g.pitch;
-      const int iy = iy_base + r, ix = c + g.min_dx;
+    if (e < plane) {
+      const int r = e / pitch, c = e - r * pitch;
+      const int iy = iy_base + r, ix = c + min_dx;
       goff[i] = (iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win) ? iy * g.Win + ix : -1;
     } else {
       goff[i] = -2;
@@ -66,9 +87,9 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const float* __restr
     const int p = m0 + wm * 64 + tm * 32 + l31;
     pix_ok[tm] = p < Mimg;
     const int pc = pix_ok[tm] ? p : Mimg - 1;
-    const int gy = pc / g.Wg, gx = pc - gy * g.Wg;
-    pix_lds[tm] = ((gy - gy0) * g.is) * g.pitch + gx * g.is + half * g.plane;
-    out_off[tm] = (gy * g.os + g.oy0) * g.Wout + gx * g.os + g.ox0;
+    const int gy = pc / Wg, gx = pc - gy * Wg;
+    pix_lds[tm] = ((gy - gy0) * g.is) * pitch + gx * g.is + half * plane;
+    out_off[tm] = (gy * g.os + oy0) * g.Wout + gx * g.os + ox0;
   }
 
   f32x16 acc[TN][2];
@@ -80,72 +101,313 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const float* __restr
       for (int r = 0; r < 16; ++r) acc[tn][tm][r] = 0.f;
 
   const float* xb = x + (long)b * g.xbs;
-  const int nw4 = g.ntaps * KC * (NT / 4);
+  const int nw4 = ntaps * KC * (NT / 4);
+  const int nchunks = (g.Cin + KC - 1) / KC;
+  int ch = blockIdx.z * g.chunks_per_split;
+  int ch_end = ch + g.chunks_per_split;
+  if (ch_end > nchunks) ch_end = nchunks;
 
-  if (g.ntaps > 0) {
-    for (int c0 = 0; c0 < g.Cin; c0 += KC) {
+  if (ntaps > 0 && ch < ch_end) {
+    float xin[KC][NI_T];
+    f32x4 win[WI];
+#define CN_PREFETCH(c0_)                                                                                   \
+  {                                                                                                        \
+    const int c0 = (c0_);                                                                                  \
+    _Pragma("unroll") for (int ci = 0; ci < KC; ++ci) {                                                    \
+      const bool cok = (c0 + ci) < g.Cin;                                                                  \
+      const float* xc = xb + (long)(c0 + ci) * HWin;                                                       \
+      _Pragma("unroll") for (int i = 0; i < NI_T; ++i) {                                                   \
+        float v = 0.f;                                                                                     \
+        if (cok && goff[i] >= 0) v = xc[goff[i]];                                                          \
+        xin[ci][i] = v;                                                                                    \
+      }                                                                                                    \
+    }                                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < WI; ++j) {                                                       \
+      const int f = tid + j * 256;                                                                         \
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                      \
+      if (f < nw4) {                                                                                       \
+        const int row = f / (NT / 4), c4 = f - row * (NT / 4);                                             \
+        const int t = row / KC, ci = row - t * KC;                                                         \
+        v = *reinterpret_cast<const f32x4*>(                                                               \
+            wp + ((long)(tap_lds[CN_MAX_TAPS + t] * g.Kpad + c0 + ci) * g.Npad + n0 + c4 * 4));            \
+      }                                                                                                    \
+      win[j] = v;                                                                                          \
+    }                                                                                                      \
+  }
+    CN_PREFETCH(ch * KC);
+    for (; ch < ch_end; ++ch) {
+      __syncthreads();  // previous chunk's MFMAs are done reading LDS
+#pragma unroll
+      for (int ci = 0; ci < KC; ++ci)
+#pragma unroll
+        for (int i = 0; i < NI_T; ++i)
+          if (goff[i] != -2) in_lds[ci * plane + tid + i * 256] = xin[ci][i];
+#pragma unroll
+      for (int j = 0; j < WI; ++j) {
+        const int f = tid + j * 256;
+        if (f < nw4) *reinterpret_cast<f32x4*>(w_lds + f * 4) = win[j];
+      }
       __syncthreads();
-      // ---- stage halo rows of KC input channels (zero outside the image / past Cin)
-#pragma unroll
-      for (int ci = 0; ci < KC; ++ci) {
-        const bool cok = (c0 + ci) < g.Cin;
-        const float* xc = xb + (long)(c0 + ci) * HWin;
-#pragma unroll
-        for (int i = 0; i < NI; ++i) {
-          if (goff[i] != -2) {
-            float v = 0.f;
-            if (cok && goff[i] >= 0) v = xc[goff[i]];
-            in_lds[ci * g.plane + tid + i * 256] = v;
-          }
-        }
+      if (ch + 1 < ch_end) CN_PREFETCH((ch + 1) * KC);  // in flight while the MFMAs below run
+      float opa[2][TN], opb[2][2];
+#define CN_LOAD_OPS(bf_, t_, cp_, toff_)                                                                   \
+  {                                                                                                        \
+    const float* wrow = w_lds + ((t_) * KC + half) * NT + wn * (TN * 32) + l31;                            \
+    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) opa[bf_][tn] = wrow[(2 * (cp_)) * NT + tn * 32];     \
+    opb[bf_][0] = in_lds[pix_lds[0] + (2 * (cp_)) * plane + (toff_)];                                      \
+    opb[bf_][1] = in_lds[pix_lds[1] + (2 * (cp_)) * plane + (toff_)];                                      \
+  }
+#define CN_MFMA(bf_)                                                                                       \
+  _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) _Pragma("unroll") for (int tm = 0; tm < 2; ++tm)       \
+      acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[bf_][tn], opb[bf_][tm], acc[tn][tm], 0, 0, 0);
+      int toff_cur = tap_lds[0];
+      CN_LOAD_OPS(0, 0, 0, toff_cur);
+#pragma unroll 1
+      for (int t = 0; t < ntaps; ++t) {
+        const int toff_nxt = (t + 1 < ntaps) ? tap_lds[t + 1] : 0;
+        CN_LOAD_OPS(1, t, 1, toff_cur);
+        CN_MFMA(0);
+        CN_LOAD_OPS(0, t, 2, toff_cur);
+        CN_MFMA(1);
+        CN_LOAD_OPS(1, t, 3, toff_cur);
+        CN_MFMA(0);
+        if (t + 1 < ntaps) CN_LOAD_OPS(0, t + 1, 0, toff_nxt);
+        CN_MFMA(1);
+        toff_cur = toff_nxt;
       }
-      // ---- stage packed weights [tap][c0..c0+KC)[n0..n0+NT)
-      for (int f = tid; f < nw4; f += 256) {
-        const int row = f / (NT / 4), c4 = f - row * (NT / 4);
-        const int t = row / KC, ci = row - t * KC;
-        const float4 v = *reinterpret_cast<const float4*>(
-            wp + ((long)(g.wt[t] * g.Kpad + c0 + ci) * g.Npad + n0 + c4 * 4));
-        *reinterpret_cast<float4*>(w_lds + row * NT + c4 * 4) = v;
-      }
-      __syncthreads();
-      // ---- MFMA over (tap, channel pair)
-      for (int t = 0; t < g.ntaps; ++t) {
-        const int tapoff = (g.dy[t] - g.min_dy) * g.pitch + (g.dx[t] - g.min_dx);
-        const float* wrow = w_lds + (t * KC + half) * NT + wn * (TN * 32) + l31;
-#pragma unroll
-        for (int cp = 0; cp < KC / 2; ++cp) {
-          float a[TN], bb[2];
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn) a[tn] = wrow[(2 * cp) * NT + tn * 32];
-#pragma unroll
-          for (int tm = 0; tm < 2; ++tm) bb[tm] = in_lds[pix_lds[tm] + (2 * cp) * g.plane + tapoff];
-#pragma unroll
-          for (int tn = 0; tn < TN; ++tn)
-#pragma unroll
-            for (int tm = 0; tm < 2; ++tm)
-              acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tn], bb[tm], acc[tn][tm], 0, 0, 0);
-        }
-      }
+#undef CN_LOAD_OPS
+#undef CN_MFMA
     }
+#undef CN_PREFETCH
   }
 
   // ---- epilogue: D[i = cout][j = pixel]; lane = pixel -> coalesced along W
   float* yb = y + (long)b * g.ybs;
   const int HWout = g.Hout * g.Wout;
+  const bool first = blockIdx.z == 0;
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = n0 + wn * (TN * 32) + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (co < g.Cout) {
-        const float bv = g.has_bias ? bias[co] : 0.f;
+        const float bv = (g.has_bias && first) ? bias[co] : 0.f;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
           if (pix_ok[tm]) {
             float* dst = yb + (long)co * HWout + out_off[tm];
-            float v = acc[tn][tm][r] + bv;
-            if (g.accumulate) v += *dst;
-            *dst = v;
+            const float v = acc[tn][tm][r] + bv;
+            if (g.atomic_out) {
+              atomicAdd(dst, v);
+            } else if (g.accumulate) {
+              *dst += v;
+            } else {
+              *dst = v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
+// Same GEMM with 16-byte staging ("flattened rows"): when channel planes are 16-byte aligned (H*W % 4 == 0) the
+// halo rows of a tile are ONE contiguous flat range of the plane, copied with aligned float4 loads into an
+// unpadded LDS image (pitch = Win). Row overruns fall outside [0, H*W) and are zero-filled per chunk; column
+// overruns wrap into the neighbouring row and are masked per lane and tap at operand-read time instead.
+// 4x fewer staging instructions than the dword path (the limiter of the f32 MFMA loop: one VMEM/LDS
+// instruction per wave moves at most 16 B per lane whatever its width).
+//   NV: float4 chunks per thread per channel (vplane <= NV*1024 floats)
+template <int WAVES_N, int TN, int TM, int NV>
+__global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ wp,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ y, const CnConvGeom g) {
+  constexpr int WAVES_M = 4 / WAVES_N;
+  constexpr int MT = WAVES_M * TM * 32;
+  constexpr int NT = WAVES_N * TN * 32;
+  constexpr int WI = (CN_MAX_TAPS * KC * (NT / 4) + 255) / 256;
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  float* in_lds = smem;               // [KC][vplane]
+  float* w_lds = smem + g.w_lds_off;  // [ntaps*KC][NT]
+  int* tap_lds = reinterpret_cast<int*>(smem + g.tap_lds_off);
+
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int wm = wid / WAVES_N, wn = wid % WAVES_N;
+
+  int ci_ = 0;
+#pragma unroll 1
+  for (int c = 1; c < g.ncls; ++c)
+    if ((int)blockIdx.x >= g.cls[c].block_begin) ci_ = c;
+  const int Hg = g.cls[ci_].Hg, Wg = g.cls[ci_].Wg, ntaps = g.cls[ci_].ntaps;
+  const int vplane = g.cls[ci_].vplane;
+  const int min_dy = g.cls[ci_].min_dy, min_dx = g.cls[ci_].min_dx;
+  const int oy0 = g.cls[ci_].oy0, ox0 = g.cls[ci_].ox0;
+  const int tiles_per_img = g.cls[ci_].tiles_per_img;
+  const int tile = blockIdx.x - g.cls[ci_].block_begin;
+  const int b = tile / tiles_per_img;
+  const int m0 = (tile - b * tiles_per_img) * MT;
+  const int Win = g.Win;
+  if (tid < ntaps) {
+    tap_lds[tid] = (g.cls[ci_].dy[tid] - min_dy) * Win + (g.cls[ci_].dx[tid] - min_dx);
+    tap_lds[CN_MAX_TAPS + tid] = g.cls[ci_].wt[tid];
+    tap_lds[2 * CN_MAX_TAPS + tid] = g.cls[ci_].dx[tid];
+  }
+  __syncthreads();
+  const int n0 = blockIdx.y * NT;
+  const int Mimg = Hg * Wg;
+  const int gy0 = m0 / Wg;
+  const int HWin = g.Hin * Win;
+  const int start = (gy0 * g.is + min_dy) * Win + min_dx;  // flat index of the LDS image's logical origin
+  const int f0 = (start >> 2) << 2;                        // aligned down (arithmetic shift: floor)
+  const int sh = start - f0;
+
+  int goff[NV];  // flat index of this thread's float4 chunk, -1 zero-fill, -2 idle
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e4 = 4 * (tid + i * 256);
+    if (e4 < vplane) {
+      const int fq = f0 + e4;
+      goff[i] = (fq >= 0 && fq + 3 < HWin) ? fq : -1;
+    } else {
+      goff[i] = -2;
+    }
+  }
+
+  int pix_lds[TM], out_off[TM];
+  unsigned colmask[TM];  // bit t: tap t's column gx*is + dx[t] lies inside [0, Win)
+  bool pix_ok[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm) {
+    const int p = m0 + wm * (TM * 32) + tm * 32 + l31;
+    pix_ok[tm] = p < Mimg;
+    const int pc = pix_ok[tm] ? p : Mimg - 1;
+    const int gy = pc / Wg, gx = pc - gy * Wg;
+    pix_lds[tm] = ((gy - gy0) * g.is) * Win + gx * g.is + sh + half * vplane;
+    out_off[tm] = (gy * g.os + oy0) * g.Wout + gx * g.os + ox0;
+    unsigned m = 0;
+    for (int t = 0; t < ntaps; ++t) {
+      const int ix = gx * g.is + tap_lds[2 * CN_MAX_TAPS + t];
+      if (ix >= 0 && ix < Win) m |= 1u << t;
+    }
+    colmask[tm] = m;
+  }
+
+  f32x16 acc[TN][TM];
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+    for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[tn][tm][r] = 0.f;
+  const float* xb = x + (long)b * g.xbs;
+  const int nw4 = ntaps * KC * (NT / 4);
+  const int nchunks = (g.Cin + KC - 1) / KC;
+  int ch = blockIdx.z * g.chunks_per_split;
+  int ch_end = ch + g.chunks_per_split;
+  if (ch_end > nchunks) ch_end = nchunks;
+
+  if (ntaps > 0 && ch < ch_end) {
+    f32x4 xin[KC][NV];
+    f32x4 win[WI];
+#define CN_PREFETCH_V(c0_)                                                                                 \
+  {                                                                                                        \
+    const int c0 = (c0_);                                                                                  \
+    _Pragma("unroll") for (int ci = 0; ci < KC; ++ci) {                                                    \
+      const bool cok = (c0 + ci) < g.Cin;                                                                  \
+      const float* xc = xb + (long)(c0 + ci) * HWin;                                                       \
+      _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                                     \
+        f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                    \
+        if (cok && goff[i] >= 0) v = *reinterpret_cast<const f32x4*>(xc + goff[i]);                        \
+        xin[ci][i] = v;                                                                                    \
+      }                                                                                                    \
+    }                                                                                                      \
+    _Pragma("unroll") for (int j = 0; j < WI; ++j) {                                                       \
+      const int f = tid + j * 256;                                                                         \
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                      \
+      if (f < nw4) {                                                                                       \
+        const int row = f / (NT / 4), c4 = f - row * (NT / 4);                                             \
+        const int t = row / KC, ci = row - t * KC;                                                         \
+        v = *reinterpret_cast<const f32x4*>(                                                               \
+            wp + ((long)(tap_lds[CN_MAX_TAPS + t] * g.Kpad + c0 + ci) * g.Npad + n0 + c4 * 4));            \
+      }                                                                                                    \
+      win[j] = v;                                                                                          \
+    }                                                                                                      \
+  }
+    CN_PREFETCH_V(ch * KC);
+    for (; ch < ch_end; ++ch) {
+      __syncthreads();
+#pragma unroll
+      for (int ci = 0; ci < KC; ++ci)
+#pragma unroll
+        for (int i = 0; i < NV; ++i)
+          if (goff[i] != -2) *reinterpret_cast<f32x4*>(in_lds + ci * vplane + 4 * (tid + i * 256)) = xin[ci][i];
+#pragma unroll
+      for (int j = 0; j < WI; ++j) {
+        const int f = tid + j * 256;
+        if (f < nw4) *reinterpret_cast<f32x4*>(w_lds + f * 4) = win[j];
+      }
+      __syncthreads();
+      if (ch + 1 < ch_end) CN_PREFETCH_V((ch + 1) * KC);
+      // Operands of step (t, cp+1) are read from LDS before the MFMAs of step (t, cp) issue (two register
+      // sets, static indices); the tap loop stays rolled to bound register pressure.
+      float opa[2][TN], opb[2][TM];
+#define CN_LOAD_OPS(bf_, t_, cp_, toff_)                                                                   \
+  {                                                                                                        \
+    const float* wrow = w_lds + ((t_) * KC + half) * NT + wn * (TN * 32) + l31;                            \
+    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) opa[bf_][tn] = wrow[(2 * (cp_)) * NT + tn * 32];     \
+    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) {                                                    \
+      const float b_ = in_lds[pix_lds[tm] + (2 * (cp_)) * vplane + (toff_)];                               \
+      opb[bf_][tm] = ((colmask[tm] >> (t_)) & 1u) ? b_ : 0.f;                                              \
+    }                                                                                                      \
+  }
+#define CN_MFMA(bf_)                                                                                       \
+  _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)      \
+      acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[bf_][tn], opb[bf_][tm], acc[tn][tm], 0, 0, 0);
+      int toff_cur = tap_lds[0];
+      CN_LOAD_OPS(0, 0, 0, toff_cur);
+#pragma unroll 1
+      for (int t = 0; t < ntaps; ++t) {
+        const int toff_nxt = (t + 1 < ntaps) ? tap_lds[t + 1] : 0;
+        CN_LOAD_OPS(1, t, 1, toff_cur);
+        CN_MFMA(0);
+        CN_LOAD_OPS(0, t, 2, toff_cur);
+        CN_MFMA(1);
+        CN_LOAD_OPS(1, t, 3, toff_cur);
+        CN_MFMA(0);
+        if (t + 1 < ntaps) CN_LOAD_OPS(0, t + 1, 0, toff_nxt);
+        CN_MFMA(1);
+        toff_cur = toff_nxt;
+      }
+#undef CN_LOAD_OPS
+#undef CN_MFMA
+    }
+#undef CN_PREFETCH_V
+  }
+
+  float* yb = y + (long)b * g.ybs;
+  const int HWout = g.Hout * g.Wout;
+  const bool first = blockIdx.z == 0;
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = n0 + wn * (TN * 32) + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < g.Cout) {
+        const float bv = (g.has_bias && first) ? bias[co] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          if (pix_ok[tm]) {
+            float* dst = yb + (long)co * HWout + out_off[tm];
+            const float v = acc[tn][tm][r] + bv;
+            if (g.atomic_out) {
+              atomicAdd(dst, v);
+            } else if (g.accumulate) {
+              *dst += v;
+            } else {
+              *dst = v;
+            }
           }
         }
       }
@@ -187,99 +449,255 @@ extern "C" int cn_pack_weights_f32(const float* w, float* wp, int T, int K, int 
   return cn_check_launch();
 }
 
-template <int WAVES_N, int TN>
-static int cn_launch_igemm(const float* x, const float* wp, const float* bias, float* y, CnConvGeom g,
-                           hipStream_t stream) {
-  constexpr int MT = (4 / WAVES_N) * 64;
+template <int WAVES_N, int TN, int TM, int NV>
+static int cn_launch_igemm_v(const float* x, const float* wp, const float* bias, float* y, CnConvGeom& g,
+                             int total_tiles, int max_taps, int splits, double flops, hipStream_t stream) {
   constexpr int NT = WAVES_N * TN * 32;
-  const int Mimg = g.Hg * g.Wg;
-  if (Mimg <= 0 || g.B <= 0) return CN_OK;
-  int rows_g = (MT + g.Wg - 2) / g.Wg + 1;
-  if (rows_g > g.Hg) rows_g = g.Hg;
-  int max_dy = g.min_dy, max_dx = g.min_dx;
-  for (int t = 0; t < g.ntaps; ++t) {
-    if (g.dy[t] > max_dy) max_dy = g.dy[t];
-    if (g.dx[t] > max_dx) max_dx = g.dx[t];
-  }
-  g.rows_cap = (rows_g - 1) * g.is + (max_dy - g.min_dy) + 1;
-  g.pitch = (g.Wg - 1) * g.is + (max_dx - g.min_dx) + 1;
-  g.plane = g.rows_cap * g.pitch;
-  if (g.plane > NI * 256) return CN_ERR_LDS;
-  g.w_lds_off = (KC * g.plane + 3) / 4 * 4;
-  g.tiles_per_img = (Mimg + MT - 1) / MT;
-  const size_t lds = (size_t)(g.w_lds_off + (g.ntaps > 0 ? g.ntaps : 1) * KC * NT) * sizeof(float);
+  g.tap_lds_off = g.w_lds_off + (max_taps > 0 ? max_taps : 1) * KC * NT;
+  const size_t lds = (size_t)(g.tap_lds_off + 3 * CN_MAX_TAPS + 1) * sizeof(float);
   if (lds > 160 * 1024) return CN_ERR_LDS;
   static bool attr_set = false;
   if (!attr_set) {
-    hipFuncSetAttribute((const void*)cn_conv_igemm_kernel<WAVES_N, TN>,
-                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    (void)hipFuncSetAttribute((const void*)cn_conv_igemm_vec_kernel<WAVES_N, TN, TM, NV>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  dim3 grid(g.B * g.tiles_per_img, (g.Cout + NT - 1) / NT);
+  dim3 grid(total_tiles, (g.Cout + NT - 1) / NT, splits);
   cn_prof_before(stream);
-  hipLaunchKernelGGL((cn_conv_igemm_kernel<WAVES_N, TN>), grid, dim3(256), lds, stream, x, wp, bias, y, g);
-  cn_prof_after(stream, NT == 128 ? 0 : 1, 2.0 * g.B * Mimg * (double)g.Cout * g.Cin * g.ntaps);
+  hipLaunchKernelGGL((cn_conv_igemm_vec_kernel<WAVES_N, TN, TM, NV>), grid, dim3(256), lds, stream, x, wp, bias, y, g);
+  cn_prof_after(stream, NT == 128 ? 0 : 1, flops);
   return cn_check_launch();
 }
 
-int cn_conv_igemm_launch(const float* x, const float* wp, const float* bias, float* y, CnConvGeom g,
-                         hipStream_t stream) {
-  if (g.ntaps < 0 || g.ntaps > CN_MAX_TAPS) return CN_ERR_ARG;
-  g.min_dy = 0;
-  g.min_dx = 0;
-  for (int t = 0; t < g.ntaps; ++t) {
-    if (t == 0 || g.dy[t] < g.min_dy) g.min_dy = g.dy[t];
-    if (t == 0 || g.dx[t] < g.min_dx) g.min_dx = g.dx[t];
+template <int WAVES_N, int TN, int NI_T>
+static int cn_launch_igemm_t(const float* x, const float* wp, const float* bias, float* y, CnConvGeom& g,
+                             int total_tiles, int max_taps, int splits, double flops, hipStream_t stream) {
+  constexpr int NT = WAVES_N * TN * 32;
+  g.tap_lds_off = g.w_lds_off + (max_taps > 0 ? max_taps : 1) * KC * NT;
+  const size_t lds = (size_t)(g.tap_lds_off + 3 * CN_MAX_TAPS + 1) * sizeof(float);
+  if (lds > 160 * 1024) return CN_ERR_LDS;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)cn_conv_igemm_kernel<WAVES_N, TN, NI_T>,
+                              hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+    attr_set = true;
   }
+  dim3 grid(total_tiles, (g.Cout + NT - 1) / NT, splits);
+  cn_prof_before(stream);
+  hipLaunchKernelGGL((cn_conv_igemm_kernel<WAVES_N, TN, NI_T>), grid, dim3(256), lds, stream, x, wp, bias, y, g);
+  cn_prof_after(stream, NT == 128 ? 0 : 1, flops);
+  return cn_check_launch();
+}
+
+// Per-class LDS / tiling geometry for pixel tiles of MT pixels.
+struct CnPlan {
+  int total_tiles, max_plane, max_vplane, max_taps;
+  double flops;
+};
+
+static CnPlan cn_plan(CnConvGeom& g, int MT) {
+  CnPlan p = {0, 0, 0, 0, 0.0};
+  for (int c = 0; c < g.ncls; ++c) {
+    CnConvClass& k = g.cls[c];
+    const int Mimg = k.Hg * k.Wg;
+    int rows_g = (MT + k.Wg - 2) / k.Wg + 1;
+    if (rows_g > k.Hg) rows_g = k.Hg;
+    k.min_dy = 0; k.min_dx = 0;
+    int max_dy = 0, max_dx = 0;
+    for (int t = 0; t < k.ntaps; ++t) {
+      if (t == 0 || k.dy[t] < k.min_dy) k.min_dy = k.dy[t];
+      if (t == 0 || k.dx[t] < k.min_dx) k.min_dx = k.dx[t];
+      if (t == 0 || k.dy[t] > max_dy) max_dy = k.dy[t];
+      if (t == 0 || k.dx[t] > max_dx) max_dx = k.dx[t];
+    }
+    const int rows = (rows_g - 1) * g.is + (max_dy - k.min_dy) + 1;
+    k.pitch = (k.Wg - 1) * g.is + (max_dx - k.min_dx) + 1;
+    k.plane = rows * k.pitch;
+    k.vplane = (rows * g.Win + (max_dx - k.min_dx) + 4 + 3) / 4 * 4;
+    k.tiles_per_img = (Mimg + MT - 1) / MT;
+    k.block_begin = p.total_tiles;
+    p.total_tiles += g.B * k.tiles_per_img;
+    if (k.plane > p.max_plane) p.max_plane = k.plane;
+    if (k.vplane > p.max_vplane) p.max_vplane = k.vplane;
+    if (k.ntaps > p.max_taps) p.max_taps = k.ntaps;
+    p.flops += 2.0 * g.B * Mimg * (double)g.Cout * g.Cin * k.ntaps;
+  }
+  return p;
+}
+
+// Tile / split-K choice. The f32 MFMA loop keeps ~2 blocks per CU resident (512 slots on the chip), so a launch
+// costs ceil(blocks / 512) rounds of (MT pixels x chunks-per-split); pick the pixel tile and the K split that
+// minimise it (e.g. 8 chips of 100x100: MT=160 gives 504 blocks = one round, MT=128 gives 632 = two).
+struct CnChoice { int cfg, splits, cps; double cost; };
+
+static CnChoice cn_choose(const CnConvGeom& g0, const int* mts, int ncfg, int NT, bool allow_split) {
+  const int nchunks = (g0.Cin + KC - 1) / KC;
+  const int ny = (g0.Cout + NT - 1) / NT;
+  CnConvGeom g = g0;
+  const CnPlan p0 = cn_plan(g, mts[0]);
+  const long base_blocks = (long)p0.total_tiles * ny;
+  CnChoice best = {0, 1, nchunks > 0 ? nchunks : 1, 1e300};
+  if (base_blocks >= 384 || !allow_split || p0.max_taps == 0 || nchunks < 4) {
+    // big launch: no K split; pick the pixel tile with the fewest (rounds x tile) units
+    for (int i = 0; i < ncfg; ++i) {
+      CnConvGeom gi = g0;
+      const CnPlan p = cn_plan(gi, mts[i]);
+      if (p.total_tiles <= 0) continue;
+      const long rounds = ((long)p.total_tiles * ny + 511) / 512;
+      const double cost = (double)rounds * mts[i] * (i == 0 ? 1.0 : 1.08);  // prefer the default tile on near-ties
+      if (cost < best.cost) best = {i, 1, best.cps, cost};
+    }
+    return best;
+  }
+  // small launch: default tile, split K so that about two blocks per CU exist
+  int splits = (int)((512 + base_blocks - 1) / base_blocks);
+  if (splits > nchunks / 2) splits = nchunks / 2;
+  if (splits > 32) splits = 32;
+  if (splits < 1) splits = 1;
+  const int cps = (nchunks + splits - 1) / splits;
+  best.cfg = 0;
+  best.cps = cps;
+  best.splits = (nchunks + cps - 1) / cps;
+  return best;
+}
+
+static int cn_finish_split(CnConvGeom& g, const CnPlan& p, int splits, int cps, float* y, hipStream_t stream) {
+  const int nchunks = (g.Cin + KC - 1) / KC;
+  g.chunks_per_split = cps > 0 ? cps : (nchunks > 0 ? nchunks : 1);
+  if (p.max_taps == 0) g.chunks_per_split = nchunks > 0 ? nchunks : 1;
+  g.atomic_out = splits > 1;
+  if (g.atomic_out && !g.accumulate) {
+    if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)g.B * g.Cout * g.Hout * g.Wout, stream) != hipSuccess)
+      return CN_ERR_LAUNCH;
+  }
+  return CN_OK;
+}
+
+template <int WAVES_N, int TN, int TM>
+static int cn_launch_vec_cfg(const float* x, const float* wp, const float* bias, float* y, CnConvGeom& g, int splits,
+                             int cps, hipStream_t stream) {
+  constexpr int MT = (4 / WAVES_N) * TM * 32;
+  const CnPlan p = cn_plan(g, MT);
+  if (p.total_tiles <= 0) return CN_OK;
+  g.w_lds_off = KC * p.max_vplane;
+  const int rc = cn_finish_split(g, p, splits, cps, y, stream);
+  if (rc != CN_OK) return rc;
+  if (p.max_vplane <= 1024)
+    return cn_launch_igemm_v<WAVES_N, TN, TM, 1>(x, wp, bias, y, g, p.total_tiles, p.max_taps, splits, p.flops, stream);
+  if (p.max_vplane <= 2048)
+    return cn_launch_igemm_v<WAVES_N, TN, TM, 2>(x, wp, bias, y, g, p.total_tiles, p.max_taps, splits, p.flops, stream);
+  return cn_launch_igemm_v<WAVES_N, TN, TM, 4>(x, wp, bias, y, g, p.total_tiles, p.max_taps, splits, p.flops, stream);
+}
+
+template <int WAVES_N, int TN>
+static int cn_launch_dword_cfg(const float* x, const float* wp, const float* bias, float* y, CnConvGeom& g,
+                               int splits, int cps, hipStream_t stream) {
+  constexpr int MT = (4 / WAVES_N) * 64;
+  const CnPlan p = cn_plan(g, MT);
+  if (p.total_tiles <= 0) return CN_OK;
+  if (p.max_plane > 12 * 256) return CN_ERR_LDS;
+  g.w_lds_off = (KC * p.max_plane + 3) / 4 * 4;
+  const int rc = cn_finish_split(g, p, splits, cps, y, stream);
+  if (rc != CN_OK) return rc;
+  if (p.max_plane <= 3 * 256)
+    return cn_launch_igemm_t<WAVES_N, TN, 3>(x, wp, bias, y, g, p.total_tiles, p.max_taps, splits, p.flops, stream);
+  if (p.max_plane <= 6 * 256)
+    return cn_launch_igemm_t<WAVES_N, TN, 6>(x, wp, bias, y, g, p.total_tiles, p.max_taps, splits, p.flops, stream);
+  return cn_launch_igemm_t<WAVES_N, TN, 12>(x, wp, bias, y, g, p.total_tiles, p.max_taps, splits, p.flops, stream);
+}
+
+int cn_conv_igemm_launch(const float* x, const float* wp, const float* bias, float* y, CnConvGeom& g,
+                         hipStream_t stream) {
+  if (g.ncls < 1 || g.ncls > CN_MAX_CLASSES || g.B <= 0) return g.B <= 0 ? CN_OK : CN_ERR_ARG;
   g.Kpad = cn_conv_kpad(g.Cin);
   g.Npad = cn_conv_npad(g.Cout);
   const int nt = cn_pick_nt(g.Cout);
-  if (nt == 32) return cn_launch_igemm<1, 1>(x, wp, bias, y, g, stream);
-  if (nt == 64) return cn_launch_igemm<1, 2>(x, wp, bias, y, g, stream);
-  return cn_launch_igemm<2, 2>(x, wp, bias, y, g, stream);
+  const bool dense_out = g.ybs == (long)g.Cout * g.Hout * g.Wout;
+  const bool allow_split = dense_out || g.accumulate;
+  bool vec = (((long)g.Hin * g.Win) % 4 == 0) && (g.xbs % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (vec) {  // the flattened-row image of the largest tile must fit 4096 floats
+    CnConvGeom t = g;
+    vec = cn_plan(t, 256).max_vplane <= 4 * 1024;
+  }
+  if (nt == 128) {
+    if (vec) {
+      static const int mts[3] = {128, 96, 160};  // MT=192 (TM=6) needs > 256 registers: one wave per SIMD
+      const CnChoice c = cn_choose(g, mts, 3, 128, allow_split);
+      switch (c.cfg) {
+        case 1: return cn_launch_vec_cfg<4, 1, 3>(x, wp, bias, y, g, c.splits, c.cps, stream);
+        case 2: return cn_launch_vec_cfg<4, 1, 5>(x, wp, bias, y, g, c.splits, c.cps, stream);
+        default: return cn_launch_vec_cfg<2, 2, 2>(x, wp, bias, y, g, c.splits, c.cps, stream);
+      }
+    }
+    static const int mts[1] = {128};
+    const CnChoice c = cn_choose(g, mts, 1, 128, allow_split);
+    return cn_launch_dword_cfg<2, 2>(x, wp, bias, y, g, c.splits, c.cps, stream);
+  }
+  static const int mts[1] = {256};
+  const CnChoice c = cn_choose(g, mts, 1, nt, allow_split);
+  if (nt == 64) {
+    if (vec) return cn_launch_vec_cfg<1, 2, 2>(x, wp, bias, y, g, c.splits, c.cps, stream);
+    return cn_launch_dword_cfg<1, 2>(x, wp, bias, y, g, c.splits, c.cps, stream);
+  }
+  if (vec) return cn_launch_vec_cfg<1, 1, 2>(x, wp, bias, y, g, c.splits, c.cps, stream);
+  return cn_launch_dword_cfg<1, 1>(x, wp, bias, y, g, c.splits, c.cps, stream);
 }
 
 static inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+// Gather form (Conv2d forward, ConvTranspose2d backward-data): one class, input coord = o*stride + k*dil - pad.
+static int cn_gather_conv(const float* x, long xbs, const float* wp, const float* bias, float* y, long ybs, int B,
+                          int Cin, int Hin, int Win, int Cout, int Hout, int Wout, int KH, int KW, int stride,
+                          int pad, int dil, int accumulate, hipStream_t stream) {
+  if (KH * KW > CN_MAX_TAPS || stride < 1 || dil < 1) return CN_ERR_ARG;
+  if (Hout <= 0 || Wout <= 0) return CN_OK;
+  CnConvGeom g = {};
+  g.B = B; g.Cin = Cin; g.Hin = Hin; g.Win = Win; g.Cout = Cout; g.Hout = Hout; g.Wout = Wout;
+  g.xbs = xbs; g.ybs = ybs; g.is = stride; g.os = 1;
+  g.ncls = 1;
+  CnConvClass& k = g.cls[0];
+  k.Hg = Hout; k.Wg = Wout; k.oy0 = 0; k.ox0 = 0;
+  k.ntaps = KH * KW;
+  for (int ky = 0; ky < KH; ++ky)
+    for (int kx = 0; kx < KW; ++kx) {
+      const int t = ky * KW + kx;
+      k.dy[t] = ky * dil - pad; k.dx[t] = kx * dil - pad; k.wt[t] = t;
+    }
+  g.accumulate = accumulate; g.has_bias = bias != nullptr;
+  return cn_conv_igemm_launch(x, wp, bias, y, g, stream);
+}
 
 // Conv2d forward. x [B,Cin,Hin,Win] (batch stride xbs), wp packed [KH*KW][Kpad(Cin)][Npad(Cout)],
 // y [B,Cout,Hout,Wout] (batch stride ybs).
 extern "C" int cn_conv2d_fwd_f32(const float* x, long xbs, const float* wp, const float* bias, float* y,
                                  long ybs, int B, int Cin, int Hin, int Win, int Cout, int KH, int KW,
                                  int stride, int pad, int dil, int accumulate, void* stream) {
-  if (KH * KW > CN_MAX_TAPS || stride < 1 || dil < 1) return CN_ERR_ARG;
-  CnConvGeom g = {};
-  g.B = B; g.Cin = Cin; g.Hin = Hin; g.Win = Win; g.Cout = Cout;
-  g.Hout = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
-  g.Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
-  g.xbs = xbs; g.ybs = ybs;
-  g.Hg = g.Hout; g.Wg = g.Wout; g.is = stride; g.os = 1; g.oy0 = 0; g.ox0 = 0;
-  g.ntaps = KH * KW;
-  for (int ky = 0; ky < KH; ++ky)
-    for (int kx = 0; kx < KW; ++kx) {
-      const int t = ky * KW + kx;
-      g.dy[t] = ky * dil - pad; g.dx[t] = kx * dil - pad; g.wt[t] = t;
-    }
-  g.accumulate = accumulate; g.has_bias = bias != nullptr;
-  return cn_conv_igemm_launch(x, wp, bias, y, g, (hipStream_t)stream);
+  const int Hout = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  return cn_gather_conv(x, xbs, wp, bias, y, ybs, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride, pad, dil,
+                        accumulate, (hipStream_t)stream);
 }
 
-// Shared by Conv2d backward-data and ConvTranspose2d forward:
+// Scatter form shared by Conv2d backward-data and ConvTranspose2d forward:
 //   out[o] (+)= bias + sum_k src[(o + pad - k*dil)/s] * W[k]   where divisible,
-// decomposed into s*s parity classes of the output grid so that no MAC is wasted.
+// as s*s parity classes of the output grid in ONE launch (no zero-stuffing, no wasted MACs).
 // src [B,Csrc,Hs,Ws], out [B,Cdst,Ho,Wo]; wp packed [KH*KW][Kpad(Csrc)][Npad(Cdst)].
 static int cn_scatter_conv(const float* src, long sbs, const float* wp, const float* bias, float* out, long obs,
                            int B, int Csrc, int Hs, int Ws, int Cdst, int Ho, int Wo, int KH, int KW,
                            int stride, int pad, int dil, int accumulate, hipStream_t stream) {
-  if (KH * KW > CN_MAX_TAPS || stride < 1 || dil < 1) return CN_ERR_ARG;
+  if (KH * KW > CN_MAX_TAPS || stride < 1 || dil < 1 || stride * stride > CN_MAX_CLASSES) return CN_ERR_ARG;
+  CnConvGeom g = {};
+  g.B = B; g.Cin = Csrc; g.Hin = Hs; g.Win = Ws; g.Cout = Cdst; g.Hout = Ho; g.Wout = Wo;
+  g.xbs = sbs; g.ybs = obs; g.is = 1; g.os = stride;
+  g.accumulate = accumulate; g.has_bias = bias != nullptr;
+  int nc = 0;
   for (int py = 0; py < stride; ++py)
     for (int px = 0; px < stride; ++px) {
-      CnConvGeom g = {};
-      g.B = B; g.Cin = Csrc; g.Hin = Hs; g.Win = Ws; g.Cout = Cdst; g.Hout = Ho; g.Wout = Wo;
-      g.xbs = sbs; g.ybs = obs;
-      g.Hg = (Ho - py + stride - 1) / stride;
-      g.Wg = (Wo - px + stride - 1) / stride;
-      if (g.Hg <= 0 || g.Wg <= 0) continue;
-      g.is = 1; g.os = stride; g.oy0 = py; g.ox0 = px;
+      CnConvClass& k = g.cls[nc];
+      k.Hg = (Ho - py + stride - 1) / stride;
+      k.Wg = (Wo - px + stride - 1) / stride;
+      if (k.Hg <= 0 || k.Wg <= 0) continue;
+      k.oy0 = py; k.ox0 = px;
       int nt = 0;
       for (int ky = 0; ky < KH; ++ky) {
         const int ny = py + pad - ky * dil;
@@ -287,16 +705,16 @@ static int cn_scatter_conv(const float* src, long sbs, const float* wp, const fl
         for (int kx = 0; kx < KW; ++kx) {
           const int nx = px + pad - kx * dil;
           if (((nx % stride) + stride) % stride != 0) continue;
-          g.dy[nt] = floordiv(ny, stride); g.dx[nt] = floordiv(nx, stride); g.wt[nt] = ky * KW + kx;
+          k.dy[nt] = floordiv(ny, stride); k.dx[nt] = floordiv(nx, stride); k.wt[nt] = ky * KW + kx;
           ++nt;
         }
       }
-      g.ntaps = nt;
-      g.accumulate = accumulate; g.has_bias = bias != nullptr;
-      const int rc = cn_conv_igemm_launch(src, wp, bias, out, g, stream);
-      if (rc != CN_OK) return rc;
+      k.ntaps = nt;
+      ++nc;
     }
-  return CN_OK;
+  g.ncls = nc;
+  if (nc == 0) return CN_OK;
+  return cn_conv_igemm_launch(src, wp, bias, out, g, stream);
 }
 
 // Conv2d backward-data: dx [B,Cin,Hin,Win] (+)= conv^T(dy [B,Cout,Hout,Wout]); wp packed with K=Cout, N=Cin.
@@ -323,21 +741,10 @@ extern "C" int cn_conv_transpose2d_fwd_f32(const float* x, long xbs, const float
 extern "C" int cn_conv_transpose2d_bwd_data_f32(const float* dy, long dybs, const float* wp_t, float* dx,
                                                 long dxbs, int B, int Cin, int Hin, int Win, int Cout, int KH,
                                                 int KW, int stride, int pad, int accumulate, void* stream) {
-  CnConvGeom g = {};
   const int Hout = (Hin - 1) * stride - 2 * pad + KH;
   const int Wout = (Win - 1) * stride - 2 * pad + KW;
-  g.B = B; g.Cin = Cout; g.Hin = Hout; g.Win = Wout; g.Cout = Cin; g.Hout = Hin; g.Wout = Win;
-  g.xbs = dybs; g.ybs = dxbs;
-  g.Hg = Hin; g.Wg = Win; g.is = stride; g.os = 1;
-  g.ntaps = KH * KW;
-  if (g.ntaps > CN_MAX_TAPS) return CN_ERR_ARG;
-  for (int ky = 0; ky < KH; ++ky)
-    for (int kx = 0; kx < KW; ++kx) {
-      const int t = ky * KW + kx;
-      g.dy[t] = ky - pad; g.dx[t] = kx - pad; g.wt[t] = t;
-    }
-  g.accumulate = accumulate; g.has_bias = 0;
-  return cn_conv_igemm_launch(dy, wp_t, nullptr, dx, g, (hipStream_t)stream);
+  return cn_gather_conv(dy, dybs, wp_t, nullptr, dx, dxbs, B, Cout, Hout, Wout, Cin, Hin, Win, KH, KW, stride, pad,
+                        1, accumulate, (hipStream_t)stream);
 }
 
 // --------------------------------------------------------------------------

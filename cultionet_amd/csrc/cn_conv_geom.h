@@ -1,23 +1,34 @@
 // Geometry of one implicit-GEMM launch (passed by value as a kernel argument).
 #pragma once
 #define CN_MAX_TAPS 9
+#define CN_MAX_CLASSES 16
+
+// One parity class of the output grid (a plain convolution has exactly one).
+//   input coord = g*is + d[t],  output coord = g*os + o0
+struct CnConvClass {
+  int Hg, Wg;        // logical pixel grid of this class (per image)
+  int oy0, ox0;
+  int ntaps;
+  int dy[CN_MAX_TAPS], dx[CN_MAX_TAPS], wt[CN_MAX_TAPS];  // input offsets; tap index in packed weights
+  int min_dy, min_dx;
+  int pitch, plane;  // LDS halo plane of this class (plane = rows * pitch <= NI*256)
+  int vplane;        // 16-byte path: floats of the flattened-row image (multiple of 4)
+  int tiles_per_img;
+  int block_begin;   // first blockIdx.x of this class
+};
 
 struct CnConvGeom {
   // gathered tensor [B, Cin, Hin, Win] and written tensor [B, Cout, Hout, Wout]
   int B, Cin, Hin, Win;
   int Cout, Hout, Wout;
   long xbs, ybs;  // batch strides in elements (channel stride is H*W)
-  // logical pixel grid of this launch (per image): input coord = g*is + d[t], output coord = g*os + o0
-  int Hg, Wg;
-  int is;
-  int os, oy0, ox0;
-  // taps: input offsets and the index of each tap in the packed weights [T][Kpad][Npad]
-  int ntaps;
-  int dy[CN_MAX_TAPS], dx[CN_MAX_TAPS], wt[CN_MAX_TAPS];
-  int min_dy, min_dx;
-  // LDS staging geometry (filled in by the launcher)
-  int rows_cap, pitch, plane, w_lds_off;
-  int Kpad, Npad;
-  int tiles_per_img;
+  int is, os;
+  int Kpad, Npad;           // packed weights [T][Kpad][Npad]
+  int w_lds_off;            // float offset of the weight tile in LDS (after KC * max plane)
+  int tap_lds_off;          // float offset of the per-class tap table in LDS
+  int chunks_per_split;     // K-chunks (of 8 channels) per grid.z slice
+  int atomic_out;           // split-K: accumulate with atomics into a pre-initialised output
   int accumulate, has_bias;
+  int ncls;
+  CnConvClass cls[CN_MAX_CLASSES];
 };

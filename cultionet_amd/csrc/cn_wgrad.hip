@@ -18,6 +18,8 @@
 #define WG_BC 32   // b-channels per block
 #define WG_NS 4    // max S elements per lane per row of the chunk  (chunk pixels <= 256)
 #define WG_NB 13   // max Bg plane elements per lane               (plane_b <= 832)
+#define WG_KS 8    // 16-byte variant: DMA instructions per wave for the S image  (arows*npix <= 8192 floats)
+#define WG_KB 12   // 16-byte variant: DMA instructions per wave for the Bg image (32*plane_b <= 12288 floats)
 
 struct CnWgradGeom {
   int N;
@@ -32,15 +34,28 @@ struct CnWgradGeom {
   int rows_b, pitch_b, plane_b;
   int a_tiles;       // 32-row tiles of A per block (1, 2 or 4)
   int chunks_per_img, total_chunks, chunks_per_split;
-  int b_lds_off;
+  int b_lds_off;   // float offset of the Bg planes inside one LDS buffer
+  int buf_stride;  // floats per LDS buffer
+  int nbuf;        // 2: double-buffered LDS-DMA pipeline, 1: single buffer
 };
 
+typedef __attribute__((address_space(3))) void* cn_lds_ptr;
+typedef const __attribute__((address_space(1))) void* cn_gbl_ptr;
+
+__device__ float cn_zero_line[64];  // zero source for out-of-image lanes of an LDS-DMA load
+
+// One LDS-DMA wave-instruction: lane l copies 4 bytes from its own `src` to lds_base[l] (no VGPR round trip).
+__device__ __forceinline__ void cn_glds4(const float* src, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((cn_gbl_ptr)src, (cn_lds_ptr)lds_wave_base, 4, 0, 0);
+}
+
+// Staging is done entirely by LDS-DMA (global_load_lds): every lane always loads (out-of-image lanes read a
+// zero line), so a chunk's ~70 wave-instructions are all in flight at once instead of round-tripping through
+// VGPRs; with two LDS buffers the next chunk lands while the MFMAs of the current one run.
 template <int T>
-__global__ __launch_bounds__(256, 2) void cn_wgrad_kernel(const float* __restrict__ S, const float* __restrict__ Bg,
+__global__ __launch_bounds__(256) void cn_wgrad_kernel(const float* __restrict__ S, const float* __restrict__ Bg,
                                                       float* __restrict__ dW, const CnWgradGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* s_lds = smem;                // [a_tiles*32][pitch_s]
-  float* b_lds = smem + g.b_lds_off;  // [WG_BC][plane_b]
 
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
@@ -48,9 +63,10 @@ __global__ __launch_bounds__(256, 2) void cn_wgrad_kernel(const float* __restric
   const int a0 = blockIdx.y * g.a_tiles * 32;
   const int b0 = blockIdx.x * WG_BC;
   const int npix = g.PR * g.Wsp;  // staged (padded) grid pixels per chunk, even
+  const float* zero = cn_zero_line + lane;
 
-  // ---- per-lane staging decode (chunk independent)
-  int so[WG_NS];  // (row << 16 | col) of the element inside the chunk; col 0xFFFF = zero pad; -2 = skip
+  // ---- per-lane staging decode (chunk independent), packed (row << 16 | col)
+  int so[WG_NS];  // col 0xFFFF = zero pad; -2 = lane idle for this piece
 #pragma unroll
   for (int i = 0; i < WG_NS; ++i) {
     const int e = lane + i * 64;
@@ -61,7 +77,7 @@ __global__ __launch_bounds__(256, 2) void cn_wgrad_kernel(const float* __restric
       so[i] = -2;
     }
   }
-  int bo[WG_NB];  // (row << 16 | col) inside the staged Bg plane; -1 -> skip
+  int bo[WG_NB];  // -1 -> lane idle
 #pragma unroll
   for (int i = 0; i < WG_NB; ++i) {
     const int e = lane + i * 64;
@@ -101,47 +117,57 @@ __global__ __launch_bounds__(256, 2) void cn_wgrad_kernel(const float* __restric
   const int e_begin = q_begin * 2;
   const int r_begin = e_begin / g.Wsp, c_begin = e_begin - r_begin * g.Wsp;
 
-  for (; chunk < chunk_end; ++chunk) {
-    const int n = chunk / g.chunks_per_img;
-    const int gy0 = (chunk - n * g.chunks_per_img) * g.PR;
+  // ---- LDS-DMA staging of one chunk into buffer `buf`
+  auto stage = [&](int ck, int buf) {
+    float* s_lds = smem + buf * g.buf_stride;
+    float* b_lds = s_lds + g.b_lds_off;
+    const int n = ck / g.chunks_per_img;
+    const int gy0 = (ck - n * g.chunks_per_img) * g.PR;
     const int pr = (g.Hs - gy0 < g.PR) ? g.Hs - gy0 : g.PR;
-    __syncthreads();
-    // ---- stage S rows [arows][PR*Wsp]; zero for a >= A, padded col, rows past the image
-    {
-      const float* Sn = S + (long)n * g.sbs + (long)gy0 * g.Ws;
-      for (int a = wid; a < arows; a += 4) {
-        const bool aok = (a0 + a) < g.A;
-        const float* Sa = Sn + (long)(a0 + a) * HWs;
+    const float* Sn = S + (long)n * g.sbs + (long)gy0 * g.Ws;
+    for (int a = wid; a < arows; a += 4) {
+      const bool aok = (a0 + a) < g.A;
+      const float* Sa = Sn + (long)(a0 + a) * HWs;
 #pragma unroll
-        for (int i = 0; i < WG_NS; ++i) {
+      for (int i = 0; i < WG_NS; ++i) {
+        if (i * 64 < npix) {  // wave-uniform
           if (so[i] != -2) {
             const int r = so[i] >> 16, c = so[i] & 0xFFFF;
-            float v = 0.f;
-            if (aok && c != 0xFFFF && r < pr) v = Sa[r * g.Ws + c];
-            s_lds[a * g.pitch_s + lane + i * 64] = v;
+            const float* src = (aok && c != 0xFFFF && r < pr) ? Sa + r * g.Ws + c : zero;
+            cn_glds4(src, s_lds + a * g.pitch_s + i * 64);
           }
         }
       }
     }
-    // ---- stage Bg halo planes [WG_BC][rows_b][pitch_b]; zero outside the image / past Bc
-    {
-      const float* Bn = Bg + (long)n * g.bbs;
-      const int iy0 = gy0 * g.s + g.min_oy;
-      for (int bl = wid; bl < WG_BC; bl += 4) {
-        const bool bok = (b0 + bl) < g.Bc;
-        const float* Bb = Bn + (long)(b0 + bl) * HWb;
+    const float* Bn = Bg + (long)n * g.bbs;
+    const int iy0 = gy0 * g.s + g.min_oy;
+    for (int bl = wid; bl < WG_BC; bl += 4) {
+      const bool bok = (b0 + bl) < g.Bc;
+      const float* Bb = Bn + (long)(b0 + bl) * HWb;
 #pragma unroll
-        for (int i = 0; i < WG_NB; ++i) {
+      for (int i = 0; i < WG_NB; ++i) {
+        if (i * 64 < g.plane_b) {  // wave-uniform
           if (bo[i] >= 0) {
             const int iy = iy0 + (bo[i] >> 16), ix = g.min_ox + (bo[i] & 0xFFFF);
-            float v = 0.f;
-            if (bok && iy >= 0 && iy < g.Hb && ix >= 0 && ix < g.Wb) v = Bb[iy * g.Wb + ix];
-            b_lds[bl * g.plane_b + lane + i * 64] = v;
+            const float* src = (bok && iy >= 0 && iy < g.Hb && ix >= 0 && ix < g.Wb) ? Bb + iy * g.Wb + ix : zero;
+            cn_glds4(src, b_lds + bl * g.plane_b + i * 64);
           }
         }
       }
     }
-    __syncthreads();
+  };
+
+  int cur = 0;
+  if (chunk < chunk_end && g.nbuf == 2) stage(chunk, 0);
+  for (; chunk < chunk_end; ++chunk) {
+    if (g.nbuf == 1) {
+      __syncthreads();  // everyone is done reading the single buffer
+      stage(chunk, 0);
+    }
+    __syncthreads();  // (vmcnt(0) first) this chunk's DMA has landed; previous compute finished
+    if (g.nbuf == 2 && chunk + 1 < chunk_end) stage(chunk + 1, cur ^ 1);
+    const float* s_lds = smem + cur * g.buf_stride;
+    const float* b_lds = s_lds + g.b_lds_off;
     // ---- MFMA: k = pixel pairs (col, col+1) of the chunk
     int r = r_begin, c = c_begin;
     for (int q = q_begin; q < q_end; ++q) {
@@ -155,6 +181,7 @@ __global__ __launch_bounds__(256, 2) void cn_wgrad_kernel(const float* __restric
       c += 2;
       if (c >= g.Wsp) { c = 0; ++r; }
     }
+    if (g.nbuf == 2) cur ^= 1;
   }
 
   // ---- epilogue: D[i = a][j = n]; lanes walk n = b*T + t -> contiguous in dW
@@ -169,6 +196,233 @@ __global__ __launch_bounds__(256, 2) void cn_wgrad_kernel(const float* __restric
       if (bok && a < g.A) atomicAdd(dW + (long)a * g.sa + (long)b0 * T + n, acc[j][r]);
     }
   }
+}
+
+__device__ float cn_zero_line16[256];  // 1 KiB of zeros: per-lane 16-byte zero source
+
+__device__ __forceinline__ void cn_glds16(const float* src, float* lds_wave_base) {
+  __builtin_amdgcn_global_load_lds((cn_gbl_ptr)src, (cn_lds_ptr)lds_wave_base, 16, 0, 0);
+}
+
+// 16-byte LDS-DMA variant ("flattened rows"): needs 16-byte aligned channel planes (Hs*Ws % 4 == 0,
+// Hb*Wb % 4 == 0, strides % 4 == 0) and (PR*Ws) % 4 == 0. The S rows of a chunk are one contiguous flat range;
+// the Bg halo rows too (unpadded, pitch = Wb), so row overruns are zero-filled per 16-byte piece by a flat
+// bound check and column overruns (which wrap into the neighbouring row) are masked per lane at operand read.
+// One DMA wave-instruction moves 1 KiB instead of 256 B: the per-CU DMA issue rate (~1 per 100 cycles)
+// is what bounded the dword version.
+template <int T>
+__global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restrict__ S, const float* __restrict__ Bg,
+                                                          float* __restrict__ dW, const CnWgradGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  const int at = wid % g.a_tiles, kp = wid / g.a_tiles, kparts = 4 / g.a_tiles;
+  const int a0 = blockIdx.y * g.a_tiles * 32;
+  const int b0 = blockIdx.x * WG_BC;
+  const int npix = g.PR * g.Ws;   // unpadded, even, multiple of 4
+  const int n4s = npix >> 2;      // float4 pieces per S row (<= 64)
+  const int n4b = g.plane_b >> 2; // float4 pieces per Bg channel image
+  const float* zero = cn_zero_line16 + 4 * lane;
+  const int HWs = g.Hs * g.Ws, HWb = g.Hb * g.Wb;
+
+  int boff[T], ox[T];
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    const int n = j * 32 + l31;
+    const int bl = n / T, t = n - bl * T;
+    boff[j] = bl * g.plane_b + (g.offy[t] - g.min_oy) * g.Wb + (g.offx[t] - g.min_ox) + half * g.s;
+    ox[j] = g.offx[t] + half * g.s;
+  }
+  const int aoff = (at * 32 + l31) * g.pitch_s + half;
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int j = 0; j < T; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int arows = g.a_tiles * 32;
+  int chunk = blockIdx.z * g.chunks_per_split;
+  int chunk_end = chunk + g.chunks_per_split;
+  if (chunk_end > g.total_chunks) chunk_end = g.total_chunks;
+
+  const int steps = npix >> 1;
+  const int q_begin = (steps * kp) / kparts, q_end = (steps * (kp + 1)) / kparts;
+  const int e_begin = q_begin * 2;
+  const int r_begin = e_begin / g.Ws, c_begin = e_begin - r_begin * g.Ws;
+
+  // dense LDS images: S [arows][npix], Bg [WG_BC][plane_b]; piece p of an image = its p-th 16 bytes, so one
+  // DMA wave-instruction (64 consecutive pieces = 1 KiB) may span several rows / channels.
+  int sp[WG_KS], bp[WG_KB];  // packed (row << 16 | piece-in-row) of this lane's piece in instruction k; -1 idle
+  {
+    const int nsp = arows * n4s, nbp = WG_BC * n4b;
+#pragma unroll
+    for (int k = 0; k < WG_KS; ++k) {
+      const int p = (wid + 4 * k) * 64 + lane;
+      sp[k] = p < nsp ? ((p / n4s) << 16) | (p % n4s) : -1;
+    }
+#pragma unroll
+    for (int k = 0; k < WG_KB; ++k) {
+      const int p = (wid + 4 * k) * 64 + lane;
+      bp[k] = p < nbp ? ((p / n4b) << 16) | (p % n4b) : -1;
+    }
+  }
+  auto stage = [&](int ck, int buf) {
+    float* s_lds = smem + buf * g.buf_stride;
+    float* b_lds = s_lds + g.b_lds_off;
+    const int n = ck / g.chunks_per_img;
+    const int gy0 = (ck - n * g.chunks_per_img) * g.PR;
+    const int nsp = arows * n4s, nbp = WG_BC * n4b;
+    {
+      const float* Sn = S + (long)n * g.sbs + (long)gy0 * g.Ws;
+      const int fs0 = gy0 * g.Ws;
+#pragma unroll
+      for (int k = 0; k < WG_KS; ++k) {
+        if ((wid + 4 * k) * 64 < nsp) {  // wave-uniform
+          if (sp[k] >= 0) {
+            const int a = sp[k] >> 16, pc = sp[k] & 0xFFFF;
+            const bool ok = (a0 + a) < g.A && (fs0 + 4 * pc + 3) < HWs;
+            const float* src = ok ? Sn + (long)(a0 + a) * HWs + 4 * pc : zero;
+            cn_glds16(src, s_lds + (wid + 4 * k) * 256);
+          }
+        }
+      }
+    }
+    {
+      const int start = (gy0 * g.s + g.min_oy) * g.Wb + g.min_ox;
+      const int f0 = (start >> 2) << 2;
+      const float* Bn = Bg + (long)n * g.bbs;
+#pragma unroll
+      for (int k = 0; k < WG_KB; ++k) {
+        if ((wid + 4 * k) * 64 < nbp) {  // wave-uniform
+          if (bp[k] >= 0) {
+            const int bl = bp[k] >> 16, fq = f0 + 4 * (bp[k] & 0xFFFF);
+            const bool ok = (b0 + bl) < g.Bc && fq >= 0 && (fq + 3) < HWb;
+            const float* src = ok ? Bn + (long)(b0 + bl) * HWb + fq : zero;
+            cn_glds16(src, b_lds + (wid + 4 * k) * 256);
+          }
+        }
+      }
+    }
+  };
+
+  int cur = 0;
+  if (chunk < chunk_end && g.nbuf == 2) stage(chunk, 0);
+  for (; chunk < chunk_end; ++chunk) {
+    if (g.nbuf == 1) {
+      __syncthreads();
+      stage(chunk, 0);
+    }
+    __syncthreads();
+    if (g.nbuf == 2 && chunk + 1 < chunk_end) stage(chunk + 1, cur ^ 1);
+    const float* s_lds = smem + cur * g.buf_stride;
+    const float* b_lds = s_lds + g.b_lds_off;
+    const int gy0c = (chunk % g.chunks_per_img) * g.PR;
+    const int start = (gy0c * g.s + g.min_oy) * g.Wb + g.min_ox;
+    const int sh = start - ((start >> 2) << 2);
+    // operands of k-step q+1 are read from LDS while the MFMAs of k-step q run (1 wave per SIMD: nothing
+    // else hides the LDS latency); column masks are only evaluated on the first/last pixel pair of a row.
+    int r = r_begin, c = c_begin;
+    float av_n, bv_n[T];
+    {
+      av_n = s_lds[aoff + r * g.Ws + c];
+      const int bbase = (r * g.s) * g.Wb + c * g.s + sh;
+#pragma unroll
+      for (int j = 0; j < T; ++j) bv_n[j] = b_lds[boff[j] + bbase];
+    }
+    for (int q = q_begin; q < q_end; ++q) {
+      const float av = av_n;
+      float bv[T];
+#pragma unroll
+      for (int j = 0; j < T; ++j) bv[j] = bv_n[j];
+      const int cs = c * g.s;
+      const bool edge = (c == 0) || (c + 2 >= g.Ws);  // wave-uniform
+      c += 2;
+      if (c >= g.Ws) { c = 0; ++r; }
+      if (q + 1 < q_end) {
+        av_n = s_lds[aoff + r * g.Ws + c];
+        const int bbase = (r * g.s) * g.Wb + c * g.s + sh;
+#pragma unroll
+        for (int j = 0; j < T; ++j) bv_n[j] = b_lds[boff[j] + bbase];
+      }
+      if (edge) {
+#pragma unroll
+        for (int j = 0; j < T; ++j) bv[j] = ((unsigned)(cs + ox[j]) < (unsigned)g.Wb) ? bv[j] : 0.f;
+      }
+#pragma unroll
+      for (int j = 0; j < T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[j], 0, 0, 0);
+    }
+    if (g.nbuf == 2) cur ^= 1;
+  }
+
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    const int n = j * 32 + l31;
+    const int bl = n / T;
+    const bool bok = (b0 + bl) < g.Bc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int a = a0 + at * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (bok && a < g.A) atomicAdd(dW + (long)a * g.sa + (long)b0 * T + n, acc[j][r]);
+    }
+  }
+}
+
+// Launch of the 16-byte variant; returns CN_ERR_ARG when its alignment preconditions do not hold.
+template <int T>
+static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgradGeom g, hipStream_t stream) {
+  const long HWs = (long)g.Hs * g.Ws, HWb = (long)g.Hb * g.Wb;
+  if (HWs % 4 || HWb % 4 || g.sbs % 4 || g.bbs % 4 || (g.Ws & 1)) return CN_ERR_ARG;
+  if ((reinterpret_cast<uintptr_t>(S) & 15) || (reinterpret_cast<uintptr_t>(Bg) & 15)) return CN_ERR_ARG;
+  g.Wsp = g.Ws;
+  g.PR = 128 / g.Ws;
+  if (g.PR < 1) g.PR = 1;
+  if (g.PR > g.Hs) g.PR = g.Hs;
+  while (g.PR > 1 && ((g.PR * g.Ws) % 4 != 0 || g.Hs % g.PR != 0)) --g.PR;
+  if ((g.PR * g.Ws) % 4 != 0 || g.PR * g.Ws > 256) return CN_ERR_ARG;
+  int max_oy = g.min_oy, max_ox = g.min_ox;
+  for (int t = 0; t < g.T; ++t) {
+    if (g.offy[t] > max_oy) max_oy = g.offy[t];
+    if (g.offx[t] > max_ox) max_ox = g.offx[t];
+  }
+  g.rows_b = (g.PR - 1) * g.s + (max_oy - g.min_oy) + 1;
+  g.pitch_b = g.Wb;
+  // last read: (rows_b-1)*Wb + (Ws-1)*s + (max_ox-min_ox) + sh(<=3)
+  g.plane_b = ((g.rows_b - 1) * g.Wb + (g.Ws - 1) * g.s + (max_ox - g.min_ox) + 4 + 3) / 4 * 4;
+  if (WG_BC * g.plane_b > WG_KB * 4 * 256) return CN_ERR_ARG;
+  g.pitch_s = g.PR * g.Ws;  // dense image (DMA pieces run across rows)
+  g.a_tiles = g.A > 32 ? 2 : 1;
+  size_t lds;
+  for (;;) {
+    g.b_lds_off = (g.a_tiles * 32 * g.pitch_s + 255) / 256 * 256;  // whole DMA instructions
+    g.buf_stride = g.b_lds_off + (WG_BC * g.plane_b + 255) / 256 * 256;
+    lds = (size_t)g.buf_stride * sizeof(float);
+    if ((lds <= 160 * 1024 && g.a_tiles * 32 * g.pitch_s <= WG_KS * 4 * 256) || g.a_tiles == 1) break;
+    g.a_tiles >>= 1;
+  }
+  if (lds > 160 * 1024 || g.a_tiles * 32 * g.pitch_s > WG_KS * 4 * 256) return CN_ERR_ARG;
+  g.nbuf = (2 * lds <= 160 * 1024) ? 2 : 1;
+  lds *= g.nbuf;
+  g.chunks_per_img = g.Hs / g.PR;
+  g.total_chunks = g.N * g.chunks_per_img;
+  const int gx = (g.Bc + WG_BC - 1) / WG_BC, gy = (g.A + g.a_tiles * 32 - 1) / (g.a_tiles * 32);
+  const int slots = (lds * 2 <= 160 * 1024) ? 512 : 256;  // resident blocks on the chip
+  int splits = slots / (gx * gy);                         // never spill into a second, mostly idle round
+  if (splits > g.total_chunks) splits = g.total_chunks;
+  if (splits < 1) splits = 1;
+  g.chunks_per_split = (g.total_chunks + splits - 1) / splits;
+  splits = (g.total_chunks + g.chunks_per_split - 1) / g.chunks_per_split;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute((const void*)cn_wgrad_vec_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    attr_set = true;
+  }
+  cn_prof_before(stream);
+  hipLaunchKernelGGL((cn_wgrad_vec_kernel<T>), dim3(gx, gy, splits), dim3(256), lds, stream, S, Bg, dW, g);
+  cn_prof_after(stream, T == 9 ? 2 : 3, 2.0 * g.N * g.Hs * g.Ws * (double)g.A * g.Bc * g.T);
+  return cn_check_launch();
 }
 
 template <int T>
@@ -199,11 +453,14 @@ static int cn_wgrad_launch_t(const float* S, const float* Bg, float* dW, CnWgrad
   size_t lds;
   for (;;) {
     g.b_lds_off = (g.a_tiles * 32 * g.pitch_s + 3) / 4 * 4;
-    lds = (size_t)(g.b_lds_off + WG_BC * g.plane_b) * sizeof(float);
+    g.buf_stride = (g.b_lds_off + WG_BC * g.plane_b + 3) / 4 * 4;
+    lds = (size_t)g.buf_stride * sizeof(float);
     if (lds <= 160 * 1024 || g.a_tiles == 1) break;
     g.a_tiles >>= 1;
   }
   if (lds > 160 * 1024) return CN_ERR_LDS;
+  g.nbuf = (2 * lds <= 160 * 1024) ? 2 : 1;
+  lds *= g.nbuf;
   g.chunks_per_img = (g.Hs + g.PR - 1) / g.PR;
   g.total_chunks = g.N * g.chunks_per_img;
   const int gx = (g.Bc + WG_BC - 1) / WG_BC, gy = (g.A + g.a_tiles * 32 - 1) / (g.a_tiles * 32);
@@ -240,9 +497,11 @@ static int cn_wgrad_generic(const float* S, long sbs, int A, int Hs, int Ws, con
     }
   g.min_oy = -pad; g.min_ox = -pad;
   g.sa = (long)Bc * g.T;
-  if (g.T == 1) return cn_wgrad_launch_t<1>(S, Bg, dW, g, stream);
-  if (g.T == 9) return cn_wgrad_launch_t<9>(S, Bg, dW, g, stream);
-  return CN_ERR_ARG;
+  if (g.T != 1 && g.T != 9) return CN_ERR_ARG;
+  // 16-byte DMA variant when the alignment preconditions hold, dword variant otherwise
+  int rc = g.T == 1 ? cn_wgrad_launch_vec<1>(S, Bg, dW, g, stream) : cn_wgrad_launch_vec<9>(S, Bg, dW, g, stream);
+  if (rc != CN_ERR_ARG) return rc;
+  return g.T == 1 ? cn_wgrad_launch_t<1>(S, Bg, dW, g, stream) : cn_wgrad_launch_t<9>(S, Bg, dW, g, stream);
 }
 
 // Conv2d: dw [Cout][Cin][KH][KW] += x (*) dy. NOTE accumulates: zero dw first for a fresh gradient.

@@ -7,7 +7,7 @@ opt = torch.optim.AdamW(m.parameters(), lr=0.01, weight_decay=1e-3, eps=1e-4, be
 x,y,b = O.seeded_batch(8, seed=7)
 print("affinity", len(os.sched_getaffinity(0)), "cpu_count", os.cpu_count())
 os.system("lscpu | egrep 'Model name|Socket|Core|Thread' ")
-for nt in (16, 32, 64, 128):
+for nt in (4, 8, 16, 24):
     torch.set_num_threads(nt)
     ts=[]
     for i in range(2):
