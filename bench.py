@@ -39,21 +39,26 @@ def parse():
     ap.add_argument("--batch", type=int, default=8, help="chips per GPU")
     ap.add_argument("--hidden", type=int, default=32)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-steps", type=int, default=2)
+    ap.add_argument("--cpu-steps", type=int, default=4)
+    ap.add_argument("--cpu-threads", type=int, default=0, help="0 = best of the documented sweep (16)")
     return ap.parse_args()
 
 
-def cpu_baseline(batch: int, hidden: int, steps: int):
+def cpu_baseline(batch: int, hidden: int, steps: int, threads: int = 0):
     """The oracle (port of the reference CPU path) timed on the host cores: fwd + loss + bwd + AdamW."""
     import torch
 
     from oracle import towerunet_oracle as O
 
-    cores = os.cpu_count() or 1
+    avail = os.cpu_count() or 1
     try:
-        cores = len(os.sched_getaffinity(0))
+        avail = len(os.sched_getaffinity(0))
     except Exception:
         pass
+    # Thread count: the best of a sweep on the GPU box's host (2 x EPYC 9575F, 256 logical CPUs), batch 8:
+    # 4 thr 2.1, 8 thr 2.8, 16 thr 3.3-3.5, 24 thr 3.0, 32 thr 2.8, 64 thr 1.6, 128 thr 0.74, 256 thr 0.03 chips/s
+    # (oneDNN scales poorly on these small 100x100 chips); `cores` reports the threads actually used.
+    cores = min(threads, avail) if threads else min(16, avail)
     torch.set_num_threads(cores)
     m = O.TowerUNet(3, 12, hidden_channels=hidden)
     m.load_state_dict(O.seeded_state_dict(m.state_dict()))
@@ -191,7 +196,7 @@ def main():
             },
         }
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, hidden, args.cpu_steps)
+            out["cpu_baseline"] = cpu_baseline(B, hidden, args.cpu_steps, args.cpu_threads)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

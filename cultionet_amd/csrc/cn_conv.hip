@@ -227,8 +227,9 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __r
   constexpr int MT = WAVES_M * TM * 32;
   constexpr int NT = WAVES_N * TN * 32;
   constexpr int WI = (CN_MAX_TAPS * KC * (NT / 4) + 255) / 256;
+  constexpr int VS = NV * 1024;  // LDS channel stride (floats): compile-time so channel-pair offsets are DS immediates
   extern __shared__ __attribute__((aligned(16))) float smem[];
-  float* in_lds = smem;               // [KC][vplane]
+  float* in_lds = smem;               // [KC][VS]
   float* w_lds = smem + g.w_lds_off;  // [ntaps*KC][NT]
   int* tap_lds = reinterpret_cast<int*>(smem + g.tap_lds_off);
 
@@ -284,7 +285,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __r
     pix_ok[tm] = p < Mimg;
     const int pc = pix_ok[tm] ? p : Mimg - 1;
     const int gy = pc / Wg, gx = pc - gy * Wg;
-    pix_lds[tm] = ((gy - gy0) * g.is) * Win + gx * g.is + sh + half * vplane;
+    pix_lds[tm] = ((gy - gy0) * g.is) * Win + gx * g.is + sh + half * VS;
     out_off[tm] = (gy * g.os + oy0) * g.Wout + gx * g.os + ox0;
     unsigned m = 0;
     for (int t = 0; t < ntaps; ++t) {
@@ -342,7 +343,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __r
       for (int ci = 0; ci < KC; ++ci)
 #pragma unroll
         for (int i = 0; i < NV; ++i)
-          if (goff[i] != -2) *reinterpret_cast<f32x4*>(in_lds + ci * vplane + 4 * (tid + i * 256)) = xin[ci][i];
+          if (goff[i] != -2) *reinterpret_cast<f32x4*>(in_lds + ci * VS + 4 * (tid + i * 256)) = xin[ci][i];
 #pragma unroll
       for (int j = 0; j < WI; ++j) {
         const int f = tid + j * 256;
@@ -350,38 +351,35 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __r
       }
       __syncthreads();
       if (ch + 1 < ch_end) CN_PREFETCH_V((ch + 1) * KC);
-      // Operands of step (t, cp+1) are read from LDS before the MFMAs of step (t, cp) issue (two register
-      // sets, static indices); the tap loop stays rolled to bound register pressure.
-      float opa[2][TN], opb[2][TM];
-#define CN_LOAD_OPS(bf_, t_, cp_, toff_)                                                                   \
-  {                                                                                                        \
-    const float* wrow = w_lds + ((t_) * KC + half) * NT + wn * (TN * 32) + l31;                            \
-    _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) opa[bf_][tn] = wrow[(2 * (cp_)) * NT + tn * 32];     \
-    _Pragma("unroll") for (int tm = 0; tm < TM; ++tm) {                                                    \
-      const float b_ = in_lds[pix_lds[tm] + (2 * (cp_)) * vplane + (toff_)];                               \
-      opb[bf_][tm] = ((colmask[tm] >> (t_)) & 1u) ? b_ : 0.f;                                              \
-    }                                                                                                      \
-  }
-#define CN_MFMA(bf_)                                                                                       \
-  _Pragma("unroll") for (int tn = 0; tn < TN; ++tn) _Pragma("unroll") for (int tm = 0; tm < TM; ++tm)      \
-      acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(opa[bf_][tn], opb[bf_][tm], acc[tn][tm], 0, 0, 0);
-      int toff_cur = tap_lds[0];
-      CN_LOAD_OPS(0, 0, 0, toff_cur);
+      // Per tap: one LDS base address and one 0/-1 column mask per pixel tile; the four channel-pair steps then
+      // need no address VALU (compile-time immediates) and one v_and per operand. The f32 MFMA shares the SIMD's
+      // vector issue port with VALU work, so instructions-per-MFMA is what bounds this loop.
 #pragma unroll 1
       for (int t = 0; t < ntaps; ++t) {
-        const int toff_nxt = (t + 1 < ntaps) ? tap_lds[t + 1] : 0;
-        CN_LOAD_OPS(1, t, 1, toff_cur);
-        CN_MFMA(0);
-        CN_LOAD_OPS(0, t, 2, toff_cur);
-        CN_MFMA(1);
-        CN_LOAD_OPS(1, t, 3, toff_cur);
-        CN_MFMA(0);
-        if (t + 1 < ntaps) CN_LOAD_OPS(0, t + 1, 0, toff_nxt);
-        CN_MFMA(1);
-        toff_cur = toff_nxt;
+        const int toff = tap_lds[t];
+        const float* wrow = w_lds + (t * KC + half) * NT + wn * (TN * 32) + l31;
+        const float* brow[TM];
+        int msk[TM];
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          brow[tm] = in_lds + pix_lds[tm] + toff;
+          msk[tm] = -(int)((colmask[tm] >> t) & 1u);
+        }
+#pragma unroll
+        for (int cp = 0; cp < KC / 2; ++cp) {
+          float a[TN], bb[TM];
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn) a[tn] = wrow[(2 * cp) * NT + tn * 32];
+#pragma unroll
+          for (int tm = 0; tm < TM; ++tm)
+            bb[tm] = __int_as_float(__float_as_int(brow[tm][(2 * cp) * VS]) & msk[tm]);
+#pragma unroll
+          for (int tn = 0; tn < TN; ++tn)
+#pragma unroll
+            for (int tm = 0; tm < TM; ++tm)
+              acc[tn][tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[tn], bb[tm], acc[tn][tm], 0, 0, 0);
+        }
       }
-#undef CN_LOAD_OPS
-#undef CN_MFMA
     }
 #undef CN_PREFETCH_V
   }
@@ -549,8 +547,8 @@ static CnChoice cn_choose(const CnConvGeom& g0, const int* mts, int ncfg, int NT
     }
     return best;
   }
-  // small launch: default tile, split K so that about two blocks per CU exist
-  int splits = (int)((512 + base_blocks - 1) / base_blocks);
+  // small launch: default tile, split K so that the launch stays within ONE round of ~2 blocks per CU
+  int splits = (int)(512 / base_blocks);
   if (splits > nchunks / 2) splits = nchunks / 2;
   if (splits > 32) splits = 32;
   if (splits < 1) splits = 1;
@@ -579,7 +577,7 @@ static int cn_launch_vec_cfg(const float* x, const float* wp, const float* bias,
   constexpr int MT = (4 / WAVES_N) * TM * 32;
   const CnPlan p = cn_plan(g, MT);
   if (p.total_tiles <= 0) return CN_OK;
-  g.w_lds_off = KC * p.max_vplane;
+  g.w_lds_off = KC * 1024 * (p.max_vplane <= 1024 ? 1 : (p.max_vplane <= 2048 ? 2 : 4));
   const int rc = cn_finish_split(g, p, splits, cps, y, stream);
   if (rc != CN_OK) return rc;
   if (p.max_vplane <= 1024)

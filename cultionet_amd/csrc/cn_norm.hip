@@ -240,23 +240,28 @@ extern "C" int cn_bn_act_bwd_f32(const float* x, long xbs, const float* dy, long
 // Per-channel sum over [B][C][L] (bias gradients): out[c] (+)= sum x[b,c,l]
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cn_channel_sum_kernel(const float* __restrict__ x, long xbs, int B, int C,
-                                                            int L, float* __restrict__ out, int accumulate) {
+                                                            int L, int splits, float* __restrict__ out) {
   __shared__ double scratch[4];
-  const int c = blockIdx.x;
+  const int c = blockIdx.x, sp = blockIdx.y;
+  const int per = (L + splits - 1) / splits;
+  const int beg = sp * per;
+  const int end = (beg + per < L) ? beg + per : L;
   double s = 0.0;
   for (int b = 0; b < B; ++b) {
     const float* xp = x + b * xbs + (long)c * L;
-    for (int l = threadIdx.x; l < L; l += 256) s += xp[l];
+    for (int l = beg + threadIdx.x; l < end; l += 256) s += xp[l];
   }
   s = cn_block_sum<double, 256>(s, scratch);
-  if (threadIdx.x == 0) out[c] = accumulate ? out[c] + (float)s : (float)s;
+  if (threadIdx.x == 0) atomicAdd(out + c, (float)s);
 }
 
 extern "C" int cn_channel_sum_f32(const float* x, long xbs, int B, int C, int L, float* out, int accumulate,
-                                  void* stream) {
+                                  void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
   if (C <= 0) return CN_OK;
-  hipLaunchKernelGGL(cn_channel_sum_kernel, dim3(C), dim3(256), 0, (hipStream_t)stream, x, xbs, B, C, L, out,
-                     accumulate);
+  if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, stream) != hipSuccess) return CN_ERR_LAUNCH;
+  const int splits = bn_splits(C, L);
+  hipLaunchKernelGGL(cn_channel_sum_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, B, C, L, splits, out);
   return cn_check_launch();
 }
 

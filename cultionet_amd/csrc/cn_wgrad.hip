@@ -19,6 +19,7 @@
 #define WG_NS 4    // max S elements per lane per row of the chunk  (chunk pixels <= 256)
 #define WG_NB 13   // max Bg plane elements per lane               (plane_b <= 832)
 #define WG_KS 8    // 16-byte variant: DMA instructions per wave for the S image  (arows*npix <= 8192 floats)
+#define WG_U 4     // 16-byte variant: k-steps per unrolled group
 #define WG_KB 12   // 16-byte variant: DMA instructions per wave for the Bg image (32*plane_b <= 12288 floats)
 
 struct CnWgradGeom {
@@ -37,6 +38,7 @@ struct CnWgradGeom {
   int b_lds_off;   // float offset of the Bg planes inside one LDS buffer
   int buf_stride;  // floats per LDS buffer
   int nbuf;        // 2: double-buffered LDS-DMA pipeline, 1: single buffer
+  int colsplit;    // 16-byte variant: waves split the columns of each row (Ws/kparts even)
 };
 
 typedef __attribute__((address_space(3))) void* cn_lds_ptr;
@@ -210,7 +212,7 @@ __device__ __forceinline__ void cn_glds16(const float* src, float* lds_wave_base
 // bound check and column overruns (which wrap into the neighbouring row) are masked per lane at operand read.
 // One DMA wave-instruction moves 1 KiB instead of 256 B: the per-CU DMA issue rate (~1 per 100 cycles)
 // is what bounded the dword version.
-template <int T>
+template <int T, int S_>
 __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restrict__ S, const float* __restrict__ Bg,
                                                           float* __restrict__ dW, const CnWgradGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -321,37 +323,61 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
     const int gy0c = (chunk % g.chunks_per_img) * g.PR;
     const int start = (gy0c * g.s + g.min_oy) * g.Wb + g.min_ox;
     const int sh = start - ((start >> 2) << 2);
-    // operands of k-step q+1 are read from LDS while the MFMAs of k-step q run (1 wave per SIMD: nothing
-    // else hides the LDS latency); column masks are only evaluated on the first/last pixel pair of a row.
-    int r = r_begin, c = c_begin;
-    float av_n, bv_n[T];
+    // One wave per SIMD issues everything in order, so instructions-per-MFMA bounds this loop: the pixel pairs
+    // of a row are walked in unrolled groups whose LDS offsets are compile-time immediates (stride S_), bases are
+    // bumped once per group, and the column masks are applied only on the first / last pair of an image row.
     {
-      av_n = s_lds[aoff + r * g.Ws + c];
-      const int bbase = (r * g.s) * g.Wb + c * g.s + sh;
+      // the pixel pairs of every row are split over the k-part waves
+      const int nq_row = g.Ws >> 1;
+      const int q_lo = (nq_row * kp) / kparts, q_hi = (nq_row * (kp + 1)) / kparts;
+      const int c_lo = 2 * q_lo;
+      const int nq = q_hi - q_lo;
+      for (int r = 0; r < g.PR; ++r) {
+        const float* ap = s_lds + aoff + r * g.Ws + c_lo;
+        const float* bp[T];
 #pragma unroll
-      for (int j = 0; j < T; ++j) bv_n[j] = b_lds[boff[j] + bbase];
-    }
-    for (int q = q_begin; q < q_end; ++q) {
-      const float av = av_n;
-      float bv[T];
+        for (int j = 0; j < T; ++j) bp[j] = b_lds + boff[j] + sh + (r * S_) * g.Wb + c_lo * S_;
+        int q = 0;
+        if (q_lo == 0 && nq > 0) {  // first pair of the row: column -1 wraps into the previous row -> mask
+          const float av = ap[0];
 #pragma unroll
-      for (int j = 0; j < T; ++j) bv[j] = bv_n[j];
-      const int cs = c * g.s;
-      const bool edge = (c == 0) || (c + 2 >= g.Ws);  // wave-uniform
-      c += 2;
-      if (c >= g.Ws) { c = 0; ++r; }
-      if (q + 1 < q_end) {
-        av_n = s_lds[aoff + r * g.Ws + c];
-        const int bbase = (r * g.s) * g.Wb + c * g.s + sh;
+          for (int j = 0; j < T; ++j) {
+            float bv = bp[j][0];
+            bv = ((unsigned)(ox[j]) < (unsigned)g.Wb) ? bv : 0.f;
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+          }
+          q = 1;
+        }
+        const int q_last = (q_hi == nq_row) ? nq - 1 : nq;  // last pair of the row handled below
+        for (; q + WG_U <= q_last; q += WG_U) {
+          const float* apq = ap + 2 * q;
 #pragma unroll
-        for (int j = 0; j < T; ++j) bv_n[j] = b_lds[boff[j] + bbase];
+          for (int u = 0; u < WG_U; ++u) {
+            const float av = apq[2 * u];
+#pragma unroll
+            for (int j = 0; j < T; ++j) {
+              const float bv = (bp[j] + 2 * q * S_)[2 * u * S_];
+              acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+            }
+          }
+        }
+        for (; q < q_last; ++q) {
+          const float av = ap[2 * q];
+#pragma unroll
+          for (int j = 0; j < T; ++j)
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[j][2 * q * S_], acc[j], 0, 0, 0);
+        }
+        if (q_last < nq) {  // last pair: column Ws wraps into the next row -> mask
+          const float av = ap[2 * q_last];
+          const int cs = (c_lo + 2 * q_last) * S_;
+#pragma unroll
+          for (int j = 0; j < T; ++j) {
+            float bv = bp[j][2 * q_last * S_];
+            bv = ((unsigned)(cs + ox[j]) < (unsigned)g.Wb) ? bv : 0.f;
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+          }
+        }
       }
-      if (edge) {
-#pragma unroll
-        for (int j = 0; j < T; ++j) bv[j] = ((unsigned)(cs + ox[j]) < (unsigned)g.Wb) ? bv[j] : 0.f;
-      }
-#pragma unroll
-      for (int j = 0; j < T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[j], 0, 0, 0);
     }
     if (g.nbuf == 2) cur ^= 1;
   }
@@ -415,12 +441,22 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
   splits = (g.total_chunks + g.chunks_per_split - 1) / g.chunks_per_split;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)cn_wgrad_vec_kernel<T>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    (void)hipFuncSetAttribute((const void*)cn_wgrad_vec_kernel<T, 1>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                              160 * 1024);
+    (void)hipFuncSetAttribute((const void*)cn_wgrad_vec_kernel<T, 2>, hipFuncAttributeMaxDynamicSharedMemorySize,
                               160 * 1024);
     attr_set = true;
   }
+  if (g.s != 1 && g.s != 2) return CN_ERR_ARG;
+  {
+    const int kparts = 4 / g.a_tiles;
+    g.colsplit = (g.Ws % (2 * kparts) == 0) ? 1 : 0;
+  }
   cn_prof_before(stream);
-  hipLaunchKernelGGL((cn_wgrad_vec_kernel<T>), dim3(gx, gy, splits), dim3(256), lds, stream, S, Bg, dW, g);
+  if (g.s == 1)
+    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 1>), dim3(gx, gy, splits), dim3(256), lds, stream, S, Bg, dW, g);
+  else
+    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 2>), dim3(gx, gy, splits), dim3(256), lds, stream, S, Bg, dW, g);
   cn_prof_after(stream, T == 9 ? 2 : 3, 2.0 * g.N * g.Hs * g.Ws * (double)g.A * g.Bc * g.T);
   return cn_check_launch();
 }
