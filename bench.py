@@ -103,8 +103,12 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm = None
-    if world > 1:
+    use_dist = world > 1 or os.environ.get("CN_FORCE_COMM") == "1"  # CN_FORCE_COMM: exercise RCCL with one rank
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"  # RCCL's version banner goes to stdout; keep stdout to ONE JSON line
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         from cultionet_amd.ddp import GradientAllReduce
 
@@ -127,7 +131,7 @@ def main():
     trainer = HipTrainer(lit, gradient_clip_val=1.0, comm=comm)
 
     def sync():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -145,7 +149,7 @@ def main():
     loss_val = float(loss.item())
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
     dt = float(t.item())
 
@@ -198,7 +202,7 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, hidden, args.cpu_steps, args.cpu_threads)
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 

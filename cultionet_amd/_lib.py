@@ -22,6 +22,7 @@ SIGNATURES = {
     "cn_conv_kpad": [I],
     "cn_conv_npad": [I],
     "cn_pack_weights_f32": [P, P, I, I, I, L, L, L, P],
+    "cn_pack_weights_batched_f32": [P, I, P],
     "cn_conv2d_fwd_f32": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
     "cn_conv2d_bwd_data_f32": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
     "cn_conv2d_bwd_weight_f32": [P, L, P, L, P, I, I, I, I, I, I, I, I, I, I, P],

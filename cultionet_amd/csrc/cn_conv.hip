@@ -426,6 +426,27 @@ __global__ void cn_pack_weights_kernel(const float* __restrict__ w, float* __res
   }
 }
 
+// Batched repack of every weight tensor of a model in ONE launch (descriptor table in device memory):
+// after an optimizer step all ~180 packed copies are stale at once.
+struct CnPackDesc {
+  const float* w;
+  float* wp;
+  int T, K, N, Kpad, Npad;
+  long sk, sn, st;
+};
+
+__global__ void cn_pack_weights_batched_kernel(const CnPackDesc* __restrict__ descs) {
+  const CnPackDesc d = descs[blockIdx.y];
+  const long total = (long)d.T * d.Kpad * d.Npad;
+  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    const int n = (int)(i % d.Npad);
+    const long r = i / d.Npad;
+    const int k = (int)(r % d.Kpad);
+    const int t = (int)(r / d.Kpad);
+    d.wp[i] = (k < d.K && n < d.N) ? d.w[k * d.sk + n * d.sn + t * d.st] : 0.f;
+  }
+}
+
 // --------------------------------------------------------------------------
 // host side: geometry + launch
 // --------------------------------------------------------------------------
@@ -444,6 +465,15 @@ extern "C" int cn_pack_weights_f32(const float* w, float* wp, int T, int K, int 
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
   hipLaunchKernelGGL(cn_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, T, K, N,
                      Kpad, Npad, sk, sn, st);
+  return cn_check_launch();
+}
+
+// descs: DEVICE array of n descriptors {w, wp, T, K, N, Kpad, Npad, sk, sn, st} (layout of CnPackDesc: two
+// pointers, five ints + 4 bytes padding, three longs = 64 bytes).
+extern "C" int cn_pack_weights_batched_f32(const void* descs, int n, void* stream) {
+  if (n <= 0) return CN_OK;
+  hipLaunchKernelGGL(cn_pack_weights_batched_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream,
+                     (const CnPackDesc*)descs);
   return cn_check_launch();
 }
 

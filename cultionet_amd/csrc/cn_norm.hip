@@ -38,29 +38,6 @@ __global__ __launch_bounds__(256) void cn_bn_partial_kernel(const float* __restr
   }
 }
 
-// Finalize: mean / rstd (biased variance), running-stat update (momentum, unbiased variance).
-__global__ void cn_bn_finalize_kernel(const double* __restrict__ part, int C, int splits, double count, float eps,
-                                      float momentum, float* __restrict__ mean, float* __restrict__ rstd,
-                                      float* __restrict__ running_mean, float* __restrict__ running_var) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0, ss = 0.0;
-  for (int i = 0; i < splits; ++i) {
-    s += part[((long)c * splits + i) * 2 + 0];
-    ss += part[((long)c * splits + i) * 2 + 1];
-  }
-  const double m = s / count;
-  double var = ss / count - m * m;
-  if (var < 0.0) var = 0.0;
-  mean[c] = (float)m;
-  rstd[c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean != nullptr) {
-    const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-    running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)m;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-  }
-}
-
 // Eval mode: mean/rstd from running statistics.
 __global__ void cn_bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
                                         int C, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
@@ -71,15 +48,45 @@ __global__ void cn_bn_eval_stats_kernel(const float* __restrict__ running_mean, 
 }
 
 // y = act(gamma * (x - mean) * rstd + beta) (+ residual). act: 0 none, 1 SiLU.
+// Training (part != nullptr): every block reduces its channel's `splits` partial sums itself (a few dozen
+// doubles) instead of waiting for a separate finalize launch; block (0, c, 0) publishes mean / rstd for the
+// backward pass and updates the running statistics.
 __global__ __launch_bounds__(256) void cn_bn_apply_kernel(const float* __restrict__ x, long xbs,
-                                                         const float* __restrict__ mean,
-                                                         const float* __restrict__ rstd,
+                                                         float* __restrict__ mean, float* __restrict__ rstd,
                                                          const float* __restrict__ gamma,
                                                          const float* __restrict__ beta,
                                                          const float* __restrict__ res, long rbs,
-                                                         float* __restrict__ y, long ybs, int B, int C, int L, int act) {
+                                                         float* __restrict__ y, long ybs, int B, int C, int L, int act,
+                                                         const double* __restrict__ part, int splits, double count,
+                                                         float eps, float momentum, float* __restrict__ running_mean,
+                                                         float* __restrict__ running_var) {
   const int c = blockIdx.y, b = blockIdx.z;
-  const float m = mean[c], sc = gamma[c] * rstd[c], be = beta[c];
+  float m, rs;
+  if (part != nullptr) {
+    double s = 0.0, ss = 0.0;
+    for (int i = 0; i < splits; ++i) {
+      s += part[((long)c * splits + i) * 2 + 0];
+      ss += part[((long)c * splits + i) * 2 + 1];
+    }
+    const double md = s / count;
+    double var = ss / count - md * md;
+    if (var < 0.0) var = 0.0;
+    m = (float)md;
+    rs = (float)(1.0 / sqrt(var + (double)eps));
+    if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+      mean[c] = m;
+      rstd[c] = rs;
+      if (running_mean != nullptr) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+        running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+      }
+    }
+  } else {
+    m = mean[c];
+    rs = rstd[c];
+  }
+  const float sc = gamma[c] * rs, be = beta[c];
   const long r0 = (long)c * L;
   const float* xp = x + b * xbs + r0;
   const float* rp = res ? res + b * rbs + r0 : nullptr;
@@ -126,42 +133,38 @@ __global__ __launch_bounds__(256) void cn_bn_bwd_partial_kernel(const float* __r
   }
 }
 
-// Reduce the partials; dgamma/dbeta (+)=; coef[c] = {s1/N, s2/N} for the apply pass.
-__global__ void cn_bn_bwd_finalize_kernel(const double* __restrict__ part, int C, int splits, double count,
-                                          float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                          float* __restrict__ coef, int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < splits; ++i) {
-    s1 += part[((long)c * splits + i) * 2 + 0];
-    s2 += part[((long)c * splits + i) * 2 + 1];
-  }
-  if (accumulate) {
-    dgamma[c] += (float)s2;
-    dbeta[c] += (float)s1;
-  } else {
-    dgamma[c] = (float)s2;
-    dbeta[c] = (float)s1;
-  }
-  coef[2 * c + 0] = (float)(s1 / count);
-  coef[2 * c + 1] = (float)(s2 / count);
-}
-
 // Backward pass 2: dx (+)= gamma*rstd*(dz - mean(dz) - xhat*mean(dz*xhat))   [train]
-//                  dx (+)= gamma*rstd*dz                                        [eval: coef == nullptr]
+//                  dx (+)= gamma*rstd*dz                                        [eval]
+// Every block reduces its channel's partial sums itself; block (0, c, 0) accumulates dgamma / dbeta.
 __global__ __launch_bounds__(256) void cn_bn_bwd_apply_kernel(const float* __restrict__ x, long xbs,
                                                              const float* __restrict__ dy, long dybs,
                                                              const float* __restrict__ mean,
                                                              const float* __restrict__ rstd,
                                                              const float* __restrict__ gamma,
                                                              const float* __restrict__ beta,
-                                                             const float* __restrict__ coef,
-                                                             float* __restrict__ dx, long dxbs, int B, int C, int L,
-                                                             int act, int accumulate) {
+                                                             const double* __restrict__ part, int splits,
+                                                             double count, int training,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int accumulate_params, float* __restrict__ dx, long dxbs,
+                                                             int B, int C, int L, int act, int accumulate) {
   const int c = blockIdx.y, b = blockIdx.z;
+  double s1 = 0.0, s2 = 0.0;
+  for (int i = 0; i < splits; ++i) {
+    s1 += part[((long)c * splits + i) * 2 + 0];
+    s2 += part[((long)c * splits + i) * 2 + 1];
+  }
+  if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+    if (accumulate_params) {
+      dgamma[c] += (float)s2;
+      dbeta[c] += (float)s1;
+    } else {
+      dgamma[c] = (float)s2;
+      dbeta[c] = (float)s1;
+    }
+  }
+  if (dx == nullptr) return;
   const float m = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
-  const float c1 = coef ? coef[2 * c] : 0.f, c2 = coef ? coef[2 * c + 1] : 0.f;
+  const float c1 = training ? (float)(s1 / count) : 0.f, c2 = training ? (float)(s2 / count) : 0.f;
   const long r0 = (long)c * L;
   const float* xp = x + b * xbs + r0;
   const float* dp = dy + b * dybs + r0;
@@ -205,14 +208,16 @@ extern "C" int cn_bn_act_fwd_f32(const float* x, long xbs, const float* gamma, c
   if (training) {
     const int splits = bn_splits(C, L);
     hipLaunchKernelGGL(cn_bn_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, B, C, L, splits, ws);
-    hipLaunchKernelGGL(cn_bn_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, ws, C, splits,
-                       (double)B * L, eps, momentum, mean, rstd, running_mean, running_var);
+    hipLaunchKernelGGL(cn_bn_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, x, xbs, mean, rstd, gamma, beta,
+                       res, rbs, y, ybs, B, C, L, act, (const double*)ws, splits, (double)B * L, eps, momentum,
+                       running_mean, running_var);
   } else {
     hipLaunchKernelGGL(cn_bn_eval_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, running_mean,
                        running_var, C, eps, mean, rstd);
+    hipLaunchKernelGGL(cn_bn_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, x, xbs, mean, rstd, gamma, beta,
+                       res, rbs, y, ybs, B, C, L, act, (const double*)nullptr, 0, 1.0, eps, momentum,
+                       (float*)nullptr, (float*)nullptr);
   }
-  hipLaunchKernelGGL(cn_bn_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, x, xbs, mean,
-                     rstd, gamma, beta, res, rbs, y, ybs, B, C, L, act);
   return cn_check_launch();
 }
 
@@ -227,12 +232,10 @@ extern "C" int cn_bn_act_bwd_f32(const float* x, long xbs, const float* dy, long
   const int splits = bn_splits(C, L);
   hipLaunchKernelGGL(cn_bn_bwd_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, dy, dybs, mean, rstd,
                      gamma, beta, B, C, L, act, splits, ws);
-  hipLaunchKernelGGL(cn_bn_bwd_finalize_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, ws, C, splits,
-                     (double)B * L, dgamma, dbeta, coef, accumulate_params);
-  if (dx != nullptr)
-    hipLaunchKernelGGL(cn_bn_bwd_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, x, xbs,
-                       dy, dybs, mean, rstd, gamma, beta, training ? coef : (const float*)nullptr, dx, dxbs, B, C,
-                       L, act, accumulate_dx);
+  (void)coef;
+  hipLaunchKernelGGL(cn_bn_bwd_apply_kernel, dx != nullptr ? plane_grid(B, C, L) : dim3(1, C, 1), dim3(256), 0,
+                     stream, x, xbs, dy, dybs, mean, rstd, gamma, beta, (const double*)ws, splits, (double)B * L,
+                     training, dgamma, dbeta, accumulate_params, dx, dxbs, B, C, L, act, accumulate_dx);
   return cn_check_launch();
 }
 

@@ -171,6 +171,8 @@ class ParamStore:
                 p.data = view
         self.version = 0  # bumped whenever parameter values change (invalidates packed weights)
         self._base = self.flat.data_ptr()
+        self._packs: T.List[T.Tuple] = []      # (PackedWeight, attr, dst tensor, w ptr, T, K, N, sk, sn, st)
+        self._pack_table: T.Optional[torch.Tensor] = None
 
     def owns(self, module: torch.nn.Module) -> bool:
         lo, hi = self._base, self._base + self.numel * 4
@@ -194,6 +196,29 @@ class ParamStore:
 
     def bump(self) -> None:
         self.version += 1
+
+    def register_pack(self, pw, attr: str, dst: torch.Tensor, w: torch.Tensor, T_: int, K: int, N: int, sk: int,
+                      sn: int, st: int) -> None:
+        self._packs.append((pw, attr, dst, w.data_ptr(), T_, K, N, sk, sn, st))
+        self._pack_table = None
+
+    def repack_all(self) -> None:
+        """Refresh every registered packed weight copy with ONE launch (after the parameters changed)."""
+        if not self._packs:
+            return
+        if self._pack_table is None:
+            import struct
+
+            buf = bytearray()
+            for (_pw, _attr, dst, wptr, T_, K, N, sk, sn, st) in self._packs:
+                kp = _lib.query("cn_conv_kpad", K)
+                np_ = _lib.query("cn_conv_npad", N)
+                buf += struct.pack("<QQiiiiiiqqq", wptr, dst.data_ptr(), T_, K, N, kp, np_, 0, sk, sn, st)
+            host = torch.frombuffer(buf, dtype=torch.uint8).clone()
+            self._pack_table = host.to(self.flat.device)
+        _lib.call("cn_pack_weights_batched_f32", self._pack_table.data_ptr(), len(self._packs), _stream())
+        for (pw, _attr, _dst, *_rest) in self._packs:
+            pw.version = self.version
 
 
 def current_store() -> ParamStore:
@@ -228,20 +253,37 @@ def pgrad(p: torch.nn.Parameter) -> torch.Tensor:
 class PackedWeight:
     """Packed copies of one weight tensor for the implicit-GEMM kernels (forward / bwd-data)."""
 
-    __slots__ = ("fwd", "bwd", "version")
+    __slots__ = ("fwd", "bwd", "version", "store_id")
 
     def __init__(self):
         self.fwd = None
         self.bwd = None
         self.version = -1
+        self.store_id = 0
 
 
-def _pack(w: torch.Tensor, T_: int, K: int, N: int, sk: int, sn: int, st: int) -> torch.Tensor:
+def _pack(pw: "PackedWeight", attr: str, w: torch.Tensor, T_: int, K: int, N: int, sk: int, sn: int,
+          st: int) -> torch.Tensor:
+    """Pack now (first use) into a persistent buffer and register it for the batched per-step repack."""
     kp = _lib.query("cn_conv_kpad", K)
     np_ = _lib.query("cn_conv_npad", N)
     out = torch.empty(T_ * kp * np_, dtype=torch.float32, device=w.device)
     _lib.call("cn_pack_weights_f32", w.data_ptr(), out.data_ptr(), T_, K, N, sk, sn, st, _stream())
+    current_store().register_pack(pw, attr, out, w, T_, K, N, sk, sn, st)
     return out
+
+
+def _sync_packs(pw: "PackedWeight") -> None:
+    """Bring all registered packed weights up to date if the parameters changed since the last pack."""
+    st = current_store()
+    if pw.store_id != id(st):  # parameters were re-flattened into a new store: drop copies of the old one
+        pw.fwd = pw.bwd = None
+        pw.store_id = id(st)
+    if pw.version != st.version:
+        if pw.fwd is None and pw.bwd is None:
+            pw.version = st.version
+        else:
+            st.repack_all()
 
 
 def packed_conv(mod, need_bwd: bool) -> PackedWeight:
@@ -250,17 +292,14 @@ def packed_conv(mod, need_bwd: bool) -> PackedWeight:
     if pw is None:
         pw = PackedWeight()
         mod.__dict__["_cn_packed"] = pw
-    ver = current_store().version
-    if pw.version != ver:
-        pw.fwd = pw.bwd = None
-        pw.version = ver
+    _sync_packs(pw)
     w = mod.weight
     cout, cin = w.shape[0], w.shape[1]
     taps = int(w[0, 0].numel()) if w.dim() > 2 else 1
     if pw.fwd is None:
-        pw.fwd = _pack(w, taps, cin, cout, taps, cin * taps, 1)
+        pw.fwd = _pack(pw, "fwd", w, taps, cin, cout, taps, cin * taps, 1)
     if need_bwd and pw.bwd is None:
-        pw.bwd = _pack(w, taps, cout, cin, cin * taps, taps, 1)
+        pw.bwd = _pack(pw, "bwd", w, taps, cout, cin, cin * taps, taps, 1)
     return pw
 
 
@@ -270,17 +309,14 @@ def packed_convT(mod, need_bwd: bool) -> PackedWeight:
     if pw is None:
         pw = PackedWeight()
         mod.__dict__["_cn_packed"] = pw
-    ver = current_store().version
-    if pw.version != ver:
-        pw.fwd = pw.bwd = None
-        pw.version = ver
+    _sync_packs(pw)
     w = mod.weight
     cin, cout = w.shape[0], w.shape[1]
     taps = int(w[0, 0].numel())
     if pw.fwd is None:
-        pw.fwd = _pack(w, taps, cin, cout, cout * taps, taps, 1)
+        pw.fwd = _pack(pw, "fwd", w, taps, cin, cout, cout * taps, taps, 1)
     if need_bwd and pw.bwd is None:
-        pw.bwd = _pack(w, taps, cout, cin, taps, cout * taps, 1)
+        pw.bwd = _pack(pw, "bwd", w, taps, cout, cin, taps, cout * taps, 1)
     return pw
 
 
@@ -382,9 +418,10 @@ def time_conv(x: Var, mod, tin: int) -> Var:
     tout = tin - k + 1
     ver = current_store().version
     pw = mod.__dict__.get("_cn_packed")
-    if pw is None or pw.version != ver:
+    if pw is None or pw.version != ver or pw.store_id != id(current_store()):
         pw = PackedWeight()
         pw.version = ver
+        pw.store_id = id(current_store())
         mod.__dict__["_cn_packed"] = pw
     if pw.fwd is None:
         n = _lib.query("cn_conv_kpad", Cin * tin) * _lib.query("cn_conv_npad", Cout * tout)

@@ -39,6 +39,9 @@ int cn_version(void);
 int cn_conv_kpad(int k_in);
 int cn_conv_npad(int n_out);
 int cn_pack_weights_f32(const float* w, float* wp, int T, int K, int N, long sk, long sn, long st, void* stream);
+/* Same for n tensors in one launch. descs: DEVICE array of 64-byte records
+ * {const float* w; float* wp; int T, K, N, Kpad, Npad; int pad; long sk, sn, st;}. */
+int cn_pack_weights_batched_f32(const void* descs, int n, void* stream);
 
 /* ---- torch.nn.Conv2d (nn/modules/convolution.py:71-120,250-395; unet_parts.py:196-224) ------
  * also nn.Linear of NeighborhoodAttention2D.qkv / .proj (convolution.py:341-350) as 1x1 convs,
