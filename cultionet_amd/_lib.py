@@ -8,13 +8,13 @@ from __future__ import annotations
 
 import ctypes
 import os
-from ctypes import c_double, c_float, c_int, c_long, c_void_p
+from ctypes import c_double, c_float, c_int, c_long, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "csrc", "libcultionet_hip.so")
 
 P = c_void_p  # device pointers are passed as integers (tensor.data_ptr())
-I, L, F = c_int, c_long, c_float
+I, L, F, U64 = c_int, c_long, c_float, c_ulonglong
 
 # name -> argtypes (restype is always int); mirrors include/cultionet_hip.h one to one
 SIGNATURES = {
@@ -35,13 +35,16 @@ SIGNATURES = {
     "cn_bn_act_bwd_f32": [P, L, P, L, P, P, P, P, P, L, P, P, P, P, I, I, I, I, I, I, I, P],
     "cn_layernorm_c_fwd_f32": [P, L, P, P, P, L, P, L, P, P, I, I, I, F, P],
     "cn_layernorm_c_bwd_f32": [P, L, P, L, P, P, P, P, L, P, P, I, I, I, I, P],
-    "cn_na2d_fwd_f32": [P, L, P, L, P, I, I, I, I, I, I, I, P],
-    "cn_na2d_bwd_f32": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, P],
+    "cn_na2d_fwd_f32": [P, L, P, L, P, I, I, I, I, I, I, I, F, U64, P],
+    "cn_na2d_bwd_f32": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, F, U64, P],
     "cn_bilinear_fwd_f32": [P, L, P, L, I, I, I, I, I, I, P],
     "cn_bilinear_bwd_f32": [P, L, P, L, I, I, I, I, I, I, I, P],
     "cn_copy_f32": [P, L, P, L, I, L, I, P],
     "cn_add_f32": [P, L, P, L, P, L, I, L, P],
     "cn_fill_f32": [P, L, F, P],
+    "cn_dropout_f32": [P, L, P, L, I, I, I, F, U64, I, I, P],
+    "cn_adaptive_maxpool_fwd_f32": [P, L, P, L, P, I, I, I, I, I, I, P],
+    "cn_adaptive_maxpool_bwd_f32": [P, L, P, P, L, I, I, I, I, I, I, I, P],
     "cn_final_combine_fwd_f32": [P, P, P, P, P, P, P, I, I, F, P],
     "cn_final_combine_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, F, P],
     "cn_tanimoto_fwd_f32": [P, L, P, P, P, I, I, I, I, I, L, I, F, I, P, P, P, F, P, P],

@@ -49,26 +49,37 @@ class ConvTranspose2d(nn.Module):
 
 
 class ConvBlock2d(nn.Module):
-    """convolution.py:71-120 (batchnorm_first=False): Conv2d(bias=False) -> BatchNorm2d -> [SiLU]."""
+    """convolution.py:71-120: Conv2d(bias=False) -> BatchNorm2d -> [SiLU], or with ``batchnorm_first``
+    BatchNorm2d(in) -> SiLU -> Conv2d(bias=True)."""
 
     def __init__(self, in_channels: int, out_channels: int, kernel_size: int, padding: int = 0, dilation: int = 1,
                  stride: int = 1, add_activation: bool = True, activation_type: str = "SiLU",
                  batchnorm_first: bool = False):
         super().__init__()
-        if batchnorm_first:
-            raise NotImplementedError("batchnorm_first=True is not on the HIP path yet (SURVEY.md 8f rank 1)")
         self.stride, self.padding, self.dilation = stride, padding, dilation
+        self.batchnorm_first = batchnorm_first
         self.act = E.ACT_SILU if add_activation else E.ACT_NONE
-        layers = [
-            nn.Conv2d(in_channels, out_channels, kernel_size, padding=padding, dilation=dilation, stride=stride,
-                      bias=False),
-            nn.BatchNorm2d(out_channels),
-        ]
-        if add_activation:
-            layers.append(SetActivation(activation_type))
+        if batchnorm_first:
+            layers = [
+                nn.BatchNorm2d(in_channels),
+                SetActivation(activation_type),
+                nn.Conv2d(in_channels, out_channels, kernel_size, padding=padding, dilation=dilation, stride=stride),
+            ]
+        else:
+            layers = [
+                nn.Conv2d(in_channels, out_channels, kernel_size, padding=padding, dilation=dilation, stride=stride,
+                          bias=False),
+                nn.BatchNorm2d(out_channels),
+            ]
+            if add_activation:
+                layers.append(SetActivation(activation_type))
         self.seq = nn.Sequential(*layers)
 
     def forward(self, x: E.Var, residual: T.Optional[E.Var] = None) -> E.Var:
+        if self.batchnorm_first:
+            h = E.bn_act(x, self.seq[0], E.ACT_SILU, training=self.training)
+            y = E.conv2d(h, self.seq[2], self.stride, self.padding, self.dilation)
+            return E.add(residual, y) if residual is not None else y
         y = E.conv2d(x, self.seq[0], self.stride, self.padding, self.dilation)
         return E.bn_act(y, self.seq[1], self.act, residual=residual, training=self.training)
 
@@ -104,16 +115,17 @@ class NeighborhoodAttention2D(nn.Module):
         super().__init__()
         if rel_pos_bias:
             raise NotImplementedError("rel_pos_bias is not used by cultionet")
-        if attn_drop or proj_drop:
-            raise NotImplementedError("NA dropout > 0 has no HIP kernel yet (dropout=0 path only)")
+        self.attn_drop, self.proj_drop = float(attn_drop), float(proj_drop)
         self.num_heads, self.kernel_size, self.dilation = num_heads, kernel_size, dilation
         self.qkv = nn.Linear(dim, dim * 3, bias=qkv_bias)
         self.proj = nn.Linear(dim, dim)
 
     def forward(self, x: E.Var) -> E.Var:
         qkv = E.conv2d(x, _as_conv(self.qkv))
-        o = E.na2d(qkv, self.num_heads, self.kernel_size, self.dilation)
-        return E.conv2d(o, _as_conv(self.proj))
+        o = E.na2d(qkv, self.num_heads, self.kernel_size, self.dilation,
+                   attn_drop=self.attn_drop if self.training else 0.0)
+        o = E.conv2d(o, _as_conv(self.proj))
+        return E.dropout(o, self.proj_drop, channelwise=False, training=self.training)
 
 
 class _LinearAsConv:
@@ -139,6 +151,28 @@ def _as_conv(lin: nn.Linear):
         v = _LinearAsConv(lin)
         lin.__dict__["_cn_conv_view"] = v
     return v
+
+
+class ResidualConv(nn.Module):
+    """convolution.py:179-247: skip(x) + ResConvBlock2d(x) (res_block_type='res'; attention None)."""
+
+    def __init__(self, in_channels: int, out_channels: int, kernel_size: int = 3, num_blocks: int = 2,
+                 attention_weights: T.Optional[str] = None, activation_type: str = "SiLU",
+                 batchnorm_first: bool = False):
+        super().__init__()
+        self.attention_weights = attention_weights
+        if self.attention_weights is not None:
+            assert self.attention_weights in [AttentionTypes.SPATIAL_CHANNEL], "The attention method is not supported."
+            raise NotImplementedError("attention_weights='spatial_channel' is not on the HIP path yet")
+        self.seq = ResConvBlock2d(in_channels, out_channels, kernel_size, num_blocks=num_blocks,
+                                  activation_type=activation_type, batchnorm_first=batchnorm_first)
+        self.skip = None
+        if in_channels != out_channels:
+            self.skip = nn.Conv2d(in_channels, out_channels, kernel_size=1, padding=0)
+
+    def forward(self, x: E.Var) -> E.Var:
+        out = E.conv2d(x, self.skip) if self.skip is not None else x
+        return self.seq(x, residual=out)
 
 
 class ResidualAConv(nn.Module):
@@ -186,7 +220,7 @@ class ResidualAConv(nn.Module):
 
 
 class PoolResidualConv(nn.Module):
-    """convolution.py:398-513: [stride-2 ConvBlock2d without activation] -> ResidualAConv -> Dropout2d."""
+    """convolution.py:398-513: [stride-2 conv | adaptive max pool] -> Residual(A)Conv -> Dropout2d."""
 
     def __init__(self, in_channels: int, out_channels: int, dropout: float = 0.0, kernel_size: int = 3,
                  num_blocks: int = 2, attention_weights: T.Optional[str] = None, activation_type: str = "SiLU",
@@ -196,26 +230,36 @@ class PoolResidualConv(nn.Module):
                  natten_proj_drop: float = 0.0):
         super().__init__()
         assert res_block_type in (ResBlockTypes.RES, ResBlockTypes.RESA)
-        if res_block_type != ResBlockTypes.RESA:
-            raise NotImplementedError("res_block_type='res' is not on the HIP path yet")
-        if pool_by_max:
-            raise NotImplementedError("pool_by_max=True is not on the HIP path yet")
-        if dropout:
-            raise NotImplementedError("dropout > 0 has no HIP kernel yet (parity runs use dropout=0)")
         self.pool_first, self.pool_by_max = pool_first, pool_by_max
-        if self.pool_first:
-            self.pool_conv = ConvBlock2d(in_channels, out_channels, kernel_size=3, padding=1, stride=2,
-                                         add_activation=False, batchnorm_first=False)
+        self.batchnorm_first = batchnorm_first
+        if self.pool_first and not self.pool_by_max:
+            if batchnorm_first:
+                self.pool_conv = nn.Conv2d(in_channels, out_channels, kernel_size=3, padding=1, stride=2)
+            else:
+                self.pool_conv = ConvBlock2d(in_channels, out_channels, kernel_size=3, padding=1, stride=2,
+                                             add_activation=False, batchnorm_first=False)
             in_channels = out_channels
-        self.res_conv = ResidualAConv(in_channels, out_channels, kernel_size=kernel_size, dilations=dilations,
-                                      num_blocks=num_blocks, attention_weights=attention_weights,
-                                      activation_type=activation_type, batchnorm_first=batchnorm_first,
-                                      natten_num_heads=natten_num_heads, natten_kernel_size=natten_kernel_size,
-                                      natten_dilation=natten_dilation, natten_attn_drop=natten_attn_drop,
-                                      natten_proj_drop=natten_proj_drop)
+        if res_block_type == ResBlockTypes.RES:
+            self.res_conv = ResidualConv(in_channels, out_channels, kernel_size=kernel_size,
+                                         attention_weights=attention_weights, num_blocks=num_blocks,
+                                         activation_type=activation_type, batchnorm_first=batchnorm_first)
+        else:
+            self.res_conv = ResidualAConv(in_channels, out_channels, kernel_size=kernel_size, dilations=dilations,
+                                          num_blocks=num_blocks, attention_weights=attention_weights,
+                                          activation_type=activation_type, batchnorm_first=batchnorm_first,
+                                          natten_num_heads=natten_num_heads, natten_kernel_size=natten_kernel_size,
+                                          natten_dilation=natten_dilation, natten_attn_drop=natten_attn_drop,
+                                          natten_proj_drop=natten_proj_drop)
         self.dropout_layer = nn.Dropout2d(p=dropout)
 
     def forward(self, x: E.Var) -> E.Var:
         if self.pool_first:
-            x = self.pool_conv(x)
-        return self.res_conv(x)
+            if self.pool_by_max:
+                h, w = x.shape[-2:]
+                x = E.adaptive_max_pool2d(x, (h // 2, w // 2))
+            elif self.batchnorm_first:
+                x = E.conv2d(x, self.pool_conv, 2, 1, 1)
+            else:
+                x = self.pool_conv(x)
+        x = self.res_conv(x)
+        return E.dropout(x, self.dropout_layer.p, channelwise=True, training=self.training)

@@ -26,12 +26,28 @@ __device__ __forceinline__ int na_window_start(int i, int len, int dil) {
   return ni;
 }
 
+// attn_drop (nn.Dropout on the soft-maxed logits): keep/(1-p) factor of tap t, recomputed from a counter hash
+// (same splitmix64 stream as cn_dropout_f32) in forward and backward; 1.0 when drop is off.
+__device__ __forceinline__ unsigned long long na_splitmix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ float na_keep(unsigned long long thresh, float scale, unsigned long long seed, long bh,
+                                         int t, int HW, int p) {
+  if (thresh == 0ull) return 1.0f;
+  const unsigned long long i = ((unsigned long long)bh * NA_KK + t) * (unsigned long long)HW + p;
+  return na_splitmix64(seed + i) >= thresh ? scale : 0.f;
+}
+
 // qkv [B][3C][H][W] (batch stride qbs); out [B][C][H][W]; attn [B][heads][9][H][W] (saved probs).
 template <int D>
 __global__ __launch_bounds__(256) void cn_na2d_fwd_kernel(const float* __restrict__ qkv, long qbs,
                                                          float* __restrict__ out, long obs,
                                                          float* __restrict__ attn, int B, int C, int heads, int H,
-                                                         int W, int dil, float scale) {
+                                                         int W, int dil, float scale, unsigned long long dthresh,
+                                                         float dscale, unsigned long long dseed) {
   const int HW = H * W;
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= HW) return;
@@ -69,6 +85,7 @@ __global__ __launch_bounds__(256) void cn_na2d_fwd_kernel(const float* __restric
   for (int t = 0; t < NA_KK; ++t) {
     lg[t] *= inv;
     if (attn) ap[(long)t * HW] = lg[t];
+    lg[t] *= na_keep(dthresh, dscale, dseed, (long)b * heads + h, t, HW, p);
   }
   float o[D];
 #pragma unroll
@@ -94,7 +111,8 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_q_kernel(const float* __restr
                                                            const float* __restrict__ attn,
                                                            float* __restrict__ dattn, float* __restrict__ dqkv,
                                                            long dqbs, int B, int C, int heads, int H, int W, int dil,
-                                                           float scale) {
+                                                           float scale, unsigned long long dthresh, float dscale,
+                                                           unsigned long long dseed) {
   const int HW = H * W;
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= HW) return;
@@ -120,6 +138,7 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_q_kernel(const float* __restr
 #pragma unroll
       for (int d = 0; d < D; ++d) s += go[d] * vp[(long)d * HW + kpix];
       pr[t] = ap[(long)t * HW];
+      s *= na_keep(dthresh, dscale, dseed, (long)b * heads + h, t, HW, p);
       dp[t] = s;
       dot += pr[t] * s;
     }
@@ -154,7 +173,9 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_kv_kernel(const float* __rest
                                                             const float* __restrict__ attn,
                                                             const float* __restrict__ dattn,
                                                             float* __restrict__ dqkv, long dqbs, int B, int C,
-                                                            int heads, int H, int W, int dil, float scale) {
+                                                            int heads, int H, int W, int dil, float scale,
+                                                            unsigned long long dthresh, float dscale,
+                                                            unsigned long long dseed) {
   const int HW = H * W;
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= HW) return;
@@ -184,7 +205,7 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_kv_kernel(const float* __rest
       const int t = i * NA_K + offx / dil;
       const int qpix = qy * W + qx;
       const float ds = dap[(long)t * HW + qpix];
-      const float pr = ap[(long)t * HW + qpix];
+      const float pr = ap[(long)t * HW + qpix] * na_keep(dthresh, dscale, dseed, (long)b * heads + h, t, HW, qpix);
 #pragma unroll
       for (int d = 0; d < D; ++d) {
         dk[d] += ds * qp[(long)d * HW + qpix];
@@ -213,30 +234,43 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_kv_kernel(const float* __rest
   }
 
 // kernel_size must be 3 (every NATTEN_PARAMS entry used by TowerUNet: unet_parts.py:19-40).
+static unsigned long long na_thresh(float p) {
+  if (!(p > 0.f)) return 0ull;
+  const double t = (double)p * 18446744073709551616.0;
+  return t >= 18446744073709551615.0 ? ~0ull : (unsigned long long)t;
+}
+
 extern "C" int cn_na2d_fwd_f32(const float* qkv, long qbs, float* out, long obs, float* attn, int B, int C,
-                               int heads, int H, int W, int kernel_size, int dilation, void* stream_) {
+                               int heads, int H, int W, int kernel_size, int dilation, float attn_drop,
+                               unsigned long long seed, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (kernel_size != NA_K || heads <= 0 || C % heads != 0) return CN_ERR_ARG;
   if (kernel_size * dilation > H || kernel_size * dilation > W) return CN_ERR_ARG;
   const int D = C / heads;
   const float scale = 1.0f / sqrtf((float)D);
   dim3 grid((H * W + 255) / 256, heads, B);
-  NA_DISPATCH(D, cn_na2d_fwd_kernel, qkv, qbs, out, obs, attn, B, C, heads, H, W, dilation, scale);
+  if (!(attn_drop >= 0.f && attn_drop < 1.f)) return CN_ERR_ARG;
+  NA_DISPATCH(D, cn_na2d_fwd_kernel, qkv, qbs, out, obs, attn, B, C, heads, H, W, dilation, scale,
+              na_thresh(attn_drop), 1.0f / (1.0f - attn_drop), seed);
   return cn_check_launch();
 }
 
 // dqkv [B][3C][H][W] is fully overwritten (dq, dk, dv); dattn is scratch of attn's size.
 extern "C" int cn_na2d_bwd_f32(const float* qkv, long qbs, const float* dout, long dobs, const float* attn,
                                float* dattn, float* dqkv, long dqbs, int B, int C, int heads, int H, int W,
-                               int kernel_size, int dilation, void* stream_) {
+                               int kernel_size, int dilation, float attn_drop, unsigned long long seed,
+                               void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (kernel_size != NA_K || heads <= 0 || C % heads != 0) return CN_ERR_ARG;
   const int D = C / heads;
   const float scale = 1.0f / sqrtf((float)D);
   dim3 grid((H * W + 255) / 256, heads, B);
+  if (!(attn_drop >= 0.f && attn_drop < 1.f)) return CN_ERR_ARG;
+  const unsigned long long th = na_thresh(attn_drop);
+  const float ds = 1.0f / (1.0f - attn_drop);
   NA_DISPATCH(D, cn_na2d_bwd_q_kernel, qkv, qbs, dout, dobs, attn, dattn, dqkv, dqbs, B, C, heads, H, W, dilation,
-              scale);
+              scale, th, ds, seed);
   NA_DISPATCH(D, cn_na2d_bwd_kv_kernel, qkv, qbs, dout, dobs, attn, dattn, dqkv, dqbs, B, C, heads, H, W, dilation,
-              scale);
+              scale, th, ds, seed);
   return cn_check_launch();
 }

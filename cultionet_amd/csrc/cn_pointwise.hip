@@ -278,3 +278,115 @@ extern "C" int cn_final_combine_bwd_f32(const float* ha, const float* hb, const 
                      dpp, B, HW, smooth);
   return cn_check_launch();
 }
+
+// ---------------------------------------------------------------------------
+// Dropout (nn.Dropout2d after each encoder block: convolution.py:495,511; natten attn_drop / proj_drop).
+// Counter-based mask: keep(i) = splitmix64(seed + i) >= p * 2^64, never stored -- backward recomputes it.
+//   channelwise != 0: one decision per (b, c) plane (Dropout2d); else one per element (Dropout).
+// y = x * keep / (1 - p). Same entry point serves backward (x := dy, accumulate into dx).
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ unsigned long long cn_splitmix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
+__global__ __launch_bounds__(256) void cn_dropout_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y,
+                                                        long ybs, int C, int L, unsigned long long thresh,
+                                                        float scale, unsigned long long seed, int channelwise,
+                                                        int accumulate) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const unsigned long long plane = (unsigned long long)b * C + c;
+  const float* xp = x + b * xbs + (long)c * L;
+  float* yp = y + b * ybs + (long)c * L;
+  float pk = 0.f;
+  if (channelwise) pk = cn_splitmix64(seed + plane) >= thresh ? scale : 0.f;
+  for (int l = blockIdx.x * 256 + threadIdx.x; l < L; l += gridDim.x * 256) {
+    const float k = channelwise ? pk : (cn_splitmix64(seed + plane * (unsigned long long)L + l) >= thresh ? scale : 0.f);
+    const float v = xp[l] * k;
+    yp[l] = accumulate ? yp[l] + v : v;
+  }
+}
+
+extern "C" int cn_dropout_f32(const float* x, long xbs, float* y, long ybs, int B, int C, int L, float p,
+                              unsigned long long seed, int channelwise, int accumulate, void* stream) {
+  if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
+  if (!(p >= 0.f && p < 1.f)) return CN_ERR_ARG;
+  const double t = (double)p * 18446744073709551616.0;  // p * 2^64
+  const unsigned long long thresh = t >= 18446744073709551615.0 ? ~0ull : (unsigned long long)t;
+  int bx = (L + 1023) / 1024;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(cn_dropout_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, x, xbs, y, ybs, C, L,
+                     thresh, 1.0f / (1.0f - p), seed, channelwise, accumulate);
+  return cn_check_launch();
+}
+
+// ---------------------------------------------------------------------------
+// F.adaptive_max_pool2d (pool_by_max=True: convolution.py:499-503). Window of output o along one axis:
+// [floor(o*In/Out), ceil((o+1)*In/Out)). idx: int32 flat argmax inside the input plane (first max, as ATen).
+// Backward in gather form (windows may overlap when In % Out != 0): deterministic, no atomics.
+// ---------------------------------------------------------------------------
+__device__ __forceinline__ int amp_start(int o, int in, int out) { return (int)(((long)o * in) / out); }
+__device__ __forceinline__ int amp_end(int o, int in, int out) { return (int)((((long)(o + 1)) * in + out - 1) / out); }
+
+__global__ __launch_bounds__(256) void cn_adaptive_maxpool_fwd_kernel(const float* __restrict__ x, long xbs,
+                                                                     float* __restrict__ y, long ybs,
+                                                                     int* __restrict__ idx, int C, int Hi, int Wi,
+                                                                     int Ho, int Wo) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= Ho * Wo) return;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int oy = p / Wo, ox = p - oy * Wo;
+  const int y0 = amp_start(oy, Hi, Ho), y1 = amp_end(oy, Hi, Ho);
+  const int x0 = amp_start(ox, Wi, Wo), x1 = amp_end(ox, Wi, Wo);
+  const float* xp = x + b * xbs + (long)c * Hi * Wi;
+  float best = -INFINITY;
+  int bi = y0 * Wi + x0;
+  for (int iy = y0; iy < y1; ++iy)
+    for (int ix = x0; ix < x1; ++ix) {
+      const float v = xp[iy * Wi + ix];
+      if (v > best || v != v) { best = v; bi = iy * Wi + ix; }
+    }
+  y[b * ybs + (long)c * Ho * Wo + p] = best;
+  if (idx) idx[((long)b * C + c) * Ho * Wo + p] = bi;
+}
+
+__global__ __launch_bounds__(256) void cn_adaptive_maxpool_bwd_kernel(const float* __restrict__ dy, long dybs,
+                                                                     const int* __restrict__ idx,
+                                                                     float* __restrict__ dx, long dxbs, int C, int Hi,
+                                                                     int Wi, int Ho, int Wo, int accumulate) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= Hi * Wi) return;
+  const int c = blockIdx.y, b = blockIdx.z;
+  const int iy = p / Wi, ix = p - iy * Wi;
+  // outputs whose window can contain (iy, ix): start(o) <= i < end(o)
+  int oy_lo = (int)(((long)iy * Ho) / Hi) - 1, oy_hi = (int)((((long)(iy + 1)) * Ho + Hi - 1) / Hi);
+  int ox_lo = (int)(((long)ix * Wo) / Wi) - 1, ox_hi = (int)((((long)(ix + 1)) * Wo + Wi - 1) / Wi);
+  oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, Ho - 1);
+  ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, Wo - 1);
+  const float* dp = dy + b * dybs + (long)c * Ho * Wo;
+  const int* ip = idx + ((long)b * C + c) * Ho * Wo;
+  float acc = 0.f;
+  for (int oy = oy_lo; oy <= oy_hi; ++oy)
+    for (int ox = ox_lo; ox <= ox_hi; ++ox)
+      if (ip[oy * Wo + ox] == p) acc += dp[oy * Wo + ox];
+  float* o = dx + b * dxbs + (long)c * Hi * Wi + p;
+  *o = accumulate ? *o + acc : acc;
+}
+
+extern "C" int cn_adaptive_maxpool_fwd_f32(const float* x, long xbs, float* y, long ybs, int* idx, int B, int C,
+                                           int Hi, int Wi, int Ho, int Wo, void* stream) {
+  if (B <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return CN_OK;
+  hipLaunchKernelGGL(cn_adaptive_maxpool_fwd_kernel, dim3((Ho * Wo + 255) / 256, C, B), dim3(256), 0,
+                     (hipStream_t)stream, x, xbs, y, ybs, idx, C, Hi, Wi, Ho, Wo);
+  return cn_check_launch();
+}
+
+extern "C" int cn_adaptive_maxpool_bwd_f32(const float* dy, long dybs, const int* idx, float* dx, long dxbs, int B,
+                                           int C, int Hi, int Wi, int Ho, int Wo, int accumulate, void* stream) {
+  if (B <= 0 || C <= 0) return CN_OK;
+  hipLaunchKernelGGL(cn_adaptive_maxpool_bwd_kernel, dim3((Hi * Wi + 255) / 256, C, B), dim3(256), 0,
+                     (hipStream_t)stream, dy, dybs, idx, dx, dxbs, C, Hi, Wi, Ho, Wo, accumulate);
+  return cn_check_launch();
+}

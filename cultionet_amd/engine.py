@@ -544,7 +544,7 @@ def layer_norm_c(x: Var, ln, residual: T.Optional[Var] = None) -> Var:
     return yv
 
 
-def na2d(qkv: Var, heads: int, kernel_size: int, dilation: int) -> Var:
+def na2d(qkv: Var, heads: int, kernel_size: int, dilation: int, attn_drop: float = 0.0) -> Var:
     """Neighborhood attention core on a [B, 3C, H, W] qkv buffer -> [B, C, H, W]."""
     tape = current_tape()
     qt = _check(qkv.t)
@@ -552,8 +552,9 @@ def na2d(qkv: Var, heads: int, kernel_size: int, dilation: int) -> Var:
     C = C3 // 3
     out = _new((B, C, H, W), qt)
     attn = _new((B, heads, kernel_size * kernel_size, H, W), qt)
+    seed = _next_seed() if attn_drop > 0.0 else 0
     _lib.call("cn_na2d_fwd_f32", qt.data_ptr(), bstride(qt), out.data_ptr(), bstride(out), attn.data_ptr(), B, C,
-              heads, H, W, kernel_size, dilation, _stream())
+              heads, H, W, kernel_size, dilation, float(attn_drop), seed, _stream())
     ov = Var(out, tape.enabled)
     if tape.enabled:
 
@@ -566,13 +567,13 @@ def na2d(qkv: Var, heads: int, kernel_size: int, dilation: int) -> Var:
                 dq = _new(qt.shape, qt)
                 _lib.call("cn_na2d_bwd_f32", qt.data_ptr(), bstride(qt), do.data_ptr(), bstride(do), attn.data_ptr(),
                           dattn.data_ptr(), dq.data_ptr(), bstride(dq), B, C, heads, H, W, kernel_size, dilation,
-                          _stream())
+                          float(attn_drop), seed, _stream())
                 qkv.grad = dq
             else:  # pragma: no cover - qkv has a single consumer in TowerUNet
                 dq = _new(qt.shape, qt)
                 _lib.call("cn_na2d_bwd_f32", qt.data_ptr(), bstride(qt), do.data_ptr(), bstride(do), attn.data_ptr(),
                           dattn.data_ptr(), dq.data_ptr(), bstride(dq), B, C, heads, H, W, kernel_size, dilation,
-                          _stream())
+                          float(attn_drop), seed, _stream())
                 give_grad(qkv, dq)
             ov.grad = None
 
@@ -763,3 +764,74 @@ def tanimoto_loss(pred: Var, *, target_f: T.Optional[torch.Tensor] = None, label
 
         tape.add(bwd)
     return loss
+
+
+# ---------------------------------------------------------------------------
+# dropout / pooling
+# ---------------------------------------------------------------------------
+_rng = {"seed": 0x5EED, "calls": 0}
+
+
+def manual_seed(seed: int) -> None:
+    """Seed of the counter-based dropout masks (each dropout call consumes one sub-stream)."""
+    _rng["seed"] = int(seed) & 0xFFFFFFFFFFFF
+    _rng["calls"] = 0
+
+
+def _next_seed() -> int:
+    _rng["calls"] += 1
+    return ((_rng["seed"] << 16) ^ (_rng["calls"] * 0x9E3779B1)) & 0xFFFFFFFFFFFFFFFF
+
+
+def dropout(x: Var, p: float, channelwise: bool, training: bool) -> Var:
+    """nn.Dropout2d (channelwise) / nn.Dropout; identity in eval mode or for p == 0."""
+    if not training or p <= 0.0:
+        return x
+    tape = current_tape()
+    xt = _check(x.t)
+    B, C = xt.shape[0], xt.shape[1]
+    L = int(xt[0, 0].numel())
+    seed = _next_seed()
+    y = _new(xt.shape, xt)
+    _lib.call("cn_dropout_f32", xt.data_ptr(), bstride(xt), y.data_ptr(), bstride(y), B, C, L, float(p), seed,
+              1 if channelwise else 0, 0, _stream())
+    yv = Var(y, tape.enabled and x.req)
+    if tape.enabled and x.req:
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            dx, acc = grad_buffer(x)
+            _lib.call("cn_dropout_f32", dy.data_ptr(), bstride(dy), dx.data_ptr(), bstride(dx), B, C, L, float(p), seed,
+                      1 if channelwise else 0, acc, _stream())
+            yv.grad = None
+
+        tape.add(bwd)
+    return yv
+
+
+def adaptive_max_pool2d(x: Var, size: T.Tuple[int, int]) -> Var:
+    """F.adaptive_max_pool2d(x, output_size=size)."""
+    tape = current_tape()
+    xt = _check(x.t)
+    B, C, Hi, Wi = xt.shape
+    Ho, Wo = int(size[0]), int(size[1])
+    y = _new((B, C, Ho, Wo), xt)
+    idx = torch.empty((B, C, Ho, Wo), dtype=torch.int32, device=xt.device)
+    _lib.call("cn_adaptive_maxpool_fwd_f32", xt.data_ptr(), bstride(xt), y.data_ptr(), bstride(y), idx.data_ptr(), B, C,
+              Hi, Wi, Ho, Wo, _stream())
+    yv = Var(y, tape.enabled and x.req)
+    if tape.enabled and x.req:
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            dx, acc = grad_buffer(x)
+            _lib.call("cn_adaptive_maxpool_bwd_f32", dy.data_ptr(), bstride(dy), idx.data_ptr(), dx.data_ptr(),
+                      bstride(dx), B, C, Hi, Wi, Ho, Wo, acc, _stream())
+            yv.grad = None
+
+        tape.add(bwd)
+    return yv

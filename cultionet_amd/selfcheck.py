@@ -12,7 +12,7 @@ def build_pair(hidden: int = 8, in_channels: int = 3, in_time: int = 12, device:
     from .lightning import CultionetLitModel
 
     lit = CultionetLitModel(in_channels=in_channels, in_time=in_time, hidden_channels=hidden, dropout=0.0, **kw)
-    okw = {k: v for k, v in kw.items() if k in ("attention_weights", "dilations")}
+    okw = {k: v for k, v in kw.items() if k in ("attention_weights", "dilations", "pool_by_max", "res_block_type", "batchnorm_first")}
     ref = O.TowerUNet(in_channels, in_time, hidden_channels=hidden, **okw)
     sd = O.seeded_state_dict(ref.state_dict())
     ref.load_state_dict(sd)

@@ -11,7 +11,7 @@ import torch
 import torch.nn as nn
 
 from . import engine as E
-from .convolution import ConvBlock2d, ConvTranspose2d, PoolResidualConv, ResidualAConv, _Marker
+from .convolution import ConvBlock2d, ConvTranspose2d, PoolResidualConv, ResidualAConv, ResidualConv, _Marker
 from .enums import AttentionTypes, InferenceNames, ResBlockTypes
 
 # unet_parts.py:19-40
@@ -123,15 +123,18 @@ class UNetUpBlock(nn.Module):
                  natten_proj_drop: float = 0.0):
         super().__init__()
         assert res_block_type in (ResBlockTypes.RES, ResBlockTypes.RESA)
-        if res_block_type != ResBlockTypes.RESA:
-            raise NotImplementedError("res_block_type='res' is not on the HIP path yet")
         if resample_up:
             self.up_conv = ConvTranspose2d(in_channels, in_channels)
-        self.res_conv = ResidualAConv(in_channels, out_channels, kernel_size=kernel_size, dilations=dilations,
-                                      attention_weights=attention_weights, activation_type=activation_type,
-                                      batchnorm_first=batchnorm_first, natten_num_heads=natten_num_heads,
-                                      natten_kernel_size=natten_kernel_size, natten_dilation=natten_dilation,
-                                      natten_attn_drop=natten_attn_drop, natten_proj_drop=natten_proj_drop)
+        if res_block_type == ResBlockTypes.RES:
+            self.res_conv = ResidualConv(in_channels, out_channels, kernel_size=kernel_size, num_blocks=num_blocks,
+                                         attention_weights=attention_weights, activation_type=activation_type,
+                                         batchnorm_first=batchnorm_first)
+        else:
+            self.res_conv = ResidualAConv(in_channels, out_channels, kernel_size=kernel_size, dilations=dilations,
+                                          attention_weights=attention_weights, activation_type=activation_type,
+                                          batchnorm_first=batchnorm_first, natten_num_heads=natten_num_heads,
+                                          natten_kernel_size=natten_kernel_size, natten_dilation=natten_dilation,
+                                          natten_attn_drop=natten_attn_drop, natten_proj_drop=natten_proj_drop)
 
     def forward(self, x: E.Var, size) -> E.Var:
         if tuple(x.shape[-2:]) != tuple(size):
@@ -213,12 +216,17 @@ class TowerUNetBlock(nn.Module):
         if tower:
             self.tower_conv = ConvTranspose2d(up_channels, up_channels, 3, 2, 1)
             in_channels += up_channels
-        self.res_conv = ResidualAConv(in_channels, out_channels, kernel_size=kernel_size, num_blocks=num_blocks,
-                                      dilations=dilations, attention_weights=attention_weights,
-                                      activation_type=activation_type, batchnorm_first=batchnorm_first,
-                                      natten_num_heads=natten_num_heads, natten_kernel_size=natten_kernel_size,
-                                      natten_dilation=natten_dilation, natten_attn_drop=natten_attn_drop,
-                                      natten_proj_drop=natten_proj_drop)
+        if res_block_type == ResBlockTypes.RES:
+            self.res_conv = ResidualConv(in_channels, out_channels, kernel_size=kernel_size, num_blocks=num_blocks,
+                                         attention_weights=attention_weights, activation_type=activation_type,
+                                         batchnorm_first=batchnorm_first)
+        else:
+            self.res_conv = ResidualAConv(in_channels, out_channels, kernel_size=kernel_size, num_blocks=num_blocks,
+                                          dilations=dilations, attention_weights=attention_weights,
+                                          activation_type=activation_type, batchnorm_first=batchnorm_first,
+                                          natten_num_heads=natten_num_heads, natten_kernel_size=natten_kernel_size,
+                                          natten_dilation=natten_dilation, natten_attn_drop=natten_attn_drop,
+                                          natten_proj_drop=natten_proj_drop)
 
     def forward(self, backbone_side: E.Var, backbone_down: E.Var, decode_side: E.Var, decode_down: E.Var,
                 tower_down: T.Optional[E.Var] = None, latlon_coords=None) -> E.Var:

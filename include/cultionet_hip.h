@@ -102,12 +102,13 @@ int cn_layernorm_c_bwd_f32(const float* x, long xbs, const float* dy, long dybs,
 
 /* ---- natten.NeighborhoodAttention2D core (convolution.py:341-350; natten 0.17.1 na2d_qk ->
  * softmax -> na2d_av, kernel 3, dilation d, no rpb). qkv [B][3C][H][W] with channel
- * (which*C + head*D + d); attn [B][heads][9][H][W] saved probabilities; dattn same-size scratch. */
+ * (which*C + head*D + d); attn [B][heads][9][H][W] saved probabilities; dattn same-size scratch.
+ * attn_drop in [0,1): dropout on the probabilities (mask recomputed from `seed`, as cn_dropout_f32). */
 int cn_na2d_fwd_f32(const float* qkv, long qbs, float* out, long obs, float* attn, int B, int C, int heads, int H,
-                    int W, int kernel_size, int dilation, void* stream);
+                    int W, int kernel_size, int dilation, float attn_drop, unsigned long long seed, void* stream);
 int cn_na2d_bwd_f32(const float* qkv, long qbs, const float* dout, long dobs, const float* attn, float* dattn,
                     float* dqkv, long dqbs, int B, int C, int heads, int H, int W, int kernel_size, int dilation,
-                    void* stream);
+                    float attn_drop, unsigned long long seed, void* stream);
 
 /* ---- F.interpolate(mode="bilinear", align_corners=True) (nn/functional.py:72-81) ------------ */
 int cn_bilinear_fwd_f32(const float* x, long xbs, float* y, long ybs, int B, int C, int Hi, int Wi, int Ho, int Wo,
@@ -119,6 +120,19 @@ int cn_bilinear_bwd_f32(const float* dy, long dybs, float* dx, long dxbs, int B,
 int cn_copy_f32(const float* src, long sbs, float* dst, long dbs, int B, long n, int accumulate, void* stream);
 int cn_add_f32(const float* a, long abs_, const float* c, long cbs, float* dst, long dbs, int B, long n, void* stream);
 int cn_fill_f32(float* p, long n, float v, void* stream);
+
+/* ---- nn.Dropout2d / nn.Dropout (convolution.py:495,511; natten attn_drop, proj_drop) -------------
+ * y (+)= x * keep / (1-p); keep = splitmix64(seed + index) >= p*2^64 is recomputed, never stored: call
+ * again with x := dy (same seed) for the backward pass. channelwise != 0: one draw per (b, c) plane. */
+int cn_dropout_f32(const float* x, long xbs, float* y, long ybs, int B, int C, int L, float p,
+                   unsigned long long seed, int channelwise, int accumulate, void* stream);
+
+/* ---- F.adaptive_max_pool2d (pool_by_max=True, convolution.py:499-503) -------------------------
+ * idx: int32 [B][C][Ho][Wo] flat argmax inside the input plane (kept for backward). */
+int cn_adaptive_maxpool_fwd_f32(const float* x, long xbs, float* y, long ybs, int* idx, int B, int C, int Hi, int Wi,
+                                int Ho, int Wo, void* stream);
+int cn_adaptive_maxpool_bwd_f32(const float* dy, long dybs, const int* idx, float* dx, long dxbs, int B, int C, int Hi,
+                                int Wi, int Ho, int Wo, int accumulate, void* stream);
 
 /* ---- TowerUNetFinalCombine + SigmoidCrisp (nn/modules/unet_parts.py:43-193), fused ----------
  * h*: [B][3][HW] fuse_conv outputs of towers a,b,c (channel = dist, edge, crop).

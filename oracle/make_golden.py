@@ -71,7 +71,8 @@ def _train_case(ns, hidden, B, H, W, with_mask, seed=7, stages=False, loss_name=
     out["margin"] = np.float64(min(float((pred[k] - 0.5).abs().min()) for k in ("distance", "edge", "crop")))
     # running statistics after one train-mode forward (BN momentum path)
     sd = m.state_dict()
-    k0 = "cultionet_TowerUNet.mask_model.tower_fusion.tower_a.res_conv.res_modules.0.block.0.seq.1."
+    k0 = next(k for k in sd if "tower_fusion.tower_a.res_conv" in k and k.endswith("running_mean"))[:-len("running_mean")]
+    out["bn_key"] = np.array(k0.replace("cultionet_TowerUNet.mask_model.", ""))
     out["bn_running_mean"] = sd[k0 + "running_mean"].numpy().copy()
     out["bn_running_var"] = sd[k0 + "running_var"].numpy().copy()
     out["meta"] = np.array([hidden, B, H, W, int(with_mask), seed])
@@ -124,6 +125,11 @@ def main():
         np.savez_compressed(path, **d)
         print(name, os.path.getsize(path) // 1024, "KiB", "loss" in d and d["loss"])
 
+    if "--variants-only" in sys.argv:
+        save("train_h8_b2_28_poolmax.npz", _train_case(ns, 8, 2, 28, 28, True, pool_by_max=True))
+        save("train_h8_b2_28_res.npz", _train_case(ns, 8, 2, 28, 28, False, res_block_type="res", attention_weights=None))
+        save("train_h8_b2_28_bnfirst.npz", _train_case(ns, 8, 2, 28, 28, False, batchnorm_first=True))
+        return
     if "--eval-only" in sys.argv:
         save("eval_h32_b1_4x25x256.npz", _eval_case(ns, 32, 1, 4, 25, 256, 256))
         save("eval_h8_b2_28.npz", _eval_case(ns, 8, 2, 3, 12, 28, 28, crop=0))
@@ -138,6 +144,10 @@ def main():
     save("train_h8_b2_28_noattn.npz", _train_case(ns, 8, 2, 28, 28, False, attention_weights=None))
     # true dilated convs (dilations entry >= 3)
     save("train_h8_b2_28_dil3.npz", _train_case(ns, 8, 2, 28, 28, False, dilations=[1, 3]))
+    # variant blocks: pool_by_max, res_block_type="res", batchnorm_first
+    save("train_h8_b2_28_poolmax.npz", _train_case(ns, 8, 2, 28, 28, True, pool_by_max=True))
+    save("train_h8_b2_28_res.npz", _train_case(ns, 8, 2, 28, 28, False, res_block_type="res", attention_weights=None))
+    save("train_h8_b2_28_bnfirst.npz", _train_case(ns, 8, 2, 28, 28, False, batchnorm_first=True))
     # (ii) BASELINE configs[0] / configs[1] shapes at hidden 32
     save("train_h32_b1_100.npz", _train_case(ns, 32, 1, 100, 100, False))
     save("train_h32_b1_100_masked.npz", _train_case(ns, 32, 1, 100, 100, True))

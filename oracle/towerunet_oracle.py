@@ -99,16 +99,21 @@ class PreTimeReduction(nn.Module):
 
 
 class ConvBlock2d(nn.Module):
-    """nn/modules/convolution.py:71-120 (batchnorm_first=False branch)."""
+    """nn/modules/convolution.py:71-120."""
 
-    def __init__(self, cin, cout, kernel_size, padding=0, dilation=1, stride=1, add_activation=True, act="SiLU"):
+    def __init__(self, cin, cout, kernel_size, padding=0, dilation=1, stride=1, add_activation=True, act="SiLU",
+                 batchnorm_first=False):
         super().__init__()
-        layers = [
-            nn.Conv2d(cin, cout, kernel_size, padding=padding, dilation=dilation, stride=stride, bias=False),
-            nn.BatchNorm2d(cout),
-        ]
-        if add_activation:
-            layers.append(Act(act))
+        if batchnorm_first:
+            layers = [nn.BatchNorm2d(cin), Act(act),
+                      nn.Conv2d(cin, cout, kernel_size, padding=padding, dilation=dilation, stride=stride)]
+        else:
+            layers = [
+                nn.Conv2d(cin, cout, kernel_size, padding=padding, dilation=dilation, stride=stride, bias=False),
+                nn.BatchNorm2d(cout),
+            ]
+            if add_activation:
+                layers.append(Act(act))
         self.seq = nn.Sequential(*layers)
 
     def forward(self, x):
@@ -118,12 +123,15 @@ class ConvBlock2d(nn.Module):
 class ResConvBlock2d(nn.Module):
     """nn/modules/convolution.py:123-176."""
 
-    def __init__(self, cin, cout, kernel_size=3, dilation=1, act="SiLU", num_blocks=2):
+    def __init__(self, cin, cout, kernel_size=3, dilation=1, act="SiLU", num_blocks=2, batchnorm_first=False):
         super().__init__()
-        blocks = [ConvBlock2d(cin, cout, kernel_size, padding=0 if kernel_size == 1 else kernel_size // 2, act=act)]
+        bf = batchnorm_first
+        blocks = [ConvBlock2d(cin, cout, kernel_size, padding=0 if kernel_size == 1 else kernel_size // 2, act=act,
+                              batchnorm_first=bf)]
         for _ in range(num_blocks - 1):
             d = 1 if kernel_size == 1 else max(1, dilation - 1)
-            blocks.append(ConvBlock2d(cout, cout, kernel_size, padding=0 if kernel_size == 1 else d, dilation=d, act=act))
+            blocks.append(ConvBlock2d(cout, cout, kernel_size, padding=0 if kernel_size == 1 else d, dilation=d, act=act,
+                                      batchnorm_first=bf))
         self.block = nn.ModuleList(blocks)
 
     def forward(self, x):
@@ -132,11 +140,26 @@ class ResConvBlock2d(nn.Module):
         return x
 
 
+class ResidualConv(nn.Module):
+    """nn/modules/convolution.py:179-247 (attention None)."""
+
+    def __init__(self, cin, cout, kernel_size=3, num_blocks=2, attention_weights=None, act="SiLU",
+                 batchnorm_first=False, **_unused):
+        super().__init__()
+        assert attention_weights is None
+        self.seq = ResConvBlock2d(cin, cout, kernel_size, act=act, num_blocks=num_blocks, batchnorm_first=batchnorm_first)
+        self.skip = nn.Conv2d(cin, cout, 1) if cin != cout else None
+
+    def forward(self, x):
+        out = self.skip(x) if self.skip is not None else x
+        return out + self.seq(x)
+
+
 class ResidualAConv(nn.Module):
     """nn/modules/convolution.py:250-395 (attention None | natten)."""
 
     def __init__(self, cin, cout, kernel_size=3, num_blocks=2, dilations=None, attention_weights=None,
-                 act="SiLU", heads=8, kernel=3, dilation=1):
+                 act="SiLU", heads=8, kernel=3, dilation=1, batchnorm_first=False, na_drop=0.0):
         super().__init__()
         if dilations is None:
             dilations = [1, 2]
@@ -147,12 +170,12 @@ class ResidualAConv(nn.Module):
             self.attention_conv = nn.Sequential(
                 _ToNHWC(),
                 nn.LayerNorm(cout),
-                NeighborhoodAttention2D(cout, heads, kernel, dilation),
+                NeighborhoodAttention2D(cout, heads, kernel, dilation, attn_drop=na_drop, proj_drop=na_drop),
                 nn.LayerNorm(cout),
                 _ToNCHW(),
             )
         self.res_modules = nn.ModuleList(
-            [ResConvBlock2d(cin, cout, kernel_size, d, act, num_blocks) for d in dilations]
+            [ResConvBlock2d(cin, cout, kernel_size, d, act, num_blocks, batchnorm_first) for d in dilations]
         )
 
     def forward(self, x):
@@ -169,14 +192,21 @@ class PoolResidualConv(nn.Module):
     """nn/modules/convolution.py:398-513 (RESA path)."""
 
     def __init__(self, cin, cout, dropout=0.0, kernel_size=3, num_blocks=2, attention_weights=None, act="SiLU",
-                 dilations=None, pool_first=True, pool_by_max=False, **na):
+                 dilations=None, pool_first=True, pool_by_max=False, batchnorm_first=False, res_block_type="resa", **na):
         super().__init__()
         self.pool_first = pool_first
         self.pool_by_max = pool_by_max
         if pool_first and not pool_by_max:
-            self.pool_conv = ConvBlock2d(cin, cout, 3, padding=1, stride=2, add_activation=False)
+            if batchnorm_first:
+                self.pool_conv = nn.Conv2d(cin, cout, 3, padding=1, stride=2)
+            else:
+                self.pool_conv = ConvBlock2d(cin, cout, 3, padding=1, stride=2, add_activation=False)
             cin = cout
-        self.res_conv = ResidualAConv(cin, cout, kernel_size, num_blocks, dilations, attention_weights, act, **na)
+        if res_block_type == "res":
+            self.res_conv = ResidualConv(cin, cout, kernel_size, num_blocks, attention_weights, act, batchnorm_first)
+        else:
+            self.res_conv = ResidualAConv(cin, cout, kernel_size, num_blocks, dilations, attention_weights, act,
+                                          batchnorm_first=batchnorm_first, **na)
         self.dropout_layer = nn.Dropout2d(p=dropout)
 
     def forward(self, x):
@@ -203,9 +233,11 @@ class UpConv(nn.Module):
 class TowerUNetEncoder(nn.Module):
     """nn/modules/unet_parts.py:377-449."""
 
-    def __init__(self, channels, dilations, act, dropout, attention_weights, pool_by_max):
+    def __init__(self, channels, dilations, act, dropout, attention_weights, pool_by_max, batchnorm_first=False,
+                 res_block_type="resa"):
         super().__init__()
-        kw = dict(dropout=dropout, act=act, pool_by_max=pool_by_max, attention_weights=attention_weights)
+        kw = dict(dropout=dropout, act=act, pool_by_max=pool_by_max, attention_weights=attention_weights,
+                  batchnorm_first=batchnorm_first, res_block_type=res_block_type)
         na = (lambda k: NATTEN_PARAMS[k]) if attention_weights else (lambda k: {})
         self.down_a = PoolResidualConv(channels[0], channels[0], dilations=dilations, pool_first=False, **kw, **na("a"))
         self.down_b = PoolResidualConv(channels[0], channels[1], dilations=dilations[:3], **kw, **na("b"))
@@ -225,11 +257,15 @@ class UNetUpBlock(nn.Module):
     """nn/modules/unet_parts.py:312-374 (num_blocks is NOT forwarded: :355-368)."""
 
     def __init__(self, cin, cout, kernel_size=3, attention_weights=None, act="SiLU", dilations=None,
-                 resample_up=True, **na):
+                 resample_up=True, num_blocks=2, batchnorm_first=False, res_block_type="resa", **na):
         super().__init__()
         if resample_up:
             self.up_conv = UpConv(cin, cin)
-        self.res_conv = ResidualAConv(cin, cout, kernel_size, 2, dilations, attention_weights, act, **na)
+        if res_block_type == "res":  # unet_parts.py:343-353: ResidualConv DOES receive num_blocks
+            self.res_conv = ResidualConv(cin, cout, kernel_size, num_blocks, attention_weights, act, batchnorm_first)
+        else:
+            self.res_conv = ResidualAConv(cin, cout, kernel_size, 2, dilations, attention_weights, act,
+                                          batchnorm_first=batchnorm_first, **na)
 
     def forward(self, x, size):
         if tuple(x.shape[-2:]) != tuple(size):
@@ -240,13 +276,15 @@ class UNetUpBlock(nn.Module):
 class TowerUNetDecoder(nn.Module):
     """nn/modules/unet_parts.py:452-525."""
 
-    def __init__(self, channels, up_channels, dilations, act, attention_weights):
+    def __init__(self, channels, up_channels, dilations, act, attention_weights, dropout=0.0, batchnorm_first=False,
+                 res_block_type="resa"):
         super().__init__()
-        na = (lambda k: NATTEN_PARAMS[k]) if attention_weights else (lambda k: {})
-        self.over_d = UNetUpBlock(channels[3], up_channels, kernel_size=1, dilations=[1], resample_up=False, act=act)
-        self.up_cu = UNetUpBlock(up_channels, up_channels, dilations=dilations[:2], attention_weights=attention_weights, act=act, **na("c"))
-        self.up_bu = UNetUpBlock(up_channels, up_channels, dilations=dilations[:3], attention_weights=attention_weights, act=act, **na("b"))
-        self.up_au = UNetUpBlock(up_channels, up_channels, dilations=dilations, attention_weights=attention_weights, act=act, **na("a"))
+        na = (lambda k: dict(NATTEN_PARAMS[k], na_drop=dropout)) if attention_weights else (lambda k: {})
+        kw = dict(act=act, batchnorm_first=batchnorm_first, res_block_type=res_block_type)
+        self.over_d = UNetUpBlock(channels[3], up_channels, kernel_size=1, dilations=[1], resample_up=False, num_blocks=1, **kw)
+        self.up_cu = UNetUpBlock(up_channels, up_channels, dilations=dilations[:2], attention_weights=attention_weights, **kw, **na("c"))
+        self.up_bu = UNetUpBlock(up_channels, up_channels, dilations=dilations[:3], attention_weights=attention_weights, **kw, **na("b"))
+        self.up_au = UNetUpBlock(up_channels, up_channels, dilations=dilations, attention_weights=attention_weights, **kw, **na("a"))
 
     def forward(self, x):
         x_du = self.over_d(x["x_d"], size=x["x_d"].shape[-2:])
@@ -260,7 +298,7 @@ class TowerUNetBlock(nn.Module):
     """nn/modules/unet_parts.py:615-760 (use_latlon=False)."""
 
     def __init__(self, side_channels, down_channels, up_channels, out_channels, tower=False, dilations=None,
-                 attention_weights=None, act="SiLU", **na):
+                 attention_weights=None, act="SiLU", batchnorm_first=False, res_block_type="resa", **na):
         super().__init__()
         cin = side_channels + down_channels + up_channels * 2
         self.backbone_down_conv = UpConv(down_channels, down_channels)
@@ -268,7 +306,11 @@ class TowerUNetBlock(nn.Module):
         if tower:
             self.tower_conv = UpConv(up_channels, up_channels)
             cin += up_channels
-        self.res_conv = ResidualAConv(cin, out_channels, 3, 2, dilations, attention_weights, act, **na)
+        if res_block_type == "res":
+            self.res_conv = ResidualConv(cin, out_channels, 3, 2, attention_weights, act, batchnorm_first)
+        else:
+            self.res_conv = ResidualAConv(cin, out_channels, 3, 2, dilations, attention_weights, act,
+                                          batchnorm_first=batchnorm_first, **na)
 
     def forward(self, backbone_side, backbone_down, decode_side, decode_down, tower_down=None):
         size = decode_side.shape[-2:]
@@ -283,10 +325,12 @@ class TowerUNetBlock(nn.Module):
 class TowerUNetFusion(nn.Module):
     """nn/modules/unet_parts.py:528-612."""
 
-    def __init__(self, channels, up_channels, dilations, act, attention_weights):
+    def __init__(self, channels, up_channels, dilations, act, attention_weights, batchnorm_first=False,
+                 res_block_type="resa"):
         super().__init__()
         na = (lambda k: NATTEN_PARAMS[k]) if attention_weights else (lambda k: {})
-        kw = dict(up_channels=up_channels, out_channels=up_channels, act=act, attention_weights=attention_weights)
+        kw = dict(up_channels=up_channels, out_channels=up_channels, act=act, attention_weights=attention_weights,
+                  batchnorm_first=batchnorm_first, res_block_type=res_block_type)
         self.tower_c = TowerUNetBlock(channels[2], channels[3], dilations=dilations[:2], **kw, **na("c"))
         self.tower_b = TowerUNetBlock(channels[1], channels[2], tower=True, dilations=dilations, **kw, **na("b"))
         self.tower_a = TowerUNetBlock(channels[0], channels[1], tower=True, dilations=dilations, **kw, **na("a"))
@@ -389,16 +433,19 @@ class TowerUNet(nn.Module):
 
     def __init__(self, in_channels, in_time, hidden_channels=64, num_classes=1, dilations=None,
                  activation_type="SiLU", dropout=0.0, attention_weights="natten", pool_by_max=False,
-                 edge_activation=True, mask_activation=True):
+                 edge_activation=True, mask_activation=True, batchnorm_first=False, res_block_type="resa"):
         super().__init__()
         if dilations is None:
             dilations = [1, 2]
         channels = [hidden_channels, hidden_channels * 2, hidden_channels * 4, hidden_channels * 8]
         up_channels = int(hidden_channels * len(channels))
         self.pre_unet = PreTimeReduction(in_channels, in_time, channels[0], activation_type)
-        self.encoder = TowerUNetEncoder(channels, dilations, activation_type, dropout, None, pool_by_max)
-        self.decoder = TowerUNetDecoder(channels, up_channels, dilations, activation_type, attention_weights)
-        self.tower_fusion = TowerUNetFusion(channels, up_channels, dilations, activation_type, None)
+        self.encoder = TowerUNetEncoder(channels, dilations, activation_type, dropout, None, pool_by_max,
+                                        batchnorm_first, res_block_type)
+        self.decoder = TowerUNetDecoder(channels, up_channels, dilations, activation_type, attention_weights, dropout,
+                                        batchnorm_first, res_block_type)
+        self.tower_fusion = TowerUNetFusion(channels, up_channels, dilations, activation_type, None, batchnorm_first,
+                                            res_block_type)
         self.final_a = TowerUNetFinal(up_channels, num_classes, activation_type)
         self.final_b = TowerUNetFinal(up_channels, num_classes, activation_type, resample_factor=2)
         self.final_c = TowerUNetFinal(up_channels, num_classes, activation_type, resample_factor=4)

@@ -22,6 +22,8 @@ def _declarations():
                 p = " ".join(p.split())
                 if "*" in p:
                     kinds.append("P")
+                elif re.match(r"(const )?unsigned long long\b", p):
+                    kinds.append("U64")
                 elif re.match(r"(const )?long\b", p):
                     kinds.append("L")
                 elif re.match(r"(const )?int\b", p):
@@ -39,7 +41,7 @@ def test_header_declares_the_binding():
 
     decls = _declarations()
     assert set(decls) == set(_lib.SIGNATURES), set(decls) ^ set(_lib.SIGNATURES)
-    names = {"P": _lib.P, "L": _lib.L, "I": _lib.I, "F": _lib.F}
+    names = {"P": _lib.P, "L": _lib.L, "I": _lib.I, "F": _lib.F, "U64": _lib.U64}
     for name, kinds in decls.items():
         assert [names[k] for k in kinds] == _lib.SIGNATURES[name], name
 

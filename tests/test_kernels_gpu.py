@@ -418,3 +418,77 @@ def test_adamw_and_clip():
                   1e-4, 1e-3, step, 1.0, sumsq.data_ptr(), 1.0, E._stream())
         torch.cuda.synchronize()
         _close(p, pr, 1e-6, f"step {step}")
+
+
+@pytest.mark.parametrize("shape,out", [((2, 8, 28, 28), (14, 14)), ((2, 16, 25, 25), (12, 12)), ((1, 4, 13, 9), (6, 4))])
+def test_adaptive_max_pool(shape, out):
+    from cultionet_amd import engine as E
+
+    x = _rand(*shape, seed=80)
+    xr = x.clone().requires_grad_(True)
+    yr = F.adaptive_max_pool2d(xr, out)
+    dy = _rand(*yr.shape, seed=81)
+    yr.backward(dy)
+    y, (dx,), _ = _engine_run(nn.Linear(1, 1), lambda v: E.adaptive_max_pool2d(v, out), [x], dy)
+    _close(y, yr, 0, "y")
+    _close(dx, xr.grad, 1e-6, "dx")
+
+
+@pytest.mark.parametrize("channelwise", [True, False])
+def test_dropout_statistics_and_backward(channelwise):
+    """Masks cannot match torch's RNG; check the contract instead: kept values are x/(1-p), the kept fraction
+    is ~1-p, the backward pass uses the same mask, and the mask is a pure function of the seed."""
+    from cultionet_amd import engine as E
+
+    dev = _dev()
+    p = 0.3
+    x = (_rand(8, 64, 20, 20, seed=82).abs() + 0.5).to(dev)
+    dy = _rand(8, 64, 20, 20, seed=83).to(dev)
+    outs = []
+    for _ in range(2):
+        E.manual_seed(1234)
+        with E.recording(True) as tape:
+            xv = E.Var(x, True)
+            yv = E.dropout(xv, p, channelwise, training=True)
+            yv.grad = dy.clone()
+            tape.backward()
+        torch.cuda.synchronize()
+        outs.append((yv.t.cpu(), xv.grad.cpu()))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    y, dx = outs[0]
+    keep = y != 0
+    assert torch.allclose(y[keep], (x.cpu() / (1 - p))[keep], rtol=1e-6)
+    assert torch.allclose(dx, torch.where(keep, dy.cpu() / (1 - p), torch.zeros(())), rtol=1e-6)
+    frac = keep.float().mean().item()
+    assert abs(frac - (1 - p)) < (0.08 if channelwise else 0.01), frac
+    if channelwise:  # whole (b, c) planes are kept or dropped together
+        plane = keep.flatten(2)
+        assert torch.equal(plane.all(-1), plane.any(-1))
+
+
+def test_train_step_with_dropout_runs():
+    """dropout=0.2 (the LitModel default): Dropout2d after encoder blocks + NA attn/proj dropout."""
+    from cultionet_amd import engine as E
+    from cultionet_amd.data import Data
+    from cultionet_amd.lightning import CultionetLitModel, HipTrainer
+    from cultionet_amd import synthetic as S
+
+    dev = _dev()
+    lit = CultionetLitModel(in_channels=3, in_time=12, hidden_channels=8, dropout=0.2)
+    m = lit.cultionet_model.mask_model
+    m.load_state_dict(S.seeded_state_dict(m.state_dict()))
+    lit = lit.to(dev).train()
+    x, y, bdist = S.seeded_batch(2, height=28, width=28, with_mask=True)
+    batch = Data(x=x.to(dev), y=y.to(dev), bdist=bdist.to(dev))
+    tr = HipTrainer(lit)
+    E.manual_seed(7)
+    l1 = float(tr.forward_backward(batch).item())
+    g1 = tr.store.flat_grad.clone()
+    E.manual_seed(7)
+    l2 = float(tr.forward_backward(batch).item())
+    assert l1 == l2 and torch.isfinite(g1).all()
+    assert 0.3 < l1 < 1.0
+    lit.eval()
+    with torch.no_grad():
+        out = m(batch.x)
+    assert torch.isfinite(out["crop"]).all()

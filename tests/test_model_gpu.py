@@ -47,6 +47,9 @@ def _check_outputs(pred, g):
     ("train_h32_b1_100", {}),
     ("train_h32_b1_100_masked", {}),
     ("train_h32_b8_100", {}),
+    ("train_h8_b2_28_poolmax", {"pool_by_max": True}),
+    ("train_h8_b2_28_res", {"res_block_type": "res", "attention_weights": None}),
+    ("train_h8_b2_28_bnfirst", {"batchnorm_first": True}),
 ])
 def test_native_train_step_matches_reference(golden_dir, name, kw):
     from cultionet_amd.lightning import HipTrainer
@@ -68,7 +71,7 @@ def test_native_train_step_matches_reference(golden_dir, name, kw):
             bad.append((str(n), norms[str(n)], float(refn)))
     assert not bad, bad[:8]
     sd = model.state_dict()
-    k0 = "tower_fusion.tower_a.res_conv.res_modules.0.block.0.seq.1."
+    k0 = str(g["bn_key"]) if "bn_key" in g.files else "tower_fusion.tower_a.res_conv.res_modules.0.block.0.seq.1."
     assert np.abs(sd[k0 + "running_mean"].cpu().numpy() - g["bn_running_mean"]).max() <= 1e-5
     assert np.abs(sd[k0 + "running_var"].cpu().numpy() - g["bn_running_var"]).max() <= 1e-5
     assert int(sd[k0 + "num_batches_tracked"]) == 1

@@ -38,6 +38,9 @@ def _run_train(g, **model_kw):
         ("train_h8_b2_28_noattn", {"attention_weights": None}, "TanimotoComplementLoss"),
         ("train_h8_b2_28_dil3", {"dilations": [1, 3]}, "TanimotoComplementLoss"),
         ("train_h32_b1_100_masked", {}, "TanimotoComplementLoss"),
+        ("train_h8_b2_28_poolmax", {"pool_by_max": True}, "TanimotoComplementLoss"),
+        ("train_h8_b2_28_res", {"res_block_type": "res", "attention_weights": None}, "TanimotoComplementLoss"),
+        ("train_h8_b2_28_bnfirst", {"batchnorm_first": True}, "TanimotoComplementLoss"),
     ],
 )
 def test_oracle_train_matches_reference_vectors(golden_dir, name, kw, loss_name):
@@ -61,7 +64,7 @@ def test_oracle_train_matches_reference_vectors(golden_dir, name, kw, loss_name)
     for n, ref in zip(names, g["grad_norms"]):
         assert abs(norms[n] - ref) <= 1e-5 * max(1.0, abs(ref)), n
     sd = m.state_dict()
-    k0 = "tower_fusion.tower_a.res_conv.res_modules.0.block.0.seq.1."
+    k0 = str(g["bn_key"]) if "bn_key" in g.files else "tower_fusion.tower_a.res_conv.res_modules.0.block.0.seq.1."
     assert np.abs(sd[k0 + "running_mean"].numpy() - g["bn_running_mean"]).max() <= TOL
     assert np.abs(sd[k0 + "running_var"].numpy() - g["bn_running_var"]).max() <= TOL
 
