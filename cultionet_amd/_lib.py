@@ -25,10 +25,10 @@ SIGNATURES = {
     "cn_pack_weights_batched_f32": [P, I, P],
     "cn_conv2d_fwd_f32": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
     "cn_conv2d_bwd_data_f32": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
-    "cn_conv2d_bwd_weight_f32": [P, L, P, L, P, I, I, I, I, I, I, I, I, I, I, P],
+    "cn_conv2d_bwd_weight_f32": [P, L, P, L, P, I, I, I, I, I, I, I, I, I, I, P, L, P],
     "cn_conv_transpose2d_fwd_f32": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, P],
     "cn_conv_transpose2d_bwd_data_f32": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, I, P],
-    "cn_conv_transpose2d_bwd_weight_f32": [P, L, P, L, P, I, I, I, I, I, I, I, I, I, P],
+    "cn_conv_transpose2d_bwd_weight_f32": [P, L, P, L, P, I, I, I, I, I, I, I, I, I, P, L, P],
     "cn_channel_sum_f32": [P, L, I, I, I, P, I, P],
     "cn_bn_workspace_doubles": [I],
     "cn_bn_act_fwd_f32": [P, L, P, P, P, P, P, L, P, L, P, P, P, I, I, I, I, F, F, I, P],

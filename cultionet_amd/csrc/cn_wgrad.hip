@@ -20,12 +20,13 @@
 #define WG_NB 13   // max Bg plane elements per lane               (plane_b <= 832)
 #define WG_KS 8    // 16-byte variant: DMA instructions per wave for the S image  (arows*npix <= 8192 floats)
 #define WG_U 4     // 16-byte variant: k-steps per unrolled group
-#define WG_KB 12   // 16-byte variant: DMA instructions per wave for the Bg image (32*plane_b <= 12288 floats)
+#define WG_KB 16   // 16-byte variant: DMA instructions per wave for the Bg image (32*plane_b <= 16384 floats)
 
 struct CnWgradGeom {
   int N;
-  int A, Hs, Ws; long sbs;
-  int Bc, Hb, Wb; long bbs;
+  int A, Hs, Ws; long sbs; long scs;   // S: channels, grid, batch stride, channel stride
+  int Bc, Hb, Wb; long bbs; long bcs;  // Bg likewise
+  double flops;                        // algorithmic FLOP of the launch (true, unpadded dims)
   int s;
   int T;
   int offy[WG_MAX_TAPS], offx[WG_MAX_TAPS];
@@ -38,7 +39,8 @@ struct CnWgradGeom {
   int b_lds_off;   // float offset of the Bg planes inside one LDS buffer
   int buf_stride;  // floats per LDS buffer
   int nbuf;        // 2: double-buffered LDS-DMA pipeline, 1: single buffer
-  int colsplit;    // 16-byte variant: waves split the columns of each row (Ws/kparts even)
+  int colsplit;    // unused
+  int mq_lo, mq_hi;  // 16-byte variant: pixel pairs [0,mq_lo) and [mq_hi, Ws/2) of a row need column masks
 };
 
 typedef __attribute__((address_space(3))) void* cn_lds_ptr;
@@ -129,7 +131,7 @@ __global__ __launch_bounds__(256) void cn_wgrad_kernel(const float* __restrict__
     const float* Sn = S + (long)n * g.sbs + (long)gy0 * g.Ws;
     for (int a = wid; a < arows; a += 4) {
       const bool aok = (a0 + a) < g.A;
-      const float* Sa = Sn + (long)(a0 + a) * HWs;
+      const float* Sa = Sn + (long)(a0 + a) * g.scs;
 #pragma unroll
       for (int i = 0; i < WG_NS; ++i) {
         if (i * 64 < npix) {  // wave-uniform
@@ -145,7 +147,7 @@ __global__ __launch_bounds__(256) void cn_wgrad_kernel(const float* __restrict__
     const int iy0 = gy0 * g.s + g.min_oy;
     for (int bl = wid; bl < WG_BC; bl += 4) {
       const bool bok = (b0 + bl) < g.Bc;
-      const float* Bb = Bn + (long)(b0 + bl) * HWb;
+      const float* Bb = Bn + (long)(b0 + bl) * g.bcs;
 #pragma unroll
       for (int i = 0; i < WG_NB; ++i) {
         if (i * 64 < g.plane_b) {  // wave-uniform
@@ -284,8 +286,8 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
         if ((wid + 4 * k) * 64 < nsp) {  // wave-uniform
           if (sp[k] >= 0) {
             const int a = sp[k] >> 16, pc = sp[k] & 0xFFFF;
-            const bool ok = (a0 + a) < g.A && (fs0 + 4 * pc + 3) < HWs;
-            const float* src = ok ? Sn + (long)(a0 + a) * HWs + 4 * pc : zero;
+            const bool ok = (a0 + a) < g.A && (fs0 + 4 * pc + 3) < (int)g.scs;
+            const float* src = ok ? Sn + (long)(a0 + a) * g.scs + 4 * pc : zero;
             cn_glds16(src, s_lds + (wid + 4 * k) * 256);
           }
         }
@@ -300,8 +302,8 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
         if ((wid + 4 * k) * 64 < nbp) {  // wave-uniform
           if (bp[k] >= 0) {
             const int bl = bp[k] >> 16, fq = f0 + 4 * (bp[k] & 0xFFFF);
-            const bool ok = (b0 + bl) < g.Bc && fq >= 0 && (fq + 3) < HWb;
-            const float* src = ok ? Bn + (long)(b0 + bl) * HWb + fq : zero;
+            const bool ok = (b0 + bl) < g.Bc && fq >= 0 && (fq + 3) < (int)g.bcs;
+            const float* src = ok ? Bn + (long)(b0 + bl) * g.bcs + fq : zero;
             cn_glds16(src, b_lds + (wid + 4 * k) * 256);
           }
         }
@@ -330,26 +332,25 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
       // the pixel pairs of every row are split over the k-part waves
       const int nq_row = g.Ws >> 1;
       const int q_lo = (nq_row * kp) / kparts, q_hi = (nq_row * (kp + 1)) / kparts;
-      const int c_lo = 2 * q_lo;
-      const int nq = q_hi - q_lo;
+      // pairs [0, mq_lo) and [mq_hi, nq_row) of a row can reach outside [0, Wb) for some tap -> masked steps
+      const int seg0 = min(max(g.mq_lo, q_lo), q_hi), seg1 = max(min(g.mq_hi, q_hi), seg0);
       for (int r = 0; r < g.PR; ++r) {
-        const float* ap = s_lds + aoff + r * g.Ws + c_lo;
+        const float* ap = s_lds + aoff + r * g.Ws;          // indexed by absolute column
         const float* bp[T];
 #pragma unroll
-        for (int j = 0; j < T; ++j) bp[j] = b_lds + boff[j] + sh + (r * S_) * g.Wb + c_lo * S_;
-        int q = 0;
-        if (q_lo == 0 && nq > 0) {  // first pair of the row: column -1 wraps into the previous row -> mask
-          const float av = ap[0];
+        for (int j = 0; j < T; ++j) bp[j] = b_lds + boff[j] + sh + (r * S_) * g.Wb;
+        int q = q_lo;
+        for (; q < seg0; ++q) {  // leading masked pairs
+          const float av = ap[2 * q];
+          const int cs = 2 * q * S_;
 #pragma unroll
           for (int j = 0; j < T; ++j) {
-            float bv = bp[j][0];
-            bv = ((unsigned)(ox[j]) < (unsigned)g.Wb) ? bv : 0.f;
+            float bv = bp[j][cs];
+            bv = ((unsigned)(cs + ox[j]) < (unsigned)g.Wb) ? bv : 0.f;
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
           }
-          q = 1;
         }
-        const int q_last = (q_hi == nq_row) ? nq - 1 : nq;  // last pair of the row handled below
-        for (; q + WG_U <= q_last; q += WG_U) {
+        for (; q + WG_U <= seg1; q += WG_U) {  // interior: no masks, immediate offsets
           const float* apq = ap + 2 * q;
 #pragma unroll
           for (int u = 0; u < WG_U; ++u) {
@@ -361,18 +362,18 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
             }
           }
         }
-        for (; q < q_last; ++q) {
+        for (; q < seg1; ++q) {
           const float av = ap[2 * q];
 #pragma unroll
           for (int j = 0; j < T; ++j)
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[j][2 * q * S_], acc[j], 0, 0, 0);
         }
-        if (q_last < nq) {  // last pair: column Ws wraps into the next row -> mask
-          const float av = ap[2 * q_last];
-          const int cs = (c_lo + 2 * q_last) * S_;
+        for (; q < q_hi; ++q) {  // trailing masked pairs
+          const float av = ap[2 * q];
+          const int cs = 2 * q * S_;
 #pragma unroll
           for (int j = 0; j < T; ++j) {
-            float bv = bp[j][2 * q_last * S_];
+            float bv = bp[j][cs];
             bv = ((unsigned)(cs + ox[j]) < (unsigned)g.Wb) ? bv : 0.f;
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
           }
@@ -398,14 +399,16 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
 // Launch of the 16-byte variant; returns CN_ERR_ARG when its alignment preconditions do not hold.
 template <int T>
 static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgradGeom g, hipStream_t stream) {
-  const long HWs = (long)g.Hs * g.Ws, HWb = (long)g.Hb * g.Wb;
-  if (HWs % 4 || HWb % 4 || g.sbs % 4 || g.bbs % 4 || (g.Ws & 1)) return CN_ERR_ARG;
+  if (g.scs % 4 || g.bcs % 4 || g.sbs % 4 || g.bbs % 4 || (g.Ws & 1)) return CN_ERR_ARG;
   if ((reinterpret_cast<uintptr_t>(S) & 15) || (reinterpret_cast<uintptr_t>(Bg) & 15)) return CN_ERR_ARG;
   g.Wsp = g.Ws;
   g.PR = 128 / g.Ws;
   if (g.PR < 1) g.PR = 1;
   if (g.PR > g.Hs) g.PR = g.Hs;
-  while (g.PR > 1 && ((g.PR * g.Ws) % 4 != 0 || g.Hs % g.PR != 0)) --g.PR;
+  // a chunk is PR whole rows = PR*Ws floats and must be whole 16-byte pieces; rows past the image in the last
+  // chunk fall outside the (zero-tailed) plane and are zero-filled by the per-piece bound check
+  while (g.PR > 1 && (g.PR * g.Ws) % 4 != 0) --g.PR;
+  if ((g.PR * g.Ws) % 4 != 0 && g.Ws % 2 == 0 && 2 * g.Ws <= 256) g.PR = 2;
   if ((g.PR * g.Ws) % 4 != 0 || g.PR * g.Ws > 256) return CN_ERR_ARG;
   int max_oy = g.min_oy, max_ox = g.min_ox;
   for (int t = 0; t < g.T; ++t) {
@@ -430,7 +433,7 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
   if (lds > 160 * 1024 || g.a_tiles * 32 * g.pitch_s > WG_KS * 4 * 256) return CN_ERR_ARG;
   g.nbuf = (2 * lds <= 160 * 1024) ? 2 : 1;
   lds *= g.nbuf;
-  g.chunks_per_img = g.Hs / g.PR;
+  g.chunks_per_img = (g.Hs + g.PR - 1) / g.PR;
   g.total_chunks = g.N * g.chunks_per_img;
   const int gx = (g.Bc + WG_BC - 1) / WG_BC, gy = (g.A + g.a_tiles * 32 - 1) / (g.a_tiles * 32);
   const int slots = (lds * 2 <= 160 * 1024) ? 512 : 256;  // resident blocks on the chip
@@ -449,15 +452,24 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
   }
   if (g.s != 1 && g.s != 2) return CN_ERR_ARG;
   {
-    const int kparts = 4 / g.a_tiles;
-    g.colsplit = (g.Ws % (2 * kparts) == 0) ? 1 : 0;
+    // pair q covers columns 2q, 2q+1: masked iff 2q*s + min_ox < 0 or (2q+1)*s + max_ox >= Wb
+    const int nq_row = g.Ws / 2;
+    int lo = (-g.min_ox + 2 * g.s - 1) / (2 * g.s);
+    if (lo < 0) lo = 0;
+    int hi_num = g.Wb - max_ox - g.s;  // first masked pair = ceil(hi_num / (2s))
+    int hi = hi_num <= 0 ? 0 : (hi_num + 2 * g.s - 1) / (2 * g.s);
+    if (lo > nq_row) lo = nq_row;
+    if (hi > nq_row) hi = nq_row;
+    if (hi < lo) hi = lo;
+    g.mq_lo = lo;
+    g.mq_hi = hi;
   }
   cn_prof_before(stream);
   if (g.s == 1)
     hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 1>), dim3(gx, gy, splits), dim3(256), lds, stream, S, Bg, dW, g);
   else
     hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 2>), dim3(gx, gy, splits), dim3(256), lds, stream, S, Bg, dW, g);
-  cn_prof_after(stream, T == 9 ? 2 : 3, 2.0 * g.N * g.Hs * g.Ws * (double)g.A * g.Bc * g.T);
+  cn_prof_after(stream, T == 9 ? 2 : 3, g.flops);
   return cn_check_launch();
 }
 
@@ -514,18 +526,44 @@ static int cn_wgrad_launch_t(const float* S, const float* Bg, float* dW, CnWgrad
   }
   cn_prof_before(stream);
   hipLaunchKernelGGL((cn_wgrad_kernel<T>), dim3(gx, gy, splits), dim3(256), lds, stream, S, Bg, dW, g);
-  cn_prof_after(stream, T == 9 ? 2 : 3, 2.0 * g.N * g.Hs * g.Ws * (double)g.A * g.Bc * g.T);
+  cn_prof_after(stream, T == 9 ? 2 : 3, g.flops);
+  return cn_check_launch();
+}
+
+// Repack [B][C][H][W] planes into [B][C][cs] with row pitch Wp >= W (zero columns) and a zero tail up to cs:
+// gives odd-sized tensors (25x25, 13x13, 99x99 ...) 16-byte aligned planes / even widths for the DMA variant.
+__global__ __launch_bounds__(256) void cn_pad_planes_kernel(const float* __restrict__ src, long sbs, long scs,
+                                                           float* __restrict__ dst, int C, int H, int W, int Wp,
+                                                           int cs) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const float* sp = src + b * sbs + (long)c * scs;
+  float* dp = dst + ((long)b * C + c) * cs;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < cs; i += gridDim.x * 256) {
+    const int r = i / Wp, col = i - r * Wp;
+    dp[i] = (r < H && col < W) ? sp[r * W + col] : 0.f;
+  }
+}
+
+static int cn_pad_planes(const float* src, long sbs, float* dst, int B, int C, int H, int W, int Wp, int cs,
+                         hipStream_t stream) {
+  int bx = (cs + 1023) / 1024;
+  if (bx < 1) bx = 1;
+  hipLaunchKernelGGL(cn_pad_planes_kernel, dim3(bx, C, B), dim3(256), 0, stream, src, sbs, (long)H * W, dst, C, H, W,
+                     Wp, cs);
   return cn_check_launch();
 }
 
 // Generic entry: dW[a][b][t] += sum S[n,a,gy,gx] * Bg[n,b,gy*s+offy[t],gx*s+offx[t]]
+// ws (optional, ws_floats floats): scratch for aligned / even-width copies of odd-sized operands.
 static int cn_wgrad_generic(const float* S, long sbs, int A, int Hs, int Ws, const float* Bg, long bbs, int Bc,
-                            int Hb, int Wb, int s, int KH, int KW, int dil, int pad, float* dW, int N,
-                            hipStream_t stream) {
+                            int Hb, int Wb, int s, int KH, int KW, int dil, int pad, float* dW, int N, float* ws,
+                            long ws_floats, hipStream_t stream) {
   CnWgradGeom g = {};
   g.N = N; g.A = A; g.Hs = Hs; g.Ws = Ws; g.sbs = sbs; g.Bc = Bc; g.Hb = Hb; g.Wb = Wb; g.bbs = bbs; g.s = s;
+  g.scs = (long)Hs * Ws; g.bcs = (long)Hb * Wb;
   g.T = KH * KW;
   if (N <= 0 || A <= 0 || Bc <= 0 || Hs <= 0 || Ws <= 0) return CN_OK;
+  g.flops = 2.0 * N * Hs * Ws * (double)A * Bc * g.T;
   for (int ky = 0; ky < KH; ++ky)
     for (int kx = 0; kx < KW; ++kx) {
       g.offy[ky * KW + kx] = ky * dil - pad;
@@ -534,28 +572,58 @@ static int cn_wgrad_generic(const float* S, long sbs, int A, int Hs, int Ws, con
   g.min_oy = -pad; g.min_ox = -pad;
   g.sa = (long)Bc * g.T;
   if (g.T != 1 && g.T != 9) return CN_ERR_ARG;
-  // 16-byte DMA variant when the alignment preconditions hold, dword variant otherwise
+  // 16-byte DMA variant when the alignment preconditions hold ...
   int rc = g.T == 1 ? cn_wgrad_launch_vec<1>(S, Bg, dW, g, stream) : cn_wgrad_launch_vec<9>(S, Bg, dW, g, stream);
   if (rc != CN_ERR_ARG) return rc;
+  // ... else through aligned copies in the caller's workspace (two streaming passes over small tensors) ...
+  if (ws != nullptr && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+    const int Wsp = (Ws + 1) & ~1;
+    const long scs = ((long)Hs * Wsp + 3) / 4 * 4, bcs = ((long)Hb * Wb + 3) / 4 * 4;
+    const long need_s = (long)N * A * scs, need_b = (long)N * Bc * bcs;
+    const bool s_ok = (g.scs % 4 == 0) && (sbs % 4 == 0) && !(Ws & 1) && !(reinterpret_cast<uintptr_t>(S) & 15);
+    const bool b_ok = (g.bcs % 4 == 0) && (bbs % 4 == 0) && !(reinterpret_cast<uintptr_t>(Bg) & 15);
+    const long need = (s_ok ? 0 : need_s) + (b_ok ? 0 : need_b);
+    if (need <= ws_floats) {
+      CnWgradGeom gp = g;
+      const float* S2 = S;
+      const float* B2 = Bg;
+      float* w = ws;
+      if (!s_ok) {
+        const int r = cn_pad_planes(S, sbs, w, N, A, Hs, Ws, Wsp, (int)scs, stream);
+        if (r != CN_OK) return r;
+        S2 = w; w += need_s;
+        gp.Ws = Wsp; gp.scs = scs; gp.sbs = (long)A * scs;
+      }
+      if (!b_ok) {
+        const int r = cn_pad_planes(Bg, bbs, w, N, Bc, Hb, Wb, Wb, (int)bcs, stream);
+        if (r != CN_OK) return r;
+        B2 = w;
+        gp.bcs = bcs; gp.bbs = (long)Bc * bcs;
+      }
+      rc = g.T == 1 ? cn_wgrad_launch_vec<1>(S2, B2, dW, gp, stream) : cn_wgrad_launch_vec<9>(S2, B2, dW, gp, stream);
+      if (rc != CN_ERR_ARG) return rc;
+    }
+  }
+  // ... else the dword variant.
   return g.T == 1 ? cn_wgrad_launch_t<1>(S, Bg, dW, g, stream) : cn_wgrad_launch_t<9>(S, Bg, dW, g, stream);
 }
 
 // Conv2d: dw [Cout][Cin][KH][KW] += x (*) dy. NOTE accumulates: zero dw first for a fresh gradient.
 extern "C" int cn_conv2d_bwd_weight_f32(const float* x, long xbs, const float* dy, long dybs, float* dw, int B,
                                         int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride, int pad,
-                                        int dil, void* stream) {
+                                        int dil, float* ws, long ws_floats, void* stream) {
   const int Hout = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
   const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
-  return cn_wgrad_generic(dy, dybs, Cout, Hout, Wout, x, xbs, Cin, Hin, Win, stride, KH, KW, dil, pad, dw, B,
-                          (hipStream_t)stream);
+  return cn_wgrad_generic(dy, dybs, Cout, Hout, Wout, x, xbs, Cin, Hin, Win, stride, KH, KW, dil, pad, dw, B, ws,
+                          ws_floats, (hipStream_t)stream);
 }
 
 // ConvTranspose2d: dw [Cin][Cout][KH][KW] += x (small grid) (*) dy (gathered at stride s).
 extern "C" int cn_conv_transpose2d_bwd_weight_f32(const float* x, long xbs, const float* dy, long dybs, float* dw,
                                                   int B, int Cin, int Hin, int Win, int Cout, int KH, int KW,
-                                                  int stride, int pad, void* stream) {
+                                                  int stride, int pad, float* ws, long ws_floats, void* stream) {
   const int Hout = (Hin - 1) * stride - 2 * pad + KH;
   const int Wout = (Win - 1) * stride - 2 * pad + KW;
-  return cn_wgrad_generic(x, xbs, Cin, Hin, Win, dy, dybs, Cout, Hout, Wout, stride, KH, KW, 1, pad, dw, B,
-                          (hipStream_t)stream);
+  return cn_wgrad_generic(x, xbs, Cin, Hin, Win, dy, dybs, Cout, Hout, Wout, stride, KH, KW, 1, pad, dw, B, ws,
+                          ws_floats, (hipStream_t)stream);
 }

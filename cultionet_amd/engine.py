@@ -328,6 +328,20 @@ def _new(shape, like: torch.Tensor) -> torch.Tensor:
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+def _pad_ws(*tensors: torch.Tensor) -> T.Tuple[T.Optional[int], int]:
+    """(pointer, floats) of scratch for aligned copies of odd-sized operands, or (None, 0) if none is needed."""
+    need = 0
+    for t in tensors:
+        H, W = t.shape[-2], t.shape[-1]
+        if (H * W) % 4 or (W & 1):
+            need += t.shape[0] * t.shape[1] * (H * (W + 1) + 3)
+    if need == 0:
+        return None, 0
+    ws = torch.empty(need, dtype=torch.float32, device=tensors[0].device)
+    _state.last_ws = ws  # keep alive until the (stream-ordered) launch that uses it has been enqueued
+    return ws.data_ptr(), need
+
+
 def conv2d(x: Var, mod, stride: int = 1, padding: int = 0, dilation: int = 1, out: T.Optional[torch.Tensor] = None) -> Var:
     """nn.Conv2d forward (+ tape node for bwd-data, bwd-weight, bias grad)."""
     tape = current_tape()
@@ -353,8 +367,9 @@ def conv2d(x: Var, mod, stride: int = 1, padding: int = 0, dilation: int = 1, ou
             if dy is None:
                 return
             s = _stream()
+            wsp, wsn = _pad_ws(xt, dy)
             _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
-                      store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, s)
+                      store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, wsp, wsn, s)
             if bias is not None:
                 _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Ho * Wo,
                           store.grad_of(bias).data_ptr(), 1, s)
@@ -392,8 +407,9 @@ def conv_transpose2d(x: Var, mod, stride: int, padding: int) -> Var:
             if dy is None:
                 return
             s = _stream()
+            wsp, wsn = _pad_ws(xt, dy)
             _lib.call("cn_conv_transpose2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
-                      store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, s)
+                      store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, wsp, wsn, s)
             if bias is not None:
                 _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Ho * Wo,
                           store.grad_of(bias).data_ptr(), 1, s)
@@ -445,7 +461,7 @@ def time_conv(x: Var, mod, tin: int) -> Var:
             s = _stream()
             dwexp = torch.zeros(Cout * tout * CT, dtype=torch.float32, device=xt.device)
             _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
-                      dwexp.data_ptr(), B, CT, H, W, Cout * tout, 1, 1, 1, 0, 1, s)
+                      dwexp.data_ptr(), B, CT, H, W, Cout * tout, 1, 1, 1, 0, 1, None, 0, s)
             _lib.call("cn_fold_timeconv_grad_f32", dwexp.data_ptr(), store.grad_of(w).data_ptr(), Cout, Cin, tin, k, s)
             if x.req:
                 dx, acc = grad_buffer(x)

@@ -52,9 +52,12 @@ int cn_conv2d_fwd_f32(const float* x, long xbs, const float* wp, const float* bi
 int cn_conv2d_bwd_data_f32(const float* dy, long dybs, const float* wp_t, float* dx, long dxbs, int B, int Cin,
                            int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, int dil, int accumulate,
                            void* stream);
-/* dw [Cout][Cin][KH][KW] += ...  (zero first) */
+/* dw [Cout][Cin][KH][KW] += ...  (zero first). ws (nullable): ws_floats floats of 16-byte aligned scratch used
+ * for aligned / even-width copies when H*W is not a multiple of 4 or W is odd (enables the 16-byte DMA path);
+ * B*(Cout*(Hout*(Wout+1)+3) + Cin*(Hin*Win+3)) floats always suffice. */
 int cn_conv2d_bwd_weight_f32(const float* x, long xbs, const float* dy, long dybs, float* dw, int B, int Cin, int Hin,
-                             int Win, int Cout, int KH, int KW, int stride, int pad, int dil, void* stream);
+                             int Win, int Cout, int KH, int KW, int stride, int pad, int dil, float* ws,
+                             long ws_floats, void* stream);
 
 /* ---- nn.Conv3d(kernel (k,1,1), no bias) of PreTimeReduction (models/nunet.py:18-57) ----------
  * run as a 1x1 conv over the [B, C*T, H, W] view with a banded weight matrix.
@@ -70,9 +73,10 @@ int cn_conv_transpose2d_fwd_f32(const float* x, long xbs, const float* wp, const
 int cn_conv_transpose2d_bwd_data_f32(const float* dy, long dybs, const float* wp_t, float* dx, long dxbs, int B,
                                      int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride, int pad,
                                      int accumulate, void* stream);
-/* dw [Cin][Cout][KH][KW] += ...  (zero first) */
+/* dw [Cin][Cout][KH][KW] += ...  (zero first); ws as for cn_conv2d_bwd_weight_f32 */
 int cn_conv_transpose2d_bwd_weight_f32(const float* x, long xbs, const float* dy, long dybs, float* dw, int B, int Cin,
-                                       int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, void* stream);
+                                       int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, float* ws,
+                                       long ws_floats, void* stream);
 
 /* bias gradients: out[c] (+)= sum_{b,l} x[b][c][l] */
 int cn_channel_sum_f32(const float* x, long xbs, int B, int C, int L, float* out, int accumulate, void* stream);

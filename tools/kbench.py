@@ -14,6 +14,7 @@ def timeit(fn, n=5):
     ts.sort(); return ts[len(ts)//2]
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+wsb = torch.empty(64 << 20, dtype=torch.float32, device=dev)  # scratch for aligned copies
 shapes = [(128,128,100,3),(480,128,100,3),(128,128,50,3),(576,128,50,3),(128,128,25,3),(640,128,25,3),(32,32,100,3),(64,64,50,3),
           (480,128,100,1),(128,384,100,1),(128,9,100,3),(256,128,13,1)]
 for Cin, Cout, H, k in shapes:
@@ -28,7 +29,7 @@ for Cin, Cout, H, k in shapes:
     f_fwd = lambda: _lib.call("cn_conv2d_fwd_f32", x.data_ptr(), E.bstride(x), pw.fwd.data_ptr(), None, y.data_ptr(), E.bstride(y), B, Cin, H, H, Cout, k, k, 1, k//2, 1, 0, s)
     f_dg = lambda: _lib.call("cn_conv2d_bwd_data_f32", dy.data_ptr(), E.bstride(dy), pw.bwd.data_ptr(), dx.data_ptr(), E.bstride(dx), B, Cin, H, H, Cout, k, k, 1, k//2, 1, 0, s)
     dw = store.grad_of(conv.weight)
-    f_wg = lambda: _lib.call("cn_conv2d_bwd_weight_f32", x.data_ptr(), E.bstride(x), dy.data_ptr(), E.bstride(dy), dw.data_ptr(), B, Cin, H, H, Cout, k, k, 1, k//2, 1, s)
+    f_wg = lambda: _lib.call("cn_conv2d_bwd_weight_f32", x.data_ptr(), E.bstride(x), dy.data_ptr(), E.bstride(dy), dw.data_ptr(), B, Cin, H, H, Cout, k, k, 1, k//2, 1, wsb.data_ptr(), wsb.numel(), s)
     t1, t2, t3 = timeit(f_fwd), timeit(f_dg), timeit(f_wg)
     print(f"B{B} {Cin:4d}->{Cout:4d} {H:3d}^2 k{k}: fwd {t1*1e3:8.1f}us {fl/t1/1e9:6.1f}TF | dgrad {t2*1e3:8.1f}us {fl/t2/1e9:6.1f}TF | wgrad {t3*1e3:8.1f}us {fl/t3/1e9:6.1f}TF", flush=True)
 # conv transpose
@@ -44,7 +45,7 @@ for C, H in [(128,50),(128,25),(256,13),(64,50)]:
     f_fwd = lambda: _lib.call("cn_conv_transpose2d_fwd_f32", x.data_ptr(), E.bstride(x), pw.fwd.data_ptr(), conv.bias.data_ptr(), y.data_ptr(), E.bstride(y), B, C, H, H, C, 3, 3, 2, 1, 0, s)
     f_dg = lambda: _lib.call("cn_conv_transpose2d_bwd_data_f32", dy.data_ptr(), E.bstride(dy), pw.bwd.data_ptr(), dx.data_ptr(), E.bstride(dx), B, C, H, H, C, 3, 3, 2, 1, 0, s)
     dw = store.grad_of(conv.weight)
-    f_wg = lambda: _lib.call("cn_conv_transpose2d_bwd_weight_f32", x.data_ptr(), E.bstride(x), dy.data_ptr(), E.bstride(dy), dw.data_ptr(), B, C, H, H, C, 3, 3, 2, 1, s)
+    f_wg = lambda: _lib.call("cn_conv_transpose2d_bwd_weight_f32", x.data_ptr(), E.bstride(x), dy.data_ptr(), E.bstride(dy), dw.data_ptr(), B, C, H, H, C, 3, 3, 2, 1, wsb.data_ptr(), wsb.numel(), s)
     t1, t2, t3 = timeit(f_fwd), timeit(f_dg), timeit(f_wg)
     print(f"B{B} convT {C:4d} {H:3d}->{Ho}: fwd {t1*1e3:8.1f}us {fl/t1/1e9:6.1f}TF | dgrad {t2*1e3:8.1f}us {fl/t2/1e9:6.1f}TF | wgrad {t3*1e3:8.1f}us {fl/t3/1e9:6.1f}TF", flush=True)
 # streaming kernels: BN fwd/bwd GB/s

@@ -17,5 +17,5 @@ for _ in range(6):
     if mode == "fwd":
         _lib.call("cn_conv2d_fwd_f32", x.data_ptr(), E.bstride(x), pw.fwd.data_ptr(), None, y.data_ptr(), E.bstride(y), B, Cin, H, H, Cout, k, k, 1, 1, 1, 0, s)
     else:
-        _lib.call("cn_conv2d_bwd_weight_f32", x.data_ptr(), E.bstride(x), dy.data_ptr(), E.bstride(dy), dw.data_ptr(), B, Cin, H, H, Cout, k, k, 1, 1, 1, s)
+        _lib.call("cn_conv2d_bwd_weight_f32", x.data_ptr(), E.bstride(x), dy.data_ptr(), E.bstride(dy), dw.data_ptr(), B, Cin, H, H, Cout, k, k, 1, 1, 1, None, 0, s)
 torch.cuda.synchronize()
