@@ -53,6 +53,8 @@ SIGNATURES = {
     "cn_adamw_step_f32": [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P],
     "cn_pack_timeconv_f32": [P, P, I, I, I, I, I, P],
     "cn_fold_timeconv_grad_f32": [P, P, I, I, I, I, P],
+    "cn_prepare_chips_f32": [P, I, P, P, P, I, I, L, F, F, F, P],
+    "cn_predictions_to_u16": [P, P, P, P, I, I, I, I, I, I, I, F, P],
     "cn_profile_begin": [],
     "cn_profile_end": [P],
 }

@@ -1,0 +1,67 @@
+// Input / output edges of the hot path, HBM-bound streaming kernels.
+//   input : EdgeDataset.get scaling + clip + z-score (/root/reference/src/cultionet/data/datasets.py:443-446,
+//           utils/normalize.py:63-82) fused into one pass from the stored integer reflectances to fp32
+//   output: LightningGTiffWriter slice-off-padding + x10000 + clip to uint16
+//           (/root/reference/src/cultionet/callbacks.py:176-227)
+#include "cn_common.h"
+
+template <typename TIn>
+__global__ __launch_bounds__(256) void cn_prepare_chips_kernel(const TIn* __restrict__ x, float* __restrict__ y,
+                                                              const float* __restrict__ mean,
+                                                              const float* __restrict__ stdv, int C, long L,
+                                                              float scale, float lo, float hi) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  const long base = ((long)b * C + c) * L;
+  const float m = mean ? mean[c] : 0.f, inv = stdv ? 1.0f / stdv[c] : 1.f;
+  for (long l = blockIdx.x * 256L + threadIdx.x; l < L; l += (long)gridDim.x * 256) {
+    float v = (float)x[base + l] * scale;
+    v = fminf(fmaxf(v, lo), hi);
+    y[base + l] = (v - m) * inv;
+  }
+}
+
+// x: [B][C][L] raw values (dtype: 0 f32, 1 i32, 2 i16, 3 u16); y: fp32 [B][C][L];
+// y = (clip(x * scale, lo, hi) - mean[c]) / std[c]   (mean/std nullable: no z-score)
+extern "C" int cn_prepare_chips_f32(const void* x, int dtype, float* y, const float* mean, const float* stdv, int B,
+                                    int C, long L, float scale, float lo, float hi, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
+  long bx = (L + 1023) / 1024;
+  if (bx > 1024) bx = 1024;
+  dim3 grid((unsigned)bx, C, B);
+  switch (dtype) {
+    case 0: hipLaunchKernelGGL(cn_prepare_chips_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, y, mean, stdv, C, L, scale, lo, hi); break;
+    case 1: hipLaunchKernelGGL(cn_prepare_chips_kernel<int>, grid, dim3(256), 0, stream, (const int*)x, y, mean, stdv, C, L, scale, lo, hi); break;
+    case 2: hipLaunchKernelGGL(cn_prepare_chips_kernel<short>, grid, dim3(256), 0, stream, (const short*)x, y, mean, stdv, C, L, scale, lo, hi); break;
+    case 3: hipLaunchKernelGGL(cn_prepare_chips_kernel<unsigned short>, grid, dim3(256), 0, stream, (const unsigned short*)x, y, mean, stdv, C, L, scale, lo, hi); break;
+    default: return CN_ERR_ARG;
+  }
+  return cn_check_launch();
+}
+
+// out[b][k][i][j] = (uint16) clip(p_k[b][pad_top+i][pad_left+j] * scale, 0, scale), k = distance, edge, crop
+__global__ __launch_bounds__(256) void cn_predictions_u16_kernel(const float* __restrict__ dist,
+                                                                const float* __restrict__ edge,
+                                                                const float* __restrict__ crop,
+                                                                unsigned short* __restrict__ out, int H, int W,
+                                                                int pad_top, int pad_left, int h, int w, float scale) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= h * w) return;
+  const int k = blockIdx.y, b = blockIdx.z;
+  const float* src = k == 0 ? dist : (k == 1 ? edge : crop);
+  const int i = p / w, j = p - i * w;
+  float v = src[(long)b * H * W + (long)(pad_top + i) * W + pad_left + j] * scale;
+  v = fminf(fmaxf(v, 0.f), scale);
+  out[((long)b * 3 + k) * h * w + p] = (unsigned short)v;
+}
+
+// dist/edge/crop: [B][1][H][W] probabilities; out: uint16 [B][3][h][w] (window without padding)
+extern "C" int cn_predictions_to_u16(const float* dist, const float* edge, const float* crop, unsigned short* out,
+                                     int B, int H, int W, int pad_top, int pad_left, int h, int w, float scale,
+                                     void* stream) {
+  if (B <= 0 || h <= 0 || w <= 0) return CN_OK;
+  if (pad_top < 0 || pad_left < 0 || pad_top + h > H || pad_left + w > W) return CN_ERR_ARG;
+  hipLaunchKernelGGL(cn_predictions_u16_kernel, dim3((h * w + 255) / 256, 3, B), dim3(256), 0, (hipStream_t)stream, dist,
+                     edge, crop, out, H, W, pad_top, pad_left, h, w, scale);
+  return cn_check_launch();
+}

@@ -169,6 +169,15 @@ int cn_adamw_step_f32(float* p, const float* g, float* m, float* v, long n, floa
                       float eps, float weight_decay, int step, float grad_scale, const double* sumsq, float max_norm,
                       void* stream);
 
+/* ---- input / output edges ------------------------------------------------
+ * prepare: EdgeDataset.get scale + clip (data/datasets.py:443-446) + NormValues z-score
+ *   (utils/normalize.py:63-82): y = (clip(x*scale, lo, hi) - mean[c]) / std[c]; x dtype 0 f32, 1 i32, 2 i16, 3 u16.
+ * predictions: LightningGTiffWriter (callbacks.py:176-227): drop padding, x scale, clip, cast to uint16. */
+int cn_prepare_chips_f32(const void* x, int dtype, float* y, const float* mean, const float* stdv, int B, int C, long L,
+                         float scale, float lo, float hi, void* stream);
+int cn_predictions_to_u16(const float* dist, const float* edge, const float* crop, unsigned short* out, int B, int H,
+                          int W, int pad_top, int pad_left, int h, int w, float scale, void* stream);
+
 /* ---- diagnostics: per-launch HIP-event timing of the contraction kernels (bench.py roofline) ---
  * begin() starts recording event pairs around every implicit-GEMM / weight-gradient launch on the
  * launch stream; end() synchronises them and fills out[4][3] = {milliseconds, algorithmic flops,

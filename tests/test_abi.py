@@ -20,7 +20,7 @@ def _declarations():
         if params and params != "void":
             for p in params.split(","):
                 p = " ".join(p.split())
-                if "*" in p:
+                if "*" in p:  # any pointer (incl. unsigned short*)
                     kinds.append("P")
                 elif re.match(r"(const )?unsigned long long\b", p):
                     kinds.append("U64")

@@ -492,3 +492,32 @@ def test_train_step_with_dropout_runs():
     with torch.no_grad():
         out = m(batch.x)
     assert torch.isfinite(out["crop"]).all()
+
+
+@pytest.mark.parametrize("dtype", [torch.int16, torch.int32, torch.float32])
+def test_prepare_chips(dtype):
+    """datasets.py:443-446 + normalize.py:63-82 fused."""
+    from cultionet_amd.edges import prepare_chips
+
+    g = torch.Generator().manual_seed(90)
+    raw = torch.randint(-50, 12000, (2, 4, 5, 17, 19), generator=g).to(dtype)
+    mean = torch.rand(4, generator=g) * 0.3
+    std = torch.rand(4, generator=g) * 0.2 + 0.05
+    ref = (raw.float() / 10_000.0).clip(1e-9, 1)
+    ref = (ref - mean.view(1, 4, 1, 1, 1)) / std.view(1, 4, 1, 1, 1)
+    out = prepare_chips(raw.to(_dev()), mean, std).cpu()
+    _close(out, ref, 1e-6, "prepared")
+
+
+def test_predictions_to_uint16():
+    """callbacks.py:176-227: slice padding, x10000, clip, uint16."""
+    from cultionet_amd.edges import predictions_to_uint16
+
+    g = torch.Generator().manual_seed(91)
+    pred = {k: torch.rand(2, 1, 40, 44, generator=g) * 1.2 - 0.1 for k in ("distance", "edge", "crop")}
+    pad, h, w = 4, 32, 36
+    ref = torch.cat([pred[k][:, :, pad:pad + h, pad:pad + w] for k in ("distance", "edge", "crop")], 1)
+    ref = (ref * 10_000.0).clip(0, 10_000.0).numpy().astype("uint16")
+    out = predictions_to_uint16({k: v.to(_dev()) for k, v in pred.items()}, pad, h, w).cpu().numpy()
+    assert (out.astype(int) - ref.astype(int)).__abs__().max() <= 1  # fp32 product rounding at integer boundaries
+    assert (out == ref).mean() > 0.999
