@@ -218,7 +218,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const float* __restr
 // 4x fewer staging instructions than the dword path (the limiter of the f32 MFMA loop: one VMEM/LDS
 // instruction per wave moves at most 16 B per lane whatever its width).
 //   NV: float4 chunks per thread per channel (vplane <= NV*1024 floats)
-template <int WAVES_N, int TN, int TM, int NV>
+template <int WAVES_N, int TN, int TM, int NV, int RP>
 __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __restrict__ x,
                                                                const float* __restrict__ wp,
                                                                const float* __restrict__ bias,
@@ -250,8 +250,11 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __r
   const int b = tile / tiles_per_img;
   const int m0 = (tile - b * tiles_per_img) * MT;
   const int Win = g.Win;
+  // RP: rows padded in LDS by a zero gap of >= 4 floats (serves both neighbours' halos); pitch % 4 == 0
+  const int pitch = RP ? ((Win + 3) / 4 * 4 + 4) : Win;
   if (tid < ntaps) {
-    tap_lds[tid] = (g.cls[ci_].dy[tid] - min_dy) * Win + (g.cls[ci_].dx[tid] - min_dx);
+    tap_lds[tid] = RP ? (g.cls[ci_].dy[tid] - min_dy) * pitch + g.cls[ci_].dx[tid]
+                      : (g.cls[ci_].dy[tid] - min_dy) * Win + (g.cls[ci_].dx[tid] - min_dx);
     tap_lds[CN_MAX_TAPS + tid] = g.cls[ci_].wt[tid];
     tap_lds[2 * CN_MAX_TAPS + tid] = g.cls[ci_].dx[tid];
   }
@@ -260,20 +263,43 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __r
   const int Mimg = Hg * Wg;
   const int gy0 = m0 / Wg;
   const int HWin = g.Hin * Win;
-  const int start = (gy0 * g.is + min_dy) * Win + min_dx;  // flat index of the LDS image's logical origin
-  const int f0 = (start >> 2) << 2;                        // aligned down (arithmetic shift: floor)
-  const int sh = start - f0;
+  // flattened-row image: RP == false: unpadded, origin `start` aligned down to 16 bytes (shift sh), column
+  // overruns masked at read time. RP == true (Win % 4 == 0): whole rows [iy_base, iy_base+rows) x [0, Win), each
+  // followed by a 4-float zero gap in LDS, so taps that step over a row end read zeros and need no mask.
+  const int start = RP ? (gy0 * g.is + min_dy) * Win : (gy0 * g.is + min_dy) * Win + min_dx;
+  const int f0 = (start >> 2) << 2;  // aligned down (arithmetic shift: floor)
+  const int sh = start - f0;         // 0 when RP == 1; 0 or 2 when RP == 2
 
-  int goff[NV];  // flat index of this thread's float4 chunk, -1 zero-fill, -2 idle
+  int goff[NV];   // flat index of this thread's float4 chunk, -1 zero-fill, -2 idle
+  int ldst[NV];   // LDS float offset of the chunk (RP == 2: of its first half) inside a channel image
+  int ldst2[NV];  // RP == 2 (Win % 4 == 2): offset of the second half -- a chunk may straddle two rows
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int e4 = 4 * (tid + i * 256);
-    if (e4 < vplane) {
-      const int fq = f0 + e4;
+    const int e4 = 4 * (tid + i * 256) - (RP ? sh : 0);  // RP: element index relative to the first staged row
+    const int lim = RP ? g.cls[ci_].rows * Win : vplane;
+    ldst[i] = 0;
+    ldst2[i] = 0;
+    if (e4 + 3 >= 0 && e4 < lim) {
+      const int fq = start + e4 - (RP ? 0 : sh);
       goff[i] = (fq >= 0 && fq + 3 < HWin) ? fq : -1;
+      if (RP == 1) {
+        const int r = e4 / Win;
+        ldst[i] = r * pitch + 4 + (e4 - r * Win);
+      } else if (RP == 2) {
+        // halves (2 floats) never straddle a row because Win is even; a half before the first row is dropped
+        const int ea = e4 < 0 ? e4 + 2 : e4, eb = e4 + 2;
+        const int ra = ea / Win, rb = eb / Win;
+        ldst[i] = e4 < 0 ? -1 : ra * pitch + 4 + (ea - ra * Win);
+        ldst2[i] = eb < lim ? rb * pitch + 4 + (eb - rb * Win) : -1;
+      } else {
+        ldst[i] = e4;
+      }
     } else {
       goff[i] = -2;
     }
+  }
+  if (RP) {  // gaps are never written by the staging: zero the channel images once
+    for (int e = tid; e < KC * VS; e += 256) in_lds[e] = 0.f;
   }
 
   int pix_lds[TM], out_off[TM];
@@ -285,7 +311,8 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __r
     pix_ok[tm] = p < Mimg;
     const int pc = pix_ok[tm] ? p : Mimg - 1;
     const int gy = pc / Wg, gx = pc - gy * Wg;
-    pix_lds[tm] = ((gy - gy0) * g.is) * Win + gx * g.is + sh + half * VS;
+    pix_lds[tm] = RP ? ((gy - gy0) * g.is) * pitch + 4 + gx * g.is + half * VS
+                     : ((gy - gy0) * g.is) * Win + gx * g.is + sh + half * VS;
     out_off[tm] = (gy * g.os + oy0) * g.Wout + gx * g.os + ox0;
     unsigned m = 0;
     for (int t = 0; t < ntaps; ++t) {
@@ -343,7 +370,14 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __r
       for (int ci = 0; ci < KC; ++ci)
 #pragma unroll
         for (int i = 0; i < NV; ++i)
-          if (goff[i] != -2) *reinterpret_cast<f32x4*>(in_lds + ci * VS + 4 * (tid + i * 256)) = xin[ci][i];
+          if (goff[i] != -2) {
+            if (RP == 2) {
+              if (ldst[i] >= 0) *reinterpret_cast<float2*>(in_lds + ci * VS + ldst[i]) = make_float2(xin[ci][i][0], xin[ci][i][1]);
+              if (ldst2[i] >= 0) *reinterpret_cast<float2*>(in_lds + ci * VS + ldst2[i]) = make_float2(xin[ci][i][2], xin[ci][i][3]);
+            } else {
+              *reinterpret_cast<f32x4*>(in_lds + ci * VS + ldst[i]) = xin[ci][i];
+            }
+          }
 #pragma unroll
       for (int j = 0; j < WI; ++j) {
         const int f = tid + j * 256;
@@ -363,7 +397,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __r
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
           brow[tm] = in_lds + pix_lds[tm] + toff;
-          msk[tm] = -(int)((colmask[tm] >> t) & 1u);
+          msk[tm] = RP ? -1 : __builtin_amdgcn_sbfe((int)colmask[tm], t, 1);
         }
 #pragma unroll
         for (int cp = 0; cp < KC / 2; ++cp) {
@@ -372,7 +406,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __r
           for (int tn = 0; tn < TN; ++tn) a[tn] = wrow[(2 * cp) * NT + tn * 32];
 #pragma unroll
           for (int tm = 0; tm < TM; ++tm)
-            bb[tm] = __int_as_float(__float_as_int(brow[tm][(2 * cp) * VS]) & msk[tm]);
+            bb[tm] = RP ? brow[tm][(2 * cp) * VS] : __int_as_float(__float_as_int(brow[tm][(2 * cp) * VS]) & msk[tm]);
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -477,7 +511,7 @@ extern "C" int cn_pack_weights_batched_f32(const void* descs, int n, void* strea
   return cn_check_launch();
 }
 
-template <int WAVES_N, int TN, int TM, int NV>
+template <int WAVES_N, int TN, int TM, int NV, int RP>
 static int cn_launch_igemm_v(const float* x, const float* wp, const float* bias, float* y, CnConvGeom& g,
                              int total_tiles, int max_taps, int splits, double flops, hipStream_t stream) {
   constexpr int NT = WAVES_N * TN * 32;
@@ -486,13 +520,13 @@ static int cn_launch_igemm_v(const float* x, const float* wp, const float* bias,
   if (lds > 160 * 1024) return CN_ERR_LDS;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute((const void*)cn_conv_igemm_vec_kernel<WAVES_N, TN, TM, NV>,
+    (void)hipFuncSetAttribute((const void*)cn_conv_igemm_vec_kernel<WAVES_N, TN, TM, NV, RP>,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
   dim3 grid(total_tiles, (g.Cout + NT - 1) / NT, splits);
   cn_prof_before(stream);
-  hipLaunchKernelGGL((cn_conv_igemm_vec_kernel<WAVES_N, TN, TM, NV>), grid, dim3(256), lds, stream, x, wp, bias, y, g);
+  hipLaunchKernelGGL((cn_conv_igemm_vec_kernel<WAVES_N, TN, TM, NV, RP>), grid, dim3(256), lds, stream, x, wp, bias, y, g);
   cn_prof_after(stream, NT == 128 ? 0 : 1, flops);
   return cn_check_launch();
 }
@@ -520,11 +554,12 @@ static int cn_launch_igemm_t(const float* x, const float* wp, const float* bias,
 // Per-class LDS / tiling geometry for pixel tiles of MT pixels.
 struct CnPlan {
   int total_tiles, max_plane, max_vplane, max_taps;
+  int max_rplane, max_absdx;  // row-padded image size (rows*(Win+4)+4) and largest |dx|
   double flops;
 };
 
 static CnPlan cn_plan(CnConvGeom& g, int MT) {
-  CnPlan p = {0, 0, 0, 0, 0.0};
+  CnPlan p = {0, 0, 0, 0, 0, 0, 0.0};
   for (int c = 0; c < g.ncls; ++c) {
     CnConvClass& k = g.cls[c];
     const int Mimg = k.Hg * k.Wg;
@@ -542,6 +577,13 @@ static CnPlan cn_plan(CnConvGeom& g, int MT) {
     k.pitch = (k.Wg - 1) * g.is + (max_dx - k.min_dx) + 1;
     k.plane = rows * k.pitch;
     k.vplane = (rows * g.Win + (max_dx - k.min_dx) + 4 + 3) / 4 * 4;
+    k.rows = rows;
+    {
+      const int rpitch = (g.Win + 3) / 4 * 4 + 4;  // row-padded image: + one chunk of slack for the aligned-down start
+      if ((rows + 1) * rpitch + 4 > p.max_rplane) p.max_rplane = (rows + 1) * rpitch + 4;
+    }
+    if (-k.min_dx > p.max_absdx) p.max_absdx = -k.min_dx;
+    if (max_dx > p.max_absdx) p.max_absdx = max_dx;
     k.tiles_per_img = (Mimg + MT - 1) / MT;
     k.block_begin = p.total_tiles;
     p.total_tiles += g.B * k.tiles_per_img;
@@ -607,14 +649,28 @@ static int cn_launch_vec_cfg(const float* x, const float* wp, const float* bias,
   constexpr int MT = (4 / WAVES_N) * TM * 32;
   const CnPlan p = cn_plan(g, MT);
   if (p.total_tiles <= 0) return CN_OK;
-  g.w_lds_off = KC * 1024 * (p.max_vplane <= 1024 ? 1 : (p.max_vplane <= 2048 ? 2 : 4));
+  // row-padded LDS image (no read-time masks) when rows are whole 16-byte pieces and the padded image fits
+  const int rp = (p.max_rplane <= 4096 && p.max_absdx <= 4) ? (g.Win % 4 == 0 ? 1 : (g.Win % 2 == 0 ? 2 : 0)) : 0;
+  const int img = rp ? p.max_rplane : p.max_vplane;
+  g.w_lds_off = KC * 1024 * (img <= 1024 ? 1 : (img <= 2048 ? 2 : 4));
   const int rc = cn_finish_split(g, p, splits, cps, y, stream);
   if (rc != CN_OK) return rc;
-  if (p.max_vplane <= 1024)
-    return cn_launch_igemm_v<WAVES_N, TN, TM, 1>(x, wp, bias, y, g, p.total_tiles, p.max_taps, splits, p.flops, stream);
-  if (p.max_vplane <= 2048)
-    return cn_launch_igemm_v<WAVES_N, TN, TM, 2>(x, wp, bias, y, g, p.total_tiles, p.max_taps, splits, p.flops, stream);
-  return cn_launch_igemm_v<WAVES_N, TN, TM, 4>(x, wp, bias, y, g, p.total_tiles, p.max_taps, splits, p.flops, stream);
+#define CN_GO(NV_, RP_) \
+  return cn_launch_igemm_v<WAVES_N, TN, TM, NV_, RP_>(x, wp, bias, y, g, p.total_tiles, p.max_taps, splits, p.flops, stream)
+  if (rp == 1) {
+    if (img <= 1024) CN_GO(1, 1);
+    if (img <= 2048) CN_GO(2, 1);
+    CN_GO(4, 1);
+  }
+  if (rp == 2) {
+    if (img <= 1024) CN_GO(1, 2);
+    if (img <= 2048) CN_GO(2, 2);
+    CN_GO(4, 2);
+  }
+  if (img <= 1024) CN_GO(1, 0);
+  if (img <= 2048) CN_GO(2, 0);
+  CN_GO(4, 0);
+#undef CN_GO
 }
 
 template <int WAVES_N, int TN>

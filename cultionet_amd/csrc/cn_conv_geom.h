@@ -13,6 +13,7 @@ struct CnConvClass {
   int min_dy, min_dx;
   int pitch, plane;  // LDS halo plane of this class (plane = rows * pitch <= NI*256)
   int vplane;        // 16-byte path: floats of the flattened-row image (multiple of 4)
+  int rows;          // input rows staged per tile
   int tiles_per_img;
   int block_begin;   // first blockIdx.x of this class
 };
