@@ -25,10 +25,7 @@
 //   NI_T: halo plane capacity = NI_T*256 floats per channel (register prefetch uses NI_T*KC VGPRs)
 // grid = (tiles over all classes and images, N tiles, K splits)
 template <int WAVES_N, int TN, int NI_T>
-__global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const float* __restrict__ x,
-                                                           const float* __restrict__ wp,
-                                                           const float* __restrict__ bias,
-                                                           float* __restrict__ y, const CnConvGeom g) {
+__global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const CnConvGeom g) {
   constexpr int WAVES_M = 4 / WAVES_N;
   constexpr int MT = WAVES_M * 64;
   constexpr int NT = WAVES_N * TN * 32;
@@ -47,6 +44,11 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const float* __restr
 #pragma unroll 1
   for (int c = 1; c < g.ncls; ++c)
     if ((int)blockIdx.x >= g.cls[c].block_begin) ci_ = c;
+  const int grp = g.cls[ci_].grp, split = blockIdx.z;
+  const float* __restrict__ x = g.gx[grp];
+  const float* __restrict__ wp = g.gwp[grp];
+  const float* __restrict__ bias = g.gbias[grp];
+  float* __restrict__ y = g.gy[grp];
   const int Hg = g.cls[ci_].Hg, Wg = g.cls[ci_].Wg, ntaps = g.cls[ci_].ntaps;
   const int pitch = g.cls[ci_].pitch, plane = g.cls[ci_].plane;
   const int min_dy = g.cls[ci_].min_dy, min_dx = g.cls[ci_].min_dx;
@@ -103,7 +105,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const float* __restr
   const float* xb = x + (long)b * g.xbs;
   const int nw4 = ntaps * KC * (NT / 4);
   const int nchunks = (g.Cin + KC - 1) / KC;
-  int ch = blockIdx.z * g.chunks_per_split;
+  int ch = split * g.chunks_per_split;
   int ch_end = ch + g.chunks_per_split;
   if (ch_end > nchunks) ch_end = nchunks;
 
@@ -184,14 +186,14 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const float* __restr
   // ---- epilogue: D[i = cout][j = pixel]; lane = pixel -> coalesced along W
   float* yb = y + (long)b * g.ybs;
   const int HWout = g.Hout * g.Wout;
-  const bool first = blockIdx.z == 0;
+  const bool first = split == 0;  // shared_y: every group adds its bias (sum semantics)
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = n0 + wn * (TN * 32) + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (co < g.Cout) {
-        const float bv = (g.has_bias && first) ? bias[co] : 0.f;
+        const float bv = (bias != nullptr && first) ? bias[co] : 0.f;
 #pragma unroll
         for (int tm = 0; tm < 2; ++tm) {
           if (pix_ok[tm]) {
@@ -219,10 +221,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const float* __restr
 // instruction per wave moves at most 16 B per lane whatever its width).
 //   NV: float4 chunks per thread per channel (vplane <= NV*1024 floats)
 template <int WAVES_N, int TN, int TM, int NV, int RP>
-__global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __restrict__ x,
-                                                               const float* __restrict__ wp,
-                                                               const float* __restrict__ bias,
-                                                               float* __restrict__ y, const CnConvGeom g) {
+__global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const CnConvGeom g) {
   constexpr int WAVES_M = 4 / WAVES_N;
   constexpr int MT = WAVES_M * TM * 32;
   constexpr int NT = WAVES_N * TN * 32;
@@ -241,6 +240,11 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __r
 #pragma unroll 1
   for (int c = 1; c < g.ncls; ++c)
     if ((int)blockIdx.x >= g.cls[c].block_begin) ci_ = c;
+  const int grp = g.cls[ci_].grp, split = blockIdx.z;
+  const float* __restrict__ x = g.gx[grp];
+  const float* __restrict__ wp = g.gwp[grp];
+  const float* __restrict__ bias = g.gbias[grp];
+  float* __restrict__ y = g.gy[grp];
   const int Hg = g.cls[ci_].Hg, Wg = g.cls[ci_].Wg, ntaps = g.cls[ci_].ntaps;
   const int vplane = g.cls[ci_].vplane;
   const int min_dy = g.cls[ci_].min_dy, min_dx = g.cls[ci_].min_dx;
@@ -332,7 +336,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __r
   const float* xb = x + (long)b * g.xbs;
   const int nw4 = ntaps * KC * (NT / 4);
   const int nchunks = (g.Cin + KC - 1) / KC;
-  int ch = blockIdx.z * g.chunks_per_split;
+  int ch = split * g.chunks_per_split;
   int ch_end = ch + g.chunks_per_split;
   if (ch_end > nchunks) ch_end = nchunks;
 
@@ -420,14 +424,14 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const float* __r
 
   float* yb = y + (long)b * g.ybs;
   const int HWout = g.Hout * g.Wout;
-  const bool first = blockIdx.z == 0;
+  const bool first = split == 0;  // shared_y: every group adds its bias (sum semantics)
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int co = n0 + wn * (TN * 32) + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
       if (co < g.Cout) {
-        const float bv = (g.has_bias && first) ? bias[co] : 0.f;
+        const float bv = (bias != nullptr && first) ? bias[co] : 0.f;
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
           if (pix_ok[tm]) {
@@ -525,8 +529,11 @@ static int cn_launch_igemm_v(const float* x, const float* wp, const float* bias,
     attr_set = true;
   }
   dim3 grid(total_tiles, (g.Cout + NT - 1) / NT, splits);
+  cn_prof_desc("igemm_vec<%d,%d,%d,%d,%d> G%d B%d %d->%d %dx%d->%dx%d taps%d cls%d is%d os%d grid%dx%dx%d", WAVES_N, TN,
+               TM, NV, RP, g.G, g.B, g.Cin, g.Cout, g.Hin, g.Win, g.Hout, g.Wout, max_taps, g.ncls, g.is, g.os,
+               total_tiles, (g.Cout + NT - 1) / NT, splits);
   cn_prof_before(stream);
-  hipLaunchKernelGGL((cn_conv_igemm_vec_kernel<WAVES_N, TN, TM, NV, RP>), grid, dim3(256), lds, stream, x, wp, bias, y, g);
+  hipLaunchKernelGGL((cn_conv_igemm_vec_kernel<WAVES_N, TN, TM, NV, RP>), grid, dim3(256), lds, stream, g);
   cn_prof_after(stream, NT == 128 ? 0 : 1, flops);
   return cn_check_launch();
 }
@@ -545,8 +552,11 @@ static int cn_launch_igemm_t(const float* x, const float* wp, const float* bias,
     attr_set = true;
   }
   dim3 grid(total_tiles, (g.Cout + NT - 1) / NT, splits);
+  cn_prof_desc("igemm_dw<%d,%d,%d> G%d B%d %d->%d %dx%d->%dx%d taps%d cls%d is%d os%d grid%dx%dx%d", WAVES_N, TN, NI_T,
+               g.G, g.B, g.Cin, g.Cout, g.Hin, g.Win, g.Hout, g.Wout, max_taps, g.ncls, g.is, g.os, total_tiles,
+               (g.Cout + NT - 1) / NT, splits);
   cn_prof_before(stream);
-  hipLaunchKernelGGL((cn_conv_igemm_kernel<WAVES_N, TN, NI_T>), grid, dim3(256), lds, stream, x, wp, bias, y, g);
+  hipLaunchKernelGGL((cn_conv_igemm_kernel<WAVES_N, TN, NI_T>), grid, dim3(256), lds, stream, g);
   cn_prof_after(stream, NT == 128 ? 0 : 1, flops);
   return cn_check_launch();
 }
@@ -632,13 +642,17 @@ static CnChoice cn_choose(const CnConvGeom& g0, const int* mts, int ncfg, int NT
 }
 
 static int cn_finish_split(CnConvGeom& g, const CnPlan& p, int splits, int cps, float* y, hipStream_t stream) {
+  (void)y;
   const int nchunks = (g.Cin + KC - 1) / KC;
   g.chunks_per_split = cps > 0 ? cps : (nchunks > 0 ? nchunks : 1);
   if (p.max_taps == 0) g.chunks_per_split = nchunks > 0 ? nchunks : 1;
-  g.atomic_out = splits > 1;
+  g.splits = splits < 1 ? 1 : splits;
+  g.atomic_out = g.splits > 1 || (g.G > 1 && g.shared_y);
   if (g.atomic_out && !g.accumulate) {
-    if (hipMemsetAsync(y, 0, sizeof(float) * (size_t)g.B * g.Cout * g.Hout * g.Wout, stream) != hipSuccess)
-      return CN_ERR_LAUNCH;
+    const int ny = g.shared_y ? 1 : g.G;
+    for (int i = 0; i < ny; ++i)
+      if (hipMemsetAsync(g.gy[i], 0, sizeof(float) * (size_t)g.B * g.Cout * g.Hout * g.Wout, stream) != hipSuccess)
+        return CN_ERR_LAUNCH;
   }
   return CN_OK;
 }
@@ -690,15 +704,18 @@ static int cn_launch_dword_cfg(const float* x, const float* wp, const float* bia
   return cn_launch_igemm_t<WAVES_N, TN, 12>(x, wp, bias, y, g, p.total_tiles, p.max_taps, splits, p.flops, stream);
 }
 
-int cn_conv_igemm_launch(const float* x, const float* wp, const float* bias, float* y, CnConvGeom& g,
-                         hipStream_t stream) {
-  if (g.ncls < 1 || g.ncls > CN_MAX_CLASSES || g.B <= 0) return g.B <= 0 ? CN_OK : CN_ERR_ARG;
+int cn_conv_igemm_launch(CnConvGeom& g, hipStream_t stream) {
+  if (g.ncls < 1 || g.ncls > CN_MAX_CLASSES || g.B <= 0 || g.G < 1) return g.B <= 0 ? CN_OK : CN_ERR_ARG;
+  g.splits = 1;
+  const float* x = g.gx[0]; const float* wp = g.gwp[0]; const float* bias = g.gbias[0]; float* y = g.gy[0];
   g.Kpad = cn_conv_kpad(g.Cin);
   g.Npad = cn_conv_npad(g.Cout);
   const int nt = cn_pick_nt(g.Cout);
   const bool dense_out = g.ybs == (long)g.Cout * g.Hout * g.Wout;
   const bool allow_split = dense_out || g.accumulate;
-  bool vec = (((long)g.Hin * g.Win) % 4 == 0) && (g.xbs % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  if (g.G > 1 && g.shared_y && !allow_split) return CN_ERR_ARG;
+  bool vec = (((long)g.Hin * g.Win) % 4 == 0) && (g.xbs % 4 == 0);
+  for (int i = 0; i < g.G; ++i) vec = vec && ((reinterpret_cast<uintptr_t>(g.gx[i]) & 15) == 0);
   if (vec) {  // the flattened-row image of the largest tile must fit 4096 floats
     CnConvGeom t = g;
     vec = cn_plan(t, 256).max_vplane <= 4 * 1024;
@@ -729,26 +746,61 @@ int cn_conv_igemm_launch(const float* x, const float* wp, const float* bias, flo
 
 static inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-// Gather form (Conv2d forward, ConvTranspose2d backward-data): one class, input coord = o*stride + k*dil - pad.
+// Fills the group tables; shared_y when every group names the same output (their results are summed).
+static int cn_set_groups(CnConvGeom& g, int G, const float* const* xs, const float* const* wps,
+                         const float* const* biases, float* const* ys) {
+  if (G < 1 || G > CN_MAX_GROUPS) return CN_ERR_ARG;
+  g.G = G;
+  int same = 0;
+  for (int i = 0; i < G; ++i) {
+    g.gx[i] = xs[i]; g.gwp[i] = wps[i]; g.gbias[i] = biases ? biases[i] : nullptr; g.gy[i] = ys[i];
+    if (ys[i] == ys[0]) ++same;
+  }
+  if (same != G && same != 1) return CN_ERR_ARG;  // all outputs distinct, or all the same
+  for (int i = 1; i < G && same == 1; ++i)
+    for (int j = 1; j < i; ++j)
+      if (ys[i] == ys[j]) return CN_ERR_ARG;
+  g.shared_y = (G > 1 && same == G) ? 1 : 0;
+  g.has_bias = 0;
+  for (int i = 0; i < G; ++i) g.has_bias |= g.gbias[i] != nullptr;
+  return CN_OK;
+}
+
+// Gather form (Conv2d forward, ConvTranspose2d backward-data): one class per group,
+// input coord = o*stride + k*dil - pad.
+static int cn_gather_conv_g(int G, const float* const* xs, long xbs, const float* const* wps,
+                            const float* const* biases, float* const* ys, long ybs, int B, int Cin, int Hin,
+                            int Win, int Cout, int Hout, int Wout, int KH, int KW, int stride, const int* pads,
+                            const int* dils, int accumulate, hipStream_t stream) {
+  if (KH * KW > CN_MAX_TAPS || stride < 1) return CN_ERR_ARG;
+  if (Hout <= 0 || Wout <= 0) return CN_OK;
+  CnConvGeom g = {};
+  const int rc = cn_set_groups(g, G, xs, wps, biases, ys);
+  if (rc != CN_OK) return rc;
+  g.B = B; g.Cin = Cin; g.Hin = Hin; g.Win = Win; g.Cout = Cout; g.Hout = Hout; g.Wout = Wout;
+  g.xbs = xbs; g.ybs = ybs; g.is = stride; g.os = 1;
+  g.ncls = G;
+  for (int i = 0; i < G; ++i) {
+    if (dils[i] < 1) return CN_ERR_ARG;
+    CnConvClass& k = g.cls[i];
+    k.grp = i;
+    k.Hg = Hout; k.Wg = Wout; k.oy0 = 0; k.ox0 = 0;
+    k.ntaps = KH * KW;
+    for (int ky = 0; ky < KH; ++ky)
+      for (int kx = 0; kx < KW; ++kx) {
+        const int t = ky * KW + kx;
+        k.dy[t] = ky * dils[i] - pads[i]; k.dx[t] = kx * dils[i] - pads[i]; k.wt[t] = t;
+      }
+  }
+  g.accumulate = accumulate;
+  return cn_conv_igemm_launch(g, stream);
+}
+
 static int cn_gather_conv(const float* x, long xbs, const float* wp, const float* bias, float* y, long ybs, int B,
                           int Cin, int Hin, int Win, int Cout, int Hout, int Wout, int KH, int KW, int stride,
                           int pad, int dil, int accumulate, hipStream_t stream) {
-  if (KH * KW > CN_MAX_TAPS || stride < 1 || dil < 1) return CN_ERR_ARG;
-  if (Hout <= 0 || Wout <= 0) return CN_OK;
-  CnConvGeom g = {};
-  g.B = B; g.Cin = Cin; g.Hin = Hin; g.Win = Win; g.Cout = Cout; g.Hout = Hout; g.Wout = Wout;
-  g.xbs = xbs; g.ybs = ybs; g.is = stride; g.os = 1;
-  g.ncls = 1;
-  CnConvClass& k = g.cls[0];
-  k.Hg = Hout; k.Wg = Wout; k.oy0 = 0; k.ox0 = 0;
-  k.ntaps = KH * KW;
-  for (int ky = 0; ky < KH; ++ky)
-    for (int kx = 0; kx < KW; ++kx) {
-      const int t = ky * KW + kx;
-      k.dy[t] = ky * dil - pad; k.dx[t] = kx * dil - pad; k.wt[t] = t;
-    }
-  g.accumulate = accumulate; g.has_bias = bias != nullptr;
-  return cn_conv_igemm_launch(x, wp, bias, y, g, stream);
+  return cn_gather_conv_g(1, &x, xbs, &wp, &bias, &y, ybs, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride, &pad,
+                          &dil, accumulate, stream);
 }
 
 // Conv2d forward. x [B,Cin,Hin,Win] (batch stride xbs), wp packed [KH*KW][Kpad(Cin)][Npad(Cout)],
@@ -766,39 +818,54 @@ extern "C" int cn_conv2d_fwd_f32(const float* x, long xbs, const float* wp, cons
 //   out[o] (+)= bias + sum_k src[(o + pad - k*dil)/s] * W[k]   where divisible,
 // as s*s parity classes of the output grid in ONE launch (no zero-stuffing, no wasted MACs).
 // src [B,Csrc,Hs,Ws], out [B,Cdst,Ho,Wo]; wp packed [KH*KW][Kpad(Csrc)][Npad(Cdst)].
+static int cn_scatter_conv_g(int G, const float* const* srcs, long sbs, const float* const* wps,
+                             const float* const* biases, float* const* outs, long obs, int B, int Csrc, int Hs,
+                             int Ws, int Cdst, int Ho, int Wo, int KH, int KW, int stride, const int* pads,
+                             const int* dils, int accumulate, hipStream_t stream) {
+  if (KH * KW > CN_MAX_TAPS || stride < 1 || G * stride * stride > CN_MAX_CLASSES) return CN_ERR_ARG;
+  CnConvGeom g = {};
+  const int rc = cn_set_groups(g, G, srcs, wps, biases, outs);
+  if (rc != CN_OK) return rc;
+  g.B = B; g.Cin = Csrc; g.Hin = Hs; g.Win = Ws; g.Cout = Cdst; g.Hout = Ho; g.Wout = Wo;
+  g.xbs = sbs; g.ybs = obs; g.is = 1; g.os = stride;
+  g.accumulate = accumulate;
+  int nc = 0;
+  for (int gi = 0; gi < G; ++gi) {
+    const int pad = pads[gi], dil = dils[gi];
+    if (dil < 1) return CN_ERR_ARG;
+    for (int py = 0; py < stride; ++py)
+      for (int px = 0; px < stride; ++px) {
+        CnConvClass& k = g.cls[nc];
+        k.grp = gi;
+        k.Hg = (Ho - py + stride - 1) / stride;
+        k.Wg = (Wo - px + stride - 1) / stride;
+        if (k.Hg <= 0 || k.Wg <= 0) continue;
+        k.oy0 = py; k.ox0 = px;
+        int nt = 0;
+        for (int ky = 0; ky < KH; ++ky) {
+          const int ny = py + pad - ky * dil;
+          if (((ny % stride) + stride) % stride != 0) continue;
+          for (int kx = 0; kx < KW; ++kx) {
+            const int nx = px + pad - kx * dil;
+            if (((nx % stride) + stride) % stride != 0) continue;
+            k.dy[nt] = floordiv(ny, stride); k.dx[nt] = floordiv(nx, stride); k.wt[nt] = ky * KW + kx;
+            ++nt;
+          }
+        }
+        k.ntaps = nt;
+        ++nc;
+      }
+  }
+  g.ncls = nc;
+  if (nc == 0) return CN_OK;
+  return cn_conv_igemm_launch(g, stream);
+}
+
 static int cn_scatter_conv(const float* src, long sbs, const float* wp, const float* bias, float* out, long obs,
                            int B, int Csrc, int Hs, int Ws, int Cdst, int Ho, int Wo, int KH, int KW,
                            int stride, int pad, int dil, int accumulate, hipStream_t stream) {
-  if (KH * KW > CN_MAX_TAPS || stride < 1 || dil < 1 || stride * stride > CN_MAX_CLASSES) return CN_ERR_ARG;
-  CnConvGeom g = {};
-  g.B = B; g.Cin = Csrc; g.Hin = Hs; g.Win = Ws; g.Cout = Cdst; g.Hout = Ho; g.Wout = Wo;
-  g.xbs = sbs; g.ybs = obs; g.is = 1; g.os = stride;
-  g.accumulate = accumulate; g.has_bias = bias != nullptr;
-  int nc = 0;
-  for (int py = 0; py < stride; ++py)
-    for (int px = 0; px < stride; ++px) {
-      CnConvClass& k = g.cls[nc];
-      k.Hg = (Ho - py + stride - 1) / stride;
-      k.Wg = (Wo - px + stride - 1) / stride;
-      if (k.Hg <= 0 || k.Wg <= 0) continue;
-      k.oy0 = py; k.ox0 = px;
-      int nt = 0;
-      for (int ky = 0; ky < KH; ++ky) {
-        const int ny = py + pad - ky * dil;
-        if (((ny % stride) + stride) % stride != 0) continue;
-        for (int kx = 0; kx < KW; ++kx) {
-          const int nx = px + pad - kx * dil;
-          if (((nx % stride) + stride) % stride != 0) continue;
-          k.dy[nt] = floordiv(ny, stride); k.dx[nt] = floordiv(nx, stride); k.wt[nt] = ky * KW + kx;
-          ++nt;
-        }
-      }
-      k.ntaps = nt;
-      ++nc;
-    }
-  g.ncls = nc;
-  if (nc == 0) return CN_OK;
-  return cn_conv_igemm_launch(src, wp, bias, out, g, stream);
+  return cn_scatter_conv_g(1, &src, sbs, &wp, &bias, &out, obs, B, Csrc, Hs, Ws, Cdst, Ho, Wo, KH, KW, stride, &pad,
+                           &dil, accumulate, stream);
 }
 
 // Conv2d backward-data: dx [B,Cin,Hin,Win] (+)= conv^T(dy [B,Cout,Hout,Wout]); wp packed with K=Cout, N=Cin.
@@ -809,6 +876,42 @@ extern "C" int cn_conv2d_bwd_data_f32(const float* dy, long dybs, const float* w
   const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   return cn_scatter_conv(dy, dybs, wp_t, nullptr, dx, dxbs, B, Cout, Hout, Wout, Cin, Hin, Win, KH, KW, stride,
                          pad, dil, accumulate, (hipStream_t)stream);
+}
+
+// Grouped Conv2d forward: G (<= 4) convolutions of identical shape (they may differ in padding / dilation as long
+// as the output size agrees) in ONE launch -- the dilation branches of ResidualAConv (convolution.py:376-395) and
+// the three head streams of TowerUNetFinal (unet_parts.py:196-224). xs/wps/biases/ys are HOST arrays of G device
+// pointers; inputs may alias (same x for every branch); outputs are all distinct or all the same (summed).
+extern "C" int cn_conv2d_fwd_grouped_f32(int G, const float* const* xs, long xbs, const float* const* wps,
+                                         const float* const* biases, float* const* ys, long ybs, int B, int Cin,
+                                         int Hin, int Win, int Cout, int KH, int KW, int stride, const int* pads,
+                                         const int* dils, int accumulate, void* stream) {
+  if (G < 1 || G > CN_MAX_GROUPS) return CN_ERR_ARG;
+  const int Hout = (Hin + 2 * pads[0] - dils[0] * (KH - 1) - 1) / stride + 1;
+  const int Wout = (Win + 2 * pads[0] - dils[0] * (KW - 1) - 1) / stride + 1;
+  for (int i = 1; i < G; ++i)
+    if ((Hin + 2 * pads[i] - dils[i] * (KH - 1) - 1) / stride + 1 != Hout ||
+        (Win + 2 * pads[i] - dils[i] * (KW - 1) - 1) / stride + 1 != Wout)
+      return CN_ERR_ARG;
+  return cn_gather_conv_g(G, xs, xbs, wps, biases, ys, ybs, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride,
+                          pads, dils, accumulate, (hipStream_t)stream);
+}
+
+// Grouped Conv2d backward-data; dxs all distinct, or all the same buffer (branches that share their input: the
+// G contributions are summed into it).
+extern "C" int cn_conv2d_bwd_data_grouped_f32(int G, const float* const* dys, long dybs, const float* const* wps_t,
+                                              float* const* dxs, long dxbs, int B, int Cin, int Hin, int Win,
+                                              int Cout, int KH, int KW, int stride, const int* pads,
+                                              const int* dils, int accumulate, void* stream) {
+  if (G < 1 || G > CN_MAX_GROUPS) return CN_ERR_ARG;
+  const int Hout = (Hin + 2 * pads[0] - dils[0] * (KH - 1) - 1) / stride + 1;
+  const int Wout = (Win + 2 * pads[0] - dils[0] * (KW - 1) - 1) / stride + 1;
+  for (int i = 1; i < G; ++i)
+    if ((Hin + 2 * pads[i] - dils[i] * (KH - 1) - 1) / stride + 1 != Hout ||
+        (Win + 2 * pads[i] - dils[i] * (KW - 1) - 1) / stride + 1 != Wout)
+      return CN_ERR_ARG;
+  return cn_scatter_conv_g(G, dys, dybs, wps_t, nullptr, dxs, dxbs, B, Cout, Hout, Wout, Cin, Hin, Win, KH, KW,
+                           stride, pads, dils, accumulate, (hipStream_t)stream);
 }
 
 // ConvTranspose2d forward: y [B,Cout,Hout,Wout], Hout = (Hin-1)*s - 2*pad + K; wp packed with K=Cin, N=Cout.

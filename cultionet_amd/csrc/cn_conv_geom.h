@@ -2,6 +2,7 @@
 #pragma once
 #define CN_MAX_TAPS 9
 #define CN_MAX_CLASSES 16
+#define CN_MAX_GROUPS 4
 
 // One parity class of the output grid (a plain convolution has exactly one).
 //   input coord = g*is + d[t],  output coord = g*os + o0
@@ -16,6 +17,7 @@ struct CnConvClass {
   int rows;          // input rows staged per tile
   int tiles_per_img;
   int block_begin;   // first blockIdx.x of this class
+  int grp;           // which (input, weights, bias, output) set this class works on
 };
 
 struct CnConvGeom {
@@ -30,6 +32,13 @@ struct CnConvGeom {
   int chunks_per_split;     // K-chunks (of 8 channels) per grid.z slice
   int atomic_out;           // split-K: accumulate with atomics into a pre-initialised output
   int accumulate, has_bias;
+  // groups: G independent (input, weights, bias, output) sets in one launch; each class names its group
+  // (CnConvClass::grp), so groups may differ in taps (dilation). shared_y: all groups sum into one output.
+  int G, splits, shared_y;
+  const float* gx[CN_MAX_GROUPS];
+  const float* gwp[CN_MAX_GROUPS];
+  const float* gbias[CN_MAX_GROUPS];
+  float* gy[CN_MAX_GROUPS];
   int ncls;
   CnConvClass cls[CN_MAX_CLASSES];
 };

@@ -464,6 +464,8 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
     g.mq_lo = lo;
     g.mq_hi = hi;
   }
+  cn_prof_desc("wgrad_vec<%d> N%d A%d %dx%d Bc%d %dx%d s%d grid%dx%dx%d nbuf%d", T, g.N, g.A, g.Hs, g.Ws, g.Bc, g.Hb, g.Wb,
+               g.s, gx, gy, splits, g.nbuf);
   cn_prof_before(stream);
   if (g.s == 1)
     hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 1>), dim3(gx, gy, splits), dim3(256), lds, stream, S, Bg, dW, g);
@@ -524,6 +526,8 @@ static int cn_wgrad_launch_t(const float* S, const float* Bg, float* dW, CnWgrad
                               160 * 1024);
     attr_set = true;
   }
+  cn_prof_desc("wgrad_dw<%d> N%d A%d %dx%d Bc%d %dx%d s%d grid%dx%dx%d", T, g.N, g.A, g.Hs, g.Ws, g.Bc, g.Hb, g.Wb, g.s,
+               gx, gy, splits);
   cn_prof_before(stream);
   hipLaunchKernelGGL((cn_wgrad_kernel<T>), dim3(gx, gy, splits), dim3(256), lds, stream, S, Bg, dW, g);
   cn_prof_after(stream, T == 9 ? 2 : 3, g.flops);

@@ -55,12 +55,13 @@ def _dense_inner(t: torch.Tensor) -> bool:
 class Var:
     """A device buffer and (during training) its gradient buffer."""
 
-    __slots__ = ("t", "grad", "req")
+    __slots__ = ("t", "grad", "req", "parent")
 
     def __init__(self, t: torch.Tensor, req: bool = False):
         self.t = t
         self.grad: T.Optional[torch.Tensor] = None
         self.req = req
+        self.parent: T.Optional[T.Tuple["Var", int, int]] = None  # channel slice [c0, c1) of another Var
 
     @property
     def shape(self):
@@ -119,6 +120,14 @@ class recording:
 def grad_buffer(v: Var) -> T.Tuple[torch.Tensor, int]:
     """(buffer, accumulate flag) to write/accumulate v's gradient into."""
     if v.grad is None:
+        if v.parent is not None:
+            # a channel slice writes straight into its parent's gradient (zero-filled once, then accumulated)
+            pv, c0, c1 = v.parent
+            if pv.grad is None:
+                pv.grad = torch.empty(pv.t.shape, dtype=torch.float32, device=pv.t.device)
+                _lib.call("cn_fill_f32", pv.grad.data_ptr(), pv.grad.numel(), 0.0, _stream())
+            v.grad = pv.grad[:, c0:c1]
+            return v.grad, 1
         v.grad = torch.empty(v.t.shape, dtype=torch.float32, device=v.t.device)
         return v.grad, 0
     return v.grad, 1
@@ -128,9 +137,11 @@ def give_grad(v: Var, g: torch.Tensor) -> None:
     """v.grad (+)= g where the op is the identity on the gradient: alias when first, else add in place."""
     if not v.req:
         return
-    if v.grad is None:
+    if v.grad is None and v.parent is None:
         v.grad = g
         return
+    if v.grad is None:
+        grad_buffer(v)
     B = g.shape[0]
     n = g[0].numel()
     _lib.call("cn_copy_f32", g.data_ptr(), bstride(g), v.grad.data_ptr(), bstride(v.grad), B, n, 1, _stream())
@@ -477,7 +488,7 @@ ACT_NONE, ACT_SILU = 0, 1
 
 
 def bn_act(x: Var, bn, act: int, residual: T.Optional[Var] = None, channels: T.Optional[int] = None,
-           training: bool = True) -> Var:
+           training: bool = True, out: T.Optional[torch.Tensor] = None) -> Var:
     """y = act(batch_norm(x)) (+ residual). x viewed as [B][C][L] with C = ``channels`` (BatchNorm3d: L = T*H*W)."""
     tape = current_tape()
     xt = _check(x.t)
@@ -485,7 +496,7 @@ def bn_act(x: Var, bn, act: int, residual: T.Optional[Var] = None, channels: T.O
     C = channels if channels is not None else xt.shape[1]
     L = int(xt[0].numel()) // C
     dev = xt.device
-    y = _new(xt.shape, xt)
+    y = out if out is not None else _new(xt.shape, xt)
     mean = _new((C,), xt)
     rstd = _new((C,), xt)
     ws = torch.empty(_lib.query("cn_bn_workspace_doubles", C), dtype=torch.float64, device=dev)
@@ -621,6 +632,97 @@ def resize_bilinear(x: Var, size: T.Tuple[int, int], out: T.Optional[torch.Tenso
             yv.grad = None
 
         tape.add(bwd)
+    return yv
+
+
+def split_channels(v: Var, sizes: T.Sequence[int]) -> T.List[Var]:
+    """Channel slices of ``v`` as Vars (views, no copies); their gradients land in v's gradient buffer."""
+    outs, c0 = [], 0
+    for c in sizes:
+        sv = Var(v.t[:, c0:c0 + c], v.req)
+        sv.parent = (v, c0, c0 + c)
+        outs.append(sv)
+        c0 += c
+    return outs
+
+
+def join_channels(parts: T.Sequence[Var], buf: torch.Tensor) -> Var:
+    """The parts ARE the consecutive channel slices of ``buf`` (written in place by ops with ``out=``):
+    torch.cat without copies. Backward hands each part its slice of the gradient."""
+    tape = current_tape()
+    c0 = 0
+    for p in parts:
+        c = p.t.shape[1]
+        if p.t.data_ptr() != buf[:, c0:c0 + c].data_ptr() or (buf.shape[0] > 1 and bstride(p.t) != bstride(buf)):
+            raise RuntimeError("join_channels: parts must be the channel slices of buf, in order")
+        c0 += c
+    yv = Var(buf, tape.enabled)
+    if tape.enabled:
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            o = 0
+            for p in parts:
+                c = p.t.shape[1]
+                give_grad(p, dy[:, o:o + c])
+                o += c
+            yv.grad = None
+
+        tape.add(bwd)
+    return yv
+
+
+def thin_conv3x3(x: Var, mods: T.Sequence, grouped: bool, dilation: int = 1,
+                 out: T.Optional[torch.Tensor] = None) -> Var:
+    """Several thin 3x3 'same' nn.Conv2d (weights [CP][Cin][3][3], padding == dilation) in one direct-kernel pass:
+    ``grouped=False``: all read x; ``grouped=True``: conv g reads channels [g*Cin, (g+1)*Cin) of x.
+    Output [B, len(mods)*CP, H, W] (channel = g*CP + c)."""
+    tape = current_tape()
+    xt = _check(x.t)
+    B, Cx, H, W = xt.shape
+    n = len(mods)
+    w0 = mods[0].weight
+    CP, Cin = w0.shape[0], w0.shape[1]
+    for m in mods:
+        if tuple(m.weight.shape) != (CP, Cin, 3, 3):
+            raise ValueError("thin_conv3x3: all weight sets must be [CP][Cin][3][3]")
+    if Cx != (n * Cin if grouped else Cin):
+        raise ValueError("thin_conv3x3: input channels do not match the weights")
+    ws = [m.weight for m in mods]
+    bs = [m.bias for m in mods]
+    has_bias = bs[0] is not None
+    wtab = _ptr_table([w.data_ptr() for w in ws])
+    btab = _ptr_table([b.data_ptr() for b in bs]) if has_bias else None
+    y = out if out is not None else _new((B, n * CP, H, W), xt)
+    g = 1 if grouped else 0
+    _lib.call("cn_thin_conv3x3_fwd_f32", xt.data_ptr(), bstride(xt), wtab, btab, y.data_ptr(), bstride(y), B, Cin, H, W,
+              n, CP, g, dilation, _stream())
+    yv = Var(y, tape.enabled)
+    if tape.enabled:
+        store = current_store()
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            s = _stream()
+            dwtab = _ptr_table([store.grad_of(w).data_ptr() for w in ws])
+            _lib.call("cn_thin_conv3x3_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy), dwtab,
+                      B, Cin, H, W, n, CP, g, dilation, s)
+            if has_bias:
+                for i, b in enumerate(bs):
+                    dyi = dy[:, i * CP:(i + 1) * CP]
+                    _lib.call("cn_channel_sum_f32", dyi.data_ptr(), bstride(dy), B, CP, H * W,
+                              store.grad_of(b).data_ptr(), 1, s)
+            if x.req:
+                dx, acc = grad_buffer(x)
+                _lib.call("cn_thin_conv3x3_bwd_data_f32", dy.data_ptr(), bstride(dy), wtab, dx.data_ptr(), bstride(dx),
+                          B, Cin, H, W, n, CP, g, dilation, acc, s)
+            yv.grad = None
+
+        tape.add(bwd, tuple(ws) + tuple(b for b in bs if b is not None))
     return yv
 
 

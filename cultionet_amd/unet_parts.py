@@ -107,9 +107,23 @@ class TowerUNetFinal(nn.Module):
     def forward(self, x: E.Var, size=None, suffix: str = "") -> E.Var:
         if size is not None:
             x = self.up_conv(x, size=size)
-        parts = [self.dist_conv(x), self.edge_conv(x), self.crop_conv(x)]
-        h = E.cat_channels(parts)
-        return self.fuse_conv(h)
+        streams = (self.dist_conv, self.edge_conv, self.crop_conv)
+        if self.num_classes != 1:  # wider crop stream: generic kernels, stream by stream
+            h = E.cat_channels([s(x) for s in streams])
+            return self.fuse_conv(h)
+        # The three streams as ONE pass per layer (direct thin-conv kernels, x read once):
+        #   128 -> 3 (x3, shared input) -> BN+SiLU per stream on channel slices -> 3 -> 1 (x3, grouped) -> fuse 3 -> 3
+        heads = [s.conv[0] for s in streams]
+        h9 = E.thin_conv3x3(x, [h.seq[0] for h in heads], grouped=False)
+        B, _, H, W = h9.shape
+        buf = torch.empty((B, 9, H, W), dtype=torch.float32, device=h9.t.device)
+        acts = [E.bn_act(p, h.seq[1], h.act, training=h.training, out=buf[:, 3 * i:3 * i + 3])
+                for i, (p, h) in enumerate(zip(E.split_channels(h9, [3, 3, 3]), heads))]
+        a9 = E.join_channels(acts, buf)
+        h3 = E.thin_conv3x3(a9, [s.conv[1] for s in streams], grouped=True)
+        f = self.fuse_conv
+        y = E.thin_conv3x3(h3, [f.seq[0]], grouped=False)
+        return E.bn_act(y, f.seq[1], f.act, training=f.training)
 
 
 class UNetUpBlock(nn.Module):

@@ -78,6 +78,37 @@ int cn_conv_transpose2d_bwd_weight_f32(const float* x, long xbs, const float* dy
                                        int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, float* ws,
                                        long ws_floats, void* stream);
 
+/* ---- grouped launches: G (<= 4) convolutions of identical shape in ONE launch -- the dilation branches of
+ * ResidualAConv (nn/modules/convolution.py:376-395): same tensor shapes, per-branch padding / dilation.
+ * xs/wps/biases/ys (dys/wps_t/dxs), pads, dils: HOST arrays of G entries (device pointers / ints). Inputs may
+ * alias; outputs are all distinct, or all the same buffer (the G results are summed into it). */
+int cn_conv2d_fwd_grouped_f32(int G, const float* const* xs, long xbs, const float* const* wps,
+                              const float* const* biases /*nullable*/, float* const* ys, long ybs, int B, int Cin,
+                              int Hin, int Win, int Cout, int KH, int KW, int stride, const int* pads,
+                              const int* dils, int accumulate, void* stream);
+int cn_conv2d_bwd_data_grouped_f32(int G, const float* const* dys, long dybs, const float* const* wps_t,
+                                   float* const* dxs, long dxbs, int B, int Cin, int Hin, int Win, int Cout, int KH,
+                                   int KW, int stride, const int* pads, const int* dils, int accumulate,
+                                   void* stream);
+
+/* ---- thin 3x3 "same" convolutions (<= 9 output channels) of the TowerUNetFinal head streams
+ * (nn/modules/unet_parts.py:196-224 StreamConv2d; :227-309 TowerUNetFinal): direct VALU kernels on the RAW
+ * nn.Conv2d weights [cout_per_set][Cin][3][3] (no packing); HBM-bound, the input is read once for all sets.
+ *   grouped == 0: every weight set sees all Cin channels of x; y channel = set*cout_per_set + c
+ *   grouped != 0: set g sees channels [g*Cin, (g+1)*Cin) of an nsets*Cin-channel x
+ * ws / biases / dws: HOST arrays of nsets device pointers. Supported (nsets, cout_per_set, grouped):
+ * (3,3,0) (3,1,1) (1,3,0) (1,1,0); anything else returns CN_ERR_ARG (use cn_conv2d_*). padding == dil.
+ * bwd_weight ACCUMULATES into dws. */
+int cn_thin_conv3x3_fwd_f32(const float* x, long xbs, const float* const* ws, const float* const* biases /*nullable*/,
+                            float* y, long ybs, int B, int Cin, int H, int W, int nsets, int cout_per_set,
+                            int grouped, int dil, void* stream);
+int cn_thin_conv3x3_bwd_data_f32(const float* dy, long dybs, const float* const* ws, float* dx, long dxbs, int B,
+                                 int Cin, int H, int W, int nsets, int cout_per_set, int grouped, int dil,
+                                 int accumulate, void* stream);
+int cn_thin_conv3x3_bwd_weight_f32(const float* x, long xbs, const float* dy, long dybs, float* const* dws, int B,
+                                   int Cin, int H, int W, int nsets, int cout_per_set, int grouped, int dil,
+                                   void* stream);
+
 /* bias gradients: out[c] (+)= sum_{b,l} x[b][c][l] */
 int cn_channel_sum_f32(const float* x, long xbs, int B, int C, int L, float* out, int accumulate, void* stream);
 

@@ -521,3 +521,144 @@ def test_predictions_to_uint16():
     out = predictions_to_uint16({k: v.to(_dev()) for k, v in pred.items()}, pad, h, w).cpu().numpy()
     assert (out.astype(int) - ref.astype(int)).__abs__().max() <= 1  # fp32 product rounding at integer boundaries
     assert (out == ref).mean() > 0.999
+
+
+# ---------------------------------------------------------------------------
+# thin (direct) 3x3 convolutions of the TowerUNetFinal head streams + grouped implicit-GEMM launches
+# ---------------------------------------------------------------------------
+
+class _Sets(nn.Module):
+    def __init__(self, n, cin, cp, bias, dil=1):
+        super().__init__()
+        self.convs = nn.ModuleList([nn.Conv2d(cin, cp, 3, padding=dil, dilation=dil, bias=bias) for _ in range(n)])
+
+
+THIN_CASES = [
+    # n sets, Cin per set, cout per set, grouped, bias, B, H, W, dil
+    (3, 40, 3, False, False, 2, 28, 28, 1),   # 128 -> 3 x3 streams on one input
+    (3, 3, 1, True, True, 2, 28, 28, 1),      # 3 -> 1 x3 streams on their own inputs (with bias)
+    (1, 3, 3, False, False, 2, 28, 28, 1),    # fuse conv
+    (1, 5, 1, False, True, 1, 9, 11, 1),      # single C -> 1 stream, ragged size
+    (3, 128, 3, False, False, 2, 100, 100, 1),  # BASELINE head size
+    (3, 7, 3, False, True, 3, 13, 17, 2),     # dilated
+]
+
+
+@pytest.mark.parametrize("case", THIN_CASES)
+def test_thin_conv3x3(case):
+    from cultionet_amd import engine as E
+
+    n, cin, cp, grouped, bias, B, H, W, dil = case
+    torch.manual_seed(5)
+    mod = _Sets(n, cin, cp, bias, dil)
+    x = _rand(B, n * cin if grouped else cin, H, W, seed=6)
+    xr = x.clone().requires_grad_(True)
+    if grouped:
+        yr = torch.cat([c(xr[:, i * cin:(i + 1) * cin]) for i, c in enumerate(mod.convs)], dim=1)
+    else:
+        yr = torch.cat([c(xr) for c in mod.convs], dim=1)
+    dy = _rand(*yr.shape, seed=7)
+    yr.backward(dy)
+    ref = {k: p.grad.clone() for k, p in mod.named_parameters()}
+    y, (dx,), pg = _engine_run(mod, lambda v: E.thin_conv3x3(v, list(mod.convs), grouped, dil), [x], dy)
+    _close(y, yr, 2e-5, "y")
+    _close(dx, xr.grad, 1e-4, "dx")
+    for k in ref:
+        _close(pg[k], ref[k], 1e-4, k)
+
+
+def test_thin_conv_unsupported_config_is_an_error():
+    from cultionet_amd import engine as E
+
+    mod = _Sets(2, 4, 2, False)
+    x = _rand(1, 4, 8, 8)
+    with pytest.raises(RuntimeError):
+        _engine_run(mod, lambda v: E.thin_conv3x3(v, list(mod.convs), False), [x], _rand(1, 4, 8, 8))
+
+
+def test_split_join_channels_plumbing():
+    """conv -> split -> per-slice BN+SiLU written in place into one buffer -> join -> conv, against torch."""
+    from cultionet_amd import engine as E
+
+    torch.manual_seed(8)
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c1 = nn.Conv2d(8, 9, 3, padding=1, bias=False)
+            self.bns = nn.ModuleList([nn.BatchNorm2d(3) for _ in range(3)])
+            self.c2 = nn.Conv2d(9, 4, 3, padding=1, bias=False)
+
+    m = M()
+    x = _rand(2, 8, 12, 12, seed=9)
+    xr = x.clone().requires_grad_(True)
+    h = m.c1(xr)
+    a = torch.cat([F.silu(bn(h[:, 3 * i:3 * i + 3])) for i, bn in enumerate(m.bns)], dim=1)
+    yr = m.c2(a)
+    dy = _rand(*yr.shape, seed=10)
+    yr.backward(dy)
+    ref = {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    def fn(v):
+        h9 = E.conv2d(v, m.c1, 1, 1, 1)
+        buf = torch.empty_like(h9.t)
+        acts = [E.bn_act(p, bn, E.ACT_SILU, out=buf[:, 3 * i:3 * i + 3])
+                for i, (p, bn) in enumerate(zip(E.split_channels(h9, [3, 3, 3]), m.bns))]
+        return E.conv2d(E.join_channels(acts, buf), m.c2, 1, 1, 1)
+
+    y, (dx,), pg = _engine_run(m, fn, [x], dy)
+    _close(y, yr, 2e-5, "y")
+    _close(dx, xr.grad, 1e-4, "dx")
+    for k in ref:
+        _close(pg[k], ref[k], 1e-4, k)
+
+
+GROUPED_CASES = [
+    # G, B, Cin, H, W, Cout, dils, shared input, shared output (dgrad sums)
+    (2, 2, 32, 28, 28, 32, (1, 2), True),
+    (2, 2, 32, 25, 25, 48, (1, 3), False),
+    (3, 1, 16, 13, 13, 16, (1, 1, 1), True),
+    (2, 8, 128, 25, 25, 128, (1, 2), True),
+]
+
+
+@pytest.mark.parametrize("case", GROUPED_CASES)
+def test_grouped_conv_launch(case):
+    """cn_conv2d_fwd_grouped_f32 / cn_conv2d_bwd_data_grouped_f32 against per-branch torch convs."""
+    import ctypes
+    from cultionet_amd import engine as E, _lib
+
+    G, B, Cin, H, W, Cout, dils, shared = case
+    dev = _dev()
+    torch.manual_seed(11)
+    convs = nn.ModuleList([nn.Conv2d(Cin, Cout, 3, padding=d, dilation=d, bias=False) for d in dils]).to(dev)
+    store = E.ParamStore(convs)
+    xs = [_rand(B, Cin, H, W, seed=20 + (0 if shared else i)).to(dev) for i in range(G)]
+    dys = [_rand(B, Cout, H, W, seed=30 + i).to(dev) for i in range(G)]
+    ys = [torch.empty(B, Cout, H, W, device=dev) for _ in range(G)]
+    with E.using_store(store):
+        pws = [E.packed_conv(c, True) for c in convs]
+    tab = lambda ptrs: (ctypes.c_void_p * G)(*ptrs)
+    ints = (ctypes.c_int * G)(*dils)
+    s = E._stream()
+    _lib.call("cn_conv2d_fwd_grouped_f32", G, tab([x.data_ptr() for x in xs]), E.bstride(xs[0]),
+              tab([p.fwd.data_ptr() for p in pws]), None, tab([y.data_ptr() for y in ys]), E.bstride(ys[0]), B, Cin, H,
+              W, Cout, 3, 3, 1, ints, ints, 0, s)
+    for i in range(G):
+        _close(ys[i], convs[i](xs[i]), 2e-5, f"y{i}")
+    # bwd-data: distinct outputs, then all branches summed into one buffer
+    dxs = [torch.empty(B, Cin, H, W, device=dev) for _ in range(G)]
+    _lib.call("cn_conv2d_bwd_data_grouped_f32", G, tab([d.data_ptr() for d in dys]), E.bstride(dys[0]),
+              tab([p.bwd.data_ptr() for p in pws]), tab([d.data_ptr() for d in dxs]), E.bstride(dxs[0]), B, Cin, H, W,
+              Cout, 3, 3, 1, ints, ints, 0, s)
+    refs = []
+    for i in range(G):
+        xr = xs[i].clone().requires_grad_(True)
+        convs[i](xr).backward(dys[i])
+        refs.append(xr.grad)
+        _close(dxs[i], xr.grad, 1e-4, f"dx{i}")
+    dsum = torch.empty(B, Cin, H, W, device=dev)
+    _lib.call("cn_conv2d_bwd_data_grouped_f32", G, tab([d.data_ptr() for d in dys]), E.bstride(dys[0]),
+              tab([p.bwd.data_ptr() for p in pws]), tab([dsum.data_ptr()] * G), E.bstride(dsum), B, Cin, H, W, Cout, 3,
+              3, 1, ints, ints, 0, s)
+    _close(dsum, sum(refs), 1e-4, "dx sum")
