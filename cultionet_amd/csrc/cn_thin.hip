@@ -156,41 +156,72 @@ __global__ __launch_bounds__(256) void cn_thin_bwd_data_kernel(const float* __re
   }
 }
 
+// Wave sum through DPP (one VALU op per step, no LDS traffic): row-wise inclusive scan, then the row totals are
+// carried across rows; the wave total ends up in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float cn_dpp_add(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __int_as_float(r);
+}
+__device__ __forceinline__ float cn_wave_sum_to_lane63(float v) {
+  v = cn_dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = cn_dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = cn_dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = cn_dpp_add<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each row holds the row total
+  v = cn_dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = cn_dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
+  return v;
+}
+
 // dw[co][ci][t] += sum_{b,p} dy[b][co][p] * x[b][ci][p + (t-1)*dil]
-// grid = (pixel chunks, input channels); a lane keeps the (output channel x tap) partial sums of its pixels in
-// registers, the block reduces them through wave shuffles + LDS and issues one atomic per weight.
+// grid = (row chunks x column tiles, input channels). A lane owns one image column and walks down the rows of its
+// chunk (two rows in flight per block: threads 0-127 / 128-255), so the row index and the vertical tap validity are
+// wave-uniform and the loop carries no divisions; the (output channel x tap) partial sums stay in registers,
+// the block reduces them (DPP wave sums + LDS) and issues one atomic per weight.
 template <int NG, int CP, bool GROUPED>
 __global__ __launch_bounds__(256) void cn_thin_bwd_weight_kernel(const float* __restrict__ x, long xbs,
                                                                 const float* __restrict__ dy, long dybs,
                                                                 float* __restrict__ dw0, float* __restrict__ dw1,
                                                                 float* __restrict__ dw2, int B, int Cin, int H,
-                                                                int W, int dil, int per_chunk) {
+                                                                int W, int dil, int rows_per_chunk, int col_tiles) {
   constexpr int NO = GROUPED ? CP : NG * CP;  // output channels paired with this input channel
   __shared__ float red[4][NO * 9];
   const int HW = H * W;
   const int cit = blockIdx.y;                  // input channel of the whole tensor
   const int grp = GROUPED ? cit / Cin : 0;
   const int ci = GROUPED ? cit - grp * Cin : cit;
-  const long P = (long)B * HW;
-  long q = (long)blockIdx.x * per_chunk + threadIdx.x;
-  long q_end = (long)(blockIdx.x + 1) * per_chunk;
-  if (q_end > P) q_end = P;
+  const int chunk = blockIdx.x / col_tiles, ct = blockIdx.x - chunk * col_tiles;
+  const int half = __builtin_amdgcn_readfirstlane(threadIdx.x >> 7);
+  const int ox = ct * 128 + (threadIdx.x & 127);
+  const bool col_ok = ox < W;
+  bool okx[3];
+#pragma unroll
+  for (int kx = 0; kx < 3; ++kx) {
+    const int ix = ox + (kx - 1) * dil;
+    okx[kx] = col_ok && ix >= 0 && ix < W;
+  }
+  const int R = B * H;
+  int r_end = (chunk + 1) * rows_per_chunk;
+  if (r_end > R) r_end = R;
   float acc[NO * 9];
 #pragma unroll
   for (int i = 0; i < NO * 9; ++i) acc[i] = 0.f;
-  for (; q < q_end; q += 256) {
-    const int b = (int)(q / HW);
-    const int pix = (int)(q - (long)b * HW);
-    const int oy = pix / W, ox = pix - oy * W;
-    const Taps tp = cn_thin_taps(oy, ox, H, W, dil, 1);
-    const float* xc = x + (long)b * xbs + (long)cit * HW;
+  for (int r = chunk * rows_per_chunk + half; r < r_end; r += 2) {
+    const int b = r / H, oy = r - b * H;
+    const float* xc = x + (long)b * xbs + (long)cit * HW + ox;
     float xv[9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) xv[t] = tp.ok[t] ? xc[tp.off[t]] : 0.f;
-    const float* dyb = dy + (long)b * dybs + (long)(GROUPED ? grp * CP : 0) * HW + pix;
+    for (int ky = 0; ky < 3; ++ky) {
+      const int iy = oy + (ky - 1) * dil;
+      const bool oky = iy >= 0 && iy < H;
+#pragma unroll
+      for (int kx = 0; kx < 3; ++kx)
+        xv[ky * 3 + kx] = (oky && okx[kx]) ? xc[iy * W + (kx - 1) * dil] : 0.f;
+    }
+    const float* dyb = dy + (long)b * dybs + (long)(GROUPED ? grp * CP : 0) * HW + oy * W + ox;
 #pragma unroll
     for (int o = 0; o < NO; ++o) {
-      const float d = dyb[(long)o * HW];
+      const float d = col_ok ? dyb[(long)o * HW] : 0.f;
 #pragma unroll
       for (int t = 0; t < 9; ++t) acc[o * 9 + t] = fmaf(d, xv[t], acc[o * 9 + t]);
     }
@@ -198,8 +229,8 @@ __global__ __launch_bounds__(256) void cn_thin_bwd_weight_kernel(const float* __
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
 #pragma unroll
   for (int i = 0; i < NO * 9; ++i) {
-    const float v = cn_wave_sum(acc[i]);
-    if (lane == 0) red[wid][i] = v;
+    const float v = cn_wave_sum_to_lane63(acc[i]);
+    if (lane == 63) red[wid][i] = v;
   }
   __syncthreads();
   for (int i = threadIdx.x; i < NO * 9; i += 256) {
@@ -215,6 +246,126 @@ __global__ __launch_bounds__(256) void cn_thin_bwd_weight_kernel(const float* __
       dst = dwg + ((long)c * Cin + ci) * 9 + t;
     }
     atomicAdd(dst, v);
+  }
+}
+
+// ---- wide-input variants (Cin >= 16, shared input): one lane per pixel leaves ~1 wave per SIMD on a 100x100
+// chip batch, so the input channels are split over the 4 waves of a block (64 pixels per block) and each wave
+// keeps ITS quarter of the weights in LDS as [ci][(o,t) = NO*9, padded to a multiple of 4] (broadcast
+// ds_read_b128; the scalar cache cannot hold the 41 KB of a 128 -> 9 layer).
+template <int NG, int CP>
+__device__ __forceinline__ void cn_thin_stage_weights(float* wl, int Cq, int Cin, const float* __restrict__ w0,
+                                                      const float* __restrict__ w1, const float* __restrict__ w2) {
+  constexpr int NO = NG * CP, RS = (NO * 9 + 3) / 4 * 4;
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  for (int idx = lane; idx < Cq * NO * 9; idx += 64) {
+    const int cil = idx / (NO * 9), r = idx - cil * (NO * 9);
+    const int o = r / 9, t = r - o * 9;
+    const int g = o / CP, c = o - g * CP;
+    const int ci = wid * Cq + cil;
+    const float* wg = g == 0 ? w0 : (g == 1 ? w1 : w2);
+    wl[(wid * Cq + cil) * RS + r] = ci < Cin ? wg[((long)c * Cin + ci) * 9 + t] : 0.f;
+  }
+}
+
+template <int NG, int CP>
+__global__ __launch_bounds__(256) void cn_thin_fwd_ks_kernel(const float* __restrict__ x, long xbs,
+                                                            const float* __restrict__ w0,
+                                                            const float* __restrict__ w1,
+                                                            const float* __restrict__ w2,
+                                                            const float* __restrict__ b0,
+                                                            const float* __restrict__ b1,
+                                                            const float* __restrict__ b2, float* __restrict__ y,
+                                                            long ybs, int Cin, int H, int W, int dil, int Cq) {
+  constexpr int NO = NG * CP, RS = (NO * 9 + 3) / 4 * 4;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* wl = sm;                   // [4][Cq][RS]
+  float* red = sm + 4 * Cq * RS;    // [4][NO][64]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int HW = H * W;
+  const int pix = blockIdx.x * 64 + lane;
+  const bool live = pix < HW;
+  const int pc = live ? pix : 0;
+  const int oy = pc / W, ox = pc - oy * W;
+  const Taps tp = cn_thin_taps(oy, ox, H, W, dil, 1);
+  cn_thin_stage_weights<NG, CP>(wl, Cq, Cin, w0, w1, w2);
+  __syncthreads();
+  const float* xb = x + (long)blockIdx.y * xbs;
+  float acc[NO];
+#pragma unroll
+  for (int o = 0; o < NO; ++o) acc[o] = 0.f;
+  for (int cil = 0; cil < Cq; ++cil) {
+    int ci = wid * Cq + cil;
+    if (ci >= Cin) ci = Cin - 1;  // its staged weights are zero
+    const float* xc = xb + (long)ci * HW;
+    float xv[9];
+#pragma unroll
+    for (int t = 0; t < 9; ++t) xv[t] = tp.ok[t] ? xc[tp.off[t]] : 0.f;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(wl + (wid * Cq + cil) * RS);
+    f32x4 wv[RS / 4];
+#pragma unroll
+    for (int j = 0; j < RS / 4; ++j) wv[j] = wp[j];
+#pragma unroll
+    for (int o = 0; o < NO; ++o)
+#pragma unroll
+      for (int t = 0; t < 9; ++t) acc[o] = fmaf(xv[t], wv[(o * 9 + t) >> 2][(o * 9 + t) & 3], acc[o]);
+  }
+#pragma unroll
+  for (int o = 0; o < NO; ++o) red[(wid * NO + o) * 64 + lane] = acc[o];
+  __syncthreads();
+  for (int idx = threadIdx.x; idx < NO * 64; idx += 256) {
+    const int o = idx >> 6, l = idx & 63;
+    const int g = o / CP, c = o - g * CP;
+    const float* bg = g == 0 ? b0 : (g == 1 ? b1 : b2);
+    float v = bg != nullptr ? bg[c] : 0.f;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) v += red[(w * NO + o) * 64 + l];
+    const int p = blockIdx.x * 64 + l;
+    if (p < HW) y[(long)blockIdx.y * ybs + (long)o * HW + p] = v;
+  }
+}
+
+template <int NG, int CP>
+__global__ __launch_bounds__(256) void cn_thin_bwd_data_ks_kernel(const float* __restrict__ dy, long dybs,
+                                                                 const float* __restrict__ w0,
+                                                                 const float* __restrict__ w1,
+                                                                 const float* __restrict__ w2,
+                                                                 float* __restrict__ dx, long dxbs, int Cin, int H,
+                                                                 int W, int dil, int accumulate, int Cq) {
+  constexpr int NO = NG * CP, RS = (NO * 9 + 3) / 4 * 4;
+  extern __shared__ __attribute__((aligned(16))) float sm[];
+  float* wl = sm;  // [4][Cq][RS]
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int HW = H * W;
+  const int pix = blockIdx.x * 64 + lane;
+  const bool live = pix < HW;
+  const int pc = live ? pix : 0;
+  const int oy = pc / W, ox = pc - oy * W;
+  const Taps tp = cn_thin_taps(oy, ox, H, W, dil, -1);
+  cn_thin_stage_weights<NG, CP>(wl, Cq, Cin, w0, w1, w2);
+  const float* dyb = dy + (long)blockIdx.y * dybs;
+  float dv[NO * 9];
+#pragma unroll
+  for (int o = 0; o < NO; ++o)
+#pragma unroll
+    for (int t = 0; t < 9; ++t) dv[o * 9 + t] = tp.ok[t] ? dyb[(long)o * HW + tp.off[t]] : 0.f;
+  __syncthreads();
+  float* dxb = dx + (long)blockIdx.y * dxbs + pix;
+  for (int cil = 0; cil < Cq; ++cil) {
+    const int ci = wid * Cq + cil;
+    if (ci >= Cin) break;
+    const f32x4* wp = reinterpret_cast<const f32x4*>(wl + (wid * Cq + cil) * RS);
+    f32x4 wv[RS / 4];
+#pragma unroll
+    for (int j = 0; j < RS / 4; ++j) wv[j] = wp[j];
+    float s[3] = {0.f, 0.f, 0.f};  // three partial sums: shorter dependent fma chains
+#pragma unroll
+    for (int i = 0; i < NO * 9; ++i) s[i % 3] = fmaf(dv[i], wv[i >> 2][i & 3], s[i % 3]);
+    const float r = (s[0] + s[1]) + s[2];
+    if (live) {
+      float* d = dxb + (long)ci * HW;
+      *d = accumulate ? *d + r : r;
+    }
   }
 }
 
@@ -249,6 +400,15 @@ extern "C" int cn_thin_conv3x3_fwd_f32(const float* x, long xbs, const float* co
   const float* b[3] = {nullptr, nullptr, nullptr};
   if (biases)
     for (int i = 0; i < nsets; ++i) b[i] = biases[i];
+  if (cfg == 0 && Cin >= 16) {
+    const int Cq = (Cin + 3) / 4;
+    const size_t lds = sizeof(float) * (size_t)(4 * Cq * 84 + 4 * 9 * 64);
+    if (lds <= 64 * 1024) {
+      hipLaunchKernelGGL((cn_thin_fwd_ks_kernel<3, 3>), dim3(cn_cdiv((long)H * W, 64), B), dim3(256), lds,
+                         (hipStream_t)stream, x, xbs, w[0], w[1], w[2], b[0], b[1], b[2], y, ybs, Cin, H, W, dil, Cq);
+      return cn_check_launch();
+    }
+  }
   const dim3 grid(cn_cdiv((long)H * W, 256), B);
 #define CN_CALL(NG_, CP_, GR_)                                                                                      \
   hipLaunchKernelGGL((cn_thin_fwd_kernel<NG_, CP_, GR_>), grid, dim3(256), 0, (hipStream_t)stream, x, xbs, w[0], w[1], \
@@ -265,6 +425,15 @@ extern "C" int cn_thin_conv3x3_bwd_data_f32(const float* dy, long dybs, const fl
   if (cfg < 0 || dil < 1 || Cin < 1) return CN_ERR_ARG;
   if (B <= 0 || H <= 0 || W <= 0) return CN_OK;
   const float* w[3] = {ws[0], nsets > 1 ? ws[1] : nullptr, nsets > 2 ? ws[2] : nullptr};
+  if (cfg == 0 && Cin >= 16) {
+    const int Cq = (Cin + 3) / 4;
+    const size_t lds = sizeof(float) * (size_t)(4 * Cq * 84);
+    if (lds <= 64 * 1024) {
+      hipLaunchKernelGGL((cn_thin_bwd_data_ks_kernel<3, 3>), dim3(cn_cdiv((long)H * W, 64), B), dim3(256), lds,
+                         (hipStream_t)stream, dy, dybs, w[0], w[1], w[2], dx, dxbs, Cin, H, W, dil, accumulate, Cq);
+      return cn_check_launch();
+    }
+  }
   const dim3 grid(cn_cdiv((long)H * W, 256), B);
 #define CN_CALL(NG_, CP_, GR_)                                                                                   \
   hipLaunchKernelGGL((cn_thin_bwd_data_kernel<NG_, CP_, GR_>), grid, dim3(256), 0, (hipStream_t)stream, dy, dybs, \
@@ -283,18 +452,19 @@ extern "C" int cn_thin_conv3x3_bwd_weight_f32(const float* x, long xbs, const fl
   if (B <= 0 || H <= 0 || W <= 0) return CN_OK;
   float* dw[3] = {dws[0], nsets > 1 ? dws[1] : nullptr, nsets > 2 ? dws[2] : nullptr};
   const int cin_total = grouped ? nsets * Cin : Cin;
-  const long P = (long)B * H * W;
-  // ~2048 blocks on the chip, but at least 16 pixels per lane so the block reduction stays a small fraction
-  long chunks = 2048 / cin_total;
+  const int col_tiles = (W + 127) / 128;
+  const int R = B * H;
+  // ~1024 blocks on the chip, but at least 16 rows per lane so the block reduction stays a small fraction
+  int chunks = 1024 / (cin_total * col_tiles);
   if (chunks < 1) chunks = 1;
-  long per = (P + chunks - 1) / chunks;
-  if (per < 16 * 256) per = 16 * 256;
-  per = (per + 255) / 256 * 256;
-  chunks = (P + per - 1) / per;
-  const dim3 grid((unsigned)chunks, cin_total);
+  int per = (R + chunks - 1) / chunks;
+  if (per < 32) per = 32;
+  per = (per + 1) & ~1;
+  chunks = (R + per - 1) / per;
+  const dim3 grid((unsigned)(chunks * col_tiles), cin_total);
 #define CN_CALL(NG_, CP_, GR_)                                                                                      \
   hipLaunchKernelGGL((cn_thin_bwd_weight_kernel<NG_, CP_, GR_>), grid, dim3(256), 0, (hipStream_t)stream, x, xbs, dy, \
-                     dybs, dw[0], dw[1], dw[2], B, Cin, H, W, dil, (int)per)
+                     dybs, dw[0], dw[1], dw[2], B, Cin, H, W, dil, per, col_tiles)
   CN_THIN_DISPATCH(cfg, CN_CALL)
 #undef CN_CALL
   return cn_check_launch();
