@@ -12,6 +12,7 @@
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
 
 static inline int cn_check_launch() {
   hipError_t e = hipGetLastError();
@@ -20,11 +21,46 @@ static inline int cn_check_launch() {
 
 static inline int cn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
+// ---- XCD-aware block order -------------------------------------------------------------------------------
+// Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2. Kernels whose neighbouring blocks
+// share data (halo rows, weight tiles, pixel chunks) are launched as a 1-D grid of cn_xcd_grid(total) blocks and
+// decode their logical (x, y, z) here, so that CONSECUTIVE logical blocks run on the SAME XCD and hit its L2.
+static inline unsigned cn_xcd_grid(long total) { return (unsigned)(((total + 7) / 8) * 8); }
+
+__device__ __forceinline__ bool cn_xcd_block(int gx, int gy, int total, int& bx, int& by, int& bz) {
+  const int lin = blockIdx.x;
+  const int per = (total + 7) >> 3;
+  const int l = (lin & 7) * per + (lin >> 3);
+  if (l >= total) return false;
+  bx = l % gx;
+  const int r = l / gx;
+  by = r % gy;
+  bz = r / gy;
+  return true;
+}
+
 // ---- wave / block reductions (64-wide wavefronts) -------------------------
 template <typename T>
 __device__ __forceinline__ T cn_wave_sum(T v) {
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// Wave sum through DPP (one VALU op per step, no LDS traffic): row-wise inclusive scan, then the row totals are
+// carried across rows; the wave total ends up in lane 63.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ float cn_dpp_add(float v) {
+  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
+  return v + __int_as_float(r);
+}
+__device__ __forceinline__ float cn_wave_sum_to_lane63(float v) {
+  v = cn_dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = cn_dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = cn_dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = cn_dpp_add<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each row holds the row total
+  v = cn_dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  v = cn_dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
   return v;
 }
 

@@ -40,11 +40,13 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const CnConvGeom g) 
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
 
   // ---- which class / image / tile
+  int bx, by, split;
+  if (!cn_xcd_block(g.grid_x, g.grid_y, g.grid_x * g.grid_y * g.splits, bx, by, split)) return;
   int ci_ = 0;
 #pragma unroll 1
   for (int c = 1; c < g.ncls; ++c)
-    if ((int)blockIdx.x >= g.cls[c].block_begin) ci_ = c;
-  const int grp = g.cls[ci_].grp, split = blockIdx.z;
+    if (bx >= g.cls[c].block_begin) ci_ = c;
+  const int grp = g.cls[ci_].grp;
   const float* __restrict__ x = g.gx[grp];
   const float* __restrict__ wp = g.gwp[grp];
   const float* __restrict__ bias = g.gbias[grp];
@@ -54,7 +56,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const CnConvGeom g) 
   const int min_dy = g.cls[ci_].min_dy, min_dx = g.cls[ci_].min_dx;
   const int oy0 = g.cls[ci_].oy0, ox0 = g.cls[ci_].ox0;
   const int tiles_per_img = g.cls[ci_].tiles_per_img;
-  const int tile = blockIdx.x - g.cls[ci_].block_begin;
+  const int tile = bx - g.cls[ci_].block_begin;
   const int b = tile / tiles_per_img;
   const int m0 = (tile - b * tiles_per_img) * MT;
   if (tid < ntaps) {
@@ -62,7 +64,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const CnConvGeom g) 
     tap_lds[CN_MAX_TAPS + tid] = g.cls[ci_].wt[tid];
   }
   __syncthreads();
-  const int n0 = blockIdx.y * NT;
+  const int n0 = by * NT;
   const int Mimg = Hg * Wg;
   const int gy0 = m0 / Wg;
   const int iy_base = gy0 * g.is + min_dy;
@@ -236,11 +238,13 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const CnConvGeom
   const int half = lane >> 5, l31 = lane & 31;
   const int wm = wid / WAVES_N, wn = wid % WAVES_N;
 
+  int bx, by, split;
+  if (!cn_xcd_block(g.grid_x, g.grid_y, g.grid_x * g.grid_y * g.splits, bx, by, split)) return;
   int ci_ = 0;
 #pragma unroll 1
   for (int c = 1; c < g.ncls; ++c)
-    if ((int)blockIdx.x >= g.cls[c].block_begin) ci_ = c;
-  const int grp = g.cls[ci_].grp, split = blockIdx.z;
+    if (bx >= g.cls[c].block_begin) ci_ = c;
+  const int grp = g.cls[ci_].grp;
   const float* __restrict__ x = g.gx[grp];
   const float* __restrict__ wp = g.gwp[grp];
   const float* __restrict__ bias = g.gbias[grp];
@@ -250,7 +254,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const CnConvGeom
   const int min_dy = g.cls[ci_].min_dy, min_dx = g.cls[ci_].min_dx;
   const int oy0 = g.cls[ci_].oy0, ox0 = g.cls[ci_].ox0;
   const int tiles_per_img = g.cls[ci_].tiles_per_img;
-  const int tile = blockIdx.x - g.cls[ci_].block_begin;
+  const int tile = bx - g.cls[ci_].block_begin;
   const int b = tile / tiles_per_img;
   const int m0 = (tile - b * tiles_per_img) * MT;
   const int Win = g.Win;
@@ -263,7 +267,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const CnConvGeom
     tap_lds[2 * CN_MAX_TAPS + tid] = g.cls[ci_].dx[tid];
   }
   __syncthreads();
-  const int n0 = blockIdx.y * NT;
+  const int n0 = by * NT;
   const int Mimg = Hg * Wg;
   const int gy0 = m0 / Wg;
   const int HWin = g.Hin * Win;
@@ -528,7 +532,10 @@ static int cn_launch_igemm_v(const float* x, const float* wp, const float* bias,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  dim3 grid(total_tiles, (g.Cout + NT - 1) / NT, splits);
+  g.grid_x = total_tiles;
+  g.grid_y = (g.Cout + NT - 1) / NT;
+  g.splits = splits < 1 ? 1 : splits;
+  dim3 grid(cn_xcd_grid((long)g.grid_x * g.grid_y * g.splits));
   cn_prof_desc("igemm_vec<%d,%d,%d,%d,%d> G%d B%d %d->%d %dx%d->%dx%d taps%d cls%d is%d os%d grid%dx%dx%d", WAVES_N, TN,
                TM, NV, RP, g.G, g.B, g.Cin, g.Cout, g.Hin, g.Win, g.Hout, g.Wout, max_taps, g.ncls, g.is, g.os,
                total_tiles, (g.Cout + NT - 1) / NT, splits);
@@ -551,7 +558,10 @@ static int cn_launch_igemm_t(const float* x, const float* wp, const float* bias,
                               hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
     attr_set = true;
   }
-  dim3 grid(total_tiles, (g.Cout + NT - 1) / NT, splits);
+  g.grid_x = total_tiles;
+  g.grid_y = (g.Cout + NT - 1) / NT;
+  g.splits = splits < 1 ? 1 : splits;
+  dim3 grid(cn_xcd_grid((long)g.grid_x * g.grid_y * g.splits));
   cn_prof_desc("igemm_dw<%d,%d,%d> G%d B%d %d->%d %dx%d->%dx%d taps%d cls%d is%d os%d grid%dx%dx%d", WAVES_N, TN, NI_T,
                g.G, g.B, g.Cin, g.Cout, g.Hin, g.Win, g.Hout, g.Wout, max_taps, g.ncls, g.is, g.os, total_tiles,
                (g.Cout + NT - 1) / NT, splits);

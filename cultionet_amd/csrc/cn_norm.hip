@@ -358,23 +358,198 @@ __global__ __launch_bounds__(256) void cn_ln_bwd_kernel(const float* __restrict_
   }
 }
 
+// ---- C <= 128: 64 pixels per block, the channels split over the 4 waves (CPW each) and held in registers, so x
+// (and dy) are read ONCE and a 100x100 chip batch gives ~5 waves per SIMD instead of ~1. The per-pixel statistics
+// are combined through LDS (two passes over the registers: mean, then centred variance, like the reference).
+template <int CPW>
+__global__ __launch_bounds__(256) void cn_ln_fwd_reg_kernel(const float* __restrict__ x, long xbs,
+                                                           const float* __restrict__ w,
+                                                           const float* __restrict__ bvec,
+                                                           const float* __restrict__ res, long rbs,
+                                                           float* __restrict__ y, long ybs, float* __restrict__ mu,
+                                                           float* __restrict__ rstd, int B, int C, int L, float eps) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const long p = blockIdx.x * 64L + lane;
+  const bool ok = p < (long)B * L;
+  const long b = ok ? p / L : 0, l = ok ? p - b * L : 0;
+  const int c0 = wid * CPW;
+  const float* xp = x + b * xbs + l + (long)c0 * L;
+  float xv[CPW];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    xv[i] = (ok && c0 + i < C) ? xp[(long)i * L] : 0.f;
+    s += xv[i];
+  }
+  red[0][wid][lane] = s;
+  __syncthreads();
+  const float m = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / C;
+  float v = 0.f;
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const float d = xv[i] - m;
+    v += (c0 + i < C) ? d * d : 0.f;
+  }
+  red[1][wid][lane] = v;
+  __syncthreads();
+  const float rs = 1.0f / sqrtf((red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / C + eps);
+  if (!ok) return;
+  if (wid == 0) {
+    mu[p] = m;
+    rstd[p] = rs;
+  }
+  float* yp = y + b * ybs + l + (long)c0 * L;
+  const float* rp = res ? res + b * rbs + l + (long)c0 * L : nullptr;
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    if (c0 + i < C) {
+      float o = (xv[i] - m) * rs * w[c0 + i] + bvec[c0 + i];
+      if (rp) o += rp[(long)i * L];
+      yp[(long)i * L] = o;
+    }
+  }
+}
+
+// Backward: tiles of 64 pixels (grid-stride), channels split over the 4 waves and held in registers. The parameter
+// gradients are kept per lane across the block's tiles, reduced once per block and written to the workspace
+// part[block][2][C] (same-address float atomics serialise at ~200 ns each: one per tile and channel was the
+// whole cost of this kernel); cn_ln_param_finalize_kernel sums the partials.
+template <int CPW>
+__global__ __launch_bounds__(256) void cn_ln_bwd_reg_kernel(const float* __restrict__ x, long xbs,
+                                                           const float* __restrict__ dy, long dybs,
+                                                           const float* __restrict__ w, const float* __restrict__ mu,
+                                                           const float* __restrict__ rstd, float* __restrict__ dx,
+                                                           long dxbs, float* __restrict__ part, int B, int C, int L,
+                                                           int accumulate_dx, int ntiles) {
+  __shared__ float red[2][4][64];
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+  const int c0 = wid * CPW;
+  float dwacc[CPW], dbacc[CPW];
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) dwacc[i] = dbacc[i] = 0.f;
+  for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x) {
+    const long p = tile * 64L + lane;
+    const bool ok = p < (long)B * L;
+    const long b = ok ? p / L : 0, l = ok ? p - b * L : 0;
+    const float m = ok ? mu[p] : 0.f, rs = ok ? rstd[p] : 0.f;
+    const float* xp = x + b * xbs + l + (long)c0 * L;
+    const float* dp = dy + b * dybs + l + (long)c0 * L;
+    float xh[CPW], g[CPW];
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < CPW; ++i) {
+      const bool cok = ok && c0 + i < C;
+      const float d = cok ? dp[(long)i * L] : 0.f;
+      xh[i] = cok ? (xp[(long)i * L] - m) * rs : 0.f;
+      g[i] = cok ? d * w[c0 + i] : 0.f;
+      s1 += g[i];
+      s2 += g[i] * xh[i];
+      dwacc[i] = fmaf(d, xh[i], dwacc[i]);
+      dbacc[i] += d;
+    }
+    __syncthreads();  // the previous tile's readers of red[] are done
+    red[0][wid][lane] = s1;
+    red[1][wid][lane] = s2;
+    __syncthreads();
+    if (ok) {
+      const float a1 = (red[0][0][lane] + red[0][1][lane] + red[0][2][lane] + red[0][3][lane]) / C;
+      const float a2 = (red[1][0][lane] + red[1][1][lane] + red[1][2][lane] + red[1][3][lane]) / C;
+      float* dxp = dx + b * dxbs + l + (long)c0 * L;
+#pragma unroll
+      for (int i = 0; i < CPW; ++i) {
+        if (c0 + i < C) {
+          float o = rs * (g[i] - a1 - xh[i] * a2);
+          if (accumulate_dx) o += dxp[(long)i * L];
+          dxp[(long)i * L] = o;
+        }
+      }
+    }
+  }
+  float* pw = part + (long)blockIdx.x * 2 * C;
+#pragma unroll
+  for (int i = 0; i < CPW; ++i) {
+    const float dwv = cn_wave_sum_to_lane63(dwacc[i]);
+    const float dbv = cn_wave_sum_to_lane63(dbacc[i]);
+    if (lane == 63 && c0 + i < C) {
+      pw[c0 + i] = dwv;
+      pw[C + c0 + i] = dbv;
+    }
+  }
+}
+
+// dw[c] += sum_blocks part[blk][0][c], db[c] += sum_blocks part[blk][1][c]; grid = (ceil(2C / 32), 16): a block
+// sums 1/16 of the block list for 32 values (8 sub-slices, LDS reduce) and issues one atomic per value.
+__global__ __launch_bounds__(256) void cn_ln_param_finalize_kernel(const float* __restrict__ part, int nblk, int C,
+                                                                  float* __restrict__ dw, float* __restrict__ db) {
+  __shared__ float red[8][32];
+  const int v = blockIdx.x * 32 + (threadIdx.x & 31), slice = blockIdx.y * 8 + (threadIdx.x >> 5);
+  float s = 0.f;
+  if (v < 2 * C)
+    for (int k = slice; k < nblk; k += 8 * gridDim.y) s += part[(long)k * 2 * C + v];
+  red[threadIdx.x >> 5][threadIdx.x & 31] = s;
+  __syncthreads();
+  if ((threadIdx.x >> 5) == 0 && v < 2 * C) {
+    float t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) t += red[k][threadIdx.x & 31];
+    atomicAdd(v < C ? dw + v : db + (v - C), t);
+  }
+}
+
 extern "C" int cn_layernorm_c_fwd_f32(const float* x, long xbs, const float* w, const float* b, const float* res,
                                       long rbs, float* y, long ybs, float* mu, float* rstd, int B, int C, int L,
                                       float eps, void* stream) {
   const long P = (long)B * L;
   if (P <= 0) return CN_OK;
+  if (C <= 128) {
+    const dim3 grid((unsigned)((P + 63) / 64));
+#define CN_LN_FWD(CPW_)                                                                                             \
+  hipLaunchKernelGGL((cn_ln_fwd_reg_kernel<CPW_>), grid, dim3(256), 0, (hipStream_t)stream, x, xbs, w, b, res, rbs, y, \
+                     ybs, mu, rstd, B, C, L, eps)
+    if (C <= 32) CN_LN_FWD(8);
+    else if (C <= 64) CN_LN_FWD(16);
+    else CN_LN_FWD(32);
+#undef CN_LN_FWD
+    return cn_check_launch();
+  }
   hipLaunchKernelGGL(cn_ln_fwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, xbs,
                      w, b, res, rbs, y, ybs, mu, rstd, B, C, L, eps);
   return cn_check_launch();
 }
 
-// dw/db are accumulated with atomics: zero them first for a fresh gradient.
+// Workspace of cn_layernorm_c_bwd_f32 in floats (per-block partial parameter gradients).
+extern "C" int cn_layernorm_c_workspace_floats(int B, int C, int L) {
+  const long ntiles = ((long)B * L + 63) / 64;
+  const long nblk = ntiles < 2048 ? ntiles : 2048;
+  return C <= 128 ? (int)(nblk * 2 * C) : 0;
+}
+
+// dw/db are ACCUMULATED: zero them first for a fresh gradient. ws: cn_layernorm_c_workspace_floats(B, C, L)
+// floats of scratch (C <= 128; wider layers use the atomic kernel and ignore it).
 extern "C" int cn_layernorm_c_bwd_f32(const float* x, long xbs, const float* dy, long dybs, const float* w,
                                       const float* mu, const float* rstd, float* dx, long dxbs, float* dw,
-                                      float* db, int B, int C, int L, int accumulate_dx, void* stream) {
+                                      float* db, int B, int C, int L, int accumulate_dx, float* ws, long ws_floats,
+                                      void* stream) {
   const long P = (long)B * L;
   if (P <= 0) return CN_OK;
   if (C > 512) return CN_ERR_ARG;
+  if (C <= 128) {
+    const long ntiles = (P + 63) / 64;
+    const int nblk = (int)(ntiles < 2048 ? ntiles : 2048);
+    if (ws == nullptr || ws_floats < (long)nblk * 2 * C) return CN_ERR_ARG;
+    const dim3 grid((unsigned)nblk);
+#define CN_LN_BWD(CPW_)                                                                                           \
+  hipLaunchKernelGGL((cn_ln_bwd_reg_kernel<CPW_>), grid, dim3(256), 0, (hipStream_t)stream, x, xbs, dy, dybs, w, mu, \
+                     rstd, dx, dxbs, ws, B, C, L, accumulate_dx, (int)ntiles)
+    if (C <= 32) CN_LN_BWD(8);
+    else if (C <= 64) CN_LN_BWD(16);
+    else CN_LN_BWD(32);
+#undef CN_LN_BWD
+    hipLaunchKernelGGL(cn_ln_param_finalize_kernel, dim3((2 * C + 31) / 32, 16), dim3(256), 0, (hipStream_t)stream, ws,
+                       nblk, C, dw, db);
+    return cn_check_launch();
+  }
   hipLaunchKernelGGL((cn_ln_bwd_kernel<512>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      x, xbs, dy, dybs, w, mu, rstd, dx, dxbs, dw, db, B, C, L, accumulate_dx);
   return cn_check_launch();

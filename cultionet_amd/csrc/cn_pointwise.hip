@@ -56,6 +56,37 @@ __global__ __launch_bounds__(256) void cn_bilinear_bwd_kernel(const float* __res
   ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, Wo - 1);
   const float* dp = dy + b * dybs + (long)c * Ho * Wo;
   float acc = 0.f;
+  if (ox_hi - ox_lo < 8) {
+    // near 1:1 resizes (every one in TowerUNet): the column weights of the <= 8 candidates are computed once
+    float wxv[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int ox = ox_lo + j;
+      float wx = 0.f;
+      if (ox <= ox_hi) {
+        int x0, x1; float lx;
+        bl_src(ox, sw, Wi, x0, x1, lx);
+        if (x0 == ix) wx += 1.f - lx;
+        if (x1 == ix) wx += lx;
+      }
+      wxv[j] = wx;
+    }
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float ly;
+      bl_src(oy, sh, Hi, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == iy) wy += 1.f - ly;
+      if (y1 == iy) wy += ly;
+      if (wy == 0.f) continue;
+      const float* row = dp + oy * Wo + ox_lo;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        if (wxv[j] != 0.f) acc += wy * wxv[j] * row[j];
+    }
+    float* o = dx + b * dxbs + (long)c * Hi * Wi + p;
+    *o = accumulate ? *o + acc : acc;
+    return;
+  }
   for (int oy = oy_lo; oy <= oy_hi; ++oy) {
     int y0, y1; float ly;
     bl_src(oy, sh, Hi, y0, y1, ly);

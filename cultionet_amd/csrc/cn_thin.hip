@@ -156,23 +156,6 @@ __global__ __launch_bounds__(256) void cn_thin_bwd_data_kernel(const float* __re
   }
 }
 
-// Wave sum through DPP (one VALU op per step, no LDS traffic): row-wise inclusive scan, then the row totals are
-// carried across rows; the wave total ends up in lane 63.
-template <int CTRL, int ROW_MASK>
-__device__ __forceinline__ float cn_dpp_add(float v) {
-  const int r = __builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, ROW_MASK, 0xf, false);
-  return v + __int_as_float(r);
-}
-__device__ __forceinline__ float cn_wave_sum_to_lane63(float v) {
-  v = cn_dpp_add<0x111, 0xf>(v);  // row_shr:1
-  v = cn_dpp_add<0x112, 0xf>(v);  // row_shr:2
-  v = cn_dpp_add<0x114, 0xf>(v);  // row_shr:4
-  v = cn_dpp_add<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each row holds the row total
-  v = cn_dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
-  v = cn_dpp_add<0x143, 0xc>(v);  // row_bcast:31 into rows 2 and 3
-  return v;
-}
-
 // dw[co][ci][t] += sum_{b,p} dy[b][co][p] * x[b][ci][p + (t-1)*dil]
 // grid = (row chunks x column tiles, input channels). A lane owns one image column and walks down the rows of its
 // chunk (two rows in flight per block: threads 0-127 / 128-255), so the row index and the vertical tap validity are
@@ -258,13 +241,13 @@ __device__ __forceinline__ void cn_thin_stage_weights(float* wl, int Cq, int Cin
                                                       const float* __restrict__ w1, const float* __restrict__ w2) {
   constexpr int NO = NG * CP, RS = (NO * 9 + 3) / 4 * 4;
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-  for (int idx = lane; idx < Cq * NO * 9; idx += 64) {
-    const int cil = idx / (NO * 9), r = idx - cil * (NO * 9);
+  for (int idx = lane; idx < Cq * RS; idx += 64) {  // pad entries are zeroed (they are multiplied, by zeros)
+    const int cil = idx / RS, r = idx - cil * RS;
     const int o = r / 9, t = r - o * 9;
     const int g = o / CP, c = o - g * CP;
     const int ci = wid * Cq + cil;
     const float* wg = g == 0 ? w0 : (g == 1 ? w1 : w2);
-    wl[(wid * Cq + cil) * RS + r] = ci < Cin ? wg[((long)c * Cin + ci) * 9 + t] : 0.f;
+    wl[(wid * Cq + cil) * RS + r] = (ci < Cin && r < NO * 9) ? wg[((long)c * Cin + ci) * 9 + t] : 0.f;
   }
 }
 
@@ -276,39 +259,52 @@ __global__ __launch_bounds__(256) void cn_thin_fwd_ks_kernel(const float* __rest
                                                             const float* __restrict__ b0,
                                                             const float* __restrict__ b1,
                                                             const float* __restrict__ b2, float* __restrict__ y,
-                                                            long ybs, int Cin, int H, int W, int dil, int Cq) {
+                                                            long ybs, int Cin, int H, int W, int dil, int Cq, int B) {
   constexpr int NO = NG * CP, RS = (NO * 9 + 3) / 4 * 4;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* wl = sm;                   // [4][Cq][RS]
   float* red = sm + 4 * Cq * RS;    // [4][NO][64]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int HW = H * W;
-  const int pix = blockIdx.x * 64 + lane;
+  int bx, by, bz;
+  const int gx = (HW + 63) / 64;
+  if (!cn_xcd_block(gx, B, gx * B, bx, by, bz)) return;
+  const int pix = bx * 64 + lane;
   const bool live = pix < HW;
   const int pc = live ? pix : 0;
   const int oy = pc / W, ox = pc - oy * W;
   const Taps tp = cn_thin_taps(oy, ox, H, W, dil, 1);
   cn_thin_stage_weights<NG, CP>(wl, Cq, Cin, w0, w1, w2);
   __syncthreads();
-  const float* xb = x + (long)blockIdx.y * xbs;
+  const float* xb = x + (long)by * xbs;
   float acc[NO];
 #pragma unroll
   for (int o = 0; o < NO; ++o) acc[o] = 0.f;
-  for (int cil = 0; cil < Cq; ++cil) {
-    int ci = wid * Cq + cil;
-    if (ci >= Cin) ci = Cin - 1;  // its staged weights are zero
-    const float* xc = xb + (long)ci * HW;
-    float xv[9];
+  // channels in groups of U: all U*9 input loads are issued before the first FMA (memory-level parallelism)
+  constexpr int U = 2;
+  for (int c0 = 0; c0 < Cq; c0 += U) {
+    float xv[U][9];
 #pragma unroll
-    for (int t = 0; t < 9; ++t) xv[t] = tp.ok[t] ? xc[tp.off[t]] : 0.f;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(wl + (wid * Cq + cil) * RS);
-    f32x4 wv[RS / 4];
+    for (int u = 0; u < U; ++u) {
+      int ci = wid * Cq + c0 + u;
+      if (ci >= Cin) ci = Cin - 1;  // staged weights of channels past the end are zero
+      const float* xc = xb + (long)ci * HW;
 #pragma unroll
-    for (int j = 0; j < RS / 4; ++j) wv[j] = wp[j];
+      for (int t = 0; t < 9; ++t) xv[u][t] = tp.ok[t] ? xc[tp.off[t]] : 0.f;
+    }
 #pragma unroll
-    for (int o = 0; o < NO; ++o)
+    for (int u = 0; u < U; ++u) {
+      if (c0 + u < Cq) {
+        const f32x4* wp = reinterpret_cast<const f32x4*>(wl + (wid * Cq + c0 + u) * RS);
+        f32x4 wv[RS / 4];
 #pragma unroll
-      for (int t = 0; t < 9; ++t) acc[o] = fmaf(xv[t], wv[(o * 9 + t) >> 2][(o * 9 + t) & 3], acc[o]);
+        for (int j = 0; j < RS / 4; ++j) wv[j] = wp[j];
+#pragma unroll
+        for (int o = 0; o < NO; ++o)
+#pragma unroll
+          for (int t = 0; t < 9; ++t) acc[o] = fmaf(xv[u][t], wv[(o * 9 + t) >> 2][(o * 9 + t) & 3], acc[o]);
+      }
+    }
   }
 #pragma unroll
   for (int o = 0; o < NO; ++o) red[(wid * NO + o) * 64 + lane] = acc[o];
@@ -320,8 +316,8 @@ __global__ __launch_bounds__(256) void cn_thin_fwd_ks_kernel(const float* __rest
     float v = bg != nullptr ? bg[c] : 0.f;
 #pragma unroll
     for (int w = 0; w < 4; ++w) v += red[(w * NO + o) * 64 + l];
-    const int p = blockIdx.x * 64 + l;
-    if (p < HW) y[(long)blockIdx.y * ybs + (long)o * HW + p] = v;
+    const int p = bx * 64 + l;
+    if (p < HW) y[(long)by * ybs + (long)o * HW + p] = v;
   }
 }
 
@@ -331,26 +327,31 @@ __global__ __launch_bounds__(256) void cn_thin_bwd_data_ks_kernel(const float* _
                                                                  const float* __restrict__ w1,
                                                                  const float* __restrict__ w2,
                                                                  float* __restrict__ dx, long dxbs, int Cin, int H,
-                                                                 int W, int dil, int accumulate, int Cq) {
+                                                                 int W, int dil, int accumulate, int Cq, int B) {
   constexpr int NO = NG * CP, RS = (NO * 9 + 3) / 4 * 4;
   extern __shared__ __attribute__((aligned(16))) float sm[];
   float* wl = sm;  // [4][Cq][RS]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int HW = H * W;
-  const int pix = blockIdx.x * 64 + lane;
+  int bx, by, bz;
+  const int gx = (HW + 63) / 64;
+  if (!cn_xcd_block(gx, B, gx * B, bx, by, bz)) return;
+  const int pix = bx * 64 + lane;
   const bool live = pix < HW;
   const int pc = live ? pix : 0;
   const int oy = pc / W, ox = pc - oy * W;
   const Taps tp = cn_thin_taps(oy, ox, H, W, dil, -1);
   cn_thin_stage_weights<NG, CP>(wl, Cq, Cin, w0, w1, w2);
-  const float* dyb = dy + (long)blockIdx.y * dybs;
-  float dv[NO * 9];
+  const float* dyb = dy + (long)by * dybs;
+  f32x2 dv[RS / 2];  // (o, t) pairs in the order of the staged weights; the pad entries are zero
 #pragma unroll
-  for (int o = 0; o < NO; ++o)
-#pragma unroll
-    for (int t = 0; t < 9; ++t) dv[o * 9 + t] = tp.ok[t] ? dyb[(long)o * HW + tp.off[t]] : 0.f;
+  for (int i = 0; i < RS; ++i) {
+    const int o = i / 9, t = i - o * 9;
+    const float v = (i < NO * 9 && tp.ok[t]) ? dyb[(long)o * HW + tp.off[t]] : 0.f;
+    dv[i >> 1][i & 1] = v;
+  }
   __syncthreads();
-  float* dxb = dx + (long)blockIdx.y * dxbs + pix;
+  float* dxb = dx + (long)by * dxbs + pix;
   for (int cil = 0; cil < Cq; ++cil) {
     const int ci = wid * Cq + cil;
     if (ci >= Cin) break;
@@ -358,10 +359,14 @@ __global__ __launch_bounds__(256) void cn_thin_bwd_data_ks_kernel(const float* _
     f32x4 wv[RS / 4];
 #pragma unroll
     for (int j = 0; j < RS / 4; ++j) wv[j] = wp[j];
-    float s[3] = {0.f, 0.f, 0.f};  // three partial sums: shorter dependent fma chains
+    f32x2 s2[2] = {{0.f, 0.f}, {0.f, 0.f}};  // packed fma (v_pk_fma_f32), two independent chains
 #pragma unroll
-    for (int i = 0; i < NO * 9; ++i) s[i % 3] = fmaf(dv[i], wv[i >> 2][i & 3], s[i % 3]);
-    const float r = (s[0] + s[1]) + s[2];
+    for (int j = 0; j < RS / 4; ++j) {
+      const f32x2 wlo = {wv[j][0], wv[j][1]}, whi = {wv[j][2], wv[j][3]};
+      s2[0] = __builtin_elementwise_fma(dv[2 * j], wlo, s2[0]);
+      s2[1] = __builtin_elementwise_fma(dv[2 * j + 1], whi, s2[1]);
+    }
+    const float r = (s2[0][0] + s2[0][1]) + (s2[1][0] + s2[1][1]);
     if (live) {
       float* d = dxb + (long)ci * HW;
       *d = accumulate ? *d + r : r;
@@ -404,8 +409,8 @@ extern "C" int cn_thin_conv3x3_fwd_f32(const float* x, long xbs, const float* co
     const int Cq = (Cin + 3) / 4;
     const size_t lds = sizeof(float) * (size_t)(4 * Cq * 84 + 4 * 9 * 64);
     if (lds <= 64 * 1024) {
-      hipLaunchKernelGGL((cn_thin_fwd_ks_kernel<3, 3>), dim3(cn_cdiv((long)H * W, 64), B), dim3(256), lds,
-                         (hipStream_t)stream, x, xbs, w[0], w[1], w[2], b[0], b[1], b[2], y, ybs, Cin, H, W, dil, Cq);
+      hipLaunchKernelGGL((cn_thin_fwd_ks_kernel<3, 3>), dim3(cn_xcd_grid((long)cn_cdiv((long)H * W, 64) * B)), dim3(256), lds,
+                         (hipStream_t)stream, x, xbs, w[0], w[1], w[2], b[0], b[1], b[2], y, ybs, Cin, H, W, dil, Cq, B);
       return cn_check_launch();
     }
   }
@@ -429,8 +434,8 @@ extern "C" int cn_thin_conv3x3_bwd_data_f32(const float* dy, long dybs, const fl
     const int Cq = (Cin + 3) / 4;
     const size_t lds = sizeof(float) * (size_t)(4 * Cq * 84);
     if (lds <= 64 * 1024) {
-      hipLaunchKernelGGL((cn_thin_bwd_data_ks_kernel<3, 3>), dim3(cn_cdiv((long)H * W, 64), B), dim3(256), lds,
-                         (hipStream_t)stream, dy, dybs, w[0], w[1], w[2], dx, dxbs, Cin, H, W, dil, accumulate, Cq);
+      hipLaunchKernelGGL((cn_thin_bwd_data_ks_kernel<3, 3>), dim3(cn_xcd_grid((long)cn_cdiv((long)H * W, 64) * B)), dim3(256), lds,
+                         (hipStream_t)stream, dy, dybs, w[0], w[1], w[2], dx, dxbs, Cin, H, W, dil, accumulate, Cq, B);
       return cn_check_launch();
     }
   }

@@ -40,6 +40,7 @@ struct CnWgradGeom {
   int buf_stride;  // floats per LDS buffer
   int nbuf;        // 2: double-buffered LDS-DMA pipeline, 1: single buffer
   int colsplit;    // unused
+  int grid_x, grid_y, grid_z;  // logical grid (Bc tiles, A tiles, splits); launched 1-D in XCD-aware order
   int mq_lo, mq_hi;  // 16-byte variant: pixel pairs [0,mq_lo) and [mq_hi, Ws/2) of a row need column masks
 };
 
@@ -64,8 +65,10 @@ __global__ __launch_bounds__(256) void cn_wgrad_kernel(const float* __restrict__
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int half = lane >> 5, l31 = lane & 31;
   const int at = wid % g.a_tiles, kp = wid / g.a_tiles, kparts = 4 / g.a_tiles;
-  const int a0 = blockIdx.y * g.a_tiles * 32;
-  const int b0 = blockIdx.x * WG_BC;
+  int bx, by, bz;
+  if (!cn_xcd_block(g.grid_x, g.grid_y, g.grid_x * g.grid_y * g.grid_z, bx, by, bz)) return;
+  const int a0 = by * g.a_tiles * 32;
+  const int b0 = bx * WG_BC;
   const int npix = g.PR * g.Wsp;  // staged (padded) grid pixels per chunk, even
   const float* zero = cn_zero_line + lane;
 
@@ -111,7 +114,7 @@ __global__ __launch_bounds__(256) void cn_wgrad_kernel(const float* __restrict__
 
   const int HWs = g.Hs * g.Ws, HWb = g.Hb * g.Wb;
   const int arows = g.a_tiles * 32;
-  int chunk = blockIdx.z * g.chunks_per_split;
+  int chunk = bz * g.chunks_per_split;
   int chunk_end = chunk + g.chunks_per_split;
   if (chunk_end > g.total_chunks) chunk_end = g.total_chunks;
 
@@ -222,8 +225,10 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int half = lane >> 5, l31 = lane & 31;
   const int at = wid % g.a_tiles, kp = wid / g.a_tiles, kparts = 4 / g.a_tiles;
-  const int a0 = blockIdx.y * g.a_tiles * 32;
-  const int b0 = blockIdx.x * WG_BC;
+  int bx, by, bz;
+  if (!cn_xcd_block(g.grid_x, g.grid_y, g.grid_x * g.grid_y * g.grid_z, bx, by, bz)) return;
+  const int a0 = by * g.a_tiles * 32;
+  const int b0 = bx * WG_BC;
   const int npix = g.PR * g.Ws;   // unpadded, even, multiple of 4
   const int n4s = npix >> 2;      // float4 pieces per S row (<= 64)
   const int n4b = g.plane_b >> 2; // float4 pieces per Bg channel image
@@ -247,7 +252,7 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int arows = g.a_tiles * 32;
-  int chunk = blockIdx.z * g.chunks_per_split;
+  int chunk = bz * g.chunks_per_split;
   int chunk_end = chunk + g.chunks_per_split;
   if (chunk_end > g.total_chunks) chunk_end = g.total_chunks;
 
@@ -466,11 +471,13 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
   }
   cn_prof_desc("wgrad_vec<%d> N%d A%d %dx%d Bc%d %dx%d s%d grid%dx%dx%d nbuf%d", T, g.N, g.A, g.Hs, g.Ws, g.Bc, g.Hb, g.Wb,
                g.s, gx, gy, splits, g.nbuf);
+  g.grid_x = gx; g.grid_y = gy; g.grid_z = splits;
+  const dim3 grid(cn_xcd_grid((long)gx * gy * splits));
   cn_prof_before(stream);
   if (g.s == 1)
-    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 1>), dim3(gx, gy, splits), dim3(256), lds, stream, S, Bg, dW, g);
+    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 1>), grid, dim3(256), lds, stream, S, Bg, dW, g);
   else
-    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 2>), dim3(gx, gy, splits), dim3(256), lds, stream, S, Bg, dW, g);
+    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 2>), grid, dim3(256), lds, stream, S, Bg, dW, g);
   cn_prof_after(stream, T == 9 ? 2 : 3, g.flops);
   return cn_check_launch();
 }
@@ -528,8 +535,10 @@ static int cn_wgrad_launch_t(const float* S, const float* Bg, float* dW, CnWgrad
   }
   cn_prof_desc("wgrad_dw<%d> N%d A%d %dx%d Bc%d %dx%d s%d grid%dx%dx%d", T, g.N, g.A, g.Hs, g.Ws, g.Bc, g.Hb, g.Wb, g.s,
                gx, gy, splits);
+  g.grid_x = gx; g.grid_y = gy; g.grid_z = splits;
   cn_prof_before(stream);
-  hipLaunchKernelGGL((cn_wgrad_kernel<T>), dim3(gx, gy, splits), dim3(256), lds, stream, S, Bg, dW, g);
+  hipLaunchKernelGGL((cn_wgrad_kernel<T>), dim3(cn_xcd_grid((long)gx * gy * splits)), dim3(256), lds, stream, S, Bg,
+                     dW, g);
   cn_prof_after(stream, T == 9 ? 2 : 3, g.flops);
   return cn_check_launch();
 }

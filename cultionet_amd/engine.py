@@ -562,9 +562,12 @@ def layer_norm_c(x: Var, ln, residual: T.Optional[Var] = None) -> Var:
             if residual is not None:
                 give_grad(residual, dy)
             dx, acc = grad_buffer(x)
+            nws = _lib.query("cn_layernorm_c_workspace_floats", B, C, L)
+            ws = torch.empty(max(nws, 1), dtype=torch.float32, device=xt.device)
             _lib.call("cn_layernorm_c_bwd_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
                       ln.weight.data_ptr(), mu.data_ptr(), rstd.data_ptr(), dx.data_ptr(), bstride(dx),
-                      store.grad_of(ln.weight).data_ptr(), store.grad_of(ln.bias).data_ptr(), B, C, L, acc, _stream())
+                      store.grad_of(ln.weight).data_ptr(), store.grad_of(ln.bias).data_ptr(), B, C, L, acc,
+                      ws.data_ptr(), nws, _stream())
             yv.grad = None
 
         tape.add(bwd, (ln.weight, ln.bias))

@@ -127,13 +127,15 @@ int cn_bn_act_bwd_f32(const float* x, long xbs, const float* dy, long dybs, cons
                       int accumulate_dx, int accumulate_params, void* stream);
 
 /* ---- nn.LayerNorm over channels, tensors kept NCHW (nunet.py:93-97, convolution.py:338-353) --
- * mu/rstd: [B][L] saved statistics. dw/db: zero first. */
+ * mu/rstd: [B][L] saved statistics. dw/db are ACCUMULATED: zero first. ws: cn_layernorm_c_workspace_floats(B,C,L)
+ * floats of scratch for the per-block partial parameter gradients (0 => not needed). */
 int cn_layernorm_c_fwd_f32(const float* x, long xbs, const float* w, const float* b, const float* res /*nullable*/,
                            long rbs, float* y, long ybs, float* mu, float* rstd, int B, int C, int L, float eps,
                            void* stream);
 int cn_layernorm_c_bwd_f32(const float* x, long xbs, const float* dy, long dybs, const float* w, const float* mu,
                            const float* rstd, float* dx, long dxbs, float* dw, float* db, int B, int C, int L,
-                           int accumulate_dx, void* stream);
+                           int accumulate_dx, float* ws, long ws_floats, void* stream);
+int cn_layernorm_c_workspace_floats(int B, int C, int L);
 
 /* ---- natten.NeighborhoodAttention2D core (convolution.py:341-350; natten 0.17.1 na2d_qk ->
  * softmax -> na2d_av, kernel 3, dilation d, no rpb). qkv [B][3C][H][W] with channel
