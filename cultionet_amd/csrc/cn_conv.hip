@@ -19,6 +19,8 @@
 #include "cn_conv_geom.h"
 #include "cn_profile.h"
 
+#include <cstdlib>
+
 #define KC 8
 
 // Software-pipelined implicit GEMM.
@@ -644,6 +646,10 @@ static CnChoice cn_choose(const CnConvGeom& g0, const int* mts, int ncfg, int NT
   if (splits > nchunks / 2) splits = nchunks / 2;
   if (splits > 32) splits = 32;
   if (splits < 1) splits = 1;
+  {
+    static const char* dbg = getenv("CN_DBG_SPLITS");  // tuning aid: force the K split of small launches
+    if (dbg) splits = atoi(dbg) < 1 ? 1 : (atoi(dbg) > nchunks ? nchunks : atoi(dbg));
+  }
   const int cps = (nchunks + splits - 1) / splits;
   best.cfg = 0;
   best.cps = cps;

@@ -49,9 +49,10 @@ __global__ __launch_bounds__(256) void cn_na2d_fwd_kernel(const float* __restric
                                                          int W, int dil, float scale, unsigned long long dthresh,
                                                          float dscale, unsigned long long dseed) {
   const int HW = H * W;
-  const int p = blockIdx.x * 256 + threadIdx.x;
+  int bx, h, b;
+  if (!cn_xcd_block((HW + 255) / 256, heads, ((HW + 255) / 256) * heads * B, bx, h, b)) return;
+  const int p = bx * 256 + threadIdx.x;
   if (p >= HW) return;
-  const int h = blockIdx.y, b = blockIdx.z;
   const int y = p / W, x = p - y * W;
   const int sy = na_window_start(y, H, dil), sx = na_window_start(x, W, dil);
   const float* qp = qkv + b * qbs + (long)(h * D) * HW;
@@ -114,9 +115,10 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_q_kernel(const float* __restr
                                                            float scale, unsigned long long dthresh, float dscale,
                                                            unsigned long long dseed) {
   const int HW = H * W;
-  const int p = blockIdx.x * 256 + threadIdx.x;
+  int bx, h, b;
+  if (!cn_xcd_block((HW + 255) / 256, heads, ((HW + 255) / 256) * heads * B, bx, h, b)) return;
+  const int p = bx * 256 + threadIdx.x;
   if (p >= HW) return;
-  const int h = blockIdx.y, b = blockIdx.z;
   const int y = p / W, x = p - y * W;
   const int sy = na_window_start(y, H, dil), sx = na_window_start(x, W, dil);
   const float* kp = qkv + b * qbs + (long)(C + h * D) * HW;
@@ -177,9 +179,10 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_kv_kernel(const float* __rest
                                                             unsigned long long dthresh, float dscale,
                                                             unsigned long long dseed) {
   const int HW = H * W;
-  const int p = blockIdx.x * 256 + threadIdx.x;
+  int bx, h, b;
+  if (!cn_xcd_block((HW + 255) / 256, heads, ((HW + 255) / 256) * heads * B, bx, h, b)) return;
+  const int p = bx * 256 + threadIdx.x;
   if (p >= HW) return;
-  const int h = blockIdx.y, b = blockIdx.z;
   const int y = p / W, x = p - y * W;
   const float* qp = qkv + b * qbs + (long)(h * D) * HW;
   const float* dop = dout + b * dobs + (long)(h * D) * HW;
@@ -248,7 +251,7 @@ extern "C" int cn_na2d_fwd_f32(const float* qkv, long qbs, float* out, long obs,
   if (kernel_size * dilation > H || kernel_size * dilation > W) return CN_ERR_ARG;
   const int D = C / heads;
   const float scale = 1.0f / sqrtf((float)D);
-  dim3 grid((H * W + 255) / 256, heads, B);
+  dim3 grid(cn_xcd_grid((long)((H * W + 255) / 256) * heads * B));  // XCD-aware order, decoded in the kernels
   if (!(attn_drop >= 0.f && attn_drop < 1.f)) return CN_ERR_ARG;
   NA_DISPATCH(D, cn_na2d_fwd_kernel, qkv, qbs, out, obs, attn, B, C, heads, H, W, dilation, scale,
               na_thresh(attn_drop), 1.0f / (1.0f - attn_drop), seed);
@@ -264,7 +267,7 @@ extern "C" int cn_na2d_bwd_f32(const float* qkv, long qbs, const float* dout, lo
   if (kernel_size != NA_K || heads <= 0 || C % heads != 0) return CN_ERR_ARG;
   const int D = C / heads;
   const float scale = 1.0f / sqrtf((float)D);
-  dim3 grid((H * W + 255) / 256, heads, B);
+  dim3 grid(cn_xcd_grid((long)((H * W + 255) / 256) * heads * B));  // XCD-aware order, decoded in the kernels
   if (!(attn_drop >= 0.f && attn_drop < 1.f)) return CN_ERR_ARG;
   const unsigned long long th = na_thresh(attn_drop);
   const float ds = 1.0f / (1.0f - attn_drop);

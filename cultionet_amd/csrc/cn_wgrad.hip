@@ -40,6 +40,7 @@ struct CnWgradGeom {
   int buf_stride;  // floats per LDS buffer
   int nbuf;        // 2: double-buffered LDS-DMA pipeline, 1: single buffer
   int colsplit;    // unused
+  long slice_stride;  // != 0: every (split, k-part) stores its partial dW into its own slice of a workspace
   int grid_x, grid_y, grid_z;  // logical grid (Bc tiles, A tiles, splits); launched 1-D in XCD-aware order
   int mq_lo, mq_hi;  // 16-byte variant: pixel pairs [0,mq_lo) and [mq_hi, Ws/2) of a row need column masks
 };
@@ -388,6 +389,9 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
     if (g.nbuf == 2) cur ^= 1;
   }
 
+  // many splits on a small dW: same-address float atomics serialise (~200 ns each), so each (split, k-part)
+  // stores its partial into a private workspace slice instead and cn_wgrad_reduce_kernel sums the slices
+  float* dWs = dW + (long)(bz * kparts + kp) * g.slice_stride;
 #pragma unroll
   for (int j = 0; j < T; ++j) {
     const int n = j * 32 + l31;
@@ -396,14 +400,33 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
 #pragma unroll
     for (int r = 0; r < 16; ++r) {
       const int a = a0 + at * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (bok && a < g.A) atomicAdd(dW + (long)a * g.sa + (long)b0 * T + n, acc[j][r]);
+      if (bok && a < g.A) {
+        if (g.slice_stride != 0) dWs[(long)a * g.sa + (long)b0 * T + n] = acc[j][r];
+        else atomicAdd(dW + (long)a * g.sa + (long)b0 * T + n, acc[j][r]);
+      }
     }
   }
 }
 
+// dW[i] += sum_s part[s][i]; grid = (ceil(n / 256), 16): 16-way atomics per address at most
+__global__ __launch_bounds__(256) void cn_wgrad_reduce_kernel(const float* __restrict__ part, long slice_stride,
+                                                             int nslices, long n, float* __restrict__ dW) {
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= n) return;
+  float s0 = 0.f, s1 = 0.f;
+  int k = blockIdx.y;
+  for (; k + (int)gridDim.y < nslices; k += 2 * gridDim.y) {
+    s0 += part[(long)k * slice_stride + i];
+    s1 += part[(long)(k + gridDim.y) * slice_stride + i];
+  }
+  if (k < nslices) s0 += part[(long)k * slice_stride + i];
+  atomicAdd(dW + i, s0 + s1);
+}
+
 // Launch of the 16-byte variant; returns CN_ERR_ARG when its alignment preconditions do not hold.
 template <int T>
-static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgradGeom g, hipStream_t stream) {
+static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgradGeom g, float* ws, long ws_floats,
+                               hipStream_t stream) {
   if (g.scs % 4 || g.bcs % 4 || g.sbs % 4 || g.bbs % 4 || (g.Ws & 1)) return CN_ERR_ARG;
   if ((reinterpret_cast<uintptr_t>(S) & 15) || (reinterpret_cast<uintptr_t>(Bg) & 15)) return CN_ERR_ARG;
   g.Wsp = g.Ws;
@@ -473,11 +496,24 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
                g.s, gx, gy, splits, g.nbuf);
   g.grid_x = gx; g.grid_y = gy; g.grid_z = splits;
   const dim3 grid(cn_xcd_grid((long)gx * gy * splits));
+  // partial-slice mode: >= 32 adds per dW address and a small dW (slices fit the caller's workspace)
+  const int kparts = 4 / g.a_tiles;
+  const long dw_floats = (long)g.A * g.sa;
+  const long nslices = (long)splits * kparts;
+  float* out = dW;
+  g.slice_stride = 0;
+  if (nslices >= 32 && dw_floats <= 64 * 1024 && ws != nullptr && nslices * dw_floats <= ws_floats) {
+    g.slice_stride = dw_floats;
+    out = ws;
+  }
   cn_prof_before(stream);
   if (g.s == 1)
-    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 1>), grid, dim3(256), lds, stream, S, Bg, dW, g);
+    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 1>), grid, dim3(256), lds, stream, S, Bg, out, g);
   else
-    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 2>), grid, dim3(256), lds, stream, S, Bg, dW, g);
+    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 2>), grid, dim3(256), lds, stream, S, Bg, out, g);
+  if (g.slice_stride != 0)
+    hipLaunchKernelGGL(cn_wgrad_reduce_kernel, dim3((unsigned)((dw_floats + 255) / 256), 16), dim3(256), 0, stream, ws,
+                       g.slice_stride, (int)nslices, dw_floats, dW);
   cn_prof_after(stream, T == 9 ? 2 : 3, g.flops);
   return cn_check_launch();
 }
@@ -586,7 +622,9 @@ static int cn_wgrad_generic(const float* S, long sbs, int A, int Hs, int Ws, con
   g.sa = (long)Bc * g.T;
   if (g.T != 1 && g.T != 9) return CN_ERR_ARG;
   // 16-byte DMA variant when the alignment preconditions hold ...
-  int rc = g.T == 1 ? cn_wgrad_launch_vec<1>(S, Bg, dW, g, stream) : cn_wgrad_launch_vec<9>(S, Bg, dW, g, stream);
+  const bool ws_ok = ws != nullptr && (reinterpret_cast<uintptr_t>(ws) & 15) == 0;
+  int rc = g.T == 1 ? cn_wgrad_launch_vec<1>(S, Bg, dW, g, ws_ok ? ws : nullptr, ws_floats, stream)
+                    : cn_wgrad_launch_vec<9>(S, Bg, dW, g, ws_ok ? ws : nullptr, ws_floats, stream);
   if (rc != CN_ERR_ARG) return rc;
   // ... else through aligned copies in the caller's workspace (two streaming passes over small tensors) ...
   if (ws != nullptr && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
@@ -613,7 +651,10 @@ static int cn_wgrad_generic(const float* S, long sbs, int A, int Hs, int Ws, con
         B2 = w;
         gp.bcs = bcs; gp.bbs = (long)Bc * bcs;
       }
-      rc = g.T == 1 ? cn_wgrad_launch_vec<1>(S2, B2, dW, gp, stream) : cn_wgrad_launch_vec<9>(S2, B2, dW, gp, stream);
+      float* wrest = ws + (need + 3) / 4 * 4;  // what the aligned copies left over serves the partial slices
+      const long nrest = ws_floats - (need + 3) / 4 * 4;
+      rc = g.T == 1 ? cn_wgrad_launch_vec<1>(S2, B2, dW, gp, wrest, nrest, stream)
+                    : cn_wgrad_launch_vec<9>(S2, B2, dW, gp, wrest, nrest, stream);
       if (rc != CN_ERR_ARG) return rc;
     }
   }

@@ -339,18 +339,25 @@ def _new(shape, like: torch.Tensor) -> torch.Tensor:
     return torch.empty(shape, dtype=torch.float32, device=like.device)
 
 
+_WS_FLOATS = 16 << 20  # persistent weight-gradient scratch (64 MB): aligned operand copies + partial dW slices
+
+
 def _pad_ws(*tensors: torch.Tensor) -> T.Tuple[T.Optional[int], int]:
-    """(pointer, floats) of scratch for aligned copies of odd-sized operands, or (None, 0) if none is needed."""
-    need = 0
+    """(pointer, floats) of the weight-gradient scratch: room for aligned copies of odd-sized operands plus the
+    partial-dW slices of many-split launches. One persistent buffer per device (launches are stream-ordered)."""
+    need = _WS_FLOATS
     for t in tensors:
         H, W = t.shape[-2], t.shape[-1]
         if (H * W) % 4 or (W & 1):
             need += t.shape[0] * t.shape[1] * (H * (W + 1) + 3)
-    if need == 0:
-        return None, 0
-    ws = torch.empty(need, dtype=torch.float32, device=tensors[0].device)
-    _state.last_ws = ws  # keep alive until the (stream-ordered) launch that uses it has been enqueued
-    return ws.data_ptr(), need
+    dev = tensors[0].device
+    pool = getattr(_state, "ws_pool", None)
+    if pool is None:
+        pool = _state.ws_pool = {}
+    ws = pool.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = pool[dev] = torch.empty(need, dtype=torch.float32, device=dev)
+    return ws.data_ptr(), ws.numel()
 
 
 def conv2d(x: Var, mod, stride: int = 1, padding: int = 0, dilation: int = 1, out: T.Optional[torch.Tensor] = None) -> Var:
