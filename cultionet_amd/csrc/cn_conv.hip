@@ -23,6 +23,8 @@
 
 #define KC 8
 
+static int cn_reduce_slices(const CnConvGeom& g, hipStream_t stream);
+
 // Software-pipelined implicit GEMM.
 //   NI_T: halo plane capacity = NI_T*256 floats per channel (register prefetch uses NI_T*KC VGPRs)
 // grid = (tiles over all classes and images, N tiles, K splits)
@@ -188,8 +190,10 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const CnConvGeom g) 
   }
 
   // ---- epilogue: D[i = cout][j = pixel]; lane = pixel -> coalesced along W
-  float* yb = y + (long)b * g.ybs;
   const int HWout = g.Hout * g.Wout;
+  const bool sliced = g.slice_stride != 0;  // split-K partials go to private workspace slices (no atomics)
+  float* yb = sliced ? g.part + (long)(grp * g.splits + split) * g.slice_stride + (long)b * g.Cout * HWout
+                     : y + (long)b * g.ybs;
   const bool first = split == 0;  // shared_y: every group adds its bias (sum semantics)
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -203,7 +207,9 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const CnConvGeom g) 
           if (pix_ok[tm]) {
             float* dst = yb + (long)co * HWout + out_off[tm];
             const float v = acc[tn][tm][r] + bv;
-            if (g.atomic_out) {
+            if (sliced) {
+              *dst = acc[tn][tm][r];
+            } else if (g.atomic_out) {
               atomicAdd(dst, v);
             } else if (g.accumulate) {
               *dst += v;
@@ -428,8 +434,10 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const CnConvGeom
 #undef CN_PREFETCH_V
   }
 
-  float* yb = y + (long)b * g.ybs;
   const int HWout = g.Hout * g.Wout;
+  const bool sliced = g.slice_stride != 0;  // split-K partials go to private workspace slices (no atomics)
+  float* yb = sliced ? g.part + (long)(grp * g.splits + split) * g.slice_stride + (long)b * g.Cout * HWout
+                     : y + (long)b * g.ybs;
   const bool first = split == 0;  // shared_y: every group adds its bias (sum semantics)
 #pragma unroll
   for (int tn = 0; tn < TN; ++tn) {
@@ -443,7 +451,9 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const CnConvGeom
           if (pix_ok[tm]) {
             float* dst = yb + (long)co * HWout + out_off[tm];
             const float v = acc[tn][tm][r] + bv;
-            if (g.atomic_out) {
+            if (sliced) {
+              *dst = acc[tn][tm][r];
+            } else if (g.atomic_out) {
               atomicAdd(dst, v);
             } else if (g.accumulate) {
               *dst += v;
@@ -543,8 +553,9 @@ static int cn_launch_igemm_v(const float* x, const float* wp, const float* bias,
                total_tiles, (g.Cout + NT - 1) / NT, splits);
   cn_prof_before(stream);
   hipLaunchKernelGGL((cn_conv_igemm_vec_kernel<WAVES_N, TN, TM, NV, RP>), grid, dim3(256), lds, stream, g);
+  const int rrc = cn_reduce_slices(g, stream);
   cn_prof_after(stream, NT == 128 ? 0 : 1, flops);
-  return cn_check_launch();
+  return rrc != CN_OK ? rrc : cn_check_launch();
 }
 
 template <int WAVES_N, int TN, int NI_T>
@@ -569,8 +580,9 @@ static int cn_launch_igemm_t(const float* x, const float* wp, const float* bias,
                (g.Cout + NT - 1) / NT, splits);
   cn_prof_before(stream);
   hipLaunchKernelGGL((cn_conv_igemm_kernel<WAVES_N, TN, NI_T>), grid, dim3(256), lds, stream, g);
+  const int rrc = cn_reduce_slices(g, stream);
   cn_prof_after(stream, NT == 128 ? 0 : 1, flops);
-  return cn_check_launch();
+  return rrc != CN_OK ? rrc : cn_check_launch();
 }
 
 // Per-class LDS / tiling geometry for pixel tiles of MT pixels.
@@ -657,6 +669,62 @@ static CnChoice cn_choose(const CnConvGeom& g0, const int* mts, int ncfg, int NT
   return best;
 }
 
+// Optional scratch for split-K partial slices (cn_conv_set_workspace): with it, a K-split launch stores each
+// split's partial tile into its own slice with plain stores and cn_conv_reduce_kernel sums the slices (+ bias)
+// into y -- no memset of y, no float atomics. Without it (or if it is too small) the atomic path is used.
+static float* g_conv_ws = nullptr;
+static long g_conv_ws_floats = 0;
+
+extern "C" int cn_conv_set_workspace(float* ws, long ws_floats) {
+  if (ws != nullptr && ((reinterpret_cast<uintptr_t>(ws) & 15) || ws_floats < 0)) return CN_ERR_ARG;
+  g_conv_ws = ws;
+  g_conv_ws_floats = ws != nullptr ? ws_floats : 0;
+  return CN_OK;
+}
+
+struct CnReduceArgs {
+  const float* part;
+  long slice_stride;
+  int nsum;  // slices summed per output (splits, or G * splits when the groups share y)
+  int ngrp;  // distinct outputs
+  float* y[CN_MAX_GROUPS];
+  const float* bias[CN_MAX_GROUPS * CN_MAX_GROUPS];  // [output][contributing group]
+  int nbias;                                          // biases per output (1, or G when shared)
+  long ybs;
+  int B, Cout, HW, accumulate;
+};
+
+// y_g[b][c][p] (+)= sum_bias + sum_s part[g * nsum + s][b][c][p]
+__global__ __launch_bounds__(256) void cn_conv_reduce_kernel(const CnReduceArgs a) {
+  const long n = (long)a.Cout * a.HW;
+  const int b = blockIdx.y, gi = blockIdx.z;
+  const float* p0 = a.part + (long)gi * a.nsum * a.slice_stride + (long)b * n;
+  float* yb = a.y[gi] + (long)b * a.ybs;
+  for (long i = (blockIdx.x * 256L + threadIdx.x) * 4; i < n; i += (long)gridDim.x * 1024) {
+    if (i + 3 < n && (n & 3) == 0 && (a.ybs & 3) == 0 && (reinterpret_cast<uintptr_t>(yb) & 15) == 0) {
+      f32x4 s = *reinterpret_cast<const f32x4*>(p0 + i);
+      for (int k = 1; k < a.nsum; ++k) s += *reinterpret_cast<const f32x4*>(p0 + (long)k * a.slice_stride + i);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int c = (int)((i + e) / a.HW);
+        for (int j = 0; j < a.nbias; ++j)
+          if (a.bias[gi * CN_MAX_GROUPS + j] != nullptr) s[e] += a.bias[gi * CN_MAX_GROUPS + j][c];
+      }
+      f32x4* d = reinterpret_cast<f32x4*>(yb + i);
+      *d = a.accumulate ? *d + s : s;
+    } else {
+      for (long e = i; e < n && e < i + 4; ++e) {
+        float s = p0[e];
+        for (int k = 1; k < a.nsum; ++k) s += p0[(long)k * a.slice_stride + e];
+        const int c = (int)(e / a.HW);
+        for (int j = 0; j < a.nbias; ++j)
+          if (a.bias[gi * CN_MAX_GROUPS + j] != nullptr) s += a.bias[gi * CN_MAX_GROUPS + j][c];
+        yb[e] = a.accumulate ? yb[e] + s : s;
+      }
+    }
+  }
+}
+
 static int cn_finish_split(CnConvGeom& g, const CnPlan& p, int splits, int cps, float* y, hipStream_t stream) {
   (void)y;
   const int nchunks = (g.Cin + KC - 1) / KC;
@@ -664,6 +732,16 @@ static int cn_finish_split(CnConvGeom& g, const CnPlan& p, int splits, int cps, 
   if (p.max_taps == 0) g.chunks_per_split = nchunks > 0 ? nchunks : 1;
   g.splits = splits < 1 ? 1 : splits;
   g.atomic_out = g.splits > 1 || (g.G > 1 && g.shared_y);
+  g.part = nullptr;
+  g.slice_stride = 0;
+  if (g.atomic_out) {
+    const long stride = ((long)g.B * g.Cout * g.Hout * g.Wout + 3) / 4 * 4;
+    if (g_conv_ws != nullptr && stride * g.G * g.splits <= g_conv_ws_floats) {
+      g.part = g_conv_ws;
+      g.slice_stride = stride;
+      return CN_OK;
+    }
+  }
   if (g.atomic_out && !g.accumulate) {
     const int ny = g.shared_y ? 1 : g.G;
     for (int i = 0; i < ny; ++i)
@@ -671,6 +749,27 @@ static int cn_finish_split(CnConvGeom& g, const CnPlan& p, int splits, int cps, 
         return CN_ERR_LAUNCH;
   }
   return CN_OK;
+}
+
+// After a sliced launch: sum the slices into the outputs.
+static int cn_reduce_slices(const CnConvGeom& g, hipStream_t stream) {
+  if (g.slice_stride == 0) return CN_OK;
+  CnReduceArgs a = {};
+  a.part = g.part;
+  a.slice_stride = g.slice_stride;
+  a.ybs = g.ybs; a.B = g.B; a.Cout = g.Cout; a.HW = g.Hout * g.Wout; a.accumulate = g.accumulate;
+  if (g.shared_y) {
+    a.nsum = g.G * g.splits; a.ngrp = 1; a.y[0] = g.gy[0]; a.nbias = g.G;
+    for (int j = 0; j < g.G; ++j) a.bias[j] = g.gbias[j];
+  } else {
+    a.nsum = g.splits; a.ngrp = g.G; a.nbias = 1;
+    for (int i = 0; i < g.G; ++i) { a.y[i] = g.gy[i]; a.bias[i * CN_MAX_GROUPS] = g.gbias[i]; }
+  }
+  const long n = (long)g.Cout * a.HW;
+  long bx = (n + 1023) / 1024;
+  if (bx > 1024) bx = 1024;
+  hipLaunchKernelGGL(cn_conv_reduce_kernel, dim3((unsigned)bx, g.B, a.ngrp), dim3(256), 0, stream, a);
+  return cn_check_launch();
 }
 
 template <int WAVES_N, int TN, int TM>
@@ -728,7 +827,10 @@ int cn_conv_igemm_launch(CnConvGeom& g, hipStream_t stream) {
   g.Npad = cn_conv_npad(g.Cout);
   const int nt = cn_pick_nt(g.Cout);
   const bool dense_out = g.ybs == (long)g.Cout * g.Hout * g.Wout;
-  const bool allow_split = dense_out || g.accumulate;
+  // strided outputs cannot be memset for the atomic path: split them only if the slices surely fit the workspace
+  const bool ws_fits = g_conv_ws != nullptr &&
+                       (((long)g.B * g.Cout * g.Hout * g.Wout + 3) / 4 * 4) * g.G * 32 <= g_conv_ws_floats;
+  const bool allow_split = dense_out || g.accumulate || ws_fits;
   if (g.G > 1 && g.shared_y && !allow_split) return CN_ERR_ARG;
   bool vec = (((long)g.Hin * g.Win) % 4 == 0) && (g.xbs % 4 == 0);
   for (int i = 0; i < g.G; ++i) vec = vec && ((reinterpret_cast<uintptr_t>(g.gx[i]) & 15) == 0);

@@ -35,6 +35,8 @@ struct CnConvGeom {
   // groups: G independent (input, weights, bias, output) sets in one launch; each class names its group
   // (CnConvClass::grp), so groups may differ in taps (dilation). shared_y: all groups sum into one output.
   int G, splits, shared_y;
+  float* part;         // split-K partial slices [(grp * splits + split)][B][Cout][Hout][Wout] (slice_stride != 0)
+  long slice_stride;
   int grid_x, grid_y;  // logical grid (pixel tiles, N tiles); z = splits. Launched 1-D in XCD-aware order
   const float* gx[CN_MAX_GROUPS];
   const float* gwp[CN_MAX_GROUPS];

@@ -408,7 +408,7 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
   }
 }
 
-// dW[i] += sum_s part[s][i]; grid = (ceil(n / 256), 16): 16-way atomics per address at most
+// dW[i] += sum_s part[s][i]; grid = (ceil(n / 256), 1 or 16): with 16 slice groups, 16-way atomics per address
 __global__ __launch_bounds__(256) void cn_wgrad_reduce_kernel(const float* __restrict__ part, long slice_stride,
                                                              int nslices, long n, float* __restrict__ dW) {
   const long i = blockIdx.x * 256L + threadIdx.x;
@@ -420,7 +420,8 @@ __global__ __launch_bounds__(256) void cn_wgrad_reduce_kernel(const float* __res
     s1 += part[(long)(k + gridDim.y) * slice_stride + i];
   }
   if (k < nslices) s0 += part[(long)k * slice_stride + i];
-  atomicAdd(dW + i, s0 + s1);
+  if (gridDim.y == 1) dW[i] += s0 + s1;
+  else atomicAdd(dW + i, s0 + s1);
 }
 
 // Launch of the 16-byte variant; returns CN_ERR_ARG when its alignment preconditions do not hold.
@@ -502,7 +503,7 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
   const long nslices = (long)splits * kparts;
   float* out = dW;
   g.slice_stride = 0;
-  if (nslices >= 32 && dw_floats <= 64 * 1024 && ws != nullptr && nslices * dw_floats <= ws_floats) {
+  if (nslices >= 32 && ws != nullptr && nslices * dw_floats <= ws_floats) {
     g.slice_stride = dw_floats;
     out = ws;
   }
@@ -512,7 +513,8 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
   else
     hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 2>), grid, dim3(256), lds, stream, S, Bg, out, g);
   if (g.slice_stride != 0)
-    hipLaunchKernelGGL(cn_wgrad_reduce_kernel, dim3((unsigned)((dw_floats + 255) / 256), 16), dim3(256), 0, stream, ws,
+    hipLaunchKernelGGL(cn_wgrad_reduce_kernel, dim3((unsigned)((dw_floats + 255) / 256), nslices > 128 ? 16 : 1),
+                       dim3(256), 0, stream, ws,
                        g.slice_stride, (int)nslices, dw_floats, dW);
   cn_prof_after(stream, T == 9 ? 2 : 3, g.flops);
   return cn_check_launch();

@@ -232,6 +232,22 @@ class ParamStore:
             pw.version = self.version
 
 
+_CONV_WS_FLOATS = 16 << 20  # split-K partial slices of the implicit-GEMM launches (64 MB, one per process)
+_conv_ws: T.Dict[str, torch.Tensor] = {}
+
+
+def _bind_conv_workspace(dev: torch.device) -> None:
+    """Give the library its split-K scratch once per process (one process drives one GPU; launches that use it are
+    stream-ordered on the current stream)."""
+    key = str(dev)
+    if key in _conv_ws:
+        return
+    ws = torch.empty(_CONV_WS_FLOATS, dtype=torch.float32, device=dev)
+    _conv_ws.clear()
+    _conv_ws[key] = ws
+    _lib.call("cn_conv_set_workspace", ws.data_ptr(), ws.numel())
+
+
 def current_store() -> ParamStore:
     st = getattr(_state, "store", None)
     if st is None:
@@ -246,6 +262,7 @@ class using_store:
     def __enter__(self):
         self.prev = getattr(_state, "store", None)
         _state.store = self.store
+        _bind_conv_workspace(self.store.flat.device)
         return self.store
 
     def __exit__(self, *exc):

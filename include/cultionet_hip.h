@@ -78,6 +78,13 @@ int cn_conv_transpose2d_bwd_weight_f32(const float* x, long xbs, const float* dy
                                        int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, float* ws,
                                        long ws_floats, void* stream);
 
+/* Optional scratch for the K-split launches of the cn_conv* entry points (small spatial sizes split the input
+ * channels over blocks): with a workspace each split stores its partial output into a private slice and a reduce
+ * kernel sums the slices (+ bias) into y; without one (ws = NULL, the default) the splits use float atomics on a
+ * zero-filled y. Process-wide setting: the caller keeps ws alive and issues the contraction launches that may use it
+ * on ONE stream. ws 16-byte aligned; 64 MB covers every TowerUNet layer at 8 chips of 100x100. */
+int cn_conv_set_workspace(float* ws, long ws_floats);
+
 /* ---- grouped launches: G (<= 4) convolutions of identical shape in ONE launch -- the dilation branches of
  * ResidualAConv (nn/modules/convolution.py:376-395): same tensor shapes, per-branch padding / dilation.
  * xs/wps/biases/ys (dys/wps_t/dxs), pads, dils: HOST arrays of G entries (device pointers / ints). Inputs may

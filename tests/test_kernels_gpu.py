@@ -662,3 +662,32 @@ def test_grouped_conv_launch(case):
               tab([p.bwd.data_ptr() for p in pws]), tab([dsum.data_ptr()] * G), E.bstride(dsum), B, Cin, H, W, Cout, 3,
               3, 1, ints, ints, 0, s)
     _close(dsum, sum(refs), 1e-4, "dx sum")
+
+
+def test_conv2d_splitk_without_workspace_uses_atomics():
+    """K-split launches (small spatial size, deep K) on the float-atomic path: no workspace bound."""
+    from cultionet_amd import engine as E, _lib
+
+    B, Cin, H, W, Cout = 2, 128, 13, 13, 128
+    conv = nn.Conv2d(Cin, Cout, 3, padding=1, bias=True)
+    x = _rand(B, Cin, H, W, seed=41)
+    xr = x.clone().requires_grad_(True)
+    yr = conv(xr)
+    dy = _rand(*yr.shape, seed=42)
+    yr.backward(dy)
+    dev = _dev()
+    conv = conv.to(dev)
+    store = E.ParamStore(conv)
+    store.zero_grad()
+    try:
+        with E.using_store(store), E.recording(True) as tape:
+            _lib.call("cn_conv_set_workspace", None, 0)   # after using_store bound one: back to atomics
+            xv = E.Var(x.to(dev), True)
+            y = E.conv2d(xv, conv, 1, 1, 1)
+            y.grad = dy.to(dev)
+            tape.backward()
+        torch.cuda.synchronize()
+        _close(y.t, yr, 2e-5, "y")
+        _close(xv.grad, xr.grad, 1e-4, "dx")
+    finally:
+        E._conv_ws.clear()  # the next forward binds the workspace again
