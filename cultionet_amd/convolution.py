@@ -210,8 +210,22 @@ class ResidualAConv(nn.Module):
     def forward(self, x: E.Var) -> E.Var:
         out = E.conv2d(x, self.skip) if isinstance(self.skip, nn.Conv2d) else x
         skip = out
-        for layer in self.res_modules:
-            out = layer(x, residual=out)  # out + SiLU(BN(conv(...))) fused in the last block
+        G = len(self.res_modules)
+        blocks0 = [m.block[0] for m in self.res_modules]
+        if 2 <= G <= 4 and all(len(m.block) == 2 for m in self.res_modules) and not blocks0[0].batchnorm_first:
+            # the G dilation branches run level by level: one grouped launch for their first convs (shared input),
+            # one for their second convs; out + SiLU(BN(.)) is fused into the last BN of each branch
+            blocks1 = [m.block[1] for m in self.res_modules]
+            ys = E.conv2d_group([x] * G, [b.seq[0] for b in blocks0], [b.padding for b in blocks0],
+                                [b.dilation for b in blocks0], blocks0[0].stride)
+            hs = [E.bn_act(y, b.seq[1], b.act, training=b.training) for y, b in zip(ys, blocks0)]
+            ys = E.conv2d_group(hs, [b.seq[0] for b in blocks1], [b.padding for b in blocks1],
+                                [b.dilation for b in blocks1], blocks1[0].stride)
+            for y, b in zip(ys, blocks1):
+                out = E.bn_act(y, b.seq[1], b.act, residual=out, training=b.training)
+        else:
+            for layer in self.res_modules:
+                out = layer(x, residual=out)  # out + SiLU(BN(conv(...))) fused in the last block
         if self.attention_weights is not None:
             a = E.layer_norm_c(skip, self.attention_conv[1])
             a = self.attention_conv[2](a)

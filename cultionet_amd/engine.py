@@ -418,6 +418,83 @@ def conv2d(x: Var, mod, stride: int = 1, padding: int = 0, dilation: int = 1, ou
     return yv
 
 
+def conv2d_group(xs: T.Sequence[Var], mods: T.Sequence, paddings: T.Sequence[int], dilations: T.Sequence[int],
+                 stride: int = 1) -> T.List[Var]:
+    """G (<= 4) nn.Conv2d of identical shapes (per-conv padding / dilation) in ONE implicit-GEMM launch -- the
+    dilation branches of ResidualAConv. ``xs`` may repeat one Var (branches sharing their input: backward sums the
+    G input gradients in the same launch). Weight gradients stay one launch per conv."""
+    import ctypes
+
+    tape = current_tape()
+    G = len(mods)
+    xts = [_check(x.t) for x in xs]
+    B, Cin, H, W = xts[0].shape
+    w0 = mods[0].weight
+    Cout, KH, KW = w0.shape[0], w0.shape[2], w0.shape[3]
+    for xt, m in zip(xts, mods):
+        if tuple(xt.shape) != (B, Cin, H, W) or tuple(m.weight.shape) != tuple(w0.shape) or bstride(xt) != bstride(xts[0]):
+            raise ValueError("conv2d_group: all inputs / weights must have the same shape")
+    Ho = (H + 2 * paddings[0] - dilations[0] * (KH - 1) - 1) // stride + 1
+    Wo = (W + 2 * paddings[0] - dilations[0] * (KW - 1) - 1) // stride + 1
+    shared_in = all(x is xs[0] for x in xs)
+    need_bwd = tape.enabled and any(x.req for x in xs)
+    pws = [packed_conv(m, need_bwd) for m in mods]
+    ys = [_new((B, Cout, Ho, Wo), xts[0]) for _ in range(G)]
+    biases = [m.bias for m in mods]
+    has_bias = biases[0] is not None
+    tab = lambda ptrs: (ctypes.c_void_p * G)(*ptrs)
+    pads_c = (ctypes.c_int * G)(*paddings)
+    dils_c = (ctypes.c_int * G)(*dilations)
+    _lib.call("cn_conv2d_fwd_grouped_f32", G, tab([t.data_ptr() for t in xts]), bstride(xts[0]),
+              tab([p.fwd.data_ptr() for p in pws]), tab([b.data_ptr() for b in biases]) if has_bias else None,
+              tab([y.data_ptr() for y in ys]), bstride(ys[0]), B, Cin, H, W, Cout, KH, KW, stride, pads_c, dils_c, 0,
+              _stream())
+    yvs = [Var(y, tape.enabled) for y in ys]
+    if tape.enabled:
+        store = current_store()
+
+        def bwd():
+            s = _stream()
+            live = [i for i in range(G) if yvs[i].grad is not None]
+            for i in live:
+                dy, m, xt = yvs[i].grad, mods[i], xts[i]
+                wsp, wsn = _pad_ws(xt, dy)
+                _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
+                          store.grad_of(m.weight).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, paddings[i],
+                          dilations[i], wsp, wsn, s)
+                if has_bias:
+                    _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Ho * Wo,
+                              store.grad_of(m.bias).data_ptr(), 1, s)
+            todo = [i for i in live if xs[i].req]
+            if todo:
+                bufs = []
+                if shared_in:
+                    dx, acc = grad_buffer(xs[0])
+                    bufs = [(dx, acc)] * len(todo)
+                else:
+                    bufs = [grad_buffer(xs[i]) for i in todo]
+                accs = {a for _, a in bufs}
+                dybs = {bstride(yvs[i].grad) for i in todo}
+                dxbs = {bstride(d) for d, _ in bufs}
+                if len(todo) == G and len(accs) == 1 and len(dybs) == 1 and len(dxbs) == 1:
+                    _lib.call("cn_conv2d_bwd_data_grouped_f32", G, tab([yvs[i].grad.data_ptr() for i in todo]),
+                              dybs.pop(), tab([p.bwd.data_ptr() for p in pws]), tab([d.data_ptr() for d, _ in bufs]),
+                              dxbs.pop(), B, Cin, H, W, Cout, KH, KW, stride, pads_c, dils_c, accs.pop(), s)
+                else:  # mixed accumulate flags / strides: conv by conv
+                    first = True
+                    for i, (d, a) in zip(todo, bufs):
+                        dy = yvs[i].grad
+                        _lib.call("cn_conv2d_bwd_data_f32", dy.data_ptr(), bstride(dy), pws[i].bwd.data_ptr(),
+                                  d.data_ptr(), bstride(d), B, Cin, H, W, Cout, KH, KW, stride, paddings[i],
+                                  dilations[i], a if (first or not shared_in) else 1, s)
+                        first = False
+            for v in yvs:
+                v.grad = None
+
+        tape.add(bwd, tuple(m.weight for m in mods) + tuple(b for b in biases if b is not None))
+    return yvs
+
+
 def conv_transpose2d(x: Var, mod, stride: int, padding: int) -> Var:
     """nn.ConvTranspose2d forward (k x k, stride s, padding p, with bias)."""
     tape = current_tape()
