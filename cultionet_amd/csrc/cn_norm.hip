@@ -179,6 +179,123 @@ __global__ __launch_bounds__(256) void cn_bn_bwd_apply_kernel(const float* __res
   }
 }
 
+// ---- small tensors (B*L <= 2048 values per channel: the 13x13 level): ONE launch, one block per
+// channel, the channel's values held in registers between the statistics and the normalisation -- x (and dy) are
+// read once and the partial-sums round trip + second launch disappear. Same fp64 statistics as the two-pass path.
+template <int NV>
+__global__ __launch_bounds__(256) void cn_bn_fused_fwd_kernel(const float* __restrict__ x, long xbs,
+                                                             float* __restrict__ mean, float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta,
+                                                             const float* __restrict__ res, long rbs,
+                                                             float* __restrict__ y, long ybs, int B, int C, int L,
+                                                             int act, float eps, float momentum,
+                                                             float* __restrict__ running_mean,
+                                                             float* __restrict__ running_var) {
+  __shared__ double scratch[4];
+  const int c = blockIdx.x, n = B * L;
+  float v[NV];
+  double s = 0.0, ss = 0.0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = threadIdx.x + k * 256;
+    v[k] = 0.f;
+    if (i < n) {
+      const int b = i / L, l = i - b * L;
+      v[k] = x[b * xbs + (long)c * L + l];
+      s += v[k];
+      ss += (double)v[k] * v[k];
+    }
+  }
+  s = cn_block_sum<double, 256>(s, scratch);
+  ss = cn_block_sum<double, 256>(ss, scratch);
+  const double count = (double)n;
+  const double md = s / count;
+  double var = ss / count - md * md;
+  if (var < 0.0) var = 0.0;
+  const float m = (float)md, rs = (float)(1.0 / sqrt(var + (double)eps));
+  if (threadIdx.x == 0) {
+    mean[c] = m;
+    rstd[c] = rs;
+    if (running_mean != nullptr) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * m;
+      running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+    }
+  }
+  const float sc = gamma[c] * rs, be = beta[c];
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = threadIdx.x + k * 256;
+    if (i < n) {
+      const int b = i / L, l = i - b * L;
+      float z = (v[k] - m) * sc + be;
+      if (act == 1) z = cn_silu(z);
+      if (res) z += res[b * rbs + (long)c * L + l];
+      y[b * ybs + (long)c * L + l] = z;
+    }
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void cn_bn_fused_bwd_kernel(const float* __restrict__ x, long xbs,
+                                                             const float* __restrict__ dy, long dybs,
+                                                             const float* __restrict__ mean,
+                                                             const float* __restrict__ rstd,
+                                                             const float* __restrict__ gamma,
+                                                             const float* __restrict__ beta, int training,
+                                                             float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                             int accumulate_params, float* __restrict__ dx, long dxbs,
+                                                             int B, int C, int L, int act, int accumulate) {
+  __shared__ double scratch[4];
+  const int c = blockIdx.x, n = B * L;
+  const float m = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
+  float xh[NV], dz[NV];
+  double s1 = 0.0, s2 = 0.0;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = threadIdx.x + k * 256;
+    xh[k] = 0.f;
+    dz[k] = 0.f;
+    if (i < n) {
+      const int b = i / L, l = i - b * L;
+      xh[k] = (x[b * xbs + (long)c * L + l] - m) * rs;
+      float d = dy[b * dybs + (long)c * L + l];
+      if (act == 1) d *= cn_silu_grad(ga * xh[k] + be);
+      dz[k] = d;
+      s1 += d;
+      s2 += (double)d * xh[k];
+    }
+  }
+  s1 = cn_block_sum<double, 256>(s1, scratch);
+  s2 = cn_block_sum<double, 256>(s2, scratch);
+  if (threadIdx.x == 0) {
+    if (accumulate_params) {
+      dgamma[c] += (float)s2;
+      dbeta[c] += (float)s1;
+    } else {
+      dgamma[c] = (float)s2;
+      dbeta[c] = (float)s1;
+    }
+  }
+  if (dx == nullptr) return;
+  const double count = (double)n;
+  const float c1 = training ? (float)(s1 / count) : 0.f, c2 = training ? (float)(s2 / count) : 0.f;
+#pragma unroll
+  for (int k = 0; k < NV; ++k) {
+    const int i = threadIdx.x + k * 256;
+    if (i < n) {
+      const int b = i / L, l = i - b * L;
+      float g = (dz[k] - c1 - xh[k] * c2) * (ga * rs);
+      float* o = dx + b * dxbs + (long)c * L + l;
+      if (accumulate) g += *o;
+      *o = g;
+    }
+  }
+}
+
+#define BN_FUSED_MAX (8 * 256)  // larger channels are faster as two wide launches than as one block per channel
+
 static int bn_splits(int C, long L) {
   int s = (1024 + C - 1) / C;
   const long maxs = (L + 511) / 512;
@@ -205,6 +322,14 @@ extern "C" int cn_bn_act_fwd_f32(const float* x, long xbs, const float* gamma, c
                                  float momentum, float eps, int act, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
+  if (training && (long)B * L <= BN_FUSED_MAX && C >= 32) {
+#define CN_BN_FWD(NV_)                                                                                               \
+  hipLaunchKernelGGL((cn_bn_fused_fwd_kernel<NV_>), dim3(C), dim3(256), 0, stream, x, xbs, mean, rstd, gamma, beta, res, \
+                     rbs, y, ybs, B, C, L, act, eps, momentum, running_mean, running_var)
+    CN_BN_FWD(8);
+#undef CN_BN_FWD
+    return cn_check_launch();
+  }
   if (training) {
     const int splits = bn_splits(C, L);
     hipLaunchKernelGGL(cn_bn_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, B, C, L, splits, ws);
@@ -229,6 +354,14 @@ extern "C" int cn_bn_act_bwd_f32(const float* x, long xbs, const float* dy, long
                                  int training, int act, int accumulate_dx, int accumulate_params, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
+  if ((long)B * L <= BN_FUSED_MAX && C >= 32) {
+#define CN_BN_BWD(NV_)                                                                                              \
+  hipLaunchKernelGGL((cn_bn_fused_bwd_kernel<NV_>), dim3(C), dim3(256), 0, stream, x, xbs, dy, dybs, mean, rstd, gamma, \
+                     beta, training, dgamma, dbeta, accumulate_params, dx, dxbs, B, C, L, act, accumulate_dx)
+    CN_BN_BWD(8);
+#undef CN_BN_BWD
+    return cn_check_launch();
+  }
   const int splits = bn_splits(C, L);
   hipLaunchKernelGGL(cn_bn_bwd_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, dy, dybs, mean, rstd,
                      gamma, beta, B, C, L, act, splits, ws);

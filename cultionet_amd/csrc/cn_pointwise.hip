@@ -107,6 +107,108 @@ __global__ __launch_bounds__(256) void cn_bilinear_bwd_kernel(const float* __res
   *o = accumulate ? *o + acc : acc;
 }
 
+// Same adjoint for resizes that shrink by less than 2x per axis (every resize of TowerUNet is within a few pixels
+// of 1:1): an input pixel then has at most 4 contributing output rows / columns. Their indices and weights depend
+// only on the pixel, so a lane computes them ONCE and reuses them for BL_CH channels (the per-channel work is the
+// <= 16 weighted loads). Pixels with more candidates than that (never, for scale > 0.5) take the general path.
+#define BL_CH 16
+__device__ __forceinline__ int bl_candidates(int i, int in_size, int out_size, float scale, float inv_scale, int* idx,
+                                             float* wgt) {
+  int lo = (int)floorf((i - 1) * inv_scale) - 1, hi = (int)ceilf((i + 1) * inv_scale) + 1;
+  if (scale == 0.f) { lo = 0; hi = out_size - 1; }
+  lo = max(lo, 0);
+  hi = min(hi, out_size - 1);
+  int n = 0;
+#pragma unroll 1
+  for (int o = lo; o <= hi; ++o) {
+    int i0, i1; float l1;
+    bl_src(o, scale, in_size, i0, i1, l1);
+    float w = 0.f;
+    if (i0 == i) w += 1.f - l1;
+    if (i1 == i) w += l1;
+    if (w != 0.f) {
+      if (n < 4) {
+        // static indexing keeps idx/wgt in registers
+        if (n == 0) { idx[0] = o; wgt[0] = w; }
+        else if (n == 1) { idx[1] = o; wgt[1] = w; }
+        else if (n == 2) { idx[2] = o; wgt[2] = w; }
+        else { idx[3] = o; wgt[3] = w; }
+      }
+      ++n;
+    }
+  }
+  return n;
+}
+
+__global__ __launch_bounds__(256) void cn_bilinear_bwd_near_kernel(const float* __restrict__ dy, long dybs,
+                                                                  float* __restrict__ dx, long dxbs, int C, int Hi,
+                                                                  int Wi, int Ho, int Wo, float sh, float sw,
+                                                                  float inv_sh, float inv_sw, int accumulate) {
+  const int p = blockIdx.x * 256 + threadIdx.x;
+  if (p >= Hi * Wi) return;
+  const int c_begin = blockIdx.y * BL_CH, b = blockIdx.z;
+  const int iy = p / Wi, ix = p - iy * Wi;
+  int oyv[4] = {0, 0, 0, 0}, oxv[4] = {0, 0, 0, 0};
+  float wyv[4] = {0.f, 0.f, 0.f, 0.f}, wxv[4] = {0.f, 0.f, 0.f, 0.f};
+  const int ny = bl_candidates(iy, Hi, Ho, sh, inv_sh, oyv, wyv);
+  const int nx = bl_candidates(ix, Wi, Wo, sw, inv_sw, oxv, wxv);
+  int c_end = c_begin + BL_CH;
+  if (c_end > C) c_end = C;
+  if (ny <= 4 && nx <= 4) {
+    // unused slots carry weight 0 and index 0: their loads hit the plane's first row / column and are multiplied out
+    float w[4][4];
+    int off[4][4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        w[k][j] = wyv[k] * wxv[j];
+        off[k][j] = oyv[k] * Wo + oxv[j];
+      }
+    for (int c = c_begin; c < c_end; ++c) {
+      const float* dp = dy + b * dybs + (long)c * Ho * Wo;
+      float acc = 0.f;
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          if (w[k][j] != 0.f) acc += w[k][j] * dp[off[k][j]];
+      float* o = dx + b * dxbs + (long)c * Hi * Wi + p;
+      *o = accumulate ? *o + acc : acc;
+    }
+    return;
+  }
+  // general path for this pixel
+  int oy_lo = (int)floorf((iy - 1) * inv_sh) - 1, oy_hi = (int)ceilf((iy + 1) * inv_sh) + 1;
+  int ox_lo = (int)floorf((ix - 1) * inv_sw) - 1, ox_hi = (int)ceilf((ix + 1) * inv_sw) + 1;
+  if (sh == 0.f) { oy_lo = 0; oy_hi = Ho - 1; }
+  if (sw == 0.f) { ox_lo = 0; ox_hi = Wo - 1; }
+  oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, Ho - 1);
+  ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, Wo - 1);
+  for (int c = c_begin; c < c_end; ++c) {
+    const float* dp = dy + b * dybs + (long)c * Ho * Wo;
+    float acc = 0.f;
+    for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+      int y0, y1; float ly;
+      bl_src(oy, sh, Hi, y0, y1, ly);
+      float wy = 0.f;
+      if (y0 == iy) wy += 1.f - ly;
+      if (y1 == iy) wy += ly;
+      if (wy == 0.f) continue;
+      for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+        int x0, x1; float lx;
+        bl_src(ox, sw, Wi, x0, x1, lx);
+        float wx = 0.f;
+        if (x0 == ix) wx += 1.f - lx;
+        if (x1 == ix) wx += lx;
+        if (wx != 0.f) acc += wy * wx * dp[oy * Wo + ox];
+      }
+    }
+    float* o = dx + b * dxbs + (long)c * Hi * Wi + p;
+    *o = accumulate ? *o + acc : acc;
+  }
+}
+
 static inline float bl_scale(int in_size, int out_size) {
   return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
 }
@@ -124,6 +226,12 @@ extern "C" int cn_bilinear_bwd_f32(const float* dy, long dybs, float* dx, long d
                                    int Ho, int Wo, int accumulate, void* stream) {
   if (B <= 0 || C <= 0) return CN_OK;
   const float sh = bl_scale(Hi, Ho), sw = bl_scale(Wi, Wo);
+  if (2 * Hi > Ho && 2 * Wi > Wo && (long)B * C * Hi * Wi >= 1 << 16) {  // near-1:1 resize of a large tensor
+    dim3 gridn((Hi * Wi + 255) / 256, (C + BL_CH - 1) / BL_CH, B);
+    hipLaunchKernelGGL(cn_bilinear_bwd_near_kernel, gridn, dim3(256), 0, (hipStream_t)stream, dy, dybs, dx, dxbs, C,
+                       Hi, Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, accumulate);
+    return cn_check_launch();
+  }
   dim3 grid((Hi * Wi + 255) / 256, C, B);
   hipLaunchKernelGGL(cn_bilinear_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dybs, dx, dxbs, C, Hi, Wi,
                      Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, accumulate);
