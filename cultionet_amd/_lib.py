@@ -39,6 +39,8 @@ SIGNATURES = {
     "cn_bn_workspace_doubles": [I],
     "cn_bn_act_fwd_f32": [P, L, P, P, P, P, P, L, P, L, P, P, P, I, I, I, I, F, F, I, P],
     "cn_bn_act_bwd_f32": [P, L, P, L, P, P, P, P, P, L, P, P, P, P, I, I, I, I, I, I, I, P],
+    "cn_bn_act_group_fwd_f32": [I, P, L, P, P, P, P, P, L, P, L, P, P, P, I, I, I, I, F, F, I, I, P],
+    "cn_bn_act_group_bwd_f32": [I, P, L, P, L, P, P, P, P, P, L, P, P, P, P, I, I, I, I, I, I, P],
     "cn_layernorm_c_fwd_f32": [P, L, P, P, P, L, P, L, P, P, I, I, I, F, P],
     "cn_layernorm_c_workspace_floats": [I, I, I],
     "cn_layernorm_c_bwd_f32": [P, L, P, L, P, P, P, P, L, P, P, I, I, I, I, P, L, P],

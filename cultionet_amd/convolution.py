@@ -218,11 +218,11 @@ class ResidualAConv(nn.Module):
             blocks1 = [m.block[1] for m in self.res_modules]
             ys = E.conv2d_group([x] * G, [b.seq[0] for b in blocks0], [b.padding for b in blocks0],
                                 [b.dilation for b in blocks0], blocks0[0].stride)
-            hs = [E.bn_act(y, b.seq[1], b.act, training=b.training) for y, b in zip(ys, blocks0)]
+            hs = E.bn_act_group(ys, [b.seq[1] for b in blocks0], blocks0[0].act, training=self.training)
             ys = E.conv2d_group(hs, [b.seq[0] for b in blocks1], [b.padding for b in blocks1],
                                 [b.dilation for b in blocks1], blocks1[0].stride)
-            for y, b in zip(ys, blocks1):
-                out = E.bn_act(y, b.seq[1], b.act, residual=out, training=b.training)
+            out = E.bn_act_group(ys, [b.seq[1] for b in blocks1], blocks1[0].act, residual=out, sum_outputs=True,
+                                 training=self.training)
         else:
             for layer in self.res_modules:
                 out = layer(x, residual=out)  # out + SiLU(BN(conv(...))) fused in the last block

@@ -373,6 +373,241 @@ extern "C" int cn_bn_act_bwd_f32(const float* x, long xbs, const float* dy, long
 }
 
 // ---------------------------------------------------------------------------
+// Grouped BatchNorm (+ SiLU): G (<= 4) BatchNorm layers over G same-shaped tensors in one launch pair -- the
+// dilation branches of ResidualAConv (convolution.py:376-395). sum_outputs != 0 fuses the ResUNet-a sum
+//   y = res + sum_g act(bn_g(x_g))
+// into the one normalisation pass (the sequential form re-reads and re-writes the running sum once per branch).
+// ---------------------------------------------------------------------------
+#define BN_MAX_GROUPS 4
+struct CnBnGroupArgs {
+  const float* x[BN_MAX_GROUPS];
+  const float* gamma[BN_MAX_GROUPS];
+  const float* beta[BN_MAX_GROUPS];
+  float* mean[BN_MAX_GROUPS];
+  float* rstd[BN_MAX_GROUPS];
+  float* running_mean[BN_MAX_GROUPS];
+  float* running_var[BN_MAX_GROUPS];
+  float* y[BN_MAX_GROUPS];         // forward outputs (sum mode: y[0] only)
+  const float* dy[BN_MAX_GROUPS];  // backward: output gradients (sum mode: all the same pointer)
+  float* dx[BN_MAX_GROUPS];
+  float* dgamma[BN_MAX_GROUPS];
+  float* dbeta[BN_MAX_GROUPS];
+  int accumulate_dx[BN_MAX_GROUPS];
+  long xbs, ybs, dybs, dxbs, rbs;
+  const float* res;
+  int G, B, C, L, act, splits, training, sum_outputs, accumulate_params;
+  float eps, momentum;
+  double* part;  // [G][C][splits][2]
+};
+
+__global__ __launch_bounds__(256) void cn_bn_group_partial_kernel(const CnBnGroupArgs a) {
+  __shared__ double scratch[4];
+  const int c = blockIdx.x, sp = blockIdx.y, g = blockIdx.z;
+  const int per = (a.L + a.splits - 1) / a.splits;
+  const int beg = sp * per;
+  const int end = (beg + per < a.L) ? beg + per : a.L;
+  double s = 0.0, ss = 0.0;
+  for (int b = 0; b < a.B; ++b) {
+    const float* xp = a.x[g] + b * a.xbs + (long)c * a.L;
+    for (int l = beg + threadIdx.x; l < end; l += 256) {
+      const float v = xp[l];
+      s += v;
+      ss += (double)v * v;
+    }
+  }
+  s = cn_block_sum<double, 256>(s, scratch);
+  ss = cn_block_sum<double, 256>(ss, scratch);
+  if (threadIdx.x == 0) {
+    double* p = a.part + (((long)g * a.C + c) * a.splits + sp) * 2;
+    p[0] = s;
+    p[1] = ss;
+  }
+}
+
+// grid = (blocks over L, C, B)
+__global__ __launch_bounds__(256) void cn_bn_group_apply_kernel(const CnBnGroupArgs a) {
+  const int c = blockIdx.y, b = blockIdx.z;
+  float m[BN_MAX_GROUPS], sc[BN_MAX_GROUPS], be[BN_MAX_GROUPS];
+  const double count = (double)a.B * a.L;
+#pragma unroll
+  for (int g = 0; g < BN_MAX_GROUPS; ++g) {
+    m[g] = sc[g] = be[g] = 0.f;
+    if (g < a.G) {
+      float rs;
+      if (a.training) {
+        double s = 0.0, ss = 0.0;
+        const double* p = a.part + ((long)g * a.C + c) * a.splits * 2;
+        for (int i = 0; i < a.splits; ++i) {
+          s += p[2 * i];
+          ss += p[2 * i + 1];
+        }
+        const double md = s / count;
+        double var = ss / count - md * md;
+        if (var < 0.0) var = 0.0;
+        m[g] = (float)md;
+        rs = (float)(1.0 / sqrt(var + (double)a.eps));
+        if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+          a.mean[g][c] = m[g];
+          a.rstd[g][c] = rs;
+          if (a.running_mean[g] != nullptr) {
+            const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+            a.running_mean[g][c] = (1.f - a.momentum) * a.running_mean[g][c] + a.momentum * m[g];
+            a.running_var[g][c] = (1.f - a.momentum) * a.running_var[g][c] + a.momentum * (float)unbiased;
+          }
+        }
+      } else {
+        m[g] = a.running_mean[g][c];
+        rs = 1.0f / sqrtf(a.running_var[g][c] + a.eps);
+        if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
+          a.mean[g][c] = m[g];
+          a.rstd[g][c] = rs;
+        }
+      }
+      sc[g] = a.gamma[g][c] * rs;
+      be[g] = a.beta[g][c];
+    }
+  }
+  const long r0 = (long)c * a.L;
+  const float* rp = a.res ? a.res + b * a.rbs + r0 : nullptr;
+  for (int l = blockIdx.x * 256 + threadIdx.x; l < a.L; l += gridDim.x * 256) {
+    float acc = rp ? rp[l] : 0.f;
+#pragma unroll
+    for (int g = 0; g < BN_MAX_GROUPS; ++g) {
+      if (g < a.G) {
+        float z = (a.x[g][b * a.xbs + r0 + l] - m[g]) * sc[g] + be[g];
+        if (a.act == 1) z = cn_silu(z);
+        if (a.sum_outputs) acc += z;  // res + f_0 + f_1 + ...: the order of the sequential form
+        else a.y[g][b * a.ybs + r0 + l] = z;
+      }
+    }
+    if (a.sum_outputs) a.y[0][b * a.ybs + r0 + l] = acc;
+  }
+}
+
+__global__ __launch_bounds__(256) void cn_bn_group_bwd_partial_kernel(const CnBnGroupArgs a) {
+  __shared__ double scratch[4];
+  const int c = blockIdx.x, sp = blockIdx.y, g = blockIdx.z;
+  const int per = (a.L + a.splits - 1) / a.splits;
+  const int beg = sp * per;
+  const int end = (beg + per < a.L) ? beg + per : a.L;
+  const float m = a.mean[g][c], rs = a.rstd[g][c], ga = a.gamma[g][c], be = a.beta[g][c];
+  double s1 = 0.0, s2 = 0.0;
+  for (int b = 0; b < a.B; ++b) {
+    const float* xp = a.x[g] + b * a.xbs + (long)c * a.L;
+    const float* dp = a.dy[g] + b * a.dybs + (long)c * a.L;
+    for (int l = beg + threadIdx.x; l < end; l += 256) {
+      const float xh = (xp[l] - m) * rs;
+      float dz = dp[l];
+      if (a.act == 1) dz *= cn_silu_grad(ga * xh + be);
+      s1 += dz;
+      s2 += (double)dz * xh;
+    }
+  }
+  s1 = cn_block_sum<double, 256>(s1, scratch);
+  s2 = cn_block_sum<double, 256>(s2, scratch);
+  if (threadIdx.x == 0) {
+    double* p = a.part + (((long)g * a.C + c) * a.splits + sp) * 2;
+    p[0] = s1;
+    p[1] = s2;
+  }
+}
+
+// grid = (blocks over L x G, C, B)
+__global__ __launch_bounds__(256) void cn_bn_group_bwd_apply_kernel(const CnBnGroupArgs a, int bx_per_group) {
+  const int g = blockIdx.x / bx_per_group, bx = blockIdx.x - g * bx_per_group;
+  const int c = blockIdx.y, b = blockIdx.z;
+  double s1 = 0.0, s2 = 0.0;
+  const double* p = a.part + ((long)g * a.C + c) * a.splits * 2;
+  for (int i = 0; i < a.splits; ++i) {
+    s1 += p[2 * i];
+    s2 += p[2 * i + 1];
+  }
+  if (bx == 0 && b == 0 && threadIdx.x == 0) {
+    if (a.accumulate_params) {
+      a.dgamma[g][c] += (float)s2;
+      a.dbeta[g][c] += (float)s1;
+    } else {
+      a.dgamma[g][c] = (float)s2;
+      a.dbeta[g][c] = (float)s1;
+    }
+  }
+  if (a.dx[g] == nullptr) return;
+  const double count = (double)a.B * a.L;
+  const float m = a.mean[g][c], rs = a.rstd[g][c], ga = a.gamma[g][c], be = a.beta[g][c];
+  const float c1 = a.training ? (float)(s1 / count) : 0.f, c2 = a.training ? (float)(s2 / count) : 0.f;
+  const long r0 = (long)c * a.L;
+  const float* xp = a.x[g] + b * a.xbs + r0;
+  const float* dp = a.dy[g] + b * a.dybs + r0;
+  float* dxp = a.dx[g] + b * a.dxbs + r0;
+  const int acc = a.accumulate_dx[g];
+  for (int l = bx * 256 + threadIdx.x; l < a.L; l += bx_per_group * 256) {
+    const float xh = (xp[l] - m) * rs;
+    float dz = dp[l];
+    if (a.act == 1) dz *= cn_silu_grad(ga * xh + be);
+    float gr = (dz - c1 - xh * c2) * (ga * rs);
+    if (acc) gr += dxp[l];
+    dxp[l] = gr;
+  }
+}
+
+// Host arrays of G device pointers; ws: G * cn_bn_workspace_doubles(C) doubles.
+// sum_outputs == 0: ys[g] = act(bn_g(xs[g])) (res must be NULL); != 0: ys[0] = res + sum_g act(bn_g(xs[g])).
+extern "C" int cn_bn_act_group_fwd_f32(int G, const float* const* xs, long xbs, const float* const* gammas,
+                                       const float* const* betas, float* const* running_means,
+                                       float* const* running_vars, const float* res, long rbs, float* const* ys,
+                                       long ybs, float* const* means, float* const* rstds, double* ws, int B, int C,
+                                       int L, int training, float momentum, float eps, int act, int sum_outputs,
+                                       void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (G < 1 || G > BN_MAX_GROUPS || (!sum_outputs && res != nullptr)) return CN_ERR_ARG;
+  if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
+  CnBnGroupArgs a = {};
+  for (int g = 0; g < G; ++g) {
+    a.x[g] = xs[g]; a.gamma[g] = gammas[g]; a.beta[g] = betas[g];
+    a.running_mean[g] = running_means ? running_means[g] : nullptr;
+    a.running_var[g] = running_vars ? running_vars[g] : nullptr;
+    if (!training && (a.running_mean[g] == nullptr || a.running_var[g] == nullptr)) return CN_ERR_ARG;
+    a.mean[g] = means[g]; a.rstd[g] = rstds[g];
+    a.y[g] = sum_outputs ? ys[0] : ys[g];
+  }
+  a.xbs = xbs; a.ybs = ybs; a.rbs = rbs; a.res = res;
+  a.G = G; a.B = B; a.C = C; a.L = L; a.act = act; a.training = training; a.sum_outputs = sum_outputs;
+  a.eps = eps; a.momentum = momentum; a.part = ws;
+  a.splits = bn_splits(C * G, L);
+  if (training)
+    hipLaunchKernelGGL(cn_bn_group_partial_kernel, dim3(C, a.splits, G), dim3(256), 0, stream, a);
+  hipLaunchKernelGGL(cn_bn_group_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, a);
+  return cn_check_launch();
+}
+
+// dys: per-group output gradients (the same pointer G times after a summed forward). dxs[g] may be NULL.
+extern "C" int cn_bn_act_group_bwd_f32(int G, const float* const* xs, long xbs, const float* const* dys, long dybs,
+                                       const float* const* means, const float* const* rstds,
+                                       const float* const* gammas, const float* const* betas, float* const* dxs,
+                                       long dxbs, const int* accumulate_dx, float* const* dgammas,
+                                       float* const* dbetas, double* ws, int B, int C, int L, int training, int act,
+                                       int accumulate_params, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (G < 1 || G > BN_MAX_GROUPS) return CN_ERR_ARG;
+  if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
+  CnBnGroupArgs a = {};
+  for (int g = 0; g < G; ++g) {
+    a.x[g] = xs[g]; a.dy[g] = dys[g]; a.gamma[g] = gammas[g]; a.beta[g] = betas[g];
+    a.mean[g] = const_cast<float*>(means[g]); a.rstd[g] = const_cast<float*>(rstds[g]);
+    a.dx[g] = dxs ? dxs[g] : nullptr; a.dgamma[g] = dgammas[g]; a.dbeta[g] = dbetas[g];
+    a.accumulate_dx[g] = accumulate_dx ? accumulate_dx[g] : 0;
+  }
+  a.xbs = xbs; a.dybs = dybs; a.dxbs = dxbs;
+  a.G = G; a.B = B; a.C = C; a.L = L; a.act = act; a.training = training; a.accumulate_params = accumulate_params;
+  a.part = ws;
+  a.splits = bn_splits(C * G, L);
+  hipLaunchKernelGGL(cn_bn_group_bwd_partial_kernel, dim3(C, a.splits, G), dim3(256), 0, stream, a);
+  const dim3 pg = plane_grid(B, C, L);
+  hipLaunchKernelGGL(cn_bn_group_bwd_apply_kernel, dim3(pg.x * G, pg.y, pg.z), dim3(256), 0, stream, a, (int)pg.x);
+  return cn_check_launch();
+}
+
+// ---------------------------------------------------------------------------
 // Per-channel sum over [B][C][L] (bias gradients): out[c] (+)= sum x[b,c,l]
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cn_channel_sum_kernel(const float* __restrict__ x, long xbs, int B, int C,

@@ -639,6 +639,79 @@ def bn_act(x: Var, bn, act: int, residual: T.Optional[Var] = None, channels: T.O
     return yv
 
 
+def bn_act_group(xs: T.Sequence[Var], bns: T.Sequence, act: int, residual: T.Optional[Var] = None,
+                 sum_outputs: bool = False, training: bool = True) -> T.Union[Var, T.List[Var]]:
+    """G BatchNorm2d(+act) over G same-shaped tensors in one launch pair. ``sum_outputs``: returns the single Var
+    ``residual + sum_g act(bn_g(x_g))`` (the ResUNet-a sum, accumulated in the order of the sequential form);
+    otherwise the list of G activations."""
+    import ctypes
+
+    tape = current_tape()
+    G = len(xs)
+    xts = [_check(x.t) for x in xs]
+    B, C = xts[0].shape[0], xts[0].shape[1]
+    L = int(xts[0][0].numel()) // C
+    for t in xts:
+        if tuple(t.shape) != tuple(xts[0].shape) or bstride(t) != bstride(xts[0]):
+            raise ValueError("bn_act_group: inputs must have the same shape and strides")
+    if residual is not None and not sum_outputs:
+        raise ValueError("bn_act_group: a residual needs sum_outputs=True")
+    dev = xts[0].device
+    use_batch = training or any(bn.running_mean is None for bn in bns)
+    tab = lambda ptrs: (ctypes.c_void_p * G)(*ptrs)
+    ys = [_new(xts[0].shape, xts[0])] if sum_outputs else [_new(xts[0].shape, xts[0]) for _ in range(G)]
+    means = [_new((C,), xts[0]) for _ in range(G)]
+    rstds = [_new((C,), xts[0]) for _ in range(G)]
+    ws = torch.empty(G * _lib.query("cn_bn_workspace_doubles", C), dtype=torch.float64, device=dev)
+    rt = residual.t if residual is not None else None
+    mom = bns[0].momentum if bns[0].momentum is not None else 0.1
+    has_running = all(bn.running_mean is not None for bn in bns)
+    _lib.call("cn_bn_act_group_fwd_f32", G, tab([t.data_ptr() for t in xts]), bstride(xts[0]),
+              tab([bn.weight.data_ptr() for bn in bns]), tab([bn.bias.data_ptr() for bn in bns]),
+              tab([bn.running_mean.data_ptr() for bn in bns]) if has_running else None,
+              tab([bn.running_var.data_ptr() for bn in bns]) if has_running else None,
+              rt.data_ptr() if rt is not None else None, bstride(rt) if rt is not None else 0,
+              (ctypes.c_void_p * len(ys))(*[y.data_ptr() for y in ys]) if not sum_outputs else tab([ys[0].data_ptr()] * G),
+              bstride(ys[0]), tab([m.data_ptr() for m in means]), tab([r.data_ptr() for r in rstds]), ws.data_ptr(),
+              B, C, L, 1 if use_batch else 0, float(mom), float(bns[0].eps), act, 1 if sum_outputs else 0, _stream())
+    yvs = [Var(y, tape.enabled) for y in ys]
+    if tape.enabled:
+        store = current_store()
+
+        def bwd():
+            s = _stream()
+            if sum_outputs:
+                dy = yvs[0].grad
+                if dy is None:
+                    return
+                if residual is not None:
+                    give_grad(residual, dy)
+                dys = [dy] * G
+            else:
+                dys = [v.grad for v in yvs]
+                if any(d is None for d in dys):
+                    raise RuntimeError("bn_act_group: every output needs a gradient")
+            bufs = [grad_buffer(x) if x.req else (None, 0) for x in xs]
+            dxbs = {bstride(d) for d, _ in bufs if d is not None}
+            dybs = {bstride(d) for d in dys}
+            if len(dxbs) > 1 or len(dybs) > 1:
+                raise RuntimeError("bn_act_group: gradient buffers must share their strides")
+            _lib.call("cn_bn_act_group_bwd_f32", G, tab([t.data_ptr() for t in xts]), bstride(xts[0]),
+                      tab([d.data_ptr() for d in dys]), dybs.pop(), tab([m.data_ptr() for m in means]),
+                      tab([r.data_ptr() for r in rstds]), tab([bn.weight.data_ptr() for bn in bns]),
+                      tab([bn.bias.data_ptr() for bn in bns]),
+                      tab([d.data_ptr() if d is not None else None for d, _ in bufs]), dxbs.pop() if dxbs else 0,
+                      (ctypes.c_int * G)(*[a for _, a in bufs]),
+                      tab([store.grad_of(bn.weight).data_ptr() for bn in bns]),
+                      tab([store.grad_of(bn.bias).data_ptr() for bn in bns]), ws.data_ptr(), B, C, L,
+                      1 if use_batch else 0, act, 1, s)
+            for v in yvs:
+                v.grad = None
+
+        tape.add(bwd, tuple(bn.weight for bn in bns) + tuple(bn.bias for bn in bns))
+    return yvs[0] if sum_outputs else yvs
+
+
 def layer_norm_c(x: Var, ln, residual: T.Optional[Var] = None) -> Var:
     """nn.LayerNorm over the channel axis of an NCHW buffer (+ residual)."""
     tape = current_tape()

@@ -133,6 +133,23 @@ int cn_bn_act_bwd_f32(const float* x, long xbs, const float* dy, long dybs, cons
                       float* dbeta, float* coef, double* ws, int B, int C, int L, int training, int act,
                       int accumulate_dx, int accumulate_params, void* stream);
 
+/* Grouped BatchNorm(+SiLU): G (<= 4) BatchNorm layers over G same-shaped tensors in one launch pair (the dilation
+ * branches of ResidualAConv, convolution.py:376-395). All pointer arguments ending in `s` are HOST arrays of G device
+ * pointers. sum_outputs == 0: ys[g] = act(bn_g(xs[g])), res must be NULL. sum_outputs != 0: the ResUNet-a sum
+ * ys[0] = res + sum_g act(bn_g(xs[g])) fused into the normalisation pass. ws: G * cn_bn_workspace_doubles(C) doubles.
+ * Backward: dys[g] = gradient of output g (the same pointer G times after a summed forward; the residual's gradient
+ * is that tensor itself); dxs[g] nullable; accumulate_dx: HOST array of G flags. */
+int cn_bn_act_group_fwd_f32(int G, const float* const* xs, long xbs, const float* const* gammas,
+                            const float* const* betas, float* const* running_means, float* const* running_vars,
+                            const float* res /*nullable*/, long rbs, float* const* ys, long ybs, float* const* means,
+                            float* const* rstds, double* ws, int B, int C, int L, int training, float momentum,
+                            float eps, int act, int sum_outputs, void* stream);
+int cn_bn_act_group_bwd_f32(int G, const float* const* xs, long xbs, const float* const* dys, long dybs,
+                            const float* const* means, const float* const* rstds, const float* const* gammas,
+                            const float* const* betas, float* const* dxs, long dxbs, const int* accumulate_dx,
+                            float* const* dgammas, float* const* dbetas, double* ws, int B, int C, int L,
+                            int training, int act, int accumulate_params, void* stream);
+
 /* ---- nn.LayerNorm over channels, tensors kept NCHW (nunet.py:93-97, convolution.py:338-353) --
  * mu/rstd: [B][L] saved statistics. dw/db are ACCUMULATED: zero first. ws: cn_layernorm_c_workspace_floats(B,C,L)
  * floats of scratch for the per-block partial parameter gradients (0 => not needed). */

@@ -693,3 +693,54 @@ def test_conv2d_splitk_without_workspace_uses_atomics():
         _close(xv.grad, xr.grad, 1e-4, "dx")
     finally:
         E._conv_ws.clear()  # the next forward binds the workspace again
+
+
+@pytest.mark.parametrize("G,shape,summed,train", [(2, (2, 16, 20, 20), False, True), (2, (2, 16, 20, 20), True, True),
+                                                   (3, (1, 40, 13, 13), True, True), (2, (2, 8, 28, 28), True, False),
+                                                   (4, (2, 32, 25, 25), False, True)])
+def test_bn_act_group(G, shape, summed, train):
+    """cn_bn_act_group_*: G BatchNorm+SiLU in one launch pair, separately or as res + sum_g f_g(x_g)."""
+    import copy
+    from cultionet_amd import engine as E
+
+    C = shape[1]
+    torch.manual_seed(50)
+    bns = nn.ModuleList([nn.BatchNorm2d(C) for _ in range(G)])
+    with torch.no_grad():
+        for i, bn in enumerate(bns):
+            bn.weight.copy_(1 + 0.1 * _rand(C, seed=60 + i))
+            bn.bias.copy_(0.1 * _rand(C, seed=70 + i))
+            bn.running_mean.copy_(0.1 * _rand(C, seed=80 + i))
+            bn.running_var.copy_(torch.rand(C, generator=torch.Generator().manual_seed(90 + i)) + 0.5)
+    bns.train(train)
+    ref = copy.deepcopy(bns)
+    xs = [_rand(*shape, seed=100 + i) * 1.5 + 0.2 for i in range(G)]
+    r = _rand(*shape, seed=120)
+    xrs = [x.clone().requires_grad_(True) for x in xs]
+    rr = r.clone().requires_grad_(True)
+    fs = [F.silu(bn(x)) for bn, x in zip(ref, xrs)]
+    if summed:
+        yr = rr
+        for f in fs:
+            yr = yr + f
+    else:
+        yr = torch.cat(fs, dim=1)
+    dy = _rand(*yr.shape, seed=121)
+    yr.backward(dy)
+
+    def fn(*vs):
+        if summed:
+            return E.bn_act_group(list(vs[:G]), list(bns), E.ACT_SILU, residual=vs[G], sum_outputs=True, training=train)
+        outs = E.bn_act_group(list(vs[:G]), list(bns), E.ACT_SILU, training=train)
+        return E.cat_channels(outs)
+
+    y, grads, pg = _engine_run(bns, fn, xs + [r], dy)
+    _close(y, yr, 2e-5, "y")
+    for i in range(G):
+        _close(grads[i], xrs[i].grad, 1e-4, f"dx{i}")
+        _close(pg[f"{i}.weight"], ref[i].weight.grad, 1e-4, f"dgamma{i}")
+        _close(pg[f"{i}.bias"], ref[i].bias.grad, 1e-4, f"dbeta{i}")
+        if train:
+            _close(bns[i].running_var.cpu(), ref[i].running_var, 1e-5, f"running_var{i}")
+    if summed:
+        _close(grads[G], rr.grad, 1e-6, "dres")
