@@ -89,6 +89,34 @@ def cpu_baseline(batch: int, hidden: int, steps: int, threads: int = 0):
     }
 
 
+# rocprof kernel-name prefixes behind each profiled kind (template instantiations of one kernel family)
+KIND_PATTERNS = {
+    0: ("cn_conv_igemm_vec_kernel<4, 1,", "cn_conv_igemm_vec_kernel<2, 2,", "cn_conv_igemm_kernel<2, 2,"),
+    1: ("cn_conv_igemm_vec_kernel<1,", "cn_conv_igemm_kernel<1,"),
+    2: ("cn_wgrad_vec_kernel<9,", "cn_wgrad_kernel<9>"),
+    3: ("cn_wgrad_vec_kernel<1,", "cn_wgrad_kernel<1>"),
+}
+
+
+def pmc_traffic(prefixes):
+    """HBM-side bytes per launch of a kernel family, from the committed PMC passes of THIS command
+    (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate rocprofv3 --pmc runs,
+    tools/pmc_traffic.py). PMC counters cannot be collected from inside the timed run, so the figure is read
+    from that file; None if it is absent."""
+    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    try:
+        with open(path) as f:
+            kernels = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    tot, n = 0.0, 0
+    for name, v in kernels.items():
+        if name.startswith(prefixes):
+            tot += v["hbm_bytes_per_launch"] * v["launches"]
+            n += v["launches"]
+    return tot / n if n else None
+
+
 def main():
     args = parse()
     import torch
@@ -188,7 +216,7 @@ def main():
                 "peak": PEAK_F32_MFMA_TFLOPS,
                 "unit": "TFLOP/s",
                 "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                "traffic": None,
+                "traffic": pmc_traffic(KIND_PATTERNS[dom]),
                 "avg_launch_us": ms * 1e3 / launches if launches else None,
                 "launches_per_step": launches / args.steps,
                 "share_of_step_time": ms * 1e-3 / dt,

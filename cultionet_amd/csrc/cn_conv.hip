@@ -553,8 +553,8 @@ static int cn_launch_igemm_v(const float* x, const float* wp, const float* bias,
                total_tiles, (g.Cout + NT - 1) / NT, splits);
   cn_prof_before(stream);
   hipLaunchKernelGGL((cn_conv_igemm_vec_kernel<WAVES_N, TN, TM, NV, RP>), grid, dim3(256), lds, stream, g);
+  cn_prof_after(stream, NT == 128 ? 0 : 1, flops);  // the contraction kernel alone (matches rocprof's per-kernel rows)
   const int rrc = cn_reduce_slices(g, stream);
-  cn_prof_after(stream, NT == 128 ? 0 : 1, flops);
   return rrc != CN_OK ? rrc : cn_check_launch();
 }
 
@@ -580,8 +580,8 @@ static int cn_launch_igemm_t(const float* x, const float* wp, const float* bias,
                (g.Cout + NT - 1) / NT, splits);
   cn_prof_before(stream);
   hipLaunchKernelGGL((cn_conv_igemm_kernel<WAVES_N, TN, NI_T>), grid, dim3(256), lds, stream, g);
+  cn_prof_after(stream, NT == 128 ? 0 : 1, flops);  // the contraction kernel alone (matches rocprof's per-kernel rows)
   const int rrc = cn_reduce_slices(g, stream);
-  cn_prof_after(stream, NT == 128 ? 0 : 1, flops);
   return rrc != CN_OK ? rrc : cn_check_launch();
 }
 

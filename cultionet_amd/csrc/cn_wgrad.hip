@@ -512,11 +512,11 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
     hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 1>), grid, dim3(256), lds, stream, S, Bg, out, g);
   else
     hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 2>), grid, dim3(256), lds, stream, S, Bg, out, g);
+  cn_prof_after(stream, T == 9 ? 2 : 3, g.flops);  // the contraction kernel alone
   if (g.slice_stride != 0)
     hipLaunchKernelGGL(cn_wgrad_reduce_kernel, dim3((unsigned)((dw_floats + 255) / 256), nslices > 128 ? 16 : 1),
                        dim3(256), 0, stream, ws,
                        g.slice_stride, (int)nslices, dw_floats, dW);
-  cn_prof_after(stream, T == 9 ? 2 : 3, g.flops);
   return cn_check_launch();
 }
 
