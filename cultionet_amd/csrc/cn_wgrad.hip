@@ -40,6 +40,10 @@ struct CnWgradGeom {
   int buf_stride;  // floats per LDS buffer
   int nbuf;        // 2: double-buffered LDS-DMA pipeline, 1: single buffer
   int colsplit;    // unused
+  int G, spg;                    // groups (same shapes, own tensors): logical z = group * spg + split
+  const float* gS[4];
+  const float* gB[4];
+  float* gdW[4];
   long slice_stride;  // != 0: every (split, k-part) stores its partial dW into its own slice of a workspace
   int grid_x, grid_y, grid_z;  // logical grid (Bc tiles, A tiles, splits); launched 1-D in XCD-aware order
   int mq_lo, mq_hi;  // 16-byte variant: pixel pairs [0,mq_lo) and [mq_hi, Ws/2) of a row need column masks
@@ -219,8 +223,8 @@ __device__ __forceinline__ void cn_glds16(const float* src, float* lds_wave_base
 // One DMA wave-instruction moves 1 KiB instead of 256 B: the per-CU DMA issue rate (~1 per 100 cycles)
 // is what bounded the dword version.
 template <int T, int S_>
-__global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restrict__ S, const float* __restrict__ Bg,
-                                                          float* __restrict__ dW, const CnWgradGeom g) {
+__global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restrict__ S0, const float* __restrict__ Bg0,
+                                                          float* __restrict__ dW0, const CnWgradGeom g) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -228,6 +232,11 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
   const int at = wid % g.a_tiles, kp = wid / g.a_tiles, kparts = 4 / g.a_tiles;
   int bx, by, bz;
   if (!cn_xcd_block(g.grid_x, g.grid_y, g.grid_x * g.grid_y * g.grid_z, bx, by, bz)) return;
+  const int grp = g.G > 1 ? bz / g.spg : 0;
+  const int split = bz - grp * g.spg;
+  const float* __restrict__ S = g.G > 1 ? g.gS[grp] : S0;
+  const float* __restrict__ Bg = g.G > 1 ? g.gB[grp] : Bg0;
+  float* __restrict__ dW = (g.G > 1 && g.slice_stride == 0) ? g.gdW[grp] : dW0;
   const int a0 = by * g.a_tiles * 32;
   const int b0 = bx * WG_BC;
   const int npix = g.PR * g.Ws;   // unpadded, even, multiple of 4
@@ -253,7 +262,7 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
     for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
 
   const int arows = g.a_tiles * 32;
-  int chunk = bz * g.chunks_per_split;
+  int chunk = split * g.chunks_per_split;
   int chunk_end = chunk + g.chunks_per_split;
   if (chunk_end > g.total_chunks) chunk_end = g.total_chunks;
 
@@ -408,28 +417,32 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
   }
 }
 
-// dW[i] += sum_s part[s][i]; grid = (ceil(n / 256), 1 or 16): with 16 slice groups, 16-way atomics per address
-__global__ __launch_bounds__(256) void cn_wgrad_reduce_kernel(const float* __restrict__ part, long slice_stride,
-                                                             int nslices, long n, float* __restrict__ dW) {
+// dW_g[i] += sum_s part[g * nslices + s][i]; grid = (ceil(n / 256), 1 or 16, groups): with 16 slice groups,
+// 16-way atomics per address
+struct CnWgradReduceArgs {
+  const float* part; long slice_stride; int nslices; long n;
+  float* dW[4];
+};
+__global__ __launch_bounds__(256) void cn_wgrad_reduce_kernel(const CnWgradReduceArgs a) {
   const long i = blockIdx.x * 256L + threadIdx.x;
-  if (i >= n) return;
+  if (i >= a.n) return;
+  const float* part = a.part + (long)blockIdx.z * a.nslices * a.slice_stride;
+  float* dW = a.dW[blockIdx.z];
   float s0 = 0.f, s1 = 0.f;
   int k = blockIdx.y;
-  for (; k + (int)gridDim.y < nslices; k += 2 * gridDim.y) {
-    s0 += part[(long)k * slice_stride + i];
-    s1 += part[(long)(k + gridDim.y) * slice_stride + i];
+  for (; k + (int)gridDim.y < a.nslices; k += 2 * gridDim.y) {
+    s0 += part[(long)k * a.slice_stride + i];
+    s1 += part[(long)(k + gridDim.y) * a.slice_stride + i];
   }
-  if (k < nslices) s0 += part[(long)k * slice_stride + i];
+  if (k < a.nslices) s0 += part[(long)k * a.slice_stride + i];
   if (gridDim.y == 1) dW[i] += s0 + s1;
   else atomicAdd(dW + i, s0 + s1);
 }
 
-// Launch of the 16-byte variant; returns CN_ERR_ARG when its alignment preconditions do not hold.
 template <int T>
 static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgradGeom g, float* ws, long ws_floats,
                                hipStream_t stream) {
   if (g.scs % 4 || g.bcs % 4 || g.sbs % 4 || g.bbs % 4 || (g.Ws & 1)) return CN_ERR_ARG;
-  if ((reinterpret_cast<uintptr_t>(S) & 15) || (reinterpret_cast<uintptr_t>(Bg) & 15)) return CN_ERR_ARG;
   g.Wsp = g.Ws;
   g.PR = 128 / g.Ws;
   if (g.PR < 1) g.PR = 1;
@@ -465,8 +478,14 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
   g.chunks_per_img = (g.Hs + g.PR - 1) / g.PR;
   g.total_chunks = g.N * g.chunks_per_img;
   const int gx = (g.Bc + WG_BC - 1) / WG_BC, gy = (g.A + g.a_tiles * 32 - 1) / (g.a_tiles * 32);
+  if (g.G < 1) {  // single set given through the arguments
+    g.G = 1;
+    g.gS[0] = S; g.gB[0] = Bg; g.gdW[0] = dW;
+  }
+  for (int i = 0; i < g.G; ++i)
+    if ((reinterpret_cast<uintptr_t>(g.gS[i]) & 15) || (reinterpret_cast<uintptr_t>(g.gB[i]) & 15)) return CN_ERR_ARG;
   const int slots = (lds * 2 <= 160 * 1024) ? 512 : 256;  // resident blocks on the chip
-  int splits = slots / (gx * gy);                         // never spill into a second, mostly idle round
+  int splits = slots / (gx * gy * g.G);                   // never spill into a second, mostly idle round
   if (splits > g.total_chunks) splits = g.total_chunks;
   if (splits < 1) splits = 1;
   g.chunks_per_split = (g.total_chunks + splits - 1) / splits;
@@ -493,30 +512,33 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
     g.mq_lo = lo;
     g.mq_hi = hi;
   }
-  cn_prof_desc("wgrad_vec<%d> N%d A%d %dx%d Bc%d %dx%d s%d grid%dx%dx%d nbuf%d", T, g.N, g.A, g.Hs, g.Ws, g.Bc, g.Hb, g.Wb,
-               g.s, gx, gy, splits, g.nbuf);
-  g.grid_x = gx; g.grid_y = gy; g.grid_z = splits;
-  const dim3 grid(cn_xcd_grid((long)gx * gy * splits));
-  // partial-slice mode: >= 32 adds per dW address and a small dW (slices fit the caller's workspace)
+  cn_prof_desc("wgrad_vec<%d> G%d N%d A%d %dx%d Bc%d %dx%d s%d grid%dx%dx%d nbuf%d", T, g.G, g.N, g.A, g.Hs, g.Ws, g.Bc,
+               g.Hb, g.Wb, g.s, gx, gy, splits, g.nbuf);
+  g.spg = splits;
+  g.grid_x = gx; g.grid_y = gy; g.grid_z = splits * g.G;
+  const dim3 grid(cn_xcd_grid((long)gx * gy * splits * g.G));
+  // partial-slice mode: >= 32 adds per dW address (slices must fit the caller's workspace)
   const int kparts = 4 / g.a_tiles;
   const long dw_floats = (long)g.A * g.sa;
-  const long nslices = (long)splits * kparts;
-  float* out = dW;
+  const long nslices = (long)splits * kparts;  // per group
+  float* out = g.gdW[0];
   g.slice_stride = 0;
-  if (nslices >= 32 && ws != nullptr && nslices * dw_floats <= ws_floats) {
+  if (nslices >= 32 && ws != nullptr && nslices * g.G * dw_floats <= ws_floats) {
     g.slice_stride = dw_floats;
     out = ws;
   }
   cn_prof_before(stream);
   if (g.s == 1)
-    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 1>), grid, dim3(256), lds, stream, S, Bg, out, g);
+    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 1>), grid, dim3(256), lds, stream, g.gS[0], g.gB[0], out, g);
   else
-    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 2>), grid, dim3(256), lds, stream, S, Bg, out, g);
-  cn_prof_after(stream, T == 9 ? 2 : 3, g.flops);  // the contraction kernel alone
-  if (g.slice_stride != 0)
-    hipLaunchKernelGGL(cn_wgrad_reduce_kernel, dim3((unsigned)((dw_floats + 255) / 256), nslices > 128 ? 16 : 1),
-                       dim3(256), 0, stream, ws,
-                       g.slice_stride, (int)nslices, dw_floats, dW);
+    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 2>), grid, dim3(256), lds, stream, g.gS[0], g.gB[0], out, g);
+  cn_prof_after(stream, T == 9 ? 2 : 3, g.flops * g.G);  // the contraction kernel alone
+  if (g.slice_stride != 0) {
+    CnWgradReduceArgs ra = {ws, g.slice_stride, (int)nslices, dw_floats, {g.gdW[0], g.gdW[1], g.gdW[2], g.gdW[3]}};
+    hipLaunchKernelGGL(cn_wgrad_reduce_kernel,
+                       dim3((unsigned)((dw_floats + 255) / 256), nslices > 128 ? 16 : 1, g.G), dim3(256), 0, stream,
+                       ra);
+  }
   return cn_check_launch();
 }
 
@@ -583,32 +605,55 @@ static int cn_wgrad_launch_t(const float* S, const float* Bg, float* dW, CnWgrad
 
 // Repack [B][C][H][W] planes into [B][C][cs] with row pitch Wp >= W (zero columns) and a zero tail up to cs:
 // gives odd-sized tensors (25x25, 13x13, 99x99 ...) 16-byte aligned planes / even widths for the DMA variant.
-__global__ __launch_bounds__(256) void cn_pad_planes_kernel(const float* __restrict__ src, long sbs, long scs,
-                                                           float* __restrict__ dst, int C, int H, int W, int Wp,
-                                                           int cs) {
-  const int c = blockIdx.y, b = blockIdx.z;
-  const float* sp = src + b * sbs + (long)c * scs;
-  float* dp = dst + ((long)b * C + c) * cs;
-  for (int i = blockIdx.x * 256 + threadIdx.x; i < cs; i += gridDim.x * 256) {
-    const int r = i / Wp, col = i - r * Wp;
-    dp[i] = (r < H && col < W) ? sp[r * W + col] : 0.f;
+struct CnPadSet {
+  const float* src; long sbs; long scs;
+  float* dst; int C, H, W, Wp, cs;
+};
+#define CN_PAD_MAX_SETS 8
+struct CnPadArgs {
+  CnPadSet set[CN_PAD_MAX_SETS];
+  int cbegin[CN_PAD_MAX_SETS + 1];  // blockIdx.y ranges of the sets
+  int nsets;
+};
+
+// All operands of one (grouped) weight gradient in ONE launch: blockIdx.y walks the channels of the sets in turn.
+__global__ __launch_bounds__(256) void cn_pad_planes_kernel(const CnPadArgs a) {
+  int si = 0;
+#pragma unroll 1
+  for (int i = 1; i < a.nsets; ++i)
+    if ((int)blockIdx.y >= a.cbegin[i]) si = i;
+  const CnPadSet& p = a.set[si];
+  const int c = blockIdx.y - a.cbegin[si], b = blockIdx.z;
+  const float* sp = p.src + b * p.sbs + (long)c * p.scs;
+  float* dp = p.dst + ((long)b * p.C + c) * p.cs;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < p.cs; i += gridDim.x * 256) {
+    const int r = i / p.Wp, col = i - r * p.Wp;
+    dp[i] = (r < p.H && col < p.W) ? sp[r * p.W + col] : 0.f;
   }
 }
 
-static int cn_pad_planes(const float* src, long sbs, float* dst, int B, int C, int H, int W, int Wp, int cs,
-                         hipStream_t stream) {
+static int cn_pad_planes(CnPadArgs& a, int B, hipStream_t stream) {
+  if (a.nsets == 0) return CN_OK;
+  int cs = 0, ctot = 0;
+  for (int i = 0; i < a.nsets; ++i) {
+    a.cbegin[i] = ctot;
+    ctot += a.set[i].C;
+    if (a.set[i].cs > cs) cs = a.set[i].cs;
+  }
+  a.cbegin[a.nsets] = ctot;
   int bx = (cs + 1023) / 1024;
   if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(cn_pad_planes_kernel, dim3(bx, C, B), dim3(256), 0, stream, src, sbs, (long)H * W, dst, C, H, W,
-                     Wp, cs);
+  hipLaunchKernelGGL(cn_pad_planes_kernel, dim3(bx, ctot, B), dim3(256), 0, stream, a);
   return cn_check_launch();
 }
 
-// Generic entry: dW[a][b][t] += sum S[n,a,gy,gx] * Bg[n,b,gy*s+offy[t],gx*s+offx[t]]
-// ws (optional, ws_floats floats): scratch for aligned / even-width copies of odd-sized operands.
-static int cn_wgrad_generic(const float* S, long sbs, int A, int Hs, int Ws, const float* Bg, long bbs, int Bc,
-                            int Hb, int Wb, int s, int KH, int KW, int dil, int pad, float* dW, int N, float* ws,
-                            long ws_floats, hipStream_t stream) {
+// Generic entry: dW_g[a][b][t] += sum S_g[n,a,gy,gx] * Bg_g[n,b,gy*s+offy[t],gx*s+offx[t]] for G (<= 4) sets of
+// identical geometry in ONE launch (G == 1: the plain weight gradient).
+// ws (optional, ws_floats floats): scratch for aligned / even-width copies of odd-sized operands and partial slices.
+static int cn_wgrad_generic_g(int G, const float* const* Ss, long sbs, int A, int Hs, int Ws, const float* const* Bgs,
+                              long bbs, int Bc, int Hb, int Wb, int s, int KH, int KW, int dil, int pad,
+                              float* const* dWs, int N, float* ws, long ws_floats, hipStream_t stream) {
+  if (G < 1 || G > 4) return CN_ERR_ARG;
   CnWgradGeom g = {};
   g.N = N; g.A = A; g.Hs = Hs; g.Ws = Ws; g.sbs = sbs; g.Bc = Bc; g.Hb = Hb; g.Wb = Wb; g.bbs = bbs; g.s = s;
   g.scs = (long)Hs * Ws; g.bcs = (long)Hb * Wb;
@@ -623,45 +668,83 @@ static int cn_wgrad_generic(const float* S, long sbs, int A, int Hs, int Ws, con
   g.min_oy = -pad; g.min_ox = -pad;
   g.sa = (long)Bc * g.T;
   if (g.T != 1 && g.T != 9) return CN_ERR_ARG;
-  // 16-byte DMA variant when the alignment preconditions hold ...
+  g.G = G;
+  for (int i = 0; i < G; ++i) { g.gS[i] = Ss[i]; g.gB[i] = Bgs[i]; g.gdW[i] = dWs[i]; }
   const bool ws_ok = ws != nullptr && (reinterpret_cast<uintptr_t>(ws) & 15) == 0;
-  int rc = g.T == 1 ? cn_wgrad_launch_vec<1>(S, Bg, dW, g, ws_ok ? ws : nullptr, ws_floats, stream)
-                    : cn_wgrad_launch_vec<9>(S, Bg, dW, g, ws_ok ? ws : nullptr, ws_floats, stream);
+  // 16-byte DMA variant when the alignment preconditions hold ...
+  int rc = g.T == 1 ? cn_wgrad_launch_vec<1>(Ss[0], Bgs[0], dWs[0], g, ws_ok ? ws : nullptr, ws_floats, stream)
+                    : cn_wgrad_launch_vec<9>(Ss[0], Bgs[0], dWs[0], g, ws_ok ? ws : nullptr, ws_floats, stream);
   if (rc != CN_ERR_ARG) return rc;
-  // ... else through aligned copies in the caller's workspace (two streaming passes over small tensors) ...
-  if (ws != nullptr && (reinterpret_cast<uintptr_t>(ws) & 15) == 0) {
+  // ... else through aligned copies in the caller's workspace (one streaming pass over small tensors) ...
+  if (ws_ok) {
     const int Wsp = (Ws + 1) & ~1;
     const long scs = ((long)Hs * Wsp + 3) / 4 * 4, bcs = ((long)Hb * Wb + 3) / 4 * 4;
     const long need_s = (long)N * A * scs, need_b = (long)N * Bc * bcs;
-    const bool s_ok = (g.scs % 4 == 0) && (sbs % 4 == 0) && !(Ws & 1) && !(reinterpret_cast<uintptr_t>(S) & 15);
-    const bool b_ok = (g.bcs % 4 == 0) && (bbs % 4 == 0) && !(reinterpret_cast<uintptr_t>(Bg) & 15);
-    const long need = (s_ok ? 0 : need_s) + (b_ok ? 0 : need_b);
+    CnWgradGeom gp = g;
+    CnPadArgs pa = {};
+    float* w = ws;
+    long need = 0;
+    bool any_s = false, any_b = false;
+    for (int i = 0; i < G; ++i) {
+      const bool s_ok = (g.scs % 4 == 0) && (sbs % 4 == 0) && !(Ws & 1) && !(reinterpret_cast<uintptr_t>(Ss[i]) & 15);
+      const bool b_ok = (g.bcs % 4 == 0) && (bbs % 4 == 0) && !(reinterpret_cast<uintptr_t>(Bgs[i]) & 15);
+      any_s |= !s_ok;
+      any_b |= !b_ok;
+    }
+    // an operand class is copied for every group or for none (the launch has one stride set)
+    for (int i = 0; i < G && any_s; ++i) {
+      pa.set[pa.nsets++] = {Ss[i], sbs, (long)Hs * Ws, w, A, Hs, Ws, Wsp, (int)scs};
+      gp.gS[i] = w; w += need_s; need += need_s;
+    }
+    for (int i = 0; i < G && any_b; ++i) {
+      int same = -1;  // branches that share their input: one copy
+      for (int j = 0; j < i; ++j)
+        if (Bgs[j] == Bgs[i]) same = j;
+      if (same >= 0) { gp.gB[i] = gp.gB[same]; continue; }
+      pa.set[pa.nsets++] = {Bgs[i], bbs, (long)Hb * Wb, w, Bc, Hb, Wb, Wb, (int)bcs};
+      gp.gB[i] = w; w += need_b; need += need_b;
+    }
+    if (any_s) { gp.Ws = Wsp; gp.scs = scs; gp.sbs = (long)A * scs; }
+    if (any_b) { gp.bcs = bcs; gp.bbs = (long)Bc * bcs; }
     if (need <= ws_floats) {
-      CnWgradGeom gp = g;
-      const float* S2 = S;
-      const float* B2 = Bg;
-      float* w = ws;
-      if (!s_ok) {
-        const int r = cn_pad_planes(S, sbs, w, N, A, Hs, Ws, Wsp, (int)scs, stream);
-        if (r != CN_OK) return r;
-        S2 = w; w += need_s;
-        gp.Ws = Wsp; gp.scs = scs; gp.sbs = (long)A * scs;
-      }
-      if (!b_ok) {
-        const int r = cn_pad_planes(Bg, bbs, w, N, Bc, Hb, Wb, Wb, (int)bcs, stream);
-        if (r != CN_OK) return r;
-        B2 = w;
-        gp.bcs = bcs; gp.bbs = (long)Bc * bcs;
-      }
+      const int r = cn_pad_planes(pa, N, stream);
+      if (r != CN_OK) return r;
       float* wrest = ws + (need + 3) / 4 * 4;  // what the aligned copies left over serves the partial slices
       const long nrest = ws_floats - (need + 3) / 4 * 4;
-      rc = g.T == 1 ? cn_wgrad_launch_vec<1>(S2, B2, dW, gp, wrest, nrest, stream)
-                    : cn_wgrad_launch_vec<9>(S2, B2, dW, gp, wrest, nrest, stream);
+      rc = g.T == 1 ? cn_wgrad_launch_vec<1>(gp.gS[0], gp.gB[0], dWs[0], gp, wrest, nrest, stream)
+                    : cn_wgrad_launch_vec<9>(gp.gS[0], gp.gB[0], dWs[0], gp, wrest, nrest, stream);
       if (rc != CN_ERR_ARG) return rc;
     }
   }
-  // ... else the dword variant.
-  return g.T == 1 ? cn_wgrad_launch_t<1>(S, Bg, dW, g, stream) : cn_wgrad_launch_t<9>(S, Bg, dW, g, stream);
+  // ... else the dword variant, set by set.
+  for (int i = 0; i < G; ++i) {
+    CnWgradGeom g1 = g;
+    g1.G = 0;
+    rc = g.T == 1 ? cn_wgrad_launch_t<1>(Ss[i], Bgs[i], dWs[i], g1, stream)
+                  : cn_wgrad_launch_t<9>(Ss[i], Bgs[i], dWs[i], g1, stream);
+    if (rc != CN_OK) return rc;
+  }
+  return CN_OK;
+}
+
+static int cn_wgrad_generic(const float* S, long sbs, int A, int Hs, int Ws, const float* Bg, long bbs, int Bc,
+                            int Hb, int Wb, int s, int KH, int KW, int dil, int pad, float* dW, int N, float* ws,
+                            long ws_floats, hipStream_t stream) {
+  return cn_wgrad_generic_g(1, &S, sbs, A, Hs, Ws, &Bg, bbs, Bc, Hb, Wb, s, KH, KW, dil, pad, &dW, N, ws, ws_floats,
+                            stream);
+}
+
+// Grouped Conv2d weight gradient: G (<= 4) convolutions of identical geometry (same padding / dilation) in ONE launch
+// -- the dilation branches of ResidualAConv. xs / dys / dws: HOST arrays of G device pointers (xs may repeat one
+// input). ACCUMULATES into dws.
+extern "C" int cn_conv2d_bwd_weight_grouped_f32(int G, const float* const* xs, long xbs, const float* const* dys,
+                                                long dybs, float* const* dws, int B, int Cin, int Hin, int Win,
+                                                int Cout, int KH, int KW, int stride, int pad, int dil, float* ws,
+                                                long ws_floats, void* stream) {
+  const int Hout = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  return cn_wgrad_generic_g(G, dys, dybs, Cout, Hout, Wout, xs, xbs, Cin, Hin, Win, stride, KH, KW, dil, pad, dws, B,
+                            ws, ws_floats, (hipStream_t)stream);
 }
 
 // Conv2d: dw [Cout][Cin][KH][KW] += x (*) dy. NOTE accumulates: zero dw first for a fresh gradient.

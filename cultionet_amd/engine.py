@@ -79,9 +79,11 @@ class Tape:
             self.nodes.append(fn)
             if params:
                 base = current_store()._base
+                idx = len(self.nodes) - 1
                 for p in params:
-                    if p is not None:
-                        self.marks[(p.data_ptr() - base) // 4] = len(self.nodes) - 1
+                    if p is not None:  # a gradient is final once backward has passed the FIRST node that used it
+                        k = (p.data_ptr() - base) // 4
+                        self.marks[k] = min(self.marks.get(k, idx), idx)
 
     def backward(self) -> None:
         nodes, self.nodes = self.nodes, []
@@ -456,8 +458,21 @@ def conv2d_group(xs: T.Sequence[Var], mods: T.Sequence, paddings: T.Sequence[int
         def bwd():
             s = _stream()
             live = [i for i in range(G) if yvs[i].grad is not None]
+            grouped_w = (len(live) == G and len(set(paddings)) == 1 and len(set(dilations)) == 1
+                         and len({bstride(yvs[i].grad) for i in live}) == 1)
+            if grouped_w:  # one launch for the G weight gradients
+                wsp, wsn = _pad_ws(*([xts[i] for i in range(G)] + [yvs[i].grad for i in range(G)]))
+                _lib.call("cn_conv2d_bwd_weight_grouped_f32", G, tab([t.data_ptr() for t in xts]), bstride(xts[0]),
+                          tab([yvs[i].grad.data_ptr() for i in range(G)]), bstride(yvs[0].grad),
+                          tab([store.grad_of(m.weight).data_ptr() for m in mods]), B, Cin, H, W, Cout, KH, KW, stride,
+                          paddings[0], dilations[0], wsp, wsn, s)
             for i in live:
                 dy, m, xt = yvs[i].grad, mods[i], xts[i]
+                if grouped_w:
+                    if has_bias:
+                        _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Ho * Wo,
+                                  store.grad_of(m.bias).data_ptr(), 1, s)
+                    continue
                 wsp, wsn = _pad_ws(xt, dy)
                 _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
                           store.grad_of(m.weight).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, paddings[i],

@@ -98,6 +98,11 @@ int cn_conv2d_bwd_data_grouped_f32(int G, const float* const* dys, long dybs, co
                                    int KW, int stride, const int* pads, const int* dils, int accumulate,
                                    void* stream);
 
+/* Grouped weight gradient (same padding / dilation for every group; xs may repeat one input). ACCUMULATES. */
+int cn_conv2d_bwd_weight_grouped_f32(int G, const float* const* xs, long xbs, const float* const* dys, long dybs,
+                                     float* const* dws, int B, int Cin, int Hin, int Win, int Cout, int KH, int KW,
+                                     int stride, int pad, int dil, float* ws, long ws_floats, void* stream);
+
 /* ---- thin 3x3 "same" convolutions (<= 9 output channels) of the TowerUNetFinal head streams
  * (nn/modules/unet_parts.py:196-224 StreamConv2d; :227-309 TowerUNetFinal): direct VALU kernels on the RAW
  * nn.Conv2d weights [cout_per_set][Cin][3][3] (no packing); HBM-bound, the input is read once for all sets.

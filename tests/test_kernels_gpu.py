@@ -744,3 +744,35 @@ def test_bn_act_group(G, shape, summed, train):
             _close(bns[i].running_var.cpu(), ref[i].running_var, 1e-5, f"running_var{i}")
     if summed:
         _close(grads[G], rr.grad, 1e-6, "dres")
+
+
+@pytest.mark.parametrize("G,B,Cin,H,W,Cout,shared", [(2, 2, 32, 28, 28, 32, True), (2, 2, 40, 25, 25, 48, False),
+                                                      (3, 1, 16, 13, 13, 16, True), (2, 8, 128, 25, 25, 128, False),
+                                                      (2, 3, 32, 50, 50, 32, True)])
+def test_grouped_weight_gradient(G, B, Cin, H, W, Cout, shared):
+    """cn_conv2d_bwd_weight_grouped_f32 (aligned and odd sizes, shared / own inputs) against torch."""
+    import ctypes
+    from cultionet_amd import engine as E, _lib
+
+    dev = _dev()
+    torch.manual_seed(12)
+    convs = nn.ModuleList([nn.Conv2d(Cin, Cout, 3, padding=1, bias=False) for _ in range(G)]).to(dev)
+    store = E.ParamStore(convs)
+    store.zero_grad()
+    xs = [_rand(B, Cin, H, W, seed=200 + (0 if shared else i)).to(dev) for i in range(G)]
+    if shared:
+        xs = [xs[0]] * G
+    dys = [_rand(B, Cout, H, W, seed=210 + i).to(dev) for i in range(G)]
+    tab = lambda ptrs: (ctypes.c_void_p * G)(*ptrs)
+    with E.using_store(store):
+        wsp, wsn = E._pad_ws(*(xs + dys))
+        _lib.call("cn_conv2d_bwd_weight_grouped_f32", G, tab([x.data_ptr() for x in xs]), E.bstride(xs[0]),
+                  tab([d.data_ptr() for d in dys]), E.bstride(dys[0]),
+                  tab([store.grad_of(c.weight).data_ptr() for c in convs]), B, Cin, H, W, Cout, 3, 3, 1, 1, 1, wsp, wsn,
+                  E._stream())
+    torch.cuda.synchronize()
+    for i, c in enumerate(convs):
+        xr = xs[i].clone().requires_grad_(True)
+        w = c.weight.detach().clone().requires_grad_(True)
+        F.conv2d(xr, w, padding=1).backward(dys[i])
+        _close(store.grad_of(c.weight), w.grad, 1e-4, f"dw{i}")
