@@ -45,6 +45,12 @@ SIGNATURES = {
     "cn_layernorm_c_fwd_f32": [P, L, P, P, P, L, P, L, P, P, I, I, I, F, P],
     "cn_layernorm_c_workspace_floats": [I, I, I],
     "cn_layernorm_c_bwd_f32": [P, L, P, L, P, P, P, P, L, P, P, I, I, I, I, P, L, P],
+    "cn_sca_pool_fwd_f32": [P, L, I, I, I, P, P, P, P, P, P],
+    "cn_sca_pool_bwd_f32": [P, P, P, P, P, P, L, I, I, I, I, P],
+    "cn_sca_mlp_fwd_f32": [P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "cn_sca_mlp_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
+    "cn_sca_apply_fwd_f32": [P, L, P, P, P, P, L, I, I, I, P],
+    "cn_sca_apply_bwd_f32": [P, L, P, L, P, P, P, P, L, I, P, P, P, P, I, I, I, P],
     "cn_na2d_fwd_f32": [P, L, P, L, P, I, I, I, I, I, I, I, F, U64, P],
     "cn_na2d_bwd_f32": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, F, U64, P],
     "cn_bilinear_fwd_f32": [P, L, P, L, I, I, I, I, I, I, P],

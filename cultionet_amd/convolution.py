@@ -106,6 +106,38 @@ class ResConvBlock2d(nn.Module):
         return x
 
 
+class ChannelAttention(nn.Module):
+    """nn/modules/attention.py:12-62 (parameter container; arithmetic in cn_sca_mlp_*)."""
+
+    def __init__(self, in_channels: int, activation_type: str):
+        super().__init__()
+        mk = lambda: nn.Sequential(
+            nn.Conv2d(in_channels, in_channels // 2, kernel_size=1, padding=0, bias=False),
+            SetActivation(activation_type),
+            nn.Conv2d(in_channels // 2, in_channels, kernel_size=1, padding=0, bias=False),
+        )
+        self.fc1 = mk()
+        self.fc2 = mk()
+
+
+class SpatialAttention(nn.Module):
+    """nn/modules/attention.py:65-86."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(2, 1, kernel_size=3, padding=1, bias=False)
+
+
+class SpatialChannelAttention(nn.Module):
+    """nn/modules/attention.py:89-126: attention = 1 + gamma * 0.5 * (channel + spatial)."""
+
+    def __init__(self, in_channels: int, activation_type: str):
+        super().__init__()
+        self.channel_attention = ChannelAttention(in_channels=in_channels, activation_type=activation_type)
+        self.spatial_attention = SpatialAttention()
+        self.gamma = nn.Parameter(torch.zeros(1, requires_grad=True))
+
+
 class NeighborhoodAttention2D(nn.Module):
     """natten.NeighborhoodAttention2D(dim, heads, k, dilation, qkv_bias=True, rel_pos_bias=False) parameters
     (``qkv``, ``proj`` Linear layers, names as in natten 0.17.1) driving the HIP NA kernel on NCHW buffers."""
@@ -163,7 +195,9 @@ class ResidualConv(nn.Module):
         self.attention_weights = attention_weights
         if self.attention_weights is not None:
             assert self.attention_weights in [AttentionTypes.SPATIAL_CHANNEL], "The attention method is not supported."
-            raise NotImplementedError("attention_weights='spatial_channel' is not on the HIP path yet")
+            # upstream constructs SpatialChannelAttention(out_channels=...) here, a keyword its ctor does not have
+            # (convolution.py:203-205): res blocks with attention fail the same way in the reference
+            raise TypeError("SpatialChannelAttention.__init__() got an unexpected keyword argument 'out_channels'")
         self.seq = ResConvBlock2d(in_channels, out_channels, kernel_size, num_blocks=num_blocks,
                                   activation_type=activation_type, batchnorm_first=batchnorm_first)
         self.skip = None
@@ -193,7 +227,9 @@ class ResidualAConv(nn.Module):
             assert self.attention_weights in [AttentionTypes.NATTEN, AttentionTypes.SPATIAL_CHANNEL], \
                 "The attention method is not supported."
             if self.attention_weights != AttentionTypes.NATTEN:
-                raise NotImplementedError("attention_weights='spatial_channel' is not on the HIP path yet")
+                self.attention_conv = SpatialChannelAttention(in_channels=out_channels,
+                                                              activation_type=activation_type)
+        if self.attention_weights == AttentionTypes.NATTEN:
             self.attention_conv = nn.Sequential(
                 _Marker(),
                 nn.LayerNorm(out_channels),
@@ -226,10 +262,12 @@ class ResidualAConv(nn.Module):
         else:
             for layer in self.res_modules:
                 out = layer(x, residual=out)  # out + SiLU(BN(conv(...))) fused in the last block
-        if self.attention_weights is not None:
+        if self.attention_weights == AttentionTypes.NATTEN:
             a = E.layer_norm_c(skip, self.attention_conv[1])
             a = self.attention_conv[2](a)
             out = E.layer_norm_c(a, self.attention_conv[3], residual=out)
+        elif self.attention_weights is not None:  # spatial_channel: out *= attention(skip)
+            out = E.spatial_channel_attention(skip, out, self.attention_conv)
         return out
 
 

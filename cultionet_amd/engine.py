@@ -800,6 +800,85 @@ def na2d(qkv: Var, heads: int, kernel_size: int, dilation: int, attn_drop: float
     return ov
 
 
+def spatial_channel_attention(skip: Var, out: Var, mod) -> Var:
+    """out * (1 + gamma * 0.5 * (channel_attention(skip) + spatial_attention(skip))) -- SpatialChannelAttention
+    (nn/modules/attention.py:89-126) applied the way ResidualAConv does (convolution.py:388-393).
+    ``mod``: the host mirror with .channel_attention.fc1/.fc2 (Conv2d 1x1 pairs), .spatial_attention.conv, .gamma."""
+    tape = current_tape()
+    st, ot = _check(skip.t), _check(out.t)
+    B, C, H, W = st.shape
+    L = H * W
+    Ch = C // 2
+    dev = st.device
+    fc1, fc2 = mod.channel_attention.fc1, mod.channel_attention.fc2
+    w1a, w2a, w1m, w2m = fc1[0].weight, fc1[2].weight, fc2[0].weight, fc2[2].weight
+    gamma = mod.gamma
+    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    avg, mx, ca = f(B, C), f(B, C), f(B, C)
+    hpre_a, hpre_m = f(B, Ch), f(B, Ch)
+    idx = torch.empty((B, C), dtype=torch.int32, device=dev)
+    cidx = torch.empty((B, L), dtype=torch.int32, device=dev)
+    pooled = f(B, 2, H, W)
+    s = _stream()
+    _lib.call("cn_sca_pool_fwd_f32", st.data_ptr(), bstride(st), B, C, L, avg.data_ptr(), mx.data_ptr(), idx.data_ptr(),
+              pooled.data_ptr(), cidx.data_ptr(), s)
+    _lib.call("cn_sca_mlp_fwd_f32", avg.data_ptr(), mx.data_ptr(), w1a.data_ptr(), w2a.data_ptr(), w1m.data_ptr(),
+              w2m.data_ptr(), hpre_a.data_ptr(), hpre_m.data_ptr(), ca.data_ptr(), B, C, Ch, s)
+    pv = Var(pooled, tape.enabled)
+    shared = {}  # d ca handed from the apply node to the pooling node
+    if tape.enabled:
+        store = current_store()
+
+        def bwd_pool():  # recorded first => runs last: after the apply node and the 3x3 conv's backward
+            dca = shared.pop("dca", None)
+            if dca is None:
+                return
+            s2 = _stream()
+            davg, dmx = f(B, C), f(B, C)
+            _lib.call("cn_sca_mlp_bwd_f32", avg.data_ptr(), mx.data_ptr(), w1a.data_ptr(), w2a.data_ptr(),
+                      w1m.data_ptr(), w2m.data_ptr(), hpre_a.data_ptr(), hpre_m.data_ptr(), ca.data_ptr(),
+                      dca.data_ptr(), store.grad_of(w1a).data_ptr(), store.grad_of(w2a).data_ptr(),
+                      store.grad_of(w1m).data_ptr(), store.grad_of(w2m).data_ptr(), davg.data_ptr(), dmx.data_ptr(),
+                      B, C, Ch, s2)
+            if skip.req:
+                dpool = pv.grad
+                if dpool is None:
+                    dpool = torch.zeros_like(pooled)
+                dx, acc = grad_buffer(skip)
+                _lib.call("cn_sca_pool_bwd_f32", davg.data_ptr(), dmx.data_ptr(), idx.data_ptr(), dpool.data_ptr(),
+                          cidx.data_ptr(), dx.data_ptr(), bstride(dx), B, C, L, acc, s2)
+            pv.grad = None
+
+        tape.add(bwd_pool, (w1a, w2a, w1m, w2m))
+    sconv = thin_conv3x3(pv, [mod.spatial_attention.conv], grouped=False)  # [B,1,H,W]
+    y = _new(ot.shape, ot)
+    _lib.call("cn_sca_apply_fwd_f32", ot.data_ptr(), bstride(ot), ca.data_ptr(), sconv.t.data_ptr(), gamma.data_ptr(),
+              y.data_ptr(), bstride(y), B, C, L, s)
+    yv = Var(y, tape.enabled)
+    if tape.enabled:
+
+        def bwd_apply():
+            dy = yv.grad
+            if dy is None:
+                return
+            s2 = _stream()
+            dca, dsconv, scratch = f(B, C), f(B, 1, H, W), f(B * C)
+            if out.req:
+                do, acc = grad_buffer(out)
+                dop, dobs = do.data_ptr(), bstride(do)
+            else:
+                dop, dobs, acc = None, 0, 0
+            _lib.call("cn_sca_apply_bwd_f32", dy.data_ptr(), bstride(dy), ot.data_ptr(), bstride(ot), ca.data_ptr(),
+                      sconv.t.data_ptr(), gamma.data_ptr(), dop, dobs, acc, dca.data_ptr(), dsconv.data_ptr(),
+                      store.grad_of(gamma).data_ptr(), scratch.data_ptr(), B, C, L, s2)
+            shared["dca"] = dca
+            give_grad(sconv, dsconv)
+            yv.grad = None
+
+        tape.add(bwd_apply, (gamma,))
+    return yv
+
+
 def resize_bilinear(x: Var, size: T.Tuple[int, int], out: T.Optional[torch.Tensor] = None) -> Var:
     """F.interpolate(mode='bilinear', align_corners=True); identity when the size already matches."""
     tape = current_tape()

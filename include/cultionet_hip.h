@@ -166,6 +166,31 @@ int cn_layernorm_c_bwd_f32(const float* x, long xbs, const float* dy, long dybs,
                            int accumulate_dx, float* ws, long ws_floats, void* stream);
 int cn_layernorm_c_workspace_floats(int B, int C, int L);
 
+/* ---- SpatialChannelAttention (attention_weights="spatial_channel"; nn/modules/attention.py:12-126, applied as
+ * out *= 1 + gamma*0.5*(ca + sa) at nn/modules/convolution.py:388-393). x viewed [B][C][L].
+ * pool_fwd: avg/mx [B][C] over L (idx: position of the first maximum), pooled [B][2][L] = mean / max over C
+ *   (cidx: channel of the first maximum). The 3x3 conv 2->1 on `pooled` is cn_thin_conv3x3_* (1 set, 1 output).
+ * mlp: w1* [C/2][C], w2* [C][C/2] (fc1 = avg branch "a", fc2 = max branch "m"); hpre_* [B][C/2] saved pre-activations;
+ *   ca [B][C]. mlp_bwd ACCUMULATES the four weight gradients and overwrites davg/dmx.
+ * apply: y = out*(1 + gamma*0.5*(ca[b,c] + sigmoid(sconv[b,l]))); apply_bwd overwrites dca [B][C], dsconv [B][L],
+ *   ACCUMULATES dgamma[1]; dout nullable; scratch: B*C floats.
+ * pool_bwd: dx (+)= the four pooling adjoints. */
+int cn_sca_pool_fwd_f32(const float* x, long xbs, int B, int C, int L, float* avg, float* mx, int* idx, float* pooled,
+                        int* cidx, void* stream);
+int cn_sca_pool_bwd_f32(const float* davg, const float* dmx, const int* idx, const float* dpooled, const int* cidx,
+                        float* dx, long dxbs, int B, int C, int L, int accumulate, void* stream);
+int cn_sca_mlp_fwd_f32(const float* avg, const float* mx, const float* w1a, const float* w2a, const float* w1m,
+                       const float* w2m, float* hpre_a, float* hpre_m, float* ca, int B, int C, int Ch, void* stream);
+int cn_sca_mlp_bwd_f32(const float* avg, const float* mx, const float* w1a, const float* w2a, const float* w1m,
+                       const float* w2m, const float* hpre_a, const float* hpre_m, const float* ca, const float* dca,
+                       float* dw1a, float* dw2a, float* dw1m, float* dw2m, float* davg, float* dmx, int B, int C,
+                       int Ch, void* stream);
+int cn_sca_apply_fwd_f32(const float* out, long obs, const float* ca, const float* sconv, const float* gamma, float* y,
+                         long ybs, int B, int C, int L, void* stream);
+int cn_sca_apply_bwd_f32(const float* dy, long dybs, const float* out, long obs, const float* ca, const float* sconv,
+                         const float* gamma, float* dout /*nullable*/, long dobs, int accumulate_dout, float* dca,
+                         float* dsconv, float* dgamma, float* scratch, int B, int C, int L, void* stream);
+
 /* ---- natten.NeighborhoodAttention2D core (convolution.py:341-350; natten 0.17.1 na2d_qk ->
  * softmax -> na2d_av, kernel 3, dilation d, no rpb). qkv [B][3C][H][W] with channel
  * (which*C + head*D + d); attn [B][heads][9][H][W] saved probabilities; dattn same-size scratch.

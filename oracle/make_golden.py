@@ -130,6 +130,9 @@ def main():
         save("train_h8_b2_28_res.npz", _train_case(ns, 8, 2, 28, 28, False, res_block_type="res", attention_weights=None))
         save("train_h8_b2_28_bnfirst.npz", _train_case(ns, 8, 2, 28, 28, False, batchnorm_first=True))
         return
+    if "--sca-only" in sys.argv:
+        save("train_h8_b2_28_sca.npz", _train_case(ns, 8, 2, 28, 28, True, attention_weights="spatial_channel"))
+        return
     if "--eval-only" in sys.argv:
         save("eval_h32_b1_4x25x256.npz", _eval_case(ns, 32, 1, 4, 25, 256, 256))
         save("eval_h8_b2_28.npz", _eval_case(ns, 8, 2, 3, 12, 28, 28, crop=0))
@@ -148,6 +151,8 @@ def main():
     save("train_h8_b2_28_poolmax.npz", _train_case(ns, 8, 2, 28, 28, True, pool_by_max=True))
     save("train_h8_b2_28_res.npz", _train_case(ns, 8, 2, 28, 28, False, res_block_type="res", attention_weights=None))
     save("train_h8_b2_28_bnfirst.npz", _train_case(ns, 8, 2, 28, 28, False, batchnorm_first=True))
+    # attention_weights="spatial_channel" (SpatialChannelAttention in the decoder's RESA blocks)
+    save("train_h8_b2_28_sca.npz", _train_case(ns, 8, 2, 28, 28, True, attention_weights="spatial_channel"))
     # (ii) BASELINE configs[0] / configs[1] shapes at hidden 32
     save("train_h32_b1_100.npz", _train_case(ns, 32, 1, 100, 100, False))
     save("train_h32_b1_100_masked.npz", _train_case(ns, 32, 1, 100, 100, True))

@@ -140,6 +140,46 @@ class ResConvBlock2d(nn.Module):
         return x
 
 
+class ChannelAttention(nn.Module):
+    """nn/modules/attention.py:12-62."""
+
+    def __init__(self, cin, act):
+        super().__init__()
+        mk = lambda: nn.Sequential(nn.Conv2d(cin, cin // 2, 1, bias=False), Act(act), nn.Conv2d(cin // 2, cin, 1, bias=False))
+        self.fc1 = mk()
+        self.fc2 = mk()
+
+    def forward(self, x):
+        avg = self.fc1(x.mean(dim=(2, 3), keepdim=True))
+        mx = self.fc2(x.amax(dim=(2, 3), keepdim=True))
+        return torch.sigmoid(avg + mx).expand(-1, -1, x.shape[2], x.shape[3])
+
+
+class SpatialAttention(nn.Module):
+    """nn/modules/attention.py:65-86."""
+
+    def __init__(self):
+        super().__init__()
+        self.conv = nn.Conv2d(2, 1, 3, padding=1, bias=False)
+
+    def forward(self, x):
+        a = torch.cat([x.mean(dim=1, keepdim=True), x.amax(dim=1, keepdim=True)], dim=1)
+        return torch.sigmoid(self.conv(a)).expand(-1, x.shape[1], -1, -1)
+
+
+class SpatialChannelAttention(nn.Module):
+    """nn/modules/attention.py:89-126."""
+
+    def __init__(self, cin, act):
+        super().__init__()
+        self.channel_attention = ChannelAttention(cin, act)
+        self.spatial_attention = SpatialAttention()
+        self.gamma = nn.Parameter(torch.zeros(1))
+
+    def forward(self, x):
+        return 1.0 + self.gamma * ((self.channel_attention(x) + self.spatial_attention(x)) * 0.5)
+
+
 class ResidualConv(nn.Module):
     """nn/modules/convolution.py:179-247 (attention None)."""
 
@@ -166,7 +206,10 @@ class ResidualAConv(nn.Module):
         self.attention_weights = attention_weights
         self.skip = nn.Conv2d(cin, cout, 1) if cin != cout else nn.Identity()
         if attention_weights is not None:
-            assert attention_weights == "natten", "The attention method is not supported."
+            assert attention_weights in ("natten", "spatial_channel"), "The attention method is not supported."
+        if attention_weights == "spatial_channel":
+            self.attention_conv = SpatialChannelAttention(cout, act)
+        elif attention_weights is not None:
             self.attention_conv = nn.Sequential(
                 _ToNHWC(),
                 nn.LayerNorm(cout),
@@ -183,8 +226,10 @@ class ResidualAConv(nn.Module):
         skip = out
         for layer in self.res_modules:
             out = out + layer(x)
-        if self.attention_weights is not None:
+        if self.attention_weights == "natten":
             out = out + self.attention_conv(skip)
+        elif self.attention_weights is not None:
+            out = out * self.attention_conv(skip)
         return out
 
 

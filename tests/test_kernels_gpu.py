@@ -776,3 +776,30 @@ def test_grouped_weight_gradient(G, B, Cin, H, W, Cout, shared):
         w = c.weight.detach().clone().requires_grad_(True)
         F.conv2d(xr, w, padding=1).backward(dys[i])
         _close(store.grad_of(c.weight), w.grad, 1e-4, f"dw{i}")
+
+
+@pytest.mark.parametrize("B,C,H,W", [(2, 16, 12, 12), (1, 40, 9, 11), (3, 128, 25, 25)])
+def test_spatial_channel_attention(B, C, H, W):
+    """cn_sca_*: out * (1 + gamma*0.5*(channel + spatial attention of skip)) against the oracle's restatement."""
+    from cultionet_amd import engine as E
+    from cultionet_amd.convolution import SpatialChannelAttention
+    from oracle import towerunet_oracle as O
+
+    torch.manual_seed(61)
+    mod = SpatialChannelAttention(C, "SiLU")
+    with torch.no_grad():
+        mod.gamma.fill_(0.7)
+    ref = O.SpatialChannelAttention(C, "SiLU")
+    ref.load_state_dict(mod.state_dict())
+    skip, out = _rand(B, C, H, W, seed=62), _rand(B, C, H, W, seed=63)
+    sr, orr = skip.clone().requires_grad_(True), out.clone().requires_grad_(True)
+    yr = orr * ref(sr)
+    dy = _rand(B, C, H, W, seed=64)
+    yr.backward(dy)
+    refg = {k: p.grad.clone() for k, p in ref.named_parameters()}
+    y, (ds, do), pg = _engine_run(mod, lambda s, o: E.spatial_channel_attention(s, o, mod), [skip, out], dy)
+    _close(y, yr, 2e-5, "y")
+    _close(do, orr.grad, 1e-4, "dout")
+    _close(ds, sr.grad, 1e-4, "dskip")
+    for k in refg:
+        _close(pg[k], refg[k], 1e-4, k)

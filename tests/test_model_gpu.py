@@ -50,6 +50,7 @@ def _check_outputs(pred, g):
     ("train_h8_b2_28_poolmax", {"pool_by_max": True}),
     ("train_h8_b2_28_res", {"res_block_type": "res", "attention_weights": None}),
     ("train_h8_b2_28_bnfirst", {"batchnorm_first": True}),
+    ("train_h8_b2_28_sca", {"attention_weights": "spatial_channel"}),
 ])
 def test_native_train_step_matches_reference(golden_dir, name, kw):
     from cultionet_amd.lightning import HipTrainer

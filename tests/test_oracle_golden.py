@@ -41,6 +41,7 @@ def _run_train(g, **model_kw):
         ("train_h8_b2_28_poolmax", {"pool_by_max": True}, "TanimotoComplementLoss"),
         ("train_h8_b2_28_res", {"res_block_type": "res", "attention_weights": None}, "TanimotoComplementLoss"),
         ("train_h8_b2_28_bnfirst", {"batchnorm_first": True}, "TanimotoComplementLoss"),
+        ("train_h8_b2_28_sca", {"attention_weights": "spatial_channel"}, "TanimotoComplementLoss"),
     ],
 )
 def test_oracle_train_matches_reference_vectors(golden_dir, name, kw, loss_name):
