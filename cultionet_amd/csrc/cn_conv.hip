@@ -634,46 +634,67 @@ static CnPlan cn_plan(CnConvGeom& g, int MT) {
 // minimise it (e.g. 8 chips of 100x100: MT=160 gives 504 blocks = one round, MT=128 gives 632 = two).
 struct CnChoice { int cfg, splits, cps; double cost; };
 
+// Cost model, in units of (one 9-tap K-chunk of one pixel row of a 128-cout tile) = 7.5 us / 128, calibrated on the
+// K-split sweeps of tools/ksplit.py (128->128 at 25^2 / 50^2, 256->256 at 13^2; within ~10 % for 1..8 splits):
+//   a block alone on its CU runs a chunk in ~MT units, two co-resident blocks in ~1.56 MT each (they share the
+//   SIMDs' MFMA pipes); staging + barriers are ~15 % of a 9-tap chunk and do not shrink with fewer taps; every
+//   round of blocks pays a fixed prologue/epilogue of ~240 units (14 us); a K-split adds the reduce launch (~140
+//   units) plus writing and re-reading the partial slices (mostly L2 / Infinity-Cache resident: ~8 TB/s). 512 blocks fit the chip at once (2 per CU).
+static double cn_launch_cost(long blocks, int cps, double chunk_units, int splits, double out_elems) {
+  const double F = 240.0, R = 140.0, CO = 1.56;
+  const long full = blocks / 512, rem = blocks % 512;
+  double c = full * (F + cps * chunk_units * CO);
+  if (rem > 0) c += F + cps * chunk_units * (rem > 256 ? CO : 1.0);
+  if (splits > 1) c += R + out_elems * 4.0 * (2.0 * splits + 1.0) / 8.0e6 * (128.0 / 7.5);
+  return c;
+}
+
+static float* g_conv_ws;
+static long g_conv_ws_floats;
+
 static CnChoice cn_choose(const CnConvGeom& g0, const int* mts, int ncfg, int NT, bool allow_split) {
   const int nchunks = (g0.Cin + KC - 1) / KC;
   const int ny = (g0.Cout + NT - 1) / NT;
-  CnConvGeom g = g0;
-  const CnPlan p0 = cn_plan(g, mts[0]);
-  const long base_blocks = (long)p0.total_tiles * ny;
+  const int G = g0.G > 0 ? g0.G : 1;
+  const double out_elems = (double)g0.B * g0.Cout * g0.Hout * g0.Wout * (g0.shared_y ? 1 : G);
   CnChoice best = {0, 1, nchunks > 0 ? nchunks : 1, 1e300};
-  if (base_blocks >= 384 || !allow_split || p0.max_taps == 0 || nchunks < 4) {
-    // big launch: no K split; pick the pixel tile with the fewest (rounds x tile) units
-    for (int i = 0; i < ncfg; ++i) {
-      CnConvGeom gi = g0;
-      const CnPlan p = cn_plan(gi, mts[i]);
-      if (p.total_tiles <= 0) continue;
-      const long rounds = ((long)p.total_tiles * ny + 511) / 512;
-      const double cost = (double)rounds * mts[i] * (i == 0 ? 1.0 : 1.08);  // prefer the default tile on near-ties
-      if (cost < best.cost) best = {i, 1, best.cps, cost};
-    }
-    return best;
-  }
-  // small launch: default tile, split K so that the launch stays within ONE round of ~2 blocks per CU
-  int splits = (int)(512 / base_blocks);
-  if (splits > nchunks / 2) splits = nchunks / 2;
-  if (splits > 32) splits = 32;
-  if (splits < 1) splits = 1;
+  int forced = 0;
   {
-    static const char* dbg = getenv("CN_DBG_SPLITS");  // tuning aid: force the K split of small launches
-    if (dbg) splits = atoi(dbg) < 1 ? 1 : (atoi(dbg) > nchunks ? nchunks : atoi(dbg));
+    static const char* dbg = getenv("CN_DBG_SPLITS");  // tuning aid: force the K split
+    if (dbg) forced = atoi(dbg) < 1 ? 1 : atoi(dbg);
   }
-  const int cps = (nchunks + splits - 1) / splits;
-  best.cfg = 0;
-  best.cps = cps;
-  best.splits = (nchunks + cps - 1) / cps;
+  // with a workspace the splits must fit it as slices (the atomic fallback on a large output is far slower)
+  long ws_cap = 32;
+  if (g_conv_ws != nullptr) {
+    const long stride = ((long)g0.B * g0.Cout * g0.Hout * g0.Wout + 3) / 4 * 4;
+    ws_cap = g_conv_ws_floats / (stride * G);
+  }
+  for (int i = 0; i < ncfg; ++i) {
+    CnConvGeom gi = g0;
+    const CnPlan p = cn_plan(gi, mts[i]);
+    if (p.total_tiles <= 0) continue;
+    const long base = (long)p.total_tiles * ny;
+    int max_splits = (allow_split && p.max_taps > 0 && nchunks >= 4) ? nchunks / 2 : 1;
+    if (max_splits > 32) max_splits = 32;
+    if (max_splits > ws_cap) max_splits = ws_cap < 1 ? 1 : (int)ws_cap;
+    // average taps per tile over the classes (parity classes of a strided scatter have 0..4 of the 9 taps)
+    const double taps = p.total_tiles > 0 ? p.flops / (2.0 * g0.Cout * g0.Cin * (double)mts[i] * p.total_tiles) : 9.0;
+    const double chunk_units = (double)mts[i] * NT / 128.0 * (0.15 + 0.85 * (taps < 9.0 ? taps : 9.0) / 9.0);
+    for (int sp = 1; sp <= max_splits; ++sp) {
+      if (forced && sp != (forced > max_splits ? max_splits : forced)) continue;
+      const int cps = (nchunks + sp - 1) / sp;
+      const int splits = (nchunks + cps - 1) / cps;  // the split count that cps really gives
+      if (splits != sp && !forced) continue;
+      const double cost = cn_launch_cost(base * splits, cps, chunk_units, splits, out_elems);
+      if (cost < best.cost * (i == best.cfg ? 1.0 : 0.98)) best = {i, splits, cps, cost};  // switch tile only for >= 2 %
+    }
+  }
   return best;
 }
 
 // Optional scratch for split-K partial slices (cn_conv_set_workspace): with it, a K-split launch stores each
 // split's partial tile into its own slice with plain stores and cn_conv_reduce_kernel sums the slices (+ bias)
 // into y -- no memset of y, no float atomics. Without it (or if it is too small) the atomic path is used.
-static float* g_conv_ws = nullptr;
-static long g_conv_ws_floats = 0;
 
 extern "C" int cn_conv_set_workspace(float* ws, long ws_floats) {
   if (ws != nullptr && ((reinterpret_cast<uintptr_t>(ws) & 15) || ws_floats < 0)) return CN_ERR_ARG;
