@@ -398,9 +398,31 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
     if (g.nbuf == 2) cur ^= 1;
   }
 
-  // many splits on a small dW: same-address float atomics serialise (~200 ns each), so each (split, k-part)
-  // stores its partial into a private workspace slice instead and cn_wgrad_reduce_kernel sums the slices
-  float* dWs = dW + (long)(bz * kparts + kp) * g.slice_stride;
+  // the k-part waves of a block hold partial sums of the SAME dW tile: add them up through LDS (free after the
+  // main loop) so the block writes its tile once
+  if (kparts > 1) {
+    __syncthreads();
+    float* red = smem;
+    if (kp > 0) {
+      float* rp = red + (long)((kp - 1) * g.a_tiles + at) * (T * 16 * 64) + lane;
+#pragma unroll
+      for (int j = 0; j < T; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rp[(j * 16 + r) * 64] = acc[j][r];
+    }
+    __syncthreads();
+    if (kp > 0) return;
+    for (int k = 1; k < kparts; ++k) {
+      const float* rp = red + (long)((k - 1) * g.a_tiles + at) * (T * 16 * 64) + lane;
+#pragma unroll
+      for (int j = 0; j < T; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] += rp[(j * 16 + r) * 64];
+    }
+  }
+  // many splits on a small dW: same-address float atomics serialise (~200 ns each), so each split stores its
+  // partial into a private workspace slice instead and cn_wgrad_reduce_kernel sums the slices
+  float* dWs = dW + (long)bz * g.slice_stride;
 #pragma unroll
   for (int j = 0; j < T; ++j) {
     const int n = j * 32 + l31;
@@ -475,6 +497,10 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
   if (lds > 160 * 1024 || g.a_tiles * 32 * g.pitch_s > WG_KS * 4 * 256) return CN_ERR_ARG;
   g.nbuf = (2 * lds <= 160 * 1024) ? 2 : 1;
   lds *= g.nbuf;
+  {  // room for the in-block reduction over the k-part waves: [kparts-1][a_tiles][T*16][64] floats
+    const size_t red = (size_t)(4 / g.a_tiles - 1) * g.a_tiles * T * 16 * 64 * sizeof(float);
+    if (red > lds) lds = red;
+  }
   g.chunks_per_img = (g.Hs + g.PR - 1) / g.PR;
   g.total_chunks = g.N * g.chunks_per_img;
   const int gx = (g.Bc + WG_BC - 1) / WG_BC, gy = (g.A + g.a_tiles * 32 - 1) / (g.a_tiles * 32);
@@ -520,10 +546,10 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
   // partial-slice mode: >= 32 adds per dW address (slices must fit the caller's workspace)
   const int kparts = 4 / g.a_tiles;
   const long dw_floats = (long)g.A * g.sa;
-  const long nslices = (long)splits * kparts;  // per group
+  const long nslices = splits;  // per group (the k-part waves of a block are summed in LDS)
   float* out = g.gdW[0];
   g.slice_stride = 0;
-  if (nslices >= 32 && ws != nullptr && nslices * g.G * dw_floats <= ws_floats) {
+  if (nslices >= 16 && ws != nullptr && nslices * g.G * dw_floats <= ws_floats) {
     g.slice_stride = dw_floats;
     out = ws;
   }
