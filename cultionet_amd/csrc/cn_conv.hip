@@ -669,7 +669,13 @@ static CnChoice cn_choose(const CnConvGeom& g0, const int* mts, int ncfg, int NT
     const long stride = ((long)g0.B * g0.Cout * g0.Hout * g0.Wout + 3) / 4 * 4;
     ws_cap = g_conv_ws_floats / (stride * G);
   }
+  int forced_cfg = -1;
+  {
+    static const char* dbgc = getenv("CN_DBG_CFG");  // tuning aid: force the pixel-tile config index
+    if (dbgc) forced_cfg = atoi(dbgc);
+  }
   for (int i = 0; i < ncfg; ++i) {
+    if (forced_cfg >= 0 && i != (forced_cfg < ncfg ? forced_cfg : ncfg - 1)) continue;
     CnConvGeom gi = g0;
     const CnPlan p = cn_plan(gi, mts[i]);
     if (p.total_tiles <= 0) continue;
@@ -840,6 +846,78 @@ static int cn_launch_dword_cfg(const float* x, const float* wp, const float* bia
   return cn_launch_igemm_t<WAVES_N, TN, 12>(x, wp, bias, y, g, p.total_tiles, p.max_taps, splits, p.flops, stream);
 }
 
+// ---- opt-in autotuning (cn_conv_set_autotune): the first overwriting launch of each distinct shape times the
+// (tile config x K split) candidates with HIP events on the launch stream and the winner is cached for the
+// process (accumulating launches of the same shape reuse it). Off by default: launches then never synchronise.
+#include <functional>
+#include <unordered_map>
+static int g_autotune = 0;
+static std::unordered_map<uint64_t, CnChoice> g_tuned;
+
+extern "C" int cn_conv_set_autotune(int on) {
+  g_autotune = on ? 1 : 0;
+  if (!on) g_tuned.clear();
+  return CN_OK;
+}
+
+static uint64_t cn_tune_key(const CnConvGeom& g, bool vec, int nt, bool allow_split) {
+  uint64_t h = 1469598103934665603ull;
+  auto mix = [&](long v) { h = (h ^ (uint64_t)v) * 1099511628211ull; };
+  mix(g.B); mix(g.Cin); mix(g.Hin); mix(g.Win); mix(g.Cout); mix(g.Hout); mix(g.Wout); mix(g.is); mix(g.os);
+  mix(g.ncls); mix(g.G); mix(g.shared_y); mix(vec); mix(nt); mix(allow_split); mix(g_conv_ws != nullptr);
+  for (int c = 0; c < g.ncls; ++c) {
+    const CnConvClass& k = g.cls[c];
+    mix(k.Hg); mix(k.Wg); mix(k.ntaps); mix(k.grp);
+    for (int t = 0; t < k.ntaps; ++t) { mix(k.dy[t]); mix(k.dx[t]); }
+  }
+  return h;
+}
+
+static CnChoice cn_autotune(const CnConvGeom& g, const int* mts, int ncfg, int nt, bool allow_split,
+                            const CnChoice& model, const std::function<int(const CnChoice&, CnConvGeom&)>& run,
+                            hipStream_t stream) {
+  static const int split_set[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32};
+  const int nchunks = (g.Cin + KC - 1) / KC;
+  const int ny = (g.Cout + nt - 1) / nt;
+  long ws_cap = 32;
+  if (g_conv_ws != nullptr) {
+    const long stride = ((long)g.B * g.Cout * g.Hout * g.Wout + 3) / 4 * 4;
+    ws_cap = g_conv_ws_floats / (stride * (g.G > 0 ? g.G : 1));
+  }
+  hipEvent_t e0, e1;
+  if (hipEventCreate(&e0) != hipSuccess || hipEventCreate(&e1) != hipSuccess) return model;
+  CnChoice best = model;
+  float best_ms = 1e30f;
+  for (int i = 0; i < ncfg; ++i) {
+    CnConvGeom gi = g;
+    const CnPlan p = cn_plan(gi, mts[i]);
+    if (p.total_tiles <= 0) continue;
+    int max_splits = (allow_split && p.max_taps > 0 && nchunks >= 4) ? nchunks / 2 : 1;
+    if (max_splits > 32) max_splits = 32;
+    if (max_splits > ws_cap) max_splits = ws_cap < 1 ? 1 : (int)ws_cap;
+    for (int sp : split_set) {
+      if (sp > max_splits) break;
+      const int cps = (nchunks + sp - 1) / sp;
+      const int splits = (nchunks + cps - 1) / cps;
+      if (splits != sp) continue;
+      if ((long)p.total_tiles * ny * splits > 8192) continue;  // far past any useful split
+      const CnChoice c = {i, splits, cps, 0.0};
+      float ms = 0.f;
+      bool ok = true;
+      for (int rep = 0; rep < 2 && ok; ++rep) {  // first run warms caches / attributes, second is timed
+        CnConvGeom gg = g;
+        ok = hipEventRecord(e0, stream) == hipSuccess && run(c, gg) == CN_OK &&
+             hipEventRecord(e1, stream) == hipSuccess && hipEventSynchronize(e1) == hipSuccess &&
+             hipEventElapsedTime(&ms, e0, e1) == hipSuccess;
+      }
+      if (ok && ms < best_ms) { best_ms = ms; best = c; }
+    }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  return best;
+}
+
 int cn_conv_igemm_launch(CnConvGeom& g, hipStream_t stream) {
   if (g.ncls < 1 || g.ncls > CN_MAX_CLASSES || g.B <= 0 || g.G < 1) return g.B <= 0 ? CN_OK : CN_ERR_ARG;
   g.splits = 1;
@@ -859,28 +937,43 @@ int cn_conv_igemm_launch(CnConvGeom& g, hipStream_t stream) {
     CnConvGeom t = g;
     vec = cn_plan(t, 256).max_vplane <= 4 * 1024;
   }
-  if (nt == 128) {
-    if (vec) {
-      static const int mts[3] = {128, 96, 160};  // MT=192 (TM=6) needs > 256 registers: one wave per SIMD
-      const CnChoice c = cn_choose(g, mts, 3, 128, allow_split);
-      switch (c.cfg) {
-        case 1: return cn_launch_vec_cfg<4, 1, 3>(x, wp, bias, y, g, c.splits, c.cps, stream);
-        case 2: return cn_launch_vec_cfg<4, 1, 5>(x, wp, bias, y, g, c.splits, c.cps, stream);
-        default: return cn_launch_vec_cfg<2, 2, 2>(x, wp, bias, y, g, c.splits, c.cps, stream);
+  // ---- configuration: tile config x K split, from the cost model or (opt-in) measured once per shape
+  static const int mts128[3] = {128, 96, 160};  // MT=192 (TM=6) needs > 256 registers: one wave per SIMD
+  static const int mts128d[1] = {128};
+  static const int mts256[1] = {256};
+  const int* mts = nt == 128 ? (vec ? mts128 : mts128d) : mts256;
+  const int ncfg = (nt == 128 && vec) ? 3 : 1;
+  auto run = [&](const CnChoice& c, CnConvGeom& gg) -> int {
+    if (nt == 128) {
+      if (vec) {
+        switch (c.cfg) {
+          case 1: return cn_launch_vec_cfg<4, 1, 3>(x, wp, bias, y, gg, c.splits, c.cps, stream);
+          case 2: return cn_launch_vec_cfg<4, 1, 5>(x, wp, bias, y, gg, c.splits, c.cps, stream);
+          default: return cn_launch_vec_cfg<2, 2, 2>(x, wp, bias, y, gg, c.splits, c.cps, stream);
+        }
       }
+      return cn_launch_dword_cfg<2, 2>(x, wp, bias, y, gg, c.splits, c.cps, stream);
     }
-    static const int mts[1] = {128};
-    const CnChoice c = cn_choose(g, mts, 1, 128, allow_split);
-    return cn_launch_dword_cfg<2, 2>(x, wp, bias, y, g, c.splits, c.cps, stream);
+    if (nt == 64) {
+      if (vec) return cn_launch_vec_cfg<1, 2, 2>(x, wp, bias, y, gg, c.splits, c.cps, stream);
+      return cn_launch_dword_cfg<1, 2>(x, wp, bias, y, gg, c.splits, c.cps, stream);
+    }
+    if (vec) return cn_launch_vec_cfg<1, 1, 2>(x, wp, bias, y, gg, c.splits, c.cps, stream);
+    return cn_launch_dword_cfg<1, 1>(x, wp, bias, y, gg, c.splits, c.cps, stream);
+  };
+  CnChoice c = cn_choose(g, mts, ncfg, nt, allow_split);
+  if (g_autotune) {
+    const uint64_t key = cn_tune_key(g, vec, nt, allow_split);
+    auto it = g_tuned.find(key);
+    if (it != g_tuned.end()) {
+      c = it->second;
+    } else if (!g.accumulate && !cn_prof_on()) {
+      // first sight of this shape on an overwriting launch: time the candidates (the output is simply rewritten)
+      c = cn_autotune(g, mts, ncfg, nt, allow_split, c, run, stream);
+      g_tuned.emplace(key, c);
+    }
   }
-  static const int mts[1] = {256};
-  const CnChoice c = cn_choose(g, mts, 1, nt, allow_split);
-  if (nt == 64) {
-    if (vec) return cn_launch_vec_cfg<1, 2, 2>(x, wp, bias, y, g, c.splits, c.cps, stream);
-    return cn_launch_dword_cfg<1, 2>(x, wp, bias, y, g, c.splits, c.cps, stream);
-  }
-  if (vec) return cn_launch_vec_cfg<1, 1, 2>(x, wp, bias, y, g, c.splits, c.cps, stream);
-  return cn_launch_dword_cfg<1, 1>(x, wp, bias, y, g, c.splits, c.cps, stream);
+  return run(c, g);
 }
 
 static inline int floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }

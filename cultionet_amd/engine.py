@@ -17,6 +17,7 @@ Design (MI355X-first, not torch.autograd):
 from __future__ import annotations
 
 import threading
+import os
 import typing as T
 
 import torch
@@ -248,6 +249,9 @@ def _bind_conv_workspace(dev: torch.device) -> None:
     _conv_ws.clear()
     _conv_ws[key] = ws
     _lib.call("cn_conv_set_workspace", ws.data_ptr(), ws.numel())
+    # CN_AUTOTUNE=1: measure the (tile, K split) candidates per conv shape during the first steps instead of
+    # trusting the launch-cost model (+0.5 % at batch 8; off by default so that runs are reproducible)
+    _lib.call("cn_conv_set_autotune", 1 if os.environ.get("CN_AUTOTUNE", "0") == "1" else 0)
 
 
 def current_store() -> ParamStore:

@@ -85,6 +85,11 @@ int cn_conv_transpose2d_bwd_weight_f32(const float* x, long xbs, const float* dy
  * on ONE stream. ws 16-byte aligned; 64 MB covers every TowerUNet layer at 8 chips of 100x100. */
 int cn_conv_set_workspace(float* ws, long ws_floats);
 
+/* Opt-in autotuning of the cn_conv* launches (off by default): the first overwriting launch of each distinct shape
+ * times the (pixel tile x K split) candidates with HIP events on the launch stream (that call synchronises) and the
+ * winner is cached for the process; later launches of the shape, accumulating ones included, reuse it. */
+int cn_conv_set_autotune(int on);
+
 /* ---- grouped launches: G (<= 4) convolutions of identical shape in ONE launch -- the dilation branches of
  * ResidualAConv (nn/modules/convolution.py:376-395): same tensor shapes, per-branch padding / dilation.
  * xs/wps/biases/ys (dys/wps_t/dxs), pads, dils: HOST arrays of G entries (device pointers / ints). Inputs may
