@@ -846,6 +846,130 @@ static int cn_launch_dword_cfg(const float* x, const float* wp, const float* bia
   return cn_launch_igemm_t<WAVES_N, TN, 12>(x, wp, bias, y, g, p.total_tiles, p.max_taps, splits, p.flops, stream);
 }
 
+// --------------------------------------------------------------------------
+// 1x1 convolutions of large pixel counts (skip convs of the tower blocks, qkv / proj of the 100x100 attention) as a
+// plain GEMM  y[co][p] = sum_ci wp[ci][co] x[ci][p]: no halo, so a K-chunk of 32 channels is staged densely
+// ([32][NT] weights + [32][MT] pixels = 36 KB) and there are 4x fewer barriers per MFMA than the 8-channel chunks
+// of the tap kernels give a single-tap layer.
+// --------------------------------------------------------------------------
+struct CnGemm1x1 {
+  int B, Cin, Cout, HW, Kpad, Npad, tiles_per_img, grid_x, grid_y, accumulate;
+  long xbs, ybs;
+};
+#define KC1 32
+
+template <int TM>
+__global__ __launch_bounds__(256) void cn_conv1x1_kernel(const float* __restrict__ x, const float* __restrict__ wp,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        const CnGemm1x1 g) {
+  constexpr int MT = TM * 32, NT = 128;
+  constexpr int NA = KC1 * NT / 4 / 256;             // weight float4 per thread per chunk (4)
+  constexpr int NB = (KC1 * MT / 4 + 255) / 256;     // pixel float4 per thread per chunk
+  __shared__ __attribute__((aligned(16))) float a_lds[KC1 * NT];
+  __shared__ __attribute__((aligned(16))) float b_lds[KC1 * MT];
+  int bx, by, bz;
+  if (!cn_xcd_block(g.grid_x, g.grid_y, g.grid_x * g.grid_y, bx, by, bz)) return;
+  const int tid = threadIdx.x, lane = tid & 63, wn = tid >> 6;
+  const int half = lane >> 5, l31 = lane & 31;
+  const int b = bx / g.tiles_per_img;
+  const int p0 = (bx - b * g.tiles_per_img) * MT;
+  const int n0 = by * NT;
+  const float* xb = x + (long)b * g.xbs;
+
+  f32x16 acc[TM];
+#pragma unroll
+  for (int tm = 0; tm < TM; ++tm)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[tm][r] = 0.f;
+
+  f32x4 ra[NA], rb[NB];
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#define CN_G1_PREFETCH(c0_)                                                                          \
+  {                                                                                                  \
+    const int c0 = (c0_);                                                                            \
+    _Pragma("unroll") for (int k = 0; k < NA; ++k) {                                                 \
+      const int i = tid + k * 256, row = i / (NT / 4), c4 = i - row * (NT / 4);                      \
+      ra[k] = (c0 + row) < g.Kpad                                                                    \
+                  ? *reinterpret_cast<const f32x4*>(wp + (long)(c0 + row) * g.Npad + n0 + c4 * 4)    \
+                  : zero4;                                                                           \
+    }                                                                                                \
+    _Pragma("unroll") for (int k = 0; k < NB; ++k) {                                                 \
+      const int i = tid + k * 256, row = i / (MT / 4), q = i - row * (MT / 4);                       \
+      const int p = p0 + q * 4;                                                                      \
+      rb[k] = (i < KC1 * MT / 4 && (c0 + row) < g.Cin && p < g.HW)                                   \
+                  ? *reinterpret_cast<const f32x4*>(xb + (long)(c0 + row) * g.HW + p)                \
+                  : zero4;                                                                           \
+    }                                                                                                \
+  }
+  const int nchunks = (g.Cin + KC1 - 1) / KC1;
+  CN_G1_PREFETCH(0);
+  for (int ch = 0; ch < nchunks; ++ch) {
+    __syncthreads();
+#pragma unroll
+    for (int k = 0; k < NA; ++k) *reinterpret_cast<f32x4*>(a_lds + (tid + k * 256) * 4) = ra[k];
+#pragma unroll
+    for (int k = 0; k < NB; ++k)
+      if (tid + k * 256 < KC1 * MT / 4) *reinterpret_cast<f32x4*>(b_lds + (tid + k * 256) * 4) = rb[k];
+    __syncthreads();
+    if (ch + 1 < nchunks) CN_G1_PREFETCH((ch + 1) * KC1);
+    const float* ap = a_lds + half * NT + wn * 32 + l31;
+    const float* bp = b_lds + half * MT + l31;
+#pragma unroll
+    for (int k2 = 0; k2 < KC1 / 2; ++k2) {
+      const float av = ap[k2 * 2 * NT];
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm)
+        acc[tm] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[k2 * 2 * MT + tm * 32], acc[tm], 0, 0, 0);
+    }
+  }
+#undef CN_G1_PREFETCH
+  float* yb = y + (long)b * g.ybs;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int co = n0 + wn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+    if (co < g.Cout) {
+      const float bv = bias != nullptr ? bias[co] : 0.f;
+#pragma unroll
+      for (int tm = 0; tm < TM; ++tm) {
+        const int p = p0 + tm * 32 + l31;
+        if (p < g.HW) {
+          float* dst = yb + (long)co * g.HW + p;
+          const float v = acc[tm][r] + bv;
+          *dst = g.accumulate ? *dst + v : v;
+        }
+      }
+    }
+  }
+}
+
+// Returns CN_ERR_ARG when the shape is not for this kernel (the caller then takes the tap kernels).
+static int cn_conv1x1_launch(const float* x, long xbs, const float* wp, const float* bias, float* y, long ybs, int B,
+                             int Cin, int HW, int Cout, int accumulate, hipStream_t stream) {
+  if ((HW & 3) || (xbs & 3) || (reinterpret_cast<uintptr_t>(x) & 15)) return CN_ERR_ARG;
+  CnGemm1x1 g = {};
+  g.B = B; g.Cin = Cin; g.Cout = Cout; g.HW = HW; g.xbs = xbs; g.ybs = ybs; g.accumulate = accumulate;
+  g.Kpad = cn_conv_kpad(Cin);
+  g.Npad = cn_conv_npad(Cout);
+  if (cn_pick_nt(Cout) != 128) return CN_ERR_ARG;
+  g.grid_y = (Cout + 127) / 128;
+  // pixel tile: 160 or 128, whichever needs fewer (rounds x tile) at 512 resident blocks
+  const long t160 = (long)B * ((HW + 159) / 160) * g.grid_y, t128 = (long)B * ((HW + 127) / 128) * g.grid_y;
+  const bool use160 = ((t160 + 511) / 512) * 160 <= ((t128 + 511) / 512) * 128;
+  const long blocks = use160 ? t160 : t128;
+  if (blocks < 256) return CN_ERR_ARG;  // small launches need the K split of the tap kernels
+  g.tiles_per_img = use160 ? (HW + 159) / 160 : (HW + 127) / 128;
+  g.grid_x = B * g.tiles_per_img;
+  const double flops = 2.0 * B * HW * (double)Cout * Cin;
+  cn_prof_desc("gemm1x1<%d> B%d %d->%d HW%d grid%dx%d", use160 ? 5 : 4, B, Cin, Cout, HW, g.grid_x, g.grid_y);
+  cn_prof_before(stream);
+  if (use160)
+    hipLaunchKernelGGL((cn_conv1x1_kernel<5>), dim3(cn_xcd_grid(blocks)), dim3(256), 0, stream, x, wp, bias, y, g);
+  else
+    hipLaunchKernelGGL((cn_conv1x1_kernel<4>), dim3(cn_xcd_grid(blocks)), dim3(256), 0, stream, x, wp, bias, y, g);
+  cn_prof_after(stream, 0, flops);
+  return cn_check_launch();
+}
+
 // ---- opt-in autotuning (cn_conv_set_autotune): the first overwriting launch of each distinct shape times the
 // (tile config x K split) candidates with HIP events on the launch stream and the winner is cached for the
 // process (accumulating launches of the same shape reuse it). Off by default: launches then never synchronise.
@@ -1006,6 +1130,11 @@ static int cn_gather_conv_g(int G, const float* const* xs, long xbs, const float
                             const int* dils, int accumulate, hipStream_t stream) {
   if (KH * KW > CN_MAX_TAPS || stride < 1) return CN_ERR_ARG;
   if (Hout <= 0 || Wout <= 0) return CN_OK;
+  if (G == 1 && KH == 1 && KW == 1 && stride == 1 && pads[0] == 0 && Hout == Hin && Wout == Win) {
+    const int r1 = cn_conv1x1_launch(xs[0], xbs, wps[0], biases ? biases[0] : nullptr, ys[0], ybs, B, Cin, Hin * Win,
+                                     Cout, accumulate, stream);
+    if (r1 != CN_ERR_ARG) return r1;
+  }
   CnConvGeom g = {};
   const int rc = cn_set_groups(g, G, xs, wps, biases, ys);
   if (rc != CN_OK) return rc;
@@ -1055,6 +1184,11 @@ static int cn_scatter_conv_g(int G, const float* const* srcs, long sbs, const fl
                              int Ws, int Cdst, int Ho, int Wo, int KH, int KW, int stride, const int* pads,
                              const int* dils, int accumulate, hipStream_t stream) {
   if (KH * KW > CN_MAX_TAPS || stride < 1 || G * stride * stride > CN_MAX_CLASSES) return CN_ERR_ARG;
+  if (G == 1 && KH == 1 && KW == 1 && stride == 1 && pads[0] == 0 && Ho == Hs && Wo == Ws) {
+    const int r1 = cn_conv1x1_launch(srcs[0], sbs, wps[0], biases ? biases[0] : nullptr, outs[0], obs, B, Csrc,
+                                     Hs * Ws, Cdst, accumulate, stream);
+    if (r1 != CN_ERR_ARG) return r1;
+  }
   CnConvGeom g = {};
   const int rc = cn_set_groups(g, G, srcs, wps, biases, outs);
   if (rc != CN_OK) return rc;

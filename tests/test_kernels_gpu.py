@@ -66,6 +66,8 @@ CONV_CASES = [
     (2, 16, 28, 28, 16, 3, 1, 2, 2, False),   # true dilated conv
     (1, 130, 9, 11, 140, 3, 1, 1, 1, True),   # ragged channels, non-square
     (3, 24, 100, 100, 32, 3, 1, 1, 1, False), # BASELINE spatial size
+    (4, 48, 100, 100, 256, 1, 1, 0, 1, True),   # large 1x1: the dedicated GEMM kernel (fwd and bwd-data)
+    (8, 130, 50, 50, 200, 1, 1, 0, 1, False),   # same, ragged channels
 ]
 
 
