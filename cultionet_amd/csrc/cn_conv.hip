@@ -637,7 +637,7 @@ struct CnChoice { int cfg, splits, cps; double cost; };
 // Cost model, in units of (one 9-tap K-chunk of one pixel row of a 128-cout tile) = 7.5 us / 128, calibrated on the
 // K-split sweeps of tools/ksplit.py (128->128 at 25^2 / 50^2, 256->256 at 13^2; within ~10 % for 1..8 splits):
 //   a block alone on its CU runs a chunk in ~MT units, two co-resident blocks in ~1.56 MT each (they share the
-//   SIMDs' MFMA pipes); staging + barriers are ~15 % of a 9-tap chunk and do not shrink with fewer taps; every
+//   SIMDs' MFMA pipes); staging + barriers are ~1/3 of a 9-tap chunk and do not shrink with fewer taps; every
 //   round of blocks pays a fixed prologue/epilogue of ~240 units (14 us); a K-split adds the reduce launch (~140
 //   units) plus writing and re-reading the partial slices (mostly L2 / Infinity-Cache resident: ~8 TB/s). 512 blocks fit the chip at once (2 per CU).
 static double cn_launch_cost(long blocks, int cps, double chunk_units, int splits, double out_elems) {
@@ -685,7 +685,7 @@ static CnChoice cn_choose(const CnConvGeom& g0, const int* mts, int ncfg, int NT
     if (max_splits > ws_cap) max_splits = ws_cap < 1 ? 1 : (int)ws_cap;
     // average taps per tile over the classes (parity classes of a strided scatter have 0..4 of the 9 taps)
     const double taps = p.total_tiles > 0 ? p.flops / (2.0 * g0.Cout * g0.Cin * (double)mts[i] * p.total_tiles) : 9.0;
-    const double chunk_units = (double)mts[i] * NT / 128.0 * (0.15 + 0.85 * (taps < 9.0 ? taps : 9.0) / 9.0);
+    const double chunk_units = (double)mts[i] * NT / 128.0 * (0.34 + 0.66 * (taps < 9.0 ? taps : 9.0) / 9.0);
     for (int sp = 1; sp <= max_splits; ++sp) {
       if (forced && sp != (forced > max_splits ? max_splits : forced)) continue;
       const int cps = (nchunks + sp - 1) / sp;

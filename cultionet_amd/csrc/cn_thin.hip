@@ -251,6 +251,23 @@ __device__ __forceinline__ void cn_thin_stage_weights(float* wl, int Cq, int Cin
   }
 }
 
+// out[ci][RS] = the NO*9 weights of input channel ci in (o, t) order, zero padded: the layout the ks kernels
+// consume. One tiny launch per call; without it every block gathers the 41 KB itself through a chain of dependent
+// global loads, which was most of the kernels' time.
+template <int NG, int CP>
+__global__ __launch_bounds__(256) void cn_thin_pack_kernel(const float* __restrict__ w0, const float* __restrict__ w1,
+                                                          const float* __restrict__ w2, float* __restrict__ out,
+                                                          int Cin) {
+  constexpr int NO = NG * CP, RS = (NO * 9 + 3) / 4 * 4;
+  const int idx = blockIdx.x * 256 + threadIdx.x;
+  if (idx >= Cin * RS) return;
+  const int ci = idx / RS, r = idx - ci * RS;
+  const int o = r / 9, t = r - o * 9;
+  const int g = o / CP, c = o - g * CP;
+  const float* wg = g == 0 ? w0 : (g == 1 ? w1 : w2);
+  out[idx] = r < NO * 9 ? wg[((long)c * Cin + ci) * 9 + t] : 0.f;
+}
+
 template <int NG, int CP>
 __global__ __launch_bounds__(256) void cn_thin_fwd_ks_kernel(const float* __restrict__ x, long xbs,
                                                             const float* __restrict__ w0,
@@ -259,11 +276,14 @@ __global__ __launch_bounds__(256) void cn_thin_fwd_ks_kernel(const float* __rest
                                                             const float* __restrict__ b0,
                                                             const float* __restrict__ b1,
                                                             const float* __restrict__ b2, float* __restrict__ y,
-                                                            long ybs, int Cin, int H, int W, int dil, int Cq, int B) {
+                                                            long ybs, int Cin, int H, int W, int dil, int Cq, int B,
+                                                            const float* __restrict__ wpk) {
   constexpr int NO = NG * CP, RS = (NO * 9 + 3) / 4 * 4;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* wl = sm;                   // [4][Cq][RS]
-  float* red = sm + 4 * Cq * RS;    // [4][NO][64]
+  // wpk != NULL: weights pre-packed [Cin][RS] in global memory (read one dword per lane, L1/L2 resident);
+  // else staged by this block into LDS [4][Cq][RS]
+  float* wl = sm;
+  float* red = wpk ? sm : sm + 4 * Cq * RS;  // [4][NO][64]
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int HW = H * W;
   int bx, by, bz;
@@ -274,8 +294,10 @@ __global__ __launch_bounds__(256) void cn_thin_fwd_ks_kernel(const float* __rest
   const int pc = live ? pix : 0;
   const int oy = pc / W, ox = pc - oy * W;
   const Taps tp = cn_thin_taps(oy, ox, H, W, dil, 1);
-  cn_thin_stage_weights<NG, CP>(wl, Cq, Cin, w0, w1, w2);
-  __syncthreads();
+  if (!wpk) {
+    cn_thin_stage_weights<NG, CP>(wl, Cq, Cin, w0, w1, w2);
+    __syncthreads();
+  }
   const float* xb = x + (long)by * xbs;
   float acc[NO];
 #pragma unroll
@@ -295,14 +317,20 @@ __global__ __launch_bounds__(256) void cn_thin_fwd_ks_kernel(const float* __rest
 #pragma unroll
     for (int u = 0; u < U; ++u) {
       if (c0 + u < Cq) {
-        const f32x4* wp = reinterpret_cast<const f32x4*>(wl + (wid * Cq + c0 + u) * RS);
-        f32x4 wv[RS / 4];
-#pragma unroll
-        for (int j = 0; j < RS / 4; ++j) wv[j] = wp[j];
+        // wave-uniform weights: one dword per lane out of LDS + v_readlane (an LDS broadcast of all RS weights to
+        // all 64 lanes made this kernel LDS-bandwidth-bound)
+        const int cw = wid * Cq + c0 + u;
+        const float* wrow = wpk ? wpk + (long)(cw < Cin ? cw : 0) * RS : wl + cw * RS;
+        const bool wok = !wpk || cw < Cin;  // packed rows exist for real channels only
+        const int wa = wok ? __float_as_int(wrow[lane]) : 0;
+        const int wb = wok ? __float_as_int(wrow[64 + (lane < RS - 64 ? lane : 0)]) : 0;
 #pragma unroll
         for (int o = 0; o < NO; ++o)
 #pragma unroll
-          for (int t = 0; t < 9; ++t) acc[o] = fmaf(xv[u][t], wv[(o * 9 + t) >> 2][(o * 9 + t) & 3], acc[o]);
+          for (int t = 0; t < 9; ++t) {
+            const int i = o * 9 + t;
+            acc[o] = fmaf(xv[u][t], __int_as_float(__builtin_amdgcn_readlane(i < 64 ? wa : wb, i & 63)), acc[o]);
+          }
       }
     }
   }
@@ -327,10 +355,11 @@ __global__ __launch_bounds__(256) void cn_thin_bwd_data_ks_kernel(const float* _
                                                                  const float* __restrict__ w1,
                                                                  const float* __restrict__ w2,
                                                                  float* __restrict__ dx, long dxbs, int Cin, int H,
-                                                                 int W, int dil, int accumulate, int Cq, int B) {
+                                                                 int W, int dil, int accumulate, int Cq, int B,
+                                                                 const float* __restrict__ wpk) {
   constexpr int NO = NG * CP, RS = (NO * 9 + 3) / 4 * 4;
   extern __shared__ __attribute__((aligned(16))) float sm[];
-  float* wl = sm;  // [4][Cq][RS]
+  float* wl = sm;  // [4][Cq][RS] (only without pre-packed weights)
   const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
   const int HW = H * W;
   int bx, by, bz;
@@ -341,7 +370,7 @@ __global__ __launch_bounds__(256) void cn_thin_bwd_data_ks_kernel(const float* _
   const int pc = live ? pix : 0;
   const int oy = pc / W, ox = pc - oy * W;
   const Taps tp = cn_thin_taps(oy, ox, H, W, dil, -1);
-  cn_thin_stage_weights<NG, CP>(wl, Cq, Cin, w0, w1, w2);
+  if (!wpk) cn_thin_stage_weights<NG, CP>(wl, Cq, Cin, w0, w1, w2);
   const float* dyb = dy + (long)by * dybs;
   f32x2 dv[RS / 2];  // (o, t) pairs in the order of the staged weights; the pad entries are zero
 #pragma unroll
@@ -355,16 +384,19 @@ __global__ __launch_bounds__(256) void cn_thin_bwd_data_ks_kernel(const float* _
   for (int cil = 0; cil < Cq; ++cil) {
     const int ci = wid * Cq + cil;
     if (ci >= Cin) break;
-    const f32x4* wp = reinterpret_cast<const f32x4*>(wl + (wid * Cq + cil) * RS);
-    f32x4 wv[RS / 4];
-#pragma unroll
-    for (int j = 0; j < RS / 4; ++j) wv[j] = wp[j];
+    // The RS weights of this channel are wave-uniform. Broadcasting them out of LDS (ds_read_b128, same address in
+    // every lane) costs the full 64-lane LDS bandwidth and made the kernel LDS-bound; instead every lane reads ONE
+    // weight (two conflict-free dword reads per channel) and v_readlane moves them to scalar registers.
+    const float* wrow = wpk ? wpk + (long)ci * RS : wl + (wid * Cq + cil) * RS;
+    const int wa = __float_as_int(wrow[lane]);
+    const int wb = __float_as_int(wrow[64 + (lane < RS - 64 ? lane : 0)]);
     f32x2 s2[2] = {{0.f, 0.f}, {0.f, 0.f}};  // packed fma (v_pk_fma_f32), two independent chains
 #pragma unroll
-    for (int j = 0; j < RS / 4; ++j) {
-      const f32x2 wlo = {wv[j][0], wv[j][1]}, whi = {wv[j][2], wv[j][3]};
-      s2[0] = __builtin_elementwise_fma(dv[2 * j], wlo, s2[0]);
-      s2[1] = __builtin_elementwise_fma(dv[2 * j + 1], whi, s2[1]);
+    for (int j = 0; j < RS / 2; ++j) {
+      const int i0 = 2 * j, i1 = 2 * j + 1;
+      const f32x2 w2 = {__int_as_float(__builtin_amdgcn_readlane(i0 < 64 ? wa : wb, i0 & 63)),
+                        __int_as_float(__builtin_amdgcn_readlane(i1 < 64 ? wa : wb, i1 & 63))};
+      s2[j & 1] = __builtin_elementwise_fma(dv[j], w2, s2[j & 1]);
     }
     const float r = (s2[0][0] + s2[0][1]) + (s2[1][0] + s2[1][1]);
     if (live) {
@@ -397,7 +429,7 @@ int cn_thin_cfg(int nsets, int cout_per_set, int grouped) {
 // Returns CN_ERR_ARG for (nsets, cout_per_set, grouped) outside {(3,3,0), (3,1,1), (1,3,0), (1,1,0)}.
 extern "C" int cn_thin_conv3x3_fwd_f32(const float* x, long xbs, const float* const* ws, const float* const* biases,
                                        float* y, long ybs, int B, int Cin, int H, int W, int nsets, int cout_per_set,
-                                       int grouped, int dil, void* stream) {
+                                       int grouped, int dil, float* wpack, void* stream) {
   const int cfg = cn_thin_cfg(nsets, cout_per_set, grouped);
   if (cfg < 0 || dil < 1 || Cin < 1) return CN_ERR_ARG;
   if (B <= 0 || H <= 0 || W <= 0) return CN_OK;
@@ -407,10 +439,16 @@ extern "C" int cn_thin_conv3x3_fwd_f32(const float* x, long xbs, const float* co
     for (int i = 0; i < nsets; ++i) b[i] = biases[i];
   if (cfg == 0 && Cin >= 16) {
     const int Cq = (Cin + 3) / 4;
-    const size_t lds = sizeof(float) * (size_t)(4 * Cq * 84 + 4 * 9 * 64);
+    // wpack (Cin * 84 floats): the weights are packed once per call and read from global memory; without it every
+    // block stages them into LDS itself
+    const size_t lds = sizeof(float) * (size_t)((wpack ? 0 : 4 * Cq * 84) + 4 * 9 * 64);
     if (lds <= 64 * 1024) {
+      if (wpack)
+        hipLaunchKernelGGL((cn_thin_pack_kernel<3, 3>), dim3(cn_cdiv((long)Cin * 84, 256)), dim3(256), 0,
+                           (hipStream_t)stream, w[0], w[1], w[2], wpack, Cin);
       hipLaunchKernelGGL((cn_thin_fwd_ks_kernel<3, 3>), dim3(cn_xcd_grid((long)cn_cdiv((long)H * W, 64) * B)), dim3(256), lds,
-                         (hipStream_t)stream, x, xbs, w[0], w[1], w[2], b[0], b[1], b[2], y, ybs, Cin, H, W, dil, Cq, B);
+                         (hipStream_t)stream, x, xbs, w[0], w[1], w[2], b[0], b[1], b[2], y, ybs, Cin, H, W, dil, Cq, B,
+                         (const float*)wpack);
       return cn_check_launch();
     }
   }
@@ -425,17 +463,21 @@ extern "C" int cn_thin_conv3x3_fwd_f32(const float* x, long xbs, const float* co
 
 extern "C" int cn_thin_conv3x3_bwd_data_f32(const float* dy, long dybs, const float* const* ws, float* dx, long dxbs,
                                             int B, int Cin, int H, int W, int nsets, int cout_per_set, int grouped,
-                                            int dil, int accumulate, void* stream) {
+                                            int dil, int accumulate, float* wpack, void* stream) {
   const int cfg = cn_thin_cfg(nsets, cout_per_set, grouped);
   if (cfg < 0 || dil < 1 || Cin < 1) return CN_ERR_ARG;
   if (B <= 0 || H <= 0 || W <= 0) return CN_OK;
   const float* w[3] = {ws[0], nsets > 1 ? ws[1] : nullptr, nsets > 2 ? ws[2] : nullptr};
   if (cfg == 0 && Cin >= 16) {
     const int Cq = (Cin + 3) / 4;
-    const size_t lds = sizeof(float) * (size_t)(4 * Cq * 84);
+    const size_t lds = sizeof(float) * (size_t)(wpack ? 0 : 4 * Cq * 84);
     if (lds <= 64 * 1024) {
+      if (wpack)
+        hipLaunchKernelGGL((cn_thin_pack_kernel<3, 3>), dim3(cn_cdiv((long)Cin * 84, 256)), dim3(256), 0,
+                           (hipStream_t)stream, w[0], w[1], w[2], wpack, Cin);
       hipLaunchKernelGGL((cn_thin_bwd_data_ks_kernel<3, 3>), dim3(cn_xcd_grid((long)cn_cdiv((long)H * W, 64) * B)), dim3(256), lds,
-                         (hipStream_t)stream, dy, dybs, w[0], w[1], w[2], dx, dxbs, Cin, H, W, dil, accumulate, Cq, B);
+                         (hipStream_t)stream, dy, dybs, w[0], w[1], w[2], dx, dxbs, Cin, H, W, dil, accumulate, Cq, B,
+                         (const float*)wpack);
       return cn_check_launch();
     }
   }

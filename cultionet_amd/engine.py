@@ -972,8 +972,9 @@ def thin_conv3x3(x: Var, mods: T.Sequence, grouped: bool, dilation: int = 1,
     btab = _ptr_table([b.data_ptr() for b in bs]) if has_bias else None
     y = out if out is not None else _new((B, n * CP, H, W), xt)
     g = 1 if grouped else 0
+    wpk = _new((Cin * 84,), xt) if (n, CP, g) == (3, 3, 0) and Cin >= 16 else None  # per-call packed weights
     _lib.call("cn_thin_conv3x3_fwd_f32", xt.data_ptr(), bstride(xt), wtab, btab, y.data_ptr(), bstride(y), B, Cin, H, W,
-              n, CP, g, dilation, _stream())
+              n, CP, g, dilation, wpk.data_ptr() if wpk is not None else None, _stream())
     yv = Var(y, tape.enabled)
     if tape.enabled:
         store = current_store()
@@ -994,7 +995,7 @@ def thin_conv3x3(x: Var, mods: T.Sequence, grouped: bool, dilation: int = 1,
             if x.req:
                 dx, acc = grad_buffer(x)
                 _lib.call("cn_thin_conv3x3_bwd_data_f32", dy.data_ptr(), bstride(dy), wtab, dx.data_ptr(), bstride(dx),
-                          B, Cin, H, W, n, CP, g, dilation, acc, s)
+                          B, Cin, H, W, n, CP, g, dilation, acc, wpk.data_ptr() if wpk is not None else None, s)
             yv.grad = None
 
         tape.add(bwd, tuple(ws) + tuple(b for b in bs if b is not None))

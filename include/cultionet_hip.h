@@ -115,13 +115,14 @@ int cn_conv2d_bwd_weight_grouped_f32(int G, const float* const* xs, long xbs, co
  *   grouped != 0: set g sees channels [g*Cin, (g+1)*Cin) of an nsets*Cin-channel x
  * ws / biases / dws: HOST arrays of nsets device pointers. Supported (nsets, cout_per_set, grouped):
  * (3,3,0) (3,1,1) (1,3,0) (1,1,0); anything else returns CN_ERR_ARG (use cn_conv2d_*). padding == dil.
+ * wpack (optional, Cin * 84 floats): scratch for the per-call packed weights of the wide (3,3,0) layers.
  * bwd_weight ACCUMULATES into dws. */
 int cn_thin_conv3x3_fwd_f32(const float* x, long xbs, const float* const* ws, const float* const* biases /*nullable*/,
                             float* y, long ybs, int B, int Cin, int H, int W, int nsets, int cout_per_set,
-                            int grouped, int dil, void* stream);
+                            int grouped, int dil, float* wpack /*nullable*/, void* stream);
 int cn_thin_conv3x3_bwd_data_f32(const float* dy, long dybs, const float* const* ws, float* dx, long dxbs, int B,
                                  int Cin, int H, int W, int nsets, int cout_per_set, int grouped, int dil,
-                                 int accumulate, void* stream);
+                                 int accumulate, float* wpack /*nullable*/, void* stream);
 int cn_thin_conv3x3_bwd_weight_f32(const float* x, long xbs, const float* dy, long dybs, float* const* dws, int B,
                                    int Cin, int H, int W, int nsets, int cout_per_set, int grouped, int dil,
                                    void* stream);
