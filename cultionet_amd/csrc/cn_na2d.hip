@@ -58,22 +58,27 @@ __global__ __launch_bounds__(256) void cn_na2d_fwd_kernel(const float* __restric
   const float* qp = qkv + b * qbs + (long)(h * D) * HW;
   const float* kp = qp + (long)C * HW;
   const float* vp = kp + (long)C * HW;
-  float q[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) q[d] = qp[(long)d * HW + p] * scale;
-  float lg[NA_KK];
-  float mx = -INFINITY;
+  // Loop order: channel plane outermost, the 9 taps inside. A tap-outer order revisits each of the D planes once
+  // per tap with the other D-1 planes in between (reuse distance D * ~1.3 KB > the 32 KB L1): every tap then
+  // misses to L2 and the kernel moves 9x the k / v bytes. Plane-outer touches a plane's few lines 9 times in a row.
+  int kpix[NA_KK];
 #pragma unroll
   for (int i = 0; i < NA_K; ++i)
 #pragma unroll
-    for (int j = 0; j < NA_K; ++j) {
-      const int kpix = (sy + i * dil) * W + sx + j * dil;
-      float s = 0.f;
+    for (int j = 0; j < NA_K; ++j) kpix[i * NA_K + j] = (sy + i * dil) * W + sx + j * dil;
+  float lg[NA_KK];
 #pragma unroll
-      for (int d = 0; d < D; ++d) s += q[d] * kp[(long)d * HW + kpix];
-      lg[i * NA_K + j] = s;
-      mx = fmaxf(mx, s);
-    }
+  for (int t = 0; t < NA_KK; ++t) lg[t] = 0.f;
+#pragma unroll 4
+  for (int d = 0; d < D; ++d) {
+    const float qd = qp[(long)d * HW + p] * scale;
+    const float* kd = kp + (long)d * HW;
+#pragma unroll
+    for (int t = 0; t < NA_KK; ++t) lg[t] += qd * kd[kpix[t]];
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NA_KK; ++t) mx = fmaxf(mx, lg[t]);
   float den = 0.f;
 #pragma unroll
   for (int t = 0; t < NA_KK; ++t) {
@@ -88,21 +93,15 @@ __global__ __launch_bounds__(256) void cn_na2d_fwd_kernel(const float* __restric
     if (attn) ap[(long)t * HW] = lg[t];
     lg[t] *= na_keep(dthresh, dscale, dseed, (long)b * heads + h, t, HW, p);
   }
-  float o[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) o[d] = 0.f;
-#pragma unroll
-  for (int i = 0; i < NA_K; ++i)
-#pragma unroll
-    for (int j = 0; j < NA_K; ++j) {
-      const int kpix = (sy + i * dil) * W + sx + j * dil;
-      const float pr = lg[i * NA_K + j];
-#pragma unroll
-      for (int d = 0; d < D; ++d) o[d] += pr * vp[(long)d * HW + kpix];
-    }
   float* op = out + b * obs + (long)(h * D) * HW + p;
+#pragma unroll 4
+  for (int d = 0; d < D; ++d) {
+    const float* vd = vp + (long)d * HW;
+    float o = 0.f;
 #pragma unroll
-  for (int d = 0; d < D; ++d) op[(long)d * HW] = o[d];
+    for (int t = 0; t < NA_KK; ++t) o += lg[t] * vd[kpix[t]];
+    op[(long)d * HW] = o;
+  }
 }
 
 // Backward, query side: dP = dOut.v ; dS = P*(dP - sum P dP) ; dq = scale * sum dS*k ; saves dS.
@@ -124,47 +123,45 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_q_kernel(const float* __restr
   const float* kp = qkv + b * qbs + (long)(C + h * D) * HW;
   const float* vp = kp + (long)C * HW;
   const float* dop = dout + b * dobs + (long)(h * D) * HW + p;
-  float go[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) go[d] = dop[(long)d * HW];
-  const float* ap = attn + ((long)(b * heads + h) * NA_KK) * HW + p;
-  float pr[NA_KK], dp[NA_KK];
-  float dot = 0.f;
+  int kpix[NA_KK];
 #pragma unroll
   for (int i = 0; i < NA_K; ++i)
 #pragma unroll
-    for (int j = 0; j < NA_K; ++j) {
-      const int t = i * NA_K + j;
-      const int kpix = (sy + i * dil) * W + sx + j * dil;
-      float s = 0.f;
+    for (int j = 0; j < NA_K; ++j) kpix[i * NA_K + j] = (sy + i * dil) * W + sx + j * dil;
+  const float* ap = attn + ((long)(b * heads + h) * NA_KK) * HW + p;
+  float pr[NA_KK], dp[NA_KK];
 #pragma unroll
-      for (int d = 0; d < D; ++d) s += go[d] * vp[(long)d * HW + kpix];
-      pr[t] = ap[(long)t * HW];
-      s *= na_keep(dthresh, dscale, dseed, (long)b * heads + h, t, HW, p);
-      dp[t] = s;
-      dot += pr[t] * s;
-    }
+  for (int t = 0; t < NA_KK; ++t) dp[t] = 0.f;
+  // plane-outer (see the forward kernel): dP[t] = sum_d dOut[d] * v[d][tap t]
+#pragma unroll 4
+  for (int d = 0; d < D; ++d) {
+    const float gd = dop[(long)d * HW];
+    const float* vd = vp + (long)d * HW;
+#pragma unroll
+    for (int t = 0; t < NA_KK; ++t) dp[t] += gd * vd[kpix[t]];
+  }
+  float dot = 0.f;
+#pragma unroll
+  for (int t = 0; t < NA_KK; ++t) {
+    pr[t] = ap[(long)t * HW];
+    dp[t] *= na_keep(dthresh, dscale, dseed, (long)b * heads + h, t, HW, p);
+    dot += pr[t] * dp[t];
+  }
   float* dap = dattn + ((long)(b * heads + h) * NA_KK) * HW + p;
 #pragma unroll
   for (int t = 0; t < NA_KK; ++t) {
     dp[t] = pr[t] * (dp[t] - dot);  // dS
     dap[(long)t * HW] = dp[t];
   }
-  float dq[D];
-#pragma unroll
-  for (int d = 0; d < D; ++d) dq[d] = 0.f;
-#pragma unroll
-  for (int i = 0; i < NA_K; ++i)
-#pragma unroll
-    for (int j = 0; j < NA_K; ++j) {
-      const int kpix = (sy + i * dil) * W + sx + j * dil;
-      const float ds = dp[i * NA_K + j];
-#pragma unroll
-      for (int d = 0; d < D; ++d) dq[d] += ds * kp[(long)d * HW + kpix];
-    }
   float* dqp = dqkv + b * dqbs + (long)(h * D) * HW + p;
+#pragma unroll 4
+  for (int d = 0; d < D; ++d) {
+    const float* kd = kp + (long)d * HW;
+    float dq = 0.f;
 #pragma unroll
-  for (int d = 0; d < D; ++d) dqp[(long)d * HW] = dq[d] * scale;
+    for (int t = 0; t < NA_KK; ++t) dq += dp[t] * kd[kpix[t]];
+    dqp[(long)d * HW] = dq * scale;
+  }
 }
 
 // Backward, key side (gather form, deterministic): for key pixel (y,x) visit every query whose
