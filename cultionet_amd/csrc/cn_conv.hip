@@ -1181,10 +1181,12 @@ extern "C" int cn_conv2d_fwd_f32(const float* x, long xbs, const float* wp, cons
 // src [B,Csrc,Hs,Ws], out [B,Cdst,Ho,Wo]; wp packed [KH*KW][Kpad(Csrc)][Npad(Cdst)].
 static int cn_scatter_conv_g(int G, const float* const* srcs, long sbs, const float* const* wps,
                              const float* const* biases, float* const* outs, long obs, int B, int Csrc, int Hs,
-                             int Ws, int Cdst, int Ho, int Wo, int KH, int KW, int stride, const int* pads,
-                             const int* dils, int accumulate, hipStream_t stream) {
-  if (KH * KW > CN_MAX_TAPS || stride < 1 || G * stride * stride > CN_MAX_CLASSES) return CN_ERR_ARG;
-  if (G == 1 && KH == 1 && KW == 1 && stride == 1 && pads[0] == 0 && Ho == Hs && Wo == Ws) {
+                             int Ws, int Cdst, int Ho, int Wo, const int* khs, const int* kws, int stride,
+                             const int* pads, const int* dils, int accumulate, hipStream_t stream) {
+  if (stride < 1 || G * stride * stride > CN_MAX_CLASSES) return CN_ERR_ARG;
+  for (int i = 0; i < G; ++i)
+    if (khs[i] * kws[i] > CN_MAX_TAPS || khs[i] < 1 || kws[i] < 1) return CN_ERR_ARG;
+  if (G == 1 && khs[0] == 1 && kws[0] == 1 && stride == 1 && pads[0] == 0 && Ho == Hs && Wo == Ws) {
     const int r1 = cn_conv1x1_launch(srcs[0], sbs, wps[0], biases ? biases[0] : nullptr, outs[0], obs, B, Csrc,
                                      Hs * Ws, Cdst, accumulate, stream);
     if (r1 != CN_ERR_ARG) return r1;
@@ -1197,7 +1199,7 @@ static int cn_scatter_conv_g(int G, const float* const* srcs, long sbs, const fl
   g.accumulate = accumulate;
   int nc = 0;
   for (int gi = 0; gi < G; ++gi) {
-    const int pad = pads[gi], dil = dils[gi];
+    const int pad = pads[gi], dil = dils[gi], KH = khs[gi], KW = kws[gi];
     if (dil < 1) return CN_ERR_ARG;
     for (int py = 0; py < stride; ++py)
       for (int px = 0; px < stride; ++px) {
@@ -1230,7 +1232,7 @@ static int cn_scatter_conv_g(int G, const float* const* srcs, long sbs, const fl
 static int cn_scatter_conv(const float* src, long sbs, const float* wp, const float* bias, float* out, long obs,
                            int B, int Csrc, int Hs, int Ws, int Cdst, int Ho, int Wo, int KH, int KW,
                            int stride, int pad, int dil, int accumulate, hipStream_t stream) {
-  return cn_scatter_conv_g(1, &src, sbs, &wp, &bias, &out, obs, B, Csrc, Hs, Ws, Cdst, Ho, Wo, KH, KW, stride, &pad,
+  return cn_scatter_conv_g(1, &src, sbs, &wp, &bias, &out, obs, B, Csrc, Hs, Ws, Cdst, Ho, Wo, &KH, &KW, stride, &pad,
                            &dil, accumulate, stream);
 }
 
@@ -1264,19 +1266,20 @@ extern "C" int cn_conv2d_fwd_grouped_f32(int G, const float* const* xs, long xbs
 }
 
 // Grouped Conv2d backward-data; dxs all distinct, or all the same buffer (branches that share their input: the
-// G contributions are summed into it).
+// G contributions are summed into it). Kernel sizes are per group (khs / kws), so the 1x1 skip convolution of a
+// ResidualAConv joins its 3x3 branches in the same launch.
 extern "C" int cn_conv2d_bwd_data_grouped_f32(int G, const float* const* dys, long dybs, const float* const* wps_t,
                                               float* const* dxs, long dxbs, int B, int Cin, int Hin, int Win,
-                                              int Cout, int KH, int KW, int stride, const int* pads,
+                                              int Cout, const int* khs, const int* kws, int stride, const int* pads,
                                               const int* dils, int accumulate, void* stream) {
   if (G < 1 || G > CN_MAX_GROUPS) return CN_ERR_ARG;
-  const int Hout = (Hin + 2 * pads[0] - dils[0] * (KH - 1) - 1) / stride + 1;
-  const int Wout = (Win + 2 * pads[0] - dils[0] * (KW - 1) - 1) / stride + 1;
+  const int Hout = (Hin + 2 * pads[0] - dils[0] * (khs[0] - 1) - 1) / stride + 1;
+  const int Wout = (Win + 2 * pads[0] - dils[0] * (kws[0] - 1) - 1) / stride + 1;
   for (int i = 1; i < G; ++i)
-    if ((Hin + 2 * pads[i] - dils[i] * (KH - 1) - 1) / stride + 1 != Hout ||
-        (Win + 2 * pads[i] - dils[i] * (KW - 1) - 1) / stride + 1 != Wout)
+    if ((Hin + 2 * pads[i] - dils[i] * (khs[i] - 1) - 1) / stride + 1 != Hout ||
+        (Win + 2 * pads[i] - dils[i] * (kws[i] - 1) - 1) / stride + 1 != Wout)
       return CN_ERR_ARG;
-  return cn_scatter_conv_g(G, dys, dybs, wps_t, nullptr, dxs, dxbs, B, Cout, Hout, Wout, Cin, Hin, Win, KH, KW,
+  return cn_scatter_conv_g(G, dys, dybs, wps_t, nullptr, dxs, dxbs, B, Cout, Hout, Wout, Cin, Hin, Win, khs, kws,
                            stride, pads, dils, accumulate, (hipStream_t)stream);
 }
 

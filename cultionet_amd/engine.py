@@ -496,9 +496,16 @@ def conv2d_group(xs: T.Sequence[Var], mods: T.Sequence, paddings: T.Sequence[int
                 dybs = {bstride(yvs[i].grad) for i in todo}
                 dxbs = {bstride(d) for d, _ in bufs}
                 if len(todo) == G and len(accs) == 1 and len(dybs) == 1 and len(dxbs) == 1:
-                    _lib.call("cn_conv2d_bwd_data_grouped_f32", G, tab([yvs[i].grad.data_ptr() for i in todo]),
-                              dybs.pop(), tab([p.bwd.data_ptr() for p in pws]), tab([d.data_ptr() for d, _ in bufs]),
-                              dxbs.pop(), B, Cin, H, W, Cout, KH, KW, stride, pads_c, dils_c, accs.pop(), s)
+                    dyp = [yvs[i].grad.data_ptr() for i in todo]
+                    wpp = [p.bwd.data_ptr() for p in pws]
+                    dxp = [d.data_ptr() for d, _ in bufs]
+                    khs, kws, pds, dls = [KH] * G, [KW] * G, list(paddings), list(dilations)
+                    n = len(dyp)
+                    ptab = lambda ptrs: (ctypes.c_void_p * n)(*ptrs)
+                    itab = lambda v: (ctypes.c_int * n)(*v)
+                    _lib.call("cn_conv2d_bwd_data_grouped_f32", n, ptab(dyp), dybs.pop(), ptab(wpp), ptab(dxp),
+                              dxbs.pop(), B, Cin, H, W, Cout, itab(khs), itab(kws), stride, itab(pds), itab(dls),
+                              accs.pop(), s)
                 else:  # mixed accumulate flags / strides: conv by conv
                     first = True
                     for i, (d, a) in zip(todo, bufs):

@@ -99,9 +99,9 @@ int cn_conv2d_fwd_grouped_f32(int G, const float* const* xs, long xbs, const flo
                               int Hin, int Win, int Cout, int KH, int KW, int stride, const int* pads,
                               const int* dils, int accumulate, void* stream);
 int cn_conv2d_bwd_data_grouped_f32(int G, const float* const* dys, long dybs, const float* const* wps_t,
-                                   float* const* dxs, long dxbs, int B, int Cin, int Hin, int Win, int Cout, int KH,
-                                   int KW, int stride, const int* pads, const int* dils, int accumulate,
-                                   void* stream);
+                                   float* const* dxs, long dxbs, int B, int Cin, int Hin, int Win, int Cout,
+                                   const int* khs, const int* kws /* per group: a 1x1 skip conv may join 3x3 branches */,
+                                   int stride, const int* pads, const int* dils, int accumulate, void* stream);
 
 /* Grouped weight gradient (same padding / dilation for every group; xs may repeat one input). ACCUMULATES. */
 int cn_conv2d_bwd_weight_grouped_f32(int G, const float* const* xs, long xbs, const float* const* dys, long dybs,

@@ -652,9 +652,10 @@ def test_grouped_conv_launch(case):
         _close(ys[i], convs[i](xs[i]), 2e-5, f"y{i}")
     # bwd-data: distinct outputs, then all branches summed into one buffer
     dxs = [torch.empty(B, Cin, H, W, device=dev) for _ in range(G)]
+    k3 = (ctypes.c_int * G)(*([3] * G))
     _lib.call("cn_conv2d_bwd_data_grouped_f32", G, tab([d.data_ptr() for d in dys]), E.bstride(dys[0]),
               tab([p.bwd.data_ptr() for p in pws]), tab([d.data_ptr() for d in dxs]), E.bstride(dxs[0]), B, Cin, H, W,
-              Cout, 3, 3, 1, ints, ints, 0, s)
+              Cout, k3, k3, 1, ints, ints, 0, s)
     refs = []
     for i in range(G):
         xr = xs[i].clone().requires_grad_(True)
@@ -663,9 +664,25 @@ def test_grouped_conv_launch(case):
         _close(dxs[i], xr.grad, 1e-4, f"dx{i}")
     dsum = torch.empty(B, Cin, H, W, device=dev)
     _lib.call("cn_conv2d_bwd_data_grouped_f32", G, tab([d.data_ptr() for d in dys]), E.bstride(dys[0]),
-              tab([p.bwd.data_ptr() for p in pws]), tab([dsum.data_ptr()] * G), E.bstride(dsum), B, Cin, H, W, Cout, 3,
-              3, 1, ints, ints, 0, s)
+              tab([p.bwd.data_ptr() for p in pws]), tab([dsum.data_ptr()] * G), E.bstride(dsum), B, Cin, H, W, Cout, k3,
+              k3, 1, ints, ints, 0, s)
     _close(dsum, sum(refs), 1e-4, "dx sum")
+    if G < 4:  # a 1x1 conv of the same input joins the 3x3 branches (the RESA skip)
+        skip = nn.Conv2d(Cin, Cout, 1, bias=False).to(dev)
+        store2 = E.ParamStore(skip)
+        with E.using_store(store2):
+            spw = E.packed_conv(skip, True)
+        dys_s = _rand(B, Cout, H, W, seed=44).to(dev)
+        xr = xs[0].clone().requires_grad_(True)
+        skip(xr).backward(dys_s)
+        n = G + 1
+        tabn = lambda ptrs: (ctypes.c_void_p * n)(*ptrs)
+        _lib.call("cn_conv2d_bwd_data_grouped_f32", n, tabn([d.data_ptr() for d in dys] + [dys_s.data_ptr()]),
+                  E.bstride(dys[0]), tabn([p.bwd.data_ptr() for p in pws] + [spw.bwd.data_ptr()]),
+                  tabn([dsum.data_ptr()] * n), E.bstride(dsum), B, Cin, H, W, Cout, (ctypes.c_int * n)(*([3] * G + [1])),
+                  (ctypes.c_int * n)(*([3] * G + [1])), 1, (ctypes.c_int * n)(*(list(dils) + [0])),
+                  (ctypes.c_int * n)(*(list(dils) + [1])), 0, s)
+        _close(dsum, sum(refs) + xr.grad, 1e-4, "dx sum + 1x1 skip")
 
 
 def test_conv2d_splitk_without_workspace_uses_atomics():
