@@ -640,11 +640,14 @@ struct CnChoice { int cfg, splits, cps; double cost; };
 //   SIMDs' MFMA pipes); staging + barriers are ~1/3 of a 9-tap chunk and do not shrink with fewer taps; every
 //   round of blocks pays a fixed prologue/epilogue of ~240 units (14 us); a K-split adds the reduce launch (~140
 //   units) plus writing and re-reading the partial slices (mostly L2 / Infinity-Cache resident: ~8 TB/s). 512 blocks fit the chip at once (2 per CU).
-static double cn_launch_cost(long blocks, int cps, double chunk_units, int splits, double out_elems) {
-  const double F = 240.0, R = 140.0, CO = 1.56;
+static double cn_launch_cost(long blocks, int cps, double mt_units, int splits, double out_elems) {
+  // per-chunk cost: alone on the CU 36.7 + 0.614 MT', two co-resident blocks 30 + 1.19 MT' each (MT' = pixel tile
+  // scaled by NT/128 and taps/9); fitted to the (tile, split) sweeps of tools/kcfg.py on 128->128 at 50^2
+  const double F = 273.0, R = 170.0;
+  const double c1 = 36.7 + 0.614 * mt_units, c2 = 30.0 + 1.19 * mt_units;
   const long full = blocks / 512, rem = blocks % 512;
-  double c = full * (F + cps * chunk_units * CO);
-  if (rem > 0) c += F + cps * chunk_units * (rem > 256 ? CO : 1.0);
+  double c = full * (F + cps * c2);
+  if (rem > 0) c += F + cps * (rem > 256 ? c2 : c1);
   if (splits > 1) c += R + out_elems * 4.0 * (2.0 * splits + 1.0) / 8.0e6 * (128.0 / 7.5);
   return c;
 }
@@ -685,7 +688,7 @@ static CnChoice cn_choose(const CnConvGeom& g0, const int* mts, int ncfg, int NT
     if (max_splits > ws_cap) max_splits = ws_cap < 1 ? 1 : (int)ws_cap;
     // average taps per tile over the classes (parity classes of a strided scatter have 0..4 of the 9 taps)
     const double taps = p.total_tiles > 0 ? p.flops / (2.0 * g0.Cout * g0.Cin * (double)mts[i] * p.total_tiles) : 9.0;
-    const double chunk_units = (double)mts[i] * NT / 128.0 * (0.34 + 0.66 * (taps < 9.0 ? taps : 9.0) / 9.0);
+    const double chunk_units = (double)mts[i] * NT / 128.0 * (taps < 9.0 ? taps : 9.0) / 9.0;
     for (int sp = 1; sp <= max_splits; ++sp) {
       if (forced && sp != (forced > max_splits ? max_splits : forced)) continue;
       const int cps = (nchunks + sp - 1) / sp;
