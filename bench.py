@@ -137,6 +137,8 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29533")
         if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
             os.environ["NCCL_DEBUG"] = "WARN"  # RCCL's version banner goes to stdout; keep stdout to ONE JSON line
+        # RCCL logs (e.g. its rsmi warnings) default to stdout too: send them to stderr
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         from cultionet_amd.ddp import GradientAllReduce
 
@@ -229,9 +231,11 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(B, hidden, args.cpu_steps, args.cpu_threads)
-        print(json.dumps(out), flush=True)
     if use_dist:
         dist.destroy_process_group()
+    if rank == 0:
+        sys.stdout.flush()
+        print(json.dumps(out), flush=True)  # the ONE stdout line, after RCCL has been torn down
 
 
 if __name__ == "__main__":
