@@ -91,7 +91,8 @@ def cpu_baseline(batch: int, hidden: int, steps: int, threads: int = 0):
 
 # rocprof kernel-name prefixes behind each profiled kind (template instantiations of one kernel family)
 KIND_PATTERNS = {
-    0: ("cn_conv_igemm_vec_kernel<4, 1,", "cn_conv_igemm_vec_kernel<2, 2,", "cn_conv_igemm_kernel<2, 2,"),
+    0: ("cn_conv_igemm_vec_kernel<4, 1,", "cn_conv_igemm_vec_kernel<2, 2,", "cn_conv_igemm_kernel<2, 2,",
+        "cn_conv1x1_kernel<"),
     1: ("cn_conv_igemm_vec_kernel<1,", "cn_conv_igemm_kernel<1,"),
     2: ("cn_wgrad_vec_kernel<9,", "cn_wgrad_kernel<9>"),
     3: ("cn_wgrad_vec_kernel<1,", "cn_wgrad_kernel<1>"),
