@@ -1172,6 +1172,7 @@ static int cn_gather_conv(const float* x, long xbs, const float* wp, const float
 extern "C" int cn_conv2d_fwd_f32(const float* x, long xbs, const float* wp, const float* bias, float* y,
                                  long ybs, int B, int Cin, int Hin, int Win, int Cout, int KH, int KW,
                                  int stride, int pad, int dil, int accumulate, void* stream) {
+  if (stride < 1) return CN_ERR_ARG;  // before it is divided by
   const int Hout = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
   const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   return cn_gather_conv(x, xbs, wp, bias, y, ybs, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride, pad, dil,
@@ -1243,6 +1244,7 @@ static int cn_scatter_conv(const float* src, long sbs, const float* wp, const fl
 extern "C" int cn_conv2d_bwd_data_f32(const float* dy, long dybs, const float* wp_t, float* dx, long dxbs,
                                       int B, int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride,
                                       int pad, int dil, int accumulate, void* stream) {
+  if (stride < 1) return CN_ERR_ARG;  // before it is divided by
   const int Hout = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
   const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   return cn_scatter_conv(dy, dybs, wp_t, nullptr, dx, dxbs, B, Cout, Hout, Wout, Cin, Hin, Win, KH, KW, stride,
@@ -1258,6 +1260,7 @@ extern "C" int cn_conv2d_fwd_grouped_f32(int G, const float* const* xs, long xbs
                                          int Hin, int Win, int Cout, int KH, int KW, int stride, const int* pads,
                                          const int* dils, int accumulate, void* stream) {
   if (G < 1 || G > CN_MAX_GROUPS) return CN_ERR_ARG;
+  if (stride < 1) return CN_ERR_ARG;  // before it is divided by
   const int Hout = (Hin + 2 * pads[0] - dils[0] * (KH - 1) - 1) / stride + 1;
   const int Wout = (Win + 2 * pads[0] - dils[0] * (KW - 1) - 1) / stride + 1;
   for (int i = 1; i < G; ++i)
@@ -1276,6 +1279,7 @@ extern "C" int cn_conv2d_bwd_data_grouped_f32(int G, const float* const* dys, lo
                                               int Cout, const int* khs, const int* kws, int stride, const int* pads,
                                               const int* dils, int accumulate, void* stream) {
   if (G < 1 || G > CN_MAX_GROUPS) return CN_ERR_ARG;
+  if (stride < 1) return CN_ERR_ARG;  // before it is divided by
   const int Hout = (Hin + 2 * pads[0] - dils[0] * (khs[0] - 1) - 1) / stride + 1;
   const int Wout = (Win + 2 * pads[0] - dils[0] * (kws[0] - 1) - 1) / stride + 1;
   for (int i = 1; i < G; ++i)

@@ -767,6 +767,7 @@ extern "C" int cn_conv2d_bwd_weight_grouped_f32(int G, const float* const* xs, l
                                                 long dybs, float* const* dws, int B, int Cin, int Hin, int Win,
                                                 int Cout, int KH, int KW, int stride, int pad, int dil, float* ws,
                                                 long ws_floats, void* stream) {
+  if (stride < 1) return CN_ERR_ARG;  // before it is divided by
   const int Hout = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
   const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   return cn_wgrad_generic_g(G, dys, dybs, Cout, Hout, Wout, xs, xbs, Cin, Hin, Win, stride, KH, KW, dil, pad, dws, B,
@@ -777,6 +778,7 @@ extern "C" int cn_conv2d_bwd_weight_grouped_f32(int G, const float* const* xs, l
 extern "C" int cn_conv2d_bwd_weight_f32(const float* x, long xbs, const float* dy, long dybs, float* dw, int B,
                                         int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride, int pad,
                                         int dil, float* ws, long ws_floats, void* stream) {
+  if (stride < 1) return CN_ERR_ARG;  // before it is divided by
   const int Hout = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
   const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   return cn_wgrad_generic(dy, dybs, Cout, Hout, Wout, x, xbs, Cin, Hin, Win, stride, KH, KW, dil, pad, dw, B, ws,

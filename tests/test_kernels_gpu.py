@@ -822,3 +822,97 @@ def test_spatial_channel_attention(B, C, H, W):
     _close(ds, sr.grad, 1e-4, "dskip")
     for k in refg:
         _close(pg[k], refg[k], 1e-4, k)
+
+
+# ---------------------------------------------------------------------------
+# edge cases at the C ABI: empty batches, invalid arguments, tiny planes, run-to-run determinism of the forward
+# ---------------------------------------------------------------------------
+
+def test_empty_batch_and_invalid_arguments():
+    import ctypes
+    from cultionet_amd import engine as E, _lib
+
+    dev = _dev()
+    conv = nn.Conv2d(8, 8, 3, padding=1, bias=False).to(dev)
+    store = E.ParamStore(conv)
+    with E.using_store(store):
+        pw = E.packed_conv(conv, True)
+    x = torch.zeros(1, 8, 6, 6, device=dev)
+    y = torch.zeros(1, 8, 6, 6, device=dev)
+    s = E._stream()
+    lib = _lib.load()
+    # B == 0: nothing to do, success
+    assert lib.cn_conv2d_fwd_f32(x.data_ptr(), 288, pw.fwd.data_ptr(), None, y.data_ptr(), 288, 0, 8, 6, 6, 8, 3, 3, 1, 1,
+                                 1, 0, s) == 0
+    assert lib.cn_bn_act_fwd_f32(x.data_ptr(), 288, None, None, None, None, None, 0, y.data_ptr(), 288, None, None, None,
+                                 0, 8, 36, 1, ctypes.c_float(0.1), ctypes.c_float(1e-5), 1, s) == 0
+    # kernels larger than 3x3 / zero stride / too many groups are argument errors, not launches
+    assert lib.cn_conv2d_fwd_f32(x.data_ptr(), 288, pw.fwd.data_ptr(), None, y.data_ptr(), 288, 1, 8, 6, 6, 8, 5, 5, 1, 2,
+                                 1, 0, s) == -1
+    assert lib.cn_conv2d_fwd_f32(x.data_ptr(), 288, pw.fwd.data_ptr(), None, y.data_ptr(), 288, 1, 8, 6, 6, 8, 3, 3, 0, 1,
+                                 1, 0, s) == -1
+    tab = (ctypes.c_void_p * 5)(*([x.data_ptr()] * 5))
+    ints = (ctypes.c_int * 5)(*([1] * 5))
+    assert lib.cn_conv2d_fwd_grouped_f32(5, tab, 288, tab, None, tab, 288, 1, 8, 6, 6, 8, 3, 3, 1, ints, ints, 0, s) == -1
+    with pytest.raises(_lib.HipKernelError):
+        _lib.call("cn_thin_conv3x3_fwd_f32", x.data_ptr(), 288, tab, None, y.data_ptr(), 288, 1, 8, 6, 6, 2, 2, 0, 1,
+                  None, s)
+    torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("H,W", [(4, 4), (5, 7), (3, 16)])
+def test_tiny_planes(H, W):
+    """Planes smaller than one tile / one wave: conv (+ split-K), BN, LayerNorm, bilinear."""
+    from cultionet_amd import engine as E
+
+    class M(nn.Module):
+        def __init__(self):
+            super().__init__()
+            self.c = nn.Conv2d(40, 24, 3, padding=1, bias=True)
+            self.bn = nn.BatchNorm2d(24)
+            self.ln = nn.LayerNorm(24)
+
+    torch.manual_seed(71)
+    m = M()
+    x = _rand(2, 40, H, W, seed=72)
+    xr = x.clone().requires_grad_(True)
+    h = F.silu(m.bn(m.c(xr)))
+    h = m.ln(h.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+    yr = F.interpolate(h, size=(H + 1, W + 2), mode="bilinear", align_corners=True)
+    dy = _rand(*yr.shape, seed=73)
+    yr.backward(dy)
+    ref = {k: p.grad.clone() for k, p in m.named_parameters()}
+
+    def fn(v):
+        h = E.bn_act(E.conv2d(v, m.c, 1, 1, 1), m.bn, E.ACT_SILU)
+        return E.resize_bilinear(E.layer_norm_c(h, m.ln), (H + 1, W + 2))
+
+    y, (dx,), pg = _engine_run(m, fn, [x], dy)
+    _close(y, yr, 2e-5, "y")
+    _close(dx, xr.grad, 2e-4, "dx")
+    for k in ref:
+        _close(pg[k], ref[k], 2e-4, k)
+
+
+def test_forward_is_bit_reproducible(golden_dir):
+    """Two eval forwards of the same model and batch give bit-identical outputs (no atomics on the forward path
+    with the split-K workspace bound), hence identical > 0.5 masks."""
+    import numpy as np
+    import os
+    from cultionet_amd import synthetic as O
+    from cultionet_amd.data import Data
+    from cultionet_amd.lightning import CultionetLitModel
+
+    dev = _dev()
+    lit = CultionetLitModel(in_channels=3, in_time=12, hidden_channels=8, dropout=0.0)
+    model = lit.cultionet_model.mask_model
+    model.load_state_dict(O.seeded_state_dict(model.state_dict()))
+    lit = lit.to(dev).eval()
+    x, y, bdist = O.seeded_batch(2, height=28, width=28, seed=5)
+    batch = Data(x=x.to(dev), y=y.to(dev), bdist=bdist.to(dev), lon=torch.zeros(2, device=dev),
+                 lat=torch.zeros(2, device=dev))
+    with torch.no_grad():
+        a = {k: v.clone() for k, v in lit(batch).items() if v is not None}
+        b = {k: v.clone() for k, v in lit(batch).items() if v is not None}
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
