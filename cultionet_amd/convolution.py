@@ -43,9 +43,11 @@ class ConvTranspose2d(nn.Module):
         self.stride, self.padding = stride, padding
         self.up_conv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding)
 
-    def forward(self, x: E.Var, size) -> E.Var:
+    def forward(self, x: E.Var, size, out: T.Optional[torch.Tensor] = None) -> E.Var:
         y = E.conv_transpose2d(x, self.up_conv, self.stride, self.padding)
-        return E.resize_bilinear(y, tuple(size))
+        if out is not None and tuple(y.shape[-2:]) == tuple(size):
+            out = None  # no resize to write through: the caller copies
+        return E.resize_bilinear(y, tuple(size), out=out)
 
 
 class ConvBlock2d(nn.Module):

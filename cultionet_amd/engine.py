@@ -1009,18 +1009,25 @@ def thin_conv3x3(x: Var, mods: T.Sequence, grouped: bool, dilation: int = 1,
     return yv
 
 
-def cat_channels(parts: T.Sequence[Var]) -> Var:
-    """torch.cat(dim=1). Backward hands each input a channel-slice VIEW of the gradient (no copies)."""
+def cat_channels(parts: T.Sequence[Var], buf: T.Optional[torch.Tensor] = None) -> Var:
+    """torch.cat(dim=1). Backward hands each input a channel-slice VIEW of the gradient (no copies).
+    ``buf``: a preallocated [B, sum C, H, W] buffer; parts that were already produced in place in their slice of it
+    (ops with ``out=``) are not copied."""
     tape = current_tape()
     t0 = _check(parts[0].t)
     B, H, W = t0.shape[0], t0.shape[2], t0.shape[3]
     Ctot = sum(p.t.shape[1] for p in parts)
-    y = _new((B, Ctot, H, W), t0)
+    y = buf if buf is not None else _new((B, Ctot, H, W), t0)
+    if tuple(y.shape) != (B, Ctot, H, W):
+        raise ValueError("cat_channels: buffer shape does not match the parts")
     off = 0
     for p in parts:
         c = p.t.shape[1]
         dst = y[:, off:off + c]
-        _lib.call("cn_copy_f32", p.t.data_ptr(), bstride(p.t), dst.data_ptr(), bstride(y), B, c * H * W, 0, _stream())
+        in_place = p.t.data_ptr() == dst.data_ptr() and (B == 1 or bstride(p.t) == bstride(y))
+        if not in_place:
+            _lib.call("cn_copy_f32", p.t.data_ptr(), bstride(p.t), dst.data_ptr(), bstride(y), B, c * H * W, 0,
+                      _stream())
         off += c
     yv = Var(y, tape.enabled)
     if tape.enabled:

@@ -245,11 +245,19 @@ class TowerUNetBlock(nn.Module):
     def forward(self, backbone_side: E.Var, backbone_down: E.Var, decode_side: E.Var, decode_down: E.Var,
                 tower_down: T.Optional[E.Var] = None, latlon_coords=None) -> E.Var:
         size = decode_side.shape[-2:]
-        parts = [backbone_side, self.backbone_down_conv(backbone_down, size=size), decode_side,
-                 self.decode_down_conv(decode_down, size=size)]
+        # the resized up-convolutions write straight into their channel slices of the concat buffer
+        cs = [backbone_side.shape[1], backbone_down.shape[1], decode_side.shape[1], decode_down.shape[1]]
         if tower_down is not None:
-            parts.append(self.tower_conv(tower_down, size=size))
-        return self.res_conv(E.cat_channels(parts))
+            cs.append(tower_down.shape[1])
+        B = decode_side.shape[0]
+        buf = torch.empty((B, sum(cs), size[0], size[1]), dtype=torch.float32, device=decode_side.t.device)
+        offs = [sum(cs[:i]) for i in range(len(cs))]
+        sl = lambda i: buf[:, offs[i]:offs[i] + cs[i]]
+        parts = [backbone_side, self.backbone_down_conv(backbone_down, size=size, out=sl(1)), decode_side,
+                 self.decode_down_conv(decode_down, size=size, out=sl(3))]
+        if tower_down is not None:
+            parts.append(self.tower_conv(tower_down, size=size, out=sl(4)))
+        return self.res_conv(E.cat_channels(parts, buf=buf))
 
 
 class TowerUNetFusion(nn.Module):
