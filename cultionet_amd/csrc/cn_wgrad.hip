@@ -365,16 +365,44 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
             acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
           }
         }
-        for (; q + WG_U <= seg1; q += WG_U) {  // interior: no masks, immediate offsets
-          const float* apq = ap + 2 * q;
-#pragma unroll
-          for (int u = 0; u < WG_U; ++u) {
-            const float av = apq[2 * u];
-#pragma unroll
-            for (int j = 0; j < T; ++j) {
-              const float bv = (bp[j] + 2 * q * S_)[2 * u * S_];
-              acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+        // Interior pairs (no masks, immediate offsets), in groups of two k-steps with the operands double-buffered
+        // in registers: the LDS reads of the NEXT group are issued before the 2*T MFMAs of the current one. One wave
+        // per SIMD issues in order, so without this every group waited out the full LDS latency with the MFMA pipe
+        // idle (the compiler emitted read-all / s_waitcnt 0 / MFMA-all).
+        {
+          const int ng = (seg1 - q) >> 1;
+          if (ng > 0) {
+            float a0[2], a1[2], b0[2][T], b1[2][T];
+#define WG_LOAD2(qq_, a_, b_)                                                    \
+  {                                                                              \
+    const float* apq_ = ap + 2 * (qq_);                                          \
+    a_[0] = apq_[0];                                                             \
+    a_[1] = apq_[2];                                                             \
+    _Pragma("unroll") for (int j = 0; j < T; ++j) {                              \
+      const float* bq_ = bp[j] + 2 * (qq_) * S_;                                 \
+      b_[0][j] = bq_[0];                                                         \
+      b_[1][j] = bq_[2 * S_];                                                    \
+    }                                                                            \
+  }
+#define WG_MFMA2(a_, b_)                                                                                   \
+  {                                                                                                        \
+    _Pragma("unroll") for (int j = 0; j < T; ++j)                                                          \
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[0], b_[0][j], acc[j], 0, 0, 0);                   \
+    _Pragma("unroll") for (int j = 0; j < T; ++j)                                                          \
+        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[1], b_[1][j], acc[j], 0, 0, 0);                   \
+  }
+            WG_LOAD2(q, a0, b0);
+            int i = 0;
+            for (; i + 2 <= ng; i += 2) {
+              WG_LOAD2(q + 2 * (i + 1), a1, b1);
+              WG_MFMA2(a0, b0);
+              if (i + 2 < ng) WG_LOAD2(q + 2 * (i + 2), a0, b0);
+              WG_MFMA2(a1, b1);
             }
+            if (i < ng) WG_MFMA2(a0, b0);
+#undef WG_LOAD2
+#undef WG_MFMA2
+            q += 2 * ng;
           }
         }
         for (; q < seg1; ++q) {
