@@ -370,39 +370,37 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
         // per SIMD issues in order, so without this every group waited out the full LDS latency with the MFMA pipe
         // idle (the compiler emitted read-all / s_waitcnt 0 / MFMA-all).
         {
-          const int ng = (seg1 - q) >> 1;
+          constexpr int GS = 2;  // k-steps per group (deeper groups were measured slower for the 1x1 case too)
+          const int ng = (seg1 - q) / GS;
           if (ng > 0) {
-            float a0[2], a1[2], b0[2][T], b1[2][T];
-#define WG_LOAD2(qq_, a_, b_)                                                    \
+            float a0[GS], a1[GS], b0[GS][T], b1[GS][T];
+#define WG_LOADG(qq_, a_, b_)                                                    \
   {                                                                              \
     const float* apq_ = ap + 2 * (qq_);                                          \
-    a_[0] = apq_[0];                                                             \
-    a_[1] = apq_[2];                                                             \
+    _Pragma("unroll") for (int u = 0; u < GS; ++u) a_[u] = apq_[2 * u];          \
     _Pragma("unroll") for (int j = 0; j < T; ++j) {                              \
       const float* bq_ = bp[j] + 2 * (qq_) * S_;                                 \
-      b_[0][j] = bq_[0];                                                         \
-      b_[1][j] = bq_[2 * S_];                                                    \
+      _Pragma("unroll") for (int u = 0; u < GS; ++u) b_[u][j] = bq_[2 * u * S_]; \
     }                                                                            \
   }
-#define WG_MFMA2(a_, b_)                                                                                   \
+#define WG_MFMAG(a_, b_)                                                                                   \
   {                                                                                                        \
-    _Pragma("unroll") for (int j = 0; j < T; ++j)                                                          \
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[0], b_[0][j], acc[j], 0, 0, 0);                   \
-    _Pragma("unroll") for (int j = 0; j < T; ++j)                                                          \
-        acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[1], b_[1][j], acc[j], 0, 0, 0);                   \
+    _Pragma("unroll") for (int u = 0; u < GS; ++u)                                                         \
+        _Pragma("unroll") for (int j = 0; j < T; ++j)                                                      \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[u], b_[u][j], acc[j], 0, 0, 0);               \
   }
-            WG_LOAD2(q, a0, b0);
+            WG_LOADG(q, a0, b0);
             int i = 0;
             for (; i + 2 <= ng; i += 2) {
-              WG_LOAD2(q + 2 * (i + 1), a1, b1);
-              WG_MFMA2(a0, b0);
-              if (i + 2 < ng) WG_LOAD2(q + 2 * (i + 2), a0, b0);
-              WG_MFMA2(a1, b1);
+              WG_LOADG(q + GS * (i + 1), a1, b1);
+              WG_MFMAG(a0, b0);
+              if (i + 2 < ng) WG_LOADG(q + GS * (i + 2), a0, b0);
+              WG_MFMAG(a1, b1);
             }
-            if (i < ng) WG_MFMA2(a0, b0);
-#undef WG_LOAD2
-#undef WG_MFMA2
-            q += 2 * ng;
+            if (i < ng) WG_MFMAG(a0, b0);
+#undef WG_LOADG
+#undef WG_MFMAG
+            q += GS * ng;
           }
         }
         for (; q < seg1; ++q) {
