@@ -369,8 +369,16 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
         // in registers: the LDS reads of the NEXT group are issued before the 2*T MFMAs of the current one. One wave
         // per SIMD issues in order, so without this every group waited out the full LDS latency with the MFMA pipe
         // idle (the compiler emitted read-all / s_waitcnt 0 / MFMA-all).
-        {
-          constexpr int GS = 2;  // k-steps per group (deeper groups were measured slower for the 1x1 case too)
+        if constexpr (T == 1) {
+          // one MFMA per k-step: the register pipeline below was measured slower (172 vs 161 us at 480->128, 100^2)
+          for (; q + WG_U <= seg1; q += WG_U) {
+            const float* apq = ap + 2 * q;
+#pragma unroll
+            for (int u = 0; u < WG_U; ++u)
+              acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(apq[2 * u], (bp[0] + 2 * q * S_)[2 * u * S_], acc[0], 0, 0, 0);
+          }
+        } else {
+          constexpr int GS = 2;  // k-steps per group
           const int ng = (seg1 - q) / GS;
           if (ng > 0) {
             float a0[GS], a1[GS], b0[GS][T], b1[GS][T];
