@@ -916,3 +916,30 @@ def test_forward_is_bit_reproducible(golden_dir):
         b = {k: v.clone() for k, v in lit(batch).items() if v is not None}
     for k in a:
         assert torch.equal(a[k], b[k]), k
+
+
+def test_conv_autotune_gives_the_same_results():
+    """cn_conv_set_autotune(1): the first launch of a shape times the candidates (output rewritten each time), later
+    launches -- accumulating ones included -- reuse the winner; results stay within the usual tolerance."""
+    from cultionet_amd import engine as E, _lib
+
+    B, Cin, H, W, Cout = 2, 96, 25, 25, 128
+    conv = nn.Conv2d(Cin, Cout, 3, padding=1, bias=True)
+    x = _rand(B, Cin, H, W, seed=81)
+    xr = x.clone().requires_grad_(True)
+    yr = conv(xr)
+    dy = _rand(*yr.shape, seed=82)
+    yr.backward(dy)
+    ref_w = conv.weight.grad.clone()
+    try:
+        def fn(v):
+            _lib.call("cn_conv_set_autotune", 1)   # after using_store bound the workspace
+            a = E.conv2d(v, conv, 1, 1, 1)
+            return E.conv2d(v, conv, 1, 1, 1) if a is not None else a  # second launch: cached choice
+
+        y, (dx,), pg = _engine_run(conv, fn, [x], dy)
+        _close(y, yr, 2e-5, "y")
+        _close(dx, xr.grad, 1e-4, "dx")           # one node had no gradient: dx comes from the second conv only
+        _close(pg["weight"], ref_w, 1e-4, "dw")
+    finally:
+        _lib.call("cn_conv_set_autotune", 0)
