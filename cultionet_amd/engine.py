@@ -666,7 +666,8 @@ def bn_act(x: Var, bn, act: int, residual: T.Optional[Var] = None, channels: T.O
 
 
 def bn_act_group(xs: T.Sequence[Var], bns: T.Sequence, act: int, residual: T.Optional[Var] = None,
-                 sum_outputs: bool = False, training: bool = True) -> T.Union[Var, T.List[Var]]:
+                 sum_outputs: bool = False, training: bool = True,
+                 outs: T.Optional[T.Sequence[torch.Tensor]] = None) -> T.Union[Var, T.List[Var]]:
     """G BatchNorm2d(+act) over G same-shaped tensors in one launch pair. ``sum_outputs``: returns the single Var
     ``residual + sum_g act(bn_g(x_g))`` (the ResUNet-a sum, accumulated in the order of the sequential form);
     otherwise the list of G activations."""
@@ -685,7 +686,12 @@ def bn_act_group(xs: T.Sequence[Var], bns: T.Sequence, act: int, residual: T.Opt
     dev = xts[0].device
     use_batch = training or any(bn.running_mean is None for bn in bns)
     tab = lambda ptrs: (ctypes.c_void_p * G)(*ptrs)
-    ys = [_new(xts[0].shape, xts[0])] if sum_outputs else [_new(xts[0].shape, xts[0]) for _ in range(G)]
+    if outs is not None:  # caller-provided outputs (e.g. channel slices of one buffer, all with the same strides)
+        ys = list(outs)
+        if len(ys) != (1 if sum_outputs else G) or any(bstride(y) != bstride(ys[0]) for y in ys):
+            raise ValueError("bn_act_group: outs must match the outputs and share their batch stride")
+    else:
+        ys = [_new(xts[0].shape, xts[0])] if sum_outputs else [_new(xts[0].shape, xts[0]) for _ in range(G)]
     means = [_new((C,), xts[0]) for _ in range(G)]
     rstds = [_new((C,), xts[0]) for _ in range(G)]
     ws = torch.empty(G * _lib.query("cn_bn_workspace_doubles", C), dtype=torch.float64, device=dev)

@@ -117,8 +117,8 @@ class TowerUNetFinal(nn.Module):
         h9 = E.thin_conv3x3(x, [h.seq[0] for h in heads], grouped=False)
         B, _, H, W = h9.shape
         buf = torch.empty((B, 9, H, W), dtype=torch.float32, device=h9.t.device)
-        acts = [E.bn_act(p, h.seq[1], h.act, training=h.training, out=buf[:, 3 * i:3 * i + 3])
-                for i, (p, h) in enumerate(zip(E.split_channels(h9, [3, 3, 3]), heads))]
+        acts = E.bn_act_group(E.split_channels(h9, [3, 3, 3]), [h.seq[1] for h in heads], heads[0].act,
+                              training=self.training, outs=[buf[:, 3 * i:3 * i + 3] for i in range(3)])
         a9 = E.join_channels(acts, buf)
         h3 = E.thin_conv3x3(a9, [s.conv[1] for s in streams], grouped=True)
         f = self.fuse_conv
