@@ -26,7 +26,7 @@ SIGNATURES = {
     "cn_conv2d_fwd_f32": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
     "cn_conv2d_bwd_data_f32": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
     "cn_conv2d_bwd_weight_f32": [P, L, P, L, P, I, I, I, I, I, I, I, I, I, I, P, L, P],
-    "cn_conv_set_workspace": [P, L],
+    "cn_conv_set_workspace": [P, P, L],
     "cn_conv_set_autotune": [I],
     "cn_conv2d_fwd_grouped_f32": [I, P, L, P, P, P, L, I, I, I, I, I, I, I, I, P, P, I, P],
     "cn_conv2d_bwd_data_grouped_f32": [I, P, L, P, P, L, I, I, I, I, I, P, P, I, P, P, I, P],

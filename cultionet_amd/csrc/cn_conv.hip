@@ -489,15 +489,52 @@ struct CnPackDesc {
   long sk, sn, st;
 };
 
-__global__ void cn_pack_weights_batched_kernel(const CnPackDesc* __restrict__ descs) {
+// Tile-transposed: the source is contiguous along (mid, tap) for a fixed index of its slowest dimension, the
+// packed copy along n. A block stages 32 (slow) x 32 (mid) x T floats through LDS so that BOTH the reads (runs of
+// 32*T floats) and the writes (runs of 32 n) are coalesced; the strided gather this replaces read 588 MB to write
+// 85 MB per step (r01 PMC pass).
+#define CN_PK_TS 32
+#define CN_PK_PITCH (32 * CN_MAX_TAPS + 1)
+__global__ __launch_bounds__(256) void cn_pack_weights_batched_kernel(const CnPackDesc* __restrict__ descs) {
+  __shared__ float tile[CN_PK_TS * CN_PK_PITCH];
   const CnPackDesc d = descs[blockIdx.y];
-  const long total = (long)d.T * d.Kpad * d.Npad;
-  for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-    const int n = (int)(i % d.Npad);
-    const long r = i / d.Npad;
-    const int k = (int)(r % d.Kpad);
-    const int t = (int)(r / d.Kpad);
-    d.wp[i] = (k < d.K && n < d.N) ? d.w[k * d.sk + n * d.sn + t * d.st] : 0.f;
+  const bool n_slow = d.sn > d.sk;             // which of (k, n) is the slowest source dimension
+  const long ss = n_slow ? d.sn : d.sk, sm = n_slow ? d.sk : d.sn;
+  const int S = n_slow ? d.N : d.K, M = n_slow ? d.K : d.N;
+  const int Spad = n_slow ? d.Npad : d.Kpad, Mpad = n_slow ? d.Kpad : d.Npad;
+  if (d.T > CN_MAX_TAPS || d.st != 1 || sm != d.T) {  // generic strides: plain gather
+    const long total = (long)d.T * d.Kpad * d.Npad;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+      const int n = (int)(i % d.Npad);
+      const long r = i / d.Npad;
+      const int k = (int)(r % d.Kpad);
+      const int t = (int)(r / d.Kpad);
+      d.wp[i] = (k < d.K && n < d.N) ? d.w[k * d.sk + n * d.sn + t * d.st] : 0.f;
+    }
+    return;
+  }
+  const int T = d.T;
+  const int ts = (Spad + CN_PK_TS - 1) / CN_PK_TS, tm = (Mpad + 31) / 32;
+  const int run = 32 * T;
+  for (int tl = blockIdx.x; tl < ts * tm; tl += gridDim.x) {
+    const int s0 = (tl / tm) * CN_PK_TS, m0 = (tl % tm) * 32;
+    __syncthreads();
+    for (int s = threadIdx.x >> 6; s < CN_PK_TS; s += 4)  // one wave per source row: contiguous run of 32*T floats
+      for (int j = threadIdx.x & 63; j < run; j += 64) {
+        const long mi = (long)m0 * T + j;
+        tile[s * CN_PK_PITCH + j] = (s0 + s < S && mi < (long)M * T) ? d.w[(s0 + s) * ss + mi] : 0.f;
+      }
+    __syncthreads();
+    // output rows: (t, k) with 32 consecutive n each
+    const int ln = threadIdx.x & 31;
+    for (int r = threadIdx.x >> 5; r < 32 * T; r += 8) {
+      const int t = r / 32, o = r % 32;  // o: the non-n index inside the tile
+      int k, n;
+      float v;
+      if (n_slow) { k = m0 + o; n = s0 + ln; v = tile[ln * CN_PK_PITCH + o * T + t]; }
+      else        { k = s0 + o; n = m0 + ln; v = tile[o * CN_PK_PITCH + ln * T + t]; }
+      if (k < d.Kpad && n < d.Npad) d.wp[((long)t * d.Kpad + k) * d.Npad + n] = v;
+    }
   }
 }
 
@@ -652,8 +689,10 @@ static double cn_launch_cost(long blocks, int cps, double mt_units, int splits, 
   return c;
 }
 
-static float* g_conv_ws;
-static long g_conv_ws_floats;
+// Split-K scratch is registered PER STREAM (cn_conv_set_workspace): launches on different streams never share a
+// buffer. Each entry point binds its stream's buffer into these thread-locals before planning the launch.
+static thread_local float* g_conv_ws;
+static thread_local long g_conv_ws_floats;
 
 static CnChoice cn_choose(const CnConvGeom& g0, const int* mts, int ncfg, int NT, bool allow_split) {
   const int nchunks = (g0.Cin + KC - 1) / KC;
@@ -705,11 +744,28 @@ static CnChoice cn_choose(const CnConvGeom& g0, const int* mts, int ncfg, int NT
 // split's partial tile into its own slice with plain stores and cn_conv_reduce_kernel sums the slices (+ bias)
 // into y -- no memset of y, no float atomics. Without it (or if it is too small) the atomic path is used.
 
-extern "C" int cn_conv_set_workspace(float* ws, long ws_floats) {
+#include <mutex>
+#include <unordered_map>
+namespace {
+struct CnWs { float* p; long n; };
+std::mutex g_ws_mu;
+std::unordered_map<void*, CnWs> g_ws_by_stream;
+}  // namespace
+
+extern "C" int cn_conv_set_workspace(void* stream, float* ws, long ws_floats) {
   if (ws != nullptr && ((reinterpret_cast<uintptr_t>(ws) & 15) || ws_floats < 0)) return CN_ERR_ARG;
-  g_conv_ws = ws;
-  g_conv_ws_floats = ws != nullptr ? ws_floats : 0;
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  if (ws == nullptr) g_ws_by_stream.erase(stream);
+  else g_ws_by_stream[stream] = {ws, ws_floats};
   return CN_OK;
+}
+
+// Bind the scratch registered for `stream` (none => the atomic split-K path) for the launch being planned.
+static void cn_bind_ws(void* stream) {
+  std::lock_guard<std::mutex> lk(g_ws_mu);
+  auto it = g_ws_by_stream.find(stream);
+  if (it == g_ws_by_stream.end()) { g_conv_ws = nullptr; g_conv_ws_floats = 0; }
+  else { g_conv_ws = it->second.p; g_conv_ws_floats = it->second.n; }
 }
 
 struct CnReduceArgs {
@@ -977,11 +1033,12 @@ static int cn_conv1x1_launch(const float* x, long xbs, const float* wp, const fl
 // (tile config x K split) candidates with HIP events on the launch stream and the winner is cached for the
 // process (accumulating launches of the same shape reuse it). Off by default: launches then never synchronise.
 #include <functional>
-#include <unordered_map>
 static int g_autotune = 0;
-static std::unordered_map<uint64_t, CnChoice> g_tuned;
+static std::unordered_map<uint64_t, CnChoice> g_tuned;  // guarded by g_tune_mu
+static std::mutex g_tune_mu;
 
 extern "C" int cn_conv_set_autotune(int on) {
+  std::lock_guard<std::mutex> lk(g_tune_mu);
   g_autotune = on ? 1 : 0;
   if (!on) g_tuned.clear();
   return CN_OK;
@@ -1090,6 +1147,7 @@ int cn_conv_igemm_launch(CnConvGeom& g, hipStream_t stream) {
   };
   CnChoice c = cn_choose(g, mts, ncfg, nt, allow_split);
   if (g_autotune) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);  // tuning runs are serialised across threads
     const uint64_t key = cn_tune_key(g, vec, nt, allow_split);
     auto it = g_tuned.find(key);
     if (it != g_tuned.end()) {
@@ -1172,6 +1230,7 @@ static int cn_gather_conv(const float* x, long xbs, const float* wp, const float
 extern "C" int cn_conv2d_fwd_f32(const float* x, long xbs, const float* wp, const float* bias, float* y,
                                  long ybs, int B, int Cin, int Hin, int Win, int Cout, int KH, int KW,
                                  int stride, int pad, int dil, int accumulate, void* stream) {
+  cn_bind_ws(stream);
   if (stride < 1) return CN_ERR_ARG;  // before it is divided by
   const int Hout = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
   const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
@@ -1244,6 +1303,7 @@ static int cn_scatter_conv(const float* src, long sbs, const float* wp, const fl
 extern "C" int cn_conv2d_bwd_data_f32(const float* dy, long dybs, const float* wp_t, float* dx, long dxbs,
                                       int B, int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride,
                                       int pad, int dil, int accumulate, void* stream) {
+  cn_bind_ws(stream);
   if (stride < 1) return CN_ERR_ARG;  // before it is divided by
   const int Hout = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
   const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
@@ -1259,6 +1319,7 @@ extern "C" int cn_conv2d_fwd_grouped_f32(int G, const float* const* xs, long xbs
                                          const float* const* biases, float* const* ys, long ybs, int B, int Cin,
                                          int Hin, int Win, int Cout, int KH, int KW, int stride, const int* pads,
                                          const int* dils, int accumulate, void* stream) {
+  cn_bind_ws(stream);
   if (G < 1 || G > CN_MAX_GROUPS) return CN_ERR_ARG;
   if (stride < 1) return CN_ERR_ARG;  // before it is divided by
   const int Hout = (Hin + 2 * pads[0] - dils[0] * (KH - 1) - 1) / stride + 1;
@@ -1278,6 +1339,7 @@ extern "C" int cn_conv2d_bwd_data_grouped_f32(int G, const float* const* dys, lo
                                               float* const* dxs, long dxbs, int B, int Cin, int Hin, int Win,
                                               int Cout, const int* khs, const int* kws, int stride, const int* pads,
                                               const int* dils, int accumulate, void* stream) {
+  cn_bind_ws(stream);
   if (G < 1 || G > CN_MAX_GROUPS) return CN_ERR_ARG;
   if (stride < 1) return CN_ERR_ARG;  // before it is divided by
   const int Hout = (Hin + 2 * pads[0] - dils[0] * (khs[0] - 1) - 1) / stride + 1;
@@ -1294,6 +1356,7 @@ extern "C" int cn_conv2d_bwd_data_grouped_f32(int G, const float* const* dys, lo
 extern "C" int cn_conv_transpose2d_fwd_f32(const float* x, long xbs, const float* wp, const float* bias,
                                            float* y, long ybs, int B, int Cin, int Hin, int Win, int Cout,
                                            int KH, int KW, int stride, int pad, int accumulate, void* stream) {
+  cn_bind_ws(stream);
   const int Hout = (Hin - 1) * stride - 2 * pad + KH;
   const int Wout = (Win - 1) * stride - 2 * pad + KW;
   return cn_scatter_conv(x, xbs, wp, bias, y, ybs, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride, pad, 1,
@@ -1304,6 +1367,7 @@ extern "C" int cn_conv_transpose2d_fwd_f32(const float* x, long xbs, const float
 extern "C" int cn_conv_transpose2d_bwd_data_f32(const float* dy, long dybs, const float* wp_t, float* dx,
                                                 long dxbs, int B, int Cin, int Hin, int Win, int Cout, int KH,
                                                 int KW, int stride, int pad, int accumulate, void* stream) {
+  cn_bind_ws(stream);
   const int Hout = (Hin - 1) * stride - 2 * pad + KH;
   const int Wout = (Win - 1) * stride - 2 * pad + KW;
   return cn_gather_conv(dy, dybs, wp_t, nullptr, dx, dxbs, B, Cout, Hout, Wout, Cin, Hin, Win, KH, KW, stride, pad,

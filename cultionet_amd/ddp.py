@@ -47,14 +47,32 @@ def plan_buckets(offsets: T.Sequence[int], sizes: T.Sequence[int], ready_node: T
     return buckets
 
 
+def broadcast_module_state(store, module=None, group=None, src: int = 0) -> None:
+    """What torch DDP does at construction (the reference's strategy="ddp"): every rank starts from rank ``src``'s
+    parameters and buffers. One broadcast of the flat parameter buffer + one per floating-point buffer (BatchNorm
+    running statistics); integer buffers (num_batches_tracked) are identical by construction."""
+    dist.broadcast(store.flat, src=src, group=group)
+    if module is not None:
+        for b in module.buffers():
+            if b.is_floating_point():
+                dist.broadcast(b, src=src, group=group)
+    store.bump()
+
+
 class GradientAllReduce:
     def __init__(self, world_size: T.Optional[int] = None, bucket_mb: float = 8.0, group=None):
         self.group = group
         self.world_size = world_size if world_size is not None else dist.get_world_size(group)
+        self.rank = dist.get_rank(group) if dist.is_available() and dist.is_initialized() else 0
         self.bucket_elems = int(bucket_mb * (1 << 20) / 4)
         self.comm_stream = None
         self._plan = None
         self._plan_key = None
+
+    def sync_initial_state(self, store, module=None) -> None:
+        """Replicas must start identical (init_conv_weights is random per process): broadcast rank 0's state."""
+        if self.world_size > 1:
+            broadcast_module_state(store, module, group=self.group, src=0)
 
     def _get_plan(self, tape, store):
         key = (len(tape.nodes), store.numel)

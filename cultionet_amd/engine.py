@@ -184,6 +184,7 @@ class ParamStore:
                 view.copy_(p.data)
                 p.data = view
         self.version = 0  # bumped whenever parameter values change (invalidates packed weights)
+        self._sig = self._signature()
         self._base = self.flat.data_ptr()
         self._packs: T.List[T.Tuple] = []      # (PackedWeight, attr, dst tensor, w ptr, T, K, N, sk, sn, st)
         self._pack_table: T.Optional[torch.Tensor] = None
@@ -211,6 +212,20 @@ class ParamStore:
     def bump(self) -> None:
         self.version += 1
 
+    def _signature(self) -> int:
+        """Sum of the parameters' torch version counters: moves whenever anything outside the engine writes a
+        parameter in place (torch optimizers in drop-in mode, ``load_state_dict`` / ``load_from_checkpoint`` through
+        nn.Module's recursion, ``param.data.copy_``). The engine's own kernels (fused AdamW) do not touch it and call
+        ``bump()`` themselves."""
+        return sum(p._version for p in self.params)
+
+    def refresh(self) -> None:
+        """Invalidate the packed weight copies if the parameters were modified behind the engine's back."""
+        sig = self._signature()
+        if sig != self._sig:
+            self._sig = sig
+            self.bump()
+
     def register_pack(self, pw, attr: str, dst: torch.Tensor, w: torch.Tensor, T_: int, K: int, N: int, sk: int,
                       sn: int, st: int) -> None:
         self._packs.append((pw, attr, dst, w.data_ptr(), T_, K, N, sk, sn, st))
@@ -236,19 +251,19 @@ class ParamStore:
 
 
 _CONV_WS_FLOATS = 16 << 20  # split-K partial slices of the implicit-GEMM launches (64 MB, one per process)
-_conv_ws: T.Dict[str, torch.Tensor] = {}
+_conv_ws: T.Dict[T.Tuple[str, int], torch.Tensor] = {}
 
 
 def _bind_conv_workspace(dev: torch.device) -> None:
-    """Give the library its split-K scratch once per process (one process drives one GPU; launches that use it are
-    stream-ordered on the current stream)."""
-    key = str(dev)
+    """Register a split-K scratch buffer for the CURRENT stream (the library keys its scratch by stream, so model
+    instances running on different streams / autograd worker threads never share one)."""
+    s = _stream()
+    key = (str(dev), s)
     if key in _conv_ws:
         return
     ws = torch.empty(_CONV_WS_FLOATS, dtype=torch.float32, device=dev)
-    _conv_ws.clear()
     _conv_ws[key] = ws
-    _lib.call("cn_conv_set_workspace", ws.data_ptr(), ws.numel())
+    _lib.call("cn_conv_set_workspace", s, ws.data_ptr(), ws.numel())
     # CN_AUTOTUNE=1: measure the (tile, K split) candidates per conv shape during the first steps instead of
     # trusting the launch-cost model (+0.5 % at batch 8; off by default so that runs are reproducible)
     _lib.call("cn_conv_set_autotune", 1 if os.environ.get("CN_AUTOTUNE", "0") == "1" else 0)
@@ -614,6 +629,15 @@ def time_conv(x: Var, mod, tin: int) -> Var:
 ACT_NONE, ACT_SILU = 0, 1
 
 
+def _bn_momentum(bn) -> float:
+    """torch's momentum=None means a cumulative moving average (factor 1/num_batches_tracked, a device counter);
+    the reference never configures it and the fused kernel takes a host scalar: refuse instead of guessing."""
+    if bn.momentum is None:
+        raise NotImplementedError("BatchNorm(momentum=None) (cumulative average) has no HIP kernel; the reference "
+                                  "uses the default momentum=0.1 everywhere")
+    return float(bn.momentum)
+
+
 def bn_act(x: Var, bn, act: int, residual: T.Optional[Var] = None, channels: T.Optional[int] = None,
            training: bool = True, out: T.Optional[torch.Tensor] = None) -> Var:
     """y = act(batch_norm(x)) (+ residual). x viewed as [B][C][L] with C = ``channels`` (BatchNorm3d: L = T*H*W)."""
@@ -628,7 +652,7 @@ def bn_act(x: Var, bn, act: int, residual: T.Optional[Var] = None, channels: T.O
     rstd = _new((C,), xt)
     ws = torch.empty(_lib.query("cn_bn_workspace_doubles", C), dtype=torch.float64, device=dev)
     rt = residual.t if residual is not None else None
-    mom = bn.momentum if bn.momentum is not None else 0.1
+    mom = _bn_momentum(bn)
     use_batch = training or (bn.running_mean is None)
     _lib.call("cn_bn_act_fwd_f32", xt.data_ptr(), bstride(xt), bn.weight.data_ptr(), bn.bias.data_ptr(),
               bn.running_mean.data_ptr() if bn.running_mean is not None else None,
@@ -696,7 +720,7 @@ def bn_act_group(xs: T.Sequence[Var], bns: T.Sequence, act: int, residual: T.Opt
     rstds = [_new((C,), xts[0]) for _ in range(G)]
     ws = torch.empty(G * _lib.query("cn_bn_workspace_doubles", C), dtype=torch.float64, device=dev)
     rt = residual.t if residual is not None else None
-    mom = bns[0].momentum if bns[0].momentum is not None else 0.1
+    mom = _bn_momentum(bns[0])
     has_running = all(bn.running_mean is not None for bn in bns)
     _lib.call("cn_bn_act_group_fwd_f32", G, tab([t.data_ptr() for t in xts]), bstride(xts[0]),
               tab([bn.weight.data_ptr() for bn in bns]), tab([bn.bias.data_ptr() for bn in bns]),

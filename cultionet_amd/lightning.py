@@ -83,9 +83,6 @@ class LightningModuleMixin(_Base):
     def __init__(self):
         super().__init__()
 
-    def __call__(self, *args, **kwargs):
-        return self.forward(*args, **kwargs)
-
     def forward(self, batch: Data, batch_idx: int = None) -> T.Dict[str, torch.Tensor]:
         """distance / edge / crop probabilities, each (B, 1, H, W); crop_type, classes_l2, classes_l3 = None."""
         return self.cultionet_model(batch)
@@ -290,13 +287,16 @@ class HipTrainer:
     """Native training step: every FLOP and byte of forward + loss + backward + clip + AdamW in HIP kernels.
 
     Semantics of lightning.Trainer(gradient_clip_val=1.0) + AdamW(lr, wd, eps, betas=(0.9, 0.98)) as configured
-    by the reference (model.py:84,168-186; lightning.py:622-629); the LR schedule is supplied by the caller
-    (``lr_fn(step) -> lr``; constant by default). With ``world_size > 1`` the flat gradient is all-reduced over
-    RCCL in buckets overlapped with the backward tape (see cultionet_amd.ddp).
+    by the reference (model.py:84,168-186; lightning.py:622-629). Learning-rate schedule: ``total_steps`` given
+    => the reference's default OneCycleLR stepped per optimizer step (lightning.py:657-664; it also cycles beta1,
+    see cultionet_amd.schedules); otherwise ``lr_fn(step) -> lr`` (or ``-> (lr, beta1)``), constant by default.
+    With ``world_size > 1`` the flat gradient is all-reduced over RCCL in buckets overlapped with the backward
+    tape (see cultionet_amd.ddp).
     """
 
     def __init__(self, lit: CultionetLitModel, gradient_clip_val: T.Optional[float] = 1.0,
-                 lr_fn: T.Optional[T.Callable[[int], float]] = None, comm=None):
+                 lr_fn: T.Optional[T.Callable[[int], T.Union[float, T.Tuple[float, float]]]] = None, comm=None,
+                 total_steps: T.Optional[int] = None):
         self.lit = lit
         self.model = lit.cultionet_model.mask_model
         self.store = self.model.param_store()
@@ -306,11 +306,25 @@ class HipTrainer:
         self.sumsq = torch.zeros(1, dtype=torch.float64, device=dev)
         self.total = torch.zeros(1, dtype=torch.float32, device=dev)
         self.clip = gradient_clip_val
-        self.lr_fn = lr_fn or (lambda step: lit.learning_rate)
+        if lr_fn is None:
+            from .schedules import ConstantLR, OneCycleLR
+
+            if total_steps is not None:
+                if str(lit.lr_scheduler) != str(LearningRateSchedulers.ONE_CYCLE_LR):
+                    raise NotImplementedError("the native step schedules OneCycleLR (the reference default); pass lr_fn")
+                lr_fn = OneCycleLR(lit.learning_rate, total_steps)
+            else:
+                lr_fn = ConstantLR(lit.learning_rate)
+        self.lr_fn = lr_fn
         self.step_count = 0
         self.comm = comm
         if lit.optimizer != "AdamW":
             raise NotImplementedError("the fused HIP optimizer implements AdamW (the reference default)")
+        if comm is not None:
+            # torch DDP (the reference's strategy="ddp", model.py:101,184) broadcasts rank 0's parameters and buffers
+            # at construction; dropout masks must differ per rank (each rank draws its own torch RNG stream upstream)
+            comm.sync_initial_state(self.store, self.model)
+            E.manual_seed(E._rng["seed"] + 0x9E37 * comm.rank)
 
     def forward_backward(self, batch: Data) -> torch.Tensor:
         """Forward + loss + backward; leaves d(loss)/d(params) in store.flat_grad. Returns the loss (1-elem tensor)."""
@@ -342,8 +356,10 @@ class HipTrainer:
         if self.clip is not None:
             _lib.call("cn_grad_sumsq_f32", store.flat_grad.data_ptr(), store.numel, self.sumsq.data_ptr(), s)
             sumsq = self.sumsq.data_ptr()
+        sched = self.lr_fn(self.step_count)
+        lr, beta1 = sched if isinstance(sched, tuple) else (sched, 0.9)
         _lib.call("cn_adamw_step_f32", store.flat.data_ptr(), store.flat_grad.data_ptr(), self.exp_avg.data_ptr(),
-                  self.exp_avg_sq.data_ptr(), store.numel, float(self.lr_fn(self.step_count)), 0.9, 0.98,
+                  self.exp_avg_sq.data_ptr(), store.numel, float(lr), float(beta1), 0.98,
                   float(lit.eps), float(lit.weight_decay), self.step_count, scale, sumsq,
                   float(self.clip) if self.clip is not None else 0.0, s)
         store.bump()

@@ -130,6 +130,18 @@ class TowerUNet(nn.Module):
                 state_dict[k.replace("pre_unet._orig_mod.", "pre_unet.")] = state_dict.pop(k)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
+    #: write checkpoints with the reference's key spelling ``pre_unet._orig_mod.*`` (upstream wraps pre_unet in
+    #: torch.compile, nunet.py:141, so ITS strict load expects that prefix). Off by default: plain keys.
+    upstream_checkpoint_keys = False
+
+    def state_dict(self, *args, **kwargs):
+        sd = super().state_dict(*args, **kwargs)
+        if self.upstream_checkpoint_keys:
+            prefix = kwargs.get("prefix", args[1] if len(args) > 1 else "")
+            for k in [k for k in sd if k.startswith(prefix + "pre_unet.")]:
+                sd[k.replace(prefix + "pre_unet.", prefix + "pre_unet._orig_mod.", 1)] = sd.pop(k)
+        return sd
+
     def load_state_dict(self, *args, **kwargs):
         out = super().load_state_dict(*args, **kwargs)
         st = self.__dict__.get("_cn_store")
@@ -151,6 +163,7 @@ class TowerUNet(nn.Module):
 
     def forward_vars(self, x: E.Var) -> T.Dict[str, E.Var]:
         """Engine-level forward: x is a Var over [B, C*T, H, W]; returns {distance, edge, crop} Vars."""
+        E.current_store().refresh()  # torch optimizers / checkpoint loads since the last pack (drop-in mode)
         emb = self.pre_unet(x)
         enc = self.encoder(emb)
         dec = self.decoder(enc)

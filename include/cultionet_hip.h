@@ -10,8 +10,13 @@
  *     `*bs` arguments are BATCH strides in elements (channel stride is always H*W), so channel
  *     slices of a concat buffer can be read/written in place;
  *   - the CALLER owns every buffer (kernels never allocate); `stream` is a hipStream_t;
- *   - returns 0 on success, <0 on error (CN_ERR_*); no exceptions cross the ABI; re-entrant,
- *     no global state;
+ *   - returns 0 on success, <0 on error (CN_ERR_*); no exceptions cross the ABI. Compute entry points keep
+ *     no state between calls and may be called from any thread on any stream. The only process state is opt-in
+ *     and keyed or locked: the split-K scratch is registered PER STREAM (cn_conv_set_workspace), the autotune
+ *     cache is mutex-guarded (cn_conv_set_autotune), and the cn_profile_* diagnostics are single-client
+ *     (documented below; never used by the product path);
+ *   - precision: entry points ending in _f32 take fp32 tensors (NCHW); entry points ending in _bf16 take
+ *     bfloat16 activations in NHWC with fp32 parameters/statistics (see the bf16 section);
  *   - `accumulate != 0` means `out += result` instead of `out = result`;
  *   - entry points documented "zero first" combine partial results with f32 atomics.
  */
@@ -80,10 +85,12 @@ int cn_conv_transpose2d_bwd_weight_f32(const float* x, long xbs, const float* dy
 
 /* Optional scratch for the K-split launches of the cn_conv* entry points (small spatial sizes split the input
  * channels over blocks): with a workspace each split stores its partial output into a private slice and a reduce
- * kernel sums the slices (+ bias) into y; without one (ws = NULL, the default) the splits use float atomics on a
- * zero-filled y. Process-wide setting: the caller keeps ws alive and issues the contraction launches that may use it
- * on ONE stream. ws 16-byte aligned; 64 MB covers every TowerUNet layer at 8 chips of 100x100. */
-int cn_conv_set_workspace(float* ws, long ws_floats);
+ * kernel sums the slices (+ bias) into y; without one (the default) the splits use float atomics on a zero-filled y.
+ * The scratch is registered FOR ONE STREAM: every cn_conv* call looks up the buffer of the stream it is given, so two
+ * streams (or two models on two streams) never share scratch; launches on one stream are stream-ordered. The caller
+ * keeps ws alive until it unregisters it (ws = NULL). ws 16-byte aligned; 64 MB covers every TowerUNet layer at
+ * 8 chips of 100x100. */
+int cn_conv_set_workspace(void* stream, float* ws, long ws_floats);
 
 /* Opt-in autotuning of the cn_conv* launches (off by default): the first overwriting launch of each distinct shape
  * times the (pixel tile x K split) candidates with HIP events on the launch stream (that call synchronises) and the

@@ -1,5 +1,5 @@
-"""GPU self-check used by __graft_entry__.smoke(): one tiny TowerUNet training step on the HIP path,
-compared with the CPU oracle (oracle/ is imported here ONLY as the checker)."""
+"""GPU self-check used by __graft_entry__.smoke() and tests/: one tiny TowerUNet training step on the HIP path,
+compared with the CPU oracle. TEST INFRASTRUCTURE (lives in oracle/, never imported by cultionet_amd)."""
 from __future__ import annotations
 
 import torch
@@ -7,9 +7,9 @@ import torch
 
 def build_pair(hidden: int = 8, in_channels: int = 3, in_time: int = 12, device: str = "cuda:0", **kw):
     """(HIP LitModel on `device`, CPU oracle TowerUNet) holding identical key-seeded weights."""
-    from oracle import towerunet_oracle as O
+    from . import towerunet_oracle as O
 
-    from .lightning import CultionetLitModel
+    from cultionet_amd.lightning import CultionetLitModel
 
     lit = CultionetLitModel(in_channels=in_channels, in_time=in_time, hidden_channels=hidden, dropout=0.0, **kw)
     okw = {k: v for k, v in kw.items() if k in ("attention_weights", "dilations", "pool_by_max", "res_block_type", "batchnorm_first")}
@@ -22,10 +22,10 @@ def build_pair(hidden: int = 8, in_channels: int = 3, in_time: int = 12, device:
 
 
 def smoke_check(device: str = "cuda:0", hidden: int = 8, B: int = 2, H: int = 28, W: int = 28, tol: float = 1e-4):
-    from oracle import towerunet_oracle as O
+    from . import towerunet_oracle as O
 
-    from .data import Data
-    from .lightning import HipTrainer
+    from cultionet_amd.data import Data
+    from cultionet_amd.lightning import HipTrainer
 
     lit, ref = build_pair(hidden=hidden, device=device)
     lit.train()

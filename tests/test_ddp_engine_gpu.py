@@ -1,0 +1,75 @@
+"""Two data-parallel ranks of the REAL engine (ParamStore + tape + GradientAllReduce + fused clip/AdamW) against the
+SURVEY 8(e) oracle: two independent CPU-oracle shards, gradients averaged, clip_grad_norm_(1.0), AdamW -- what torch
+DDP under Lightning computes for the reference (model.py:101,168-186). BatchNorm statistics stay per rank."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_two_ranks_real_engine_match_two_oracle_shards(tmp_path):
+    from oracle import towerunet_oracle as O
+
+    hidden, B, H, W, world = 8, 2, 28, 28, 2
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    env = dict(os.environ)
+    env["HSA_ENABLE_IPC_MODE_LEGACY"] = "0"
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, "tests", "ddp_worker.py"), str(r), str(world),
+                               str(port), str(tmp_path), str(hidden), str(B), str(H), str(W)], env=env,
+                              stdout=subprocess.PIPE, stderr=subprocess.STDOUT) for r in range(world)]
+    outs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=600)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            raise
+        outs.append(out.decode(errors="replace"))
+    for p, o in zip(procs, outs):
+        assert p.returncode == 0, o[-3000:]
+    got = [torch.load(os.path.join(tmp_path, f"rank{r}.pt"), weights_only=False) for r in range(world)]
+    assert all(g["buckets"] >= 2 for g in got), [g["buckets"] for g in got]
+
+    # the oracle: identical key-seeded weights, one shard per rank, averaged gradients, clip, AdamW
+    models, losses = [], []
+    for r in range(world):
+        m = O.TowerUNet(3, 12, hidden_channels=hidden)
+        m.load_state_dict(O.seeded_state_dict(m.state_dict()))
+        m.train()
+        x, y, bdist = O.seeded_batch(B, height=H, width=W, seed=7 + r, with_mask=True)
+        loss, _ = O.calc_loss(m(x), y, bdist)
+        loss.backward()
+        models.append(m)
+        losses.append(float(loss))
+    ref = models[0]
+    with torch.no_grad():
+        for ps in zip(*[m.parameters() for m in models]):
+            ps[0].grad = sum(p.grad for p in ps) / world
+    torch.nn.utils.clip_grad_norm_(ref.parameters(), 1.0)
+    opt = torch.optim.AdamW(ref.parameters(), lr=0.01, weight_decay=1e-3, eps=1e-4, betas=(0.9, 0.98))
+    opt.step()
+
+    for r in range(world):
+        assert abs(got[r]["loss"] - losses[r]) <= 1e-4, (r, got[r]["loss"], losses[r])  # per-rank loss (no sync_dist)
+    refp = dict(ref.named_parameters())
+    for r in range(world):
+        for n, pr in refp.items():
+            d = (got[r]["state"][n] - pr.detach()).abs().max()
+            assert d <= 2e-4, (r, n, float(d))
+    # replicas are bitwise identical after the step (same averaged gradient, same update)
+    for n in refp:
+        assert torch.equal(got[0]["state"][n], got[1]["state"][n]), n
+    # BatchNorm running statistics stay per rank (different shards => different statistics)
+    k = next(k for k in got[0]["state"] if k.endswith("running_mean") and "tower_a" in k)
+    assert not torch.equal(got[0]["state"][k], got[1]["state"][k])

@@ -702,7 +702,7 @@ def test_conv2d_splitk_without_workspace_uses_atomics():
     store.zero_grad()
     try:
         with E.using_store(store), E.recording(True) as tape:
-            _lib.call("cn_conv_set_workspace", None, 0)   # after using_store bound one: back to atomics
+            _lib.call("cn_conv_set_workspace", E._stream(), None, 0)   # unregister this stream's scratch: atomics
             xv = E.Var(x.to(dev), True)
             y = E.conv2d(xv, conv, 1, 1, 1)
             y.grad = dy.to(dev)
@@ -943,3 +943,34 @@ def test_conv_autotune_gives_the_same_results():
         _close(pg["weight"], ref_w, 1e-4, "dw")
     finally:
         _lib.call("cn_conv_set_autotune", 0)
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 3), (130, 72, 3), (128, 480, 1), (3, 128, 3), (256, 40, 1)])
+def test_pack_weights_batched_matches_single(shape):
+    """The tile-transposed batched repack (all layers in one launch) against the plain gather pack, for the four
+    stride patterns of include/cultionet_hip.h (Conv2d fwd / bwd-data, ConvTranspose2d fwd / bwd-data)."""
+    import struct
+
+    from cultionet_amd import _lib
+
+    cout, cin, k = shape
+    taps = k * k
+    dev = _dev()
+    w = _rand(cout, cin, k, k, seed=5).to(dev)
+    s = torch.cuda.current_stream().cuda_stream
+    pats = [(cin, cout, taps, cin * taps), (cout, cin, cin * taps, taps),  # conv fwd, conv bwd-data
+            (cout, cin, cin * taps, taps), (cin, cout, taps, cin * taps)]  # convT fwd (w as [Cin=cout][Cout=cin]), bwd
+    singles, outs, buf = [], [], bytearray()
+    for (K, N, sk, sn) in pats:
+        kp, np_ = _lib.query("cn_conv_kpad", K), _lib.query("cn_conv_npad", N)
+        a = torch.full((taps * kp * np_,), float("nan"), device=dev)
+        b = torch.full((taps * kp * np_,), float("nan"), device=dev)
+        _lib.call("cn_pack_weights_f32", w.data_ptr(), a.data_ptr(), taps, K, N, sk, sn, 1, s)
+        buf += struct.pack("<QQiiiiiiqqq", w.data_ptr(), b.data_ptr(), taps, K, N, kp, np_, 0, sk, sn, 1)
+        singles.append(a)
+        outs.append(b)
+    table = torch.frombuffer(buf, dtype=torch.uint8).clone().to(dev)
+    _lib.call("cn_pack_weights_batched_f32", table.data_ptr(), len(pats), s)
+    torch.cuda.synchronize()
+    for a, b in zip(singles, outs):
+        assert torch.equal(a.cpu(), b.cpu())

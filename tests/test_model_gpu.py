@@ -18,7 +18,7 @@ KEYS = ("distance", "edge", "crop")
 
 def _setup(g, **kw):
     from cultionet_amd.data import Data
-    from cultionet_amd.selfcheck import build_pair
+    from oracle.selfcheck import build_pair
     from oracle import towerunet_oracle as O
 
     hidden, B, H, W, with_mask, seed = (int(v) for v in g["meta"])
@@ -124,7 +124,7 @@ def test_stage_activations(golden_dir):
 
 def test_eval_mode(golden_dir):
     g = np.load(os.path.join(golden_dir, "eval_h8_b2_28.npz"))
-    from cultionet_amd.selfcheck import build_pair
+    from oracle.selfcheck import build_pair
     from oracle import towerunet_oracle as O
 
     hidden, B, C, Tn, H, W, seed = (int(v) for v in g["meta"])
@@ -144,7 +144,7 @@ def test_eval_mode(golden_dir):
 def test_large_tile_eval(golden_dir):
     """BASELINE configs[4]: [1,4,25,256,256] eval forward, checked by checksums + a 64x64 crop."""
     g = np.load(os.path.join(golden_dir, "eval_h32_b1_4x25x256.npz"))
-    from cultionet_amd.selfcheck import build_pair
+    from oracle.selfcheck import build_pair
     from oracle import towerunet_oracle as O
 
     hidden, B, C, Tn, H, W, seed = (int(v) for v in g["meta"])
@@ -184,3 +184,35 @@ def test_adamw_step_matches_oracle(golden_dir):
     model = lit.cultionet_model.mask_model
     for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
         assert (p.detach().cpu() - pr.detach()).abs().max() <= 2e-4, n
+
+
+def test_dropin_torch_optimizer_step_refreshes_packed_weights(golden_dir):
+    """Drop-in mode (lightning.Trainer + torch.optim.AdamW from configure_optimizers): the optimizer writes the
+    parameters in place behind the engine's back; the second forward must see the NEW weights in every packed
+    implicit-GEMM copy. Checked against the oracle taking the same two steps on the CPU."""
+    from oracle import towerunet_oracle as O
+
+    g = np.load(os.path.join(golden_dir, "train_h8_b2_28.npz"))
+    lit, ref, batch = _setup(g)
+    lit.train()
+    ref.train()
+    model = lit.cultionet_model.mask_model
+    opt = torch.optim.AdamW(model.parameters(), lr=0.01, weight_decay=1e-3, eps=1e-4, betas=(0.9, 0.98))
+    ropt = torch.optim.AdamW(ref.parameters(), lr=0.01, weight_decay=1e-3, eps=1e-4, betas=(0.9, 0.98))
+    x, y, bdist = batch.x.cpu(), batch.y.cpu(), batch.bdist.cpu()
+    losses, rlosses = [], []
+    for _ in range(3):
+        opt.zero_grad(set_to_none=True)
+        loss, _ = lit.calc_loss(batch, lit(batch))
+        loss.backward()
+        opt.step()
+        losses.append(float(loss))
+        ropt.zero_grad(set_to_none=True)
+        rl, _ = O.calc_loss(ref(x), y, bdist)
+        rl.backward()
+        ropt.step()
+        rlosses.append(float(rl))
+    assert abs(losses[0] - rlosses[0]) <= TOL
+    assert abs(losses[1] - rlosses[1]) <= 5e-4, (losses, rlosses)  # one AdamW step apart: not bitwise, but the same weights
+    assert abs(losses[2] - rlosses[2]) <= 2e-3, (losses, rlosses)
+    assert abs(losses[1] - losses[0]) > 1e-3  # the step did change the loss (a stale pack would hide in this gap)
