@@ -175,7 +175,7 @@ def main():
         loss = trainer.training_step(batch)
     sync()
     dt = time.perf_counter() - t0
-    prof = (ctypes.c_double * 12)()
+    prof = (ctypes.c_double * 24)()
     _lib.call("cn_profile_end", prof)
     loss_val = float(loss.item())
 

@@ -72,6 +72,33 @@ SIGNATURES = {
     "cn_fold_timeconv_grad_f32": [P, P, I, I, I, I, P],
     "cn_prepare_chips_f32": [P, I, P, P, P, I, I, L, F, F, F, P],
     "cn_predictions_to_u16": [P, P, P, P, I, I, I, I, I, I, I, F, P],
+    # ---- bf16 NHWC mixed-precision path ----
+    "cn_bconv_packed_elems": [I, I, I],
+    "cn_pack_weights_bf16": [P, P, I, I, I, L, L, L, P],
+    "cn_pack_weights_batched_bf16": [P, I, P],
+    "cn_conv2d_fwd_bf16": [P, L, P, P, P, L, L, I, I, I, I, I, I, I, I, I, I, I, I, P, P],
+    "cn_conv2d_fwd_grouped_bf16": [I, P, L, P, P, P, L, I, I, I, I, I, I, I, I, P, P, I, P],
+    "cn_conv2d_bwd_data_bf16": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
+    "cn_conv2d_bwd_data_grouped_bf16": [I, P, L, P, P, L, I, I, I, I, I, I, I, I, P, P, I, P],
+    "cn_conv_transpose2d_fwd_bf16": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, P],
+    "cn_conv_transpose2d_bwd_data_bf16": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, I, P],
+    "cn_bwgrad_workspace_floats": [I, I, I, I, I, I, I, I, I, I, I],
+    "cn_conv2d_bwd_weight_bf16": [P, L, P, L, P, I, I, I, I, I, I, I, I, I, I, P, L, P],
+    "cn_conv_transpose2d_bwd_weight_bf16": [P, L, P, L, P, I, I, I, I, I, I, I, I, I, P, L, P],
+    "cn_bn_workspace_floats_bf16": [I],
+    "cn_bn_act_fwd_bf16": [P, L, P, P, P, P, P, L, P, L, P, P, P, L, I, I, F, F, I, P, P],
+    "cn_bn_act_bwd_bf16": [P, L, P, L, P, P, P, P, P, L, P, P, P, L, I, I, I, I, P],
+    "cn_layernorm_c_fwd_bf16": [P, L, P, P, P, L, P, L, L, I, F, P],
+    "cn_layernorm_c_bwd_bf16": [P, L, P, L, P, P, L, P, P, L, I, F, I, P],
+    "cn_convert_f32nchw_to_bf16nhwc": [P, L, P, L, I, I, I, I, P],
+    "cn_convert_bf16nhwc_to_f32nchw": [P, L, P, L, I, I, I, I, P],
+    "cn_copy_bf16": [P, L, P, L, L, I, I, P],
+    "cn_add_bf16": [P, L, P, L, P, L, L, I, P],
+    "cn_zero_bf16": [P, L, L, I, P],
+    "cn_bilinear_fwd_bf16": [P, L, P, L, I, I, I, I, I, I, P],
+    "cn_bilinear_bwd_bf16": [P, L, P, L, I, I, I, I, I, I, I, P],
+    "cn_na2d_fwd_bf16": [P, L, P, L, P, I, I, I, I, I, I, I, P],
+    "cn_na2d_bwd_bf16": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, P],
     "cn_profile_begin": [],
     "cn_profile_end": [P],
 }
@@ -108,7 +135,7 @@ def load() -> ctypes.CDLL:
         except AttributeError as e:  # pragma: no cover
             raise HipLibraryMissing(f"symbol {name} missing from {LIB_PATH}; rebuild the extension") from e
         fn.argtypes = argtypes
-        fn.restype = c_int
+        fn.restype = c_long if name in LONG_RESULT else c_int
     _lib = lib
     return lib
 
@@ -119,6 +146,9 @@ def call(name: str, *args) -> int:
     if rc != 0:
         raise HipKernelError(f"{name} failed: {ERRORS.get(rc, rc)}")
     return rc
+
+
+LONG_RESULT = {"cn_bconv_packed_elems", "cn_bwgrad_workspace_floats", "cn_bn_workspace_floats_bf16"}
 
 
 def query(name: str, *args) -> int:

@@ -1,0 +1,598 @@
+// bf16 implicit-GEMM convolution for gfx950 (MI355X): v_mfma_f32_32x32x16_bf16, fp32 accumulation.
+//
+// Mixed-precision path of BASELINE configs[2] (the reference's default precision="16-mixed",
+// /root/reference/src/cultionet/model.py:168-186): activations and activation gradients are bf16 in HBM,
+// laid out NHWC ([B][H][W][C], `ld` = elements between consecutive pixels, so a channel slice of a concat buffer is
+// consumed / produced in place), parameters stay fp32 masters and are re-packed to bf16 MFMA fragments once per
+// optimizer step. One kernel serves nn.Conv2d forward, its backward-data, nn.ConvTranspose2d forward and its
+// backward-data (convolution.py:45-120): a launch is a set of CLASSES, each a stride-1 walk over a logical pixel
+// grid with its own tap list
+//     input pixel = g*is + d[t]        output pixel = g*os + o0
+// (a plain conv has one class; a strided scatter has s*s parity classes: no zero-stuffing, no wasted MACs).
+//
+// Why NHWC for bf16 (the fp32 path is NCHW): a bf16 MFMA operand is 8 CONSECUTIVE k (input channels) per lane. With
+// channels innermost a lane's fragment is one ds_read_b128 from a [halo pixel][32 channels] LDS image and a tap is a
+// row offset into that image -- no im2col, no transposes, every tap aligned.
+//
+// Block = 256 threads = 4 waves; tile = TH x TW logical pixels (<= 128, four 32-pixel MFMA columns) x 32*WN output
+// channels. A = weights (rows = cout), B = pixels (cols): the accumulator's lane index is the pixel and its registers
+// hold 4 consecutive couts x 4 groups, i.e. 8-byte packed bf16 stores straight into NHWC. Wave w owns cout tile
+// w % WN and the pixel columns {w / WN + i * (4 / WN)}: its weight fragments come straight from global memory
+// (packed in fragment order: one 16-byte load per lane serves WN MFMAs, no cross-wave reuse exists to stage for),
+// the pixel image is staged once per 32-channel chunk and shared by the four waves and all taps.
+#include "cn_bf16.h"
+#include "cn_profile.h"
+
+#define CNB_MAX_TAPS 9
+#define CNB_MAX_CLASSES 16
+#define CNB_MAX_GROUPS 4
+#define CNB_PITCH 80  // bytes per halo pixel in LDS: 64 B of channels + 16 B pad => conflict-free ds_read_b128
+
+struct CnBClass {
+  int ntaps;
+  int wt[CNB_MAX_TAPS];    // tap index in the packed weights
+  int doff[CNB_MAX_TAPS];  // LDS byte offset of the tap inside the halo image
+  int oy0, ox0;            // output coordinate offset
+  int Hg, Wg;              // logical grid
+  int tiles_x, tiles_per_img;
+  int block_begin;         // first logical block of this class
+  int iy_off, ix_off;      // input coordinate of halo pixel (0,0) relative to (tile origin * is)
+  int IH, IW;              // halo image size in pixels
+  int grp;
+};
+
+struct CnBGeom {
+  const bf16_t* x[CNB_MAX_GROUPS];
+  const bf16_t* wp[CNB_MAX_GROUPS];
+  const float* bias[CNB_MAX_GROUPS];
+  void* y[CNB_MAX_GROUPS];
+  long ldx, ldy;
+  long y_bs;      // out_kind 1: batch stride of the f32 NCHW output (elements)
+  int B, Cin, Hin, Win, Cout, Hout, Wout;
+  int is, os;
+  int TH, TW;
+  int KS;         // 16-channel k-steps (ceil(Cin / 16))
+  int NT;         // 32-cout tiles (ceil(Cout / 32))
+  int nblk_n;     // cout blocks (of 32*WN) per pixel tile
+  int out_kind;   // 0: bf16 NHWC   1: f32 NCHW (thin head convolutions)
+  int accumulate;
+  int total;      // logical blocks
+  int ncls;
+  float* stats;   // nullable: per-cout {sum, sum of squares} of the fp32 results (2 * Cout floats, atomically added)
+  CnBClass cls[CNB_MAX_CLASSES];
+};
+
+__device__ __forceinline__ f32x16 cnb_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
+}
+
+template <int WN, int NP>
+__global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  constexpr int WM = 4 / WN;   // waves along the pixel columns
+  constexpr int MPW = WN;      // 32-pixel columns per wave (4 columns per block)
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int r = lane & 31, h = lane >> 5;
+  const int wn = wid % WN, wm = wid / WN;
+
+  // ---- logical block (XCD-aware order: consecutive logical blocks share an L2) ----
+  int L;
+  {
+    const int lin = blockIdx.x;
+    const int per = (g.total + 7) >> 3;
+    L = (lin & 7) * per + (lin >> 3);
+    if (L >= g.total) return;
+  }
+  int ci = 0;
+#pragma unroll 1
+  for (int c = 1; c < g.ncls; ++c)
+    if (L >= g.cls[c].block_begin) ci = c;
+  const CnBClass& k = g.cls[ci];
+  const int grp = k.grp;
+  const int local = L - k.block_begin;
+  const int nb = local % g.nblk_n;
+  const int tile = local / g.nblk_n;
+  const int b = tile / k.tiles_per_img;
+  const int tl = tile - b * k.tiles_per_img;
+  const int tyi = tl / k.tiles_x, txi = tl - tyi * k.tiles_x;
+  const int gy0 = tyi * g.TH, gx0 = txi * g.TW;  // logical tile origin
+  const int ntile = nb * WN + wn;                // this wave's 32-cout tile
+  const bool n_live = ntile < g.NT;
+  const int IW = k.IW;
+  const int npix = g.TH * g.TW;
+
+  // ---- staging descriptors: piece q = 16 bytes (8 channels) of one halo pixel ----
+  const bf16_t* __restrict__ xg = g.x[grp];
+  long goff[NP];
+  int lw[NP];
+  const int npieces = k.IH * IW * 4;
+  const int iy0 = gy0 * g.is + k.iy_off, ix0 = gx0 * g.is + k.ix_off;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    const int q = tid + i * 256;
+    const int p = q >> 2, s = q & 3;
+    const int hy = p / IW, hx = p - hy * IW;
+    const int iy = iy0 + hy, ix = ix0 + hx;
+    const bool ok = q < npieces && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
+    goff[i] = ok ? (((long)b * g.Hin + iy) * g.Win + ix) * g.ldx + s * 8 : -1;
+    lw[i] = q < npieces ? p * CNB_PITCH + s * 16 : -1;
+  }
+
+  // ---- this wave's pixel columns: LDS base of each lane's pixel ----
+  int pbase[MPW];
+#pragma unroll
+  for (int i = 0; i < MPW; ++i) {
+    const int m = (wm + i * WM) * 32 + r;
+    const int ty = m / g.TW, tx = m - ty * g.TW;
+    pbase[i] = m < npix ? ((ty * g.is) * IW + tx * g.is) * CNB_PITCH + h * 16 : h * 16;
+  }
+
+  f32x16 acc[MPW];
+#pragma unroll
+  for (int i = 0; i < MPW; ++i)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+
+  const int nchunks = (g.KS + 1) >> 1;
+  const int ntaps = k.ntaps;
+  const bf16x8* __restrict__ wfrag = reinterpret_cast<const bf16x8*>(g.wp[grp]);
+  // fragment index of (tap, kstep): ((wt * KS + kstep) * NT + ntile) * 64 + lane
+  auto afrag = [&](int t, int kstep) -> bf16x8 {
+    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (!n_live || kstep >= g.KS) return z;
+    return wfrag[((long)(k.wt[t] * g.KS + kstep) * g.NT + ntile) * 64 + lane];
+  };
+
+  if (ntaps > 0) {
+    bf16x8 a0 = afrag(0, 0), a1 = afrag(0, 1);
+#pragma unroll 1
+    for (int ch = 0; ch < nchunks; ++ch) {
+      const int c0 = ch * 32;
+      // stage the halo image of this 32-channel chunk
+      u32x4 sv[NP];
+#pragma unroll
+      for (int i = 0; i < NP; ++i) {
+        const int s8 = ((tid + i * 256) & 3) * 8;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (goff[i] >= 0 && c0 + s8 < g.Cin) v = *reinterpret_cast<const u32x4*>(xg + goff[i] + c0);
+        sv[i] = v;
+      }
+      __syncthreads();  // the previous chunk's reads are done
+#pragma unroll
+      for (int i = 0; i < NP; ++i)
+        if (lw[i] >= 0) *reinterpret_cast<u32x4*>(lds + lw[i]) = sv[i];
+      __syncthreads();
+#pragma unroll 1
+      for (int t = 0; t < ntaps; ++t) {
+        // prefetch the next tap's weight fragments (next chunk's first tap at the end of this one)
+        const int tn = t + 1 < ntaps ? t + 1 : 0;
+        const int chn = t + 1 < ntaps ? ch : ch + 1;
+        const bf16x8 n0 = afrag(tn, chn * 2), n1 = afrag(tn, chn * 2 + 1);
+        const int toff = k.doff[t];
+#pragma unroll
+        for (int i = 0; i < MPW; ++i) {
+          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(lds + pbase[i] + toff);
+          acc[i] = cnb_mfma(a0, b0, acc[i]);
+        }
+#pragma unroll
+        for (int i = 0; i < MPW; ++i) {
+          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(lds + pbase[i] + toff + 32);
+          acc[i] = cnb_mfma(a1, b1, acc[i]);
+        }
+        a0 = n0;
+        a1 = n1;
+      }
+    }
+  }
+
+  // ---- epilogue: lane = pixel, registers = 4 groups of 4 consecutive couts ----
+  if (!n_live) return;
+  const float* __restrict__ bias = g.bias[grp];
+  const int n0 = ntile * 32;
+  float bsum[16];
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * h;
+    bsum[j] = (bias != nullptr && n < g.Cout) ? bias[n] : 0.f;
+  }
+  float s1[16], s2[16];
+  if (g.stats != nullptr) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) s1[j] = s2[j] = 0.f;
+  }
+#pragma unroll
+  for (int i = 0; i < MPW; ++i) {
+    const int m = (wm + i * WM) * 32 + r;
+    const int ty = m / g.TW, tx = m - ty * g.TW;
+    const int gy = gy0 + ty, gx = gx0 + tx;
+    const bool ok = m < npix && gy < k.Hg && gx < k.Wg;
+    const int oy = gy * g.os + k.oy0, ox = gx * g.os + k.ox0;
+    if (g.stats != nullptr) {
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const float v = ok ? acc[i][j] + bsum[j] : 0.f;
+        s1[j] += v;
+        s2[j] += v * v;
+      }
+    }
+    if (!ok) continue;
+    if (g.out_kind == 0) {
+      bf16_t* yp = reinterpret_cast<bf16_t*>(g.y[grp]) + (((long)b * g.Hout + oy) * g.Wout + ox) * g.ldy + n0 + 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int n = n0 + 8 * q + 4 * h;
+        if (n >= g.Cout) continue;
+        float v0 = acc[i][4 * q] + bsum[4 * q], v1 = acc[i][4 * q + 1] + bsum[4 * q + 1];
+        float v2 = acc[i][4 * q + 2] + bsum[4 * q + 2], v3 = acc[i][4 * q + 3] + bsum[4 * q + 3];
+        if (n + 3 < g.Cout) {
+          u32x2* dst = reinterpret_cast<u32x2*>(yp + 8 * q);
+          if (g.accumulate) {
+            const u32x2 o = *dst;
+            v0 += cn_bf16_lo(o[0]); v1 += cn_bf16_hi(o[0]); v2 += cn_bf16_lo(o[1]); v3 += cn_bf16_hi(o[1]);
+          }
+          u32x2 pk = {cn_pack_bf16(v0, v1), cn_pack_bf16(v2, v3)};
+          *dst = pk;
+        } else {  // ragged cout tail
+          const float vv[4] = {v0, v1, v2, v3};
+          for (int e = 0; e < 4 && n + e < g.Cout; ++e) {
+            float v = vv[e];
+            if (g.accumulate) v += cn_bf16_to_f32(yp[8 * q + e]);
+            yp[8 * q + e] = cn_f32_to_bf16(v);
+          }
+        }
+      }
+    } else {
+      float* yp = reinterpret_cast<float*>(g.y[grp]) + (long)b * g.y_bs + (long)oy * g.Wout + ox;
+      const long cs = (long)g.Hout * g.Wout;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * h;
+        if (n >= g.Cout) continue;
+        const float v = acc[i][j] + bsum[j];
+        if (g.accumulate) yp[n * cs] += v; else yp[n * cs] = v;
+      }
+    }
+  }
+  if (g.stats != nullptr) {
+    // per-cout sums over this wave's pixels: reduce the 32 lanes of each half, then one atomic per cout
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      float a = s1[j], c = s2[j];
+#pragma unroll
+      for (int off = 16; off > 0; off >>= 1) {
+        a += __shfl_xor(a, off, 64);
+        c += __shfl_xor(c, off, 64);
+      }
+      const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * h;
+      if (r == 0 && n < g.Cout) {
+        atomicAdd(g.stats + n, a);
+        atomicAdd(g.stats + g.Cout + n, c);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// packed weights: fragment order [tap][kstep][ntile][lane][8], element j of lane l = w[k = kstep*16 + 8*(l>>5) + j]
+// [n = ntile*32 + (l&31)] of tap t (zero beyond K / N)
+// ------------------------------------------------------------------------------------------------------------
+struct CnBPackDesc {
+  const float* w;
+  bf16_t* wp;
+  int T, K, N, KS, NT;
+  int pad;
+  long sk, sn, st;
+};
+
+__global__ __launch_bounds__(256) void cn_bpack_kernel(const CnBPackDesc* __restrict__ descs) {
+  const CnBPackDesc d = descs[blockIdx.y];
+  const long total = (long)d.T * d.KS * d.NT * 64;  // 16-byte fragments
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int l = (int)(i & 63);
+    long q = i >> 6;
+    const int nt = (int)(q % d.NT);
+    q /= d.NT;
+    const int ks = (int)(q % d.KS);
+    const int t = (int)(q / d.KS);
+    const int n = nt * 32 + (l & 31);
+    const int k0 = ks * 16 + 8 * (l >> 5);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = (n < d.N && k0 + j < d.K) ? d.w[(k0 + j) * d.sk + n * d.sn + t * d.st] : 0.f;
+    u32x4 o = {cn_pack_bf16(v[0], v[1]), cn_pack_bf16(v[2], v[3]), cn_pack_bf16(v[4], v[5]), cn_pack_bf16(v[6], v[7])};
+    reinterpret_cast<u32x4*>(d.wp)[i] = o;
+  }
+}
+
+extern "C" long cn_bconv_packed_elems(int T, int K, int N) {
+  return (long)T * ((K + 15) / 16) * ((N + 31) / 32) * 512;
+}
+
+// descs: DEVICE array of n 64-byte records {const float* w; bf16* wp; int T, K, N, KS, NT, pad; long sk, sn, st}
+extern "C" int cn_pack_weights_batched_bf16(const void* descs, int n, void* stream) {
+  if (n <= 0) return CN_OK;
+  hipLaunchKernelGGL(cn_bpack_kernel, dim3(32, n), dim3(256), 0, (hipStream_t)stream, (const CnBPackDesc*)descs);
+  return cn_check_launch();
+}
+
+__global__ __launch_bounds__(256) void cn_bpack_one_kernel(const CnBPackDesc d) {
+  const long total = (long)d.T * d.KS * d.NT * 64;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const int l = (int)(i & 63);
+    long q = i >> 6;
+    const int nt = (int)(q % d.NT);
+    q /= d.NT;
+    const int ks = (int)(q % d.KS);
+    const int t = (int)(q / d.KS);
+    const int n = nt * 32 + (l & 31);
+    const int k0 = ks * 16 + 8 * (l >> 5);
+    float v[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+      v[j] = (n < d.N && k0 + j < d.K) ? d.w[(k0 + j) * d.sk + n * d.sn + t * d.st] : 0.f;
+    u32x4 o = {cn_pack_bf16(v[0], v[1]), cn_pack_bf16(v[2], v[3]), cn_pack_bf16(v[4], v[5]), cn_pack_bf16(v[6], v[7])};
+    reinterpret_cast<u32x4*>(d.wp)[i] = o;
+  }
+}
+
+extern "C" int cn_pack_weights_bf16(const float* w, void* wp, int T, int K, int N, long sk, long sn, long st,
+                                    void* stream) {
+  CnBPackDesc d = {w, (bf16_t*)wp, T, K, N, (K + 15) / 16, (N + 31) / 32, 0, sk, sn, st};
+  const long total = (long)d.T * d.KS * d.NT * 64;
+  const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  hipLaunchKernelGGL(cn_bpack_one_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d);
+  return cn_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// host side: classes, tiles, launch
+// ------------------------------------------------------------------------------------------------------------
+static inline int cnb_floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
+
+// Pixel tile (TH x TW <= 128) for a logical grid: exact covers first (5x25 covers 100, 50 and 25 exactly).
+static void cnb_pick_tile(int Hg, int Wg, int is, int span, int& TH, int& TW) {
+  static const int cand[][2] = {{5, 25}, {8, 16}, {4, 32}, {16, 8}, {2, 64}, {10, 12}, {6, 20}, {9, 14}, {11, 11},
+                                {13, 9}, {7, 18}, {3, 42}, {1, 128}, {4, 16}, {8, 8}, {2, 32}, {4, 8}, {2, 16}};
+  double best = 1e300;
+  TH = 8; TW = 16;
+  for (auto& c : cand) {
+    const int th = c[0], tw = c[1];
+    const long ih = (long)(th - 1) * is + span + 1, iw = (long)(tw - 1) * is + span + 1;
+    if (ih * iw > 640) continue;  // staging budget: 10 pieces per thread, 51 KB of LDS
+    const long tiles = (long)((Hg + th - 1) / th) * ((Wg + tw - 1) / tw);
+    // cost ~ MFMA columns issued (tiles * ceil(pixels/32)) with a small penalty for halo bytes
+    const double cols = (double)tiles * ((th * tw + 31) / 32);
+    const double cost = cols * 32.0 + 0.05 * tiles * ih * iw;
+    if (cost < best) { best = cost; TH = th; TW = tw; }
+  }
+}
+
+static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
+  // tiles: one (TH, TW) for the launch, from the largest class grid and the widest tap span
+  int span = 0, Hg = 1, Wg = 1;
+  for (int c = 0; c < g.ncls; ++c) {
+    CnBClass& k = g.cls[c];
+    int mn_y = 0, mx_y = 0, mn_x = 0, mx_x = 0;
+    for (int t = 0; t < k.ntaps; ++t) {
+      const int dy = k.doff[t] >> 16, dx = (short)(k.doff[t] & 0xffff);  // packed (dy, dx) from the builders
+      if (t == 0) { mn_y = mx_y = dy; mn_x = mx_x = dx; }
+      mn_y = dy < mn_y ? dy : mn_y; mx_y = dy > mx_y ? dy : mx_y;
+      mn_x = dx < mn_x ? dx : mn_x; mx_x = dx > mx_x ? dx : mx_x;
+    }
+    k.iy_off = mn_y; k.ix_off = mn_x;
+    const int sp = (mx_y - mn_y) > (mx_x - mn_x) ? (mx_y - mn_y) : (mx_x - mn_x);
+    span = sp > span ? sp : span;
+    Hg = k.Hg > Hg ? k.Hg : Hg; Wg = k.Wg > Wg ? k.Wg : Wg;
+    // stash the spans for the second pass
+    k.IH = mx_y - mn_y; k.IW = mx_x - mn_x;
+  }
+  cnb_pick_tile(Hg, Wg, g.is, span, g.TH, g.TW);
+  g.KS = (g.Cin + 15) / 16;
+  g.NT = (g.Cout + 31) / 32;
+  const int WN = g.NT >= 4 ? 4 : (g.NT >= 2 ? 2 : 1);
+  g.nblk_n = (g.NT + WN - 1) / WN;
+  long total = 0;
+  int max_pix = 0;
+  for (int c = 0; c < g.ncls; ++c) {
+    CnBClass& k = g.cls[c];
+    const int sy = k.IH, sx = k.IW;
+    k.IH = (g.TH - 1) * g.is + sy + 1;
+    k.IW = (g.TW - 1) * g.is + sx + 1;
+    for (int t = 0; t < k.ntaps; ++t) {
+      const int dy = k.doff[t] >> 16, dx = (short)(k.doff[t] & 0xffff);
+      k.doff[t] = ((dy - k.iy_off) * k.IW + (dx - k.ix_off)) * CNB_PITCH;
+    }
+    k.tiles_x = (k.Wg + g.TW - 1) / g.TW;
+    k.tiles_per_img = k.tiles_x * ((k.Hg + g.TH - 1) / g.TH);
+    k.block_begin = (int)total;
+    total += (long)k.tiles_per_img * g.B * g.nblk_n;
+    max_pix = k.IH * k.IW > max_pix ? k.IH * k.IW : max_pix;
+  }
+  if (total <= 0) return CN_OK;
+  if (total > 0x7fffff00L) return CN_ERR_ARG;
+  g.total = (int)total;
+  const int np = (max_pix * 4 + 255) / 256;
+  if (np > 10) return CN_ERR_LDS;
+  const size_t shmem = (size_t)max_pix * CNB_PITCH;
+  const dim3 grid(cn_xcd_grid(total)), block(256);
+  cn_prof_desc("bconv B%d %dx%d %d->%d cls%d taps%d s%d/%d", g.B, g.Hin, g.Win, g.Cin, g.Cout, g.ncls, g.cls[0].ntaps,
+               g.is, g.os);
+  cn_prof_before(stream);
+#define CNB_GO(WN_, NP_) hipLaunchKernelGGL((cn_bconv_kernel<WN_, NP_>), grid, block, shmem, stream, g)
+  if (np <= 4) {
+    if (WN == 4) CNB_GO(4, 4); else if (WN == 2) CNB_GO(2, 4); else CNB_GO(1, 4);
+  } else {
+    if (WN == 4) CNB_GO(4, 10); else if (WN == 2) CNB_GO(2, 10); else CNB_GO(1, 10);
+  }
+#undef CNB_GO
+  cn_prof_after(stream, 4, flops);
+  return cn_check_launch();
+}
+
+static inline int cnb_pack_d(int dy, int dx) { return (dy << 16) | (dx & 0xffff); }
+
+// Gather form: in = o*stride + k*dil - pad (Conv2d forward, ConvTranspose2d backward-data).
+static int cnb_gather(int G, const bf16_t* const* xs, long ldx, const bf16_t* const* wps, const float* const* biases,
+                      void* const* ys, long ldy, long y_bs, int B, int Cin, int Hin, int Win, int Cout, int Hout,
+                      int Wout, int KH, int KW, int stride, const int* pads, const int* dils, int accumulate,
+                      int out_kind, float* stats, hipStream_t stream) {
+  if (G < 1 || G > CNB_MAX_GROUPS || KH * KW > CNB_MAX_TAPS || stride < 1) return CN_ERR_ARG;
+  if (Hout <= 0 || Wout <= 0 || B <= 0) return CN_OK;
+  CnBGeom g = {};
+  for (int i = 0; i < G; ++i) {
+    g.x[i] = xs[i]; g.wp[i] = wps[i]; g.bias[i] = biases ? biases[i] : nullptr; g.y[i] = ys[i];
+  }
+  g.ldx = ldx; g.ldy = ldy; g.y_bs = y_bs;
+  g.B = B; g.Cin = Cin; g.Hin = Hin; g.Win = Win; g.Cout = Cout; g.Hout = Hout; g.Wout = Wout;
+  g.is = stride; g.os = 1; g.out_kind = out_kind; g.accumulate = accumulate; g.stats = stats;
+  g.ncls = G;
+  for (int i = 0; i < G; ++i) {
+    if (dils[i] < 1) return CN_ERR_ARG;
+    CnBClass& k = g.cls[i];
+    k.grp = i; k.Hg = Hout; k.Wg = Wout; k.oy0 = 0; k.ox0 = 0; k.ntaps = KH * KW;
+    for (int ky = 0; ky < KH; ++ky)
+      for (int kx = 0; kx < KW; ++kx) {
+        const int t = ky * KW + kx;
+        k.doff[t] = cnb_pack_d(ky * dils[i] - pads[i], kx * dils[i] - pads[i]);
+        k.wt[t] = t;
+      }
+  }
+  const double flops = 2.0 * B * Hout * Wout * (double)Cout * Cin * KH * KW * G;
+  return cnb_launch(g, G, stream, flops);
+}
+
+// Scatter form: out[o] = bias + sum_k src[(o + pad - k*dil)/s] W[k] where divisible (Conv2d backward-data,
+// ConvTranspose2d forward), as s*s parity classes in one launch.
+static int cnb_scatter(int G, const bf16_t* const* srcs, long lds_, const bf16_t* const* wps,
+                       const float* const* biases, void* const* outs, long ldo, int B, int Csrc, int Hs, int Ws,
+                       int Cdst, int Ho, int Wo, int KH, int KW, int stride, const int* pads, const int* dils,
+                       int accumulate, float* stats, hipStream_t stream) {
+  if (G < 1 || G > CNB_MAX_GROUPS || KH * KW > CNB_MAX_TAPS || stride < 1 || G * stride * stride > CNB_MAX_CLASSES)
+    return CN_ERR_ARG;
+  if (Ho <= 0 || Wo <= 0 || B <= 0) return CN_OK;
+  CnBGeom g = {};
+  for (int i = 0; i < G; ++i) {
+    g.x[i] = srcs[i]; g.wp[i] = wps[i]; g.bias[i] = biases ? biases[i] : nullptr; g.y[i] = outs[i];
+  }
+  g.ldx = lds_; g.ldy = ldo;
+  g.B = B; g.Cin = Csrc; g.Hin = Hs; g.Win = Ws; g.Cout = Cdst; g.Hout = Ho; g.Wout = Wo;
+  g.is = 1; g.os = stride; g.out_kind = 0; g.accumulate = accumulate; g.stats = stats;
+  int nc = 0;
+  double macs = 0.0;
+  for (int gi = 0; gi < G; ++gi) {
+    const int pad = pads[gi], dil = dils[gi];
+    if (dil < 1) return CN_ERR_ARG;
+    for (int py = 0; py < stride; ++py)
+      for (int px = 0; px < stride; ++px) {
+        CnBClass& k = g.cls[nc];
+        k = CnBClass{};
+        k.grp = gi;
+        k.Hg = (Ho - py + stride - 1) / stride;
+        k.Wg = (Wo - px + stride - 1) / stride;
+        if (k.Hg <= 0 || k.Wg <= 0) continue;
+        k.oy0 = py; k.ox0 = px;
+        int nt = 0;
+        for (int ky = 0; ky < KH; ++ky) {
+          const int ny = py + pad - ky * dil;
+          if (((ny % stride) + stride) % stride != 0) continue;
+          for (int kx = 0; kx < KW; ++kx) {
+            const int nx = px + pad - kx * dil;
+            if (((nx % stride) + stride) % stride != 0) continue;
+            k.doff[nt] = cnb_pack_d(cnb_floordiv(ny, stride), cnb_floordiv(nx, stride));
+            k.wt[nt] = ky * KW + kx;
+            ++nt;
+          }
+        }
+        k.ntaps = nt;
+        macs += (double)k.Hg * k.Wg * nt;
+        ++nc;
+      }
+  }
+  g.ncls = nc;
+  if (nc == 0) return CN_OK;
+  return cnb_launch(g, G, stream, 2.0 * B * macs * Csrc * Cdst);
+}
+
+// ---- C ABI ---------------------------------------------------------------------------------------------------
+// nn.Conv2d forward (convolution.py:71-120). x bf16 NHWC [B,Hin,Win,>=Cin] (ldx), wp from cn_pack_weights_bf16 with
+// K = Cin, N = Cout; y bf16 NHWC (out_kind 0, ldy) or f32 NCHW (out_kind 1, batch stride y_bs). stats (nullable):
+// 2*Cout floats, zeroed by the caller, receive the per-channel sum / sum of squares of the fp32 results
+// (BatchNorm batch statistics without re-reading y).
+extern "C" int cn_conv2d_fwd_bf16(const void* x, long ldx, const void* wp, const float* bias, void* y, long ldy,
+                                  long y_bs, int B, int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride,
+                                  int pad, int dil, int accumulate, int out_kind, float* stats, void* stream) {
+  if (stride < 1) return CN_ERR_ARG;
+  const int Hout = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  const bf16_t* xs = (const bf16_t*)x;
+  const bf16_t* ws = (const bf16_t*)wp;
+  return cnb_gather(1, &xs, ldx, &ws, &bias, &y, ldy, y_bs, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride, &pad,
+                    &dil, accumulate, out_kind, stats, (hipStream_t)stream);
+}
+
+// G (<= 4) convolutions of one shape in one launch (the dilation branches of ResidualAConv, convolution.py:376-395).
+extern "C" int cn_conv2d_fwd_grouped_bf16(int G, const void* const* xs, long ldx, const void* const* wps,
+                                          const float* const* biases, void* const* ys, long ldy, int B, int Cin,
+                                          int Hin, int Win, int Cout, int KH, int KW, int stride, const int* pads,
+                                          const int* dils, int accumulate, void* stream) {
+  if (stride < 1 || G < 1 || G > CNB_MAX_GROUPS) return CN_ERR_ARG;
+  const int Hout = (Hin + 2 * pads[0] - dils[0] * (KH - 1) - 1) / stride + 1;
+  const int Wout = (Win + 2 * pads[0] - dils[0] * (KW - 1) - 1) / stride + 1;
+  for (int i = 1; i < G; ++i)
+    if ((Hin + 2 * pads[i] - dils[i] * (KH - 1) - 1) / stride + 1 != Hout ||
+        (Win + 2 * pads[i] - dils[i] * (KW - 1) - 1) / stride + 1 != Wout)
+      return CN_ERR_ARG;
+  return cnb_gather(G, (const bf16_t* const*)xs, ldx, (const bf16_t* const*)wps, biases, ys, ldy, 0, B, Cin, Hin, Win,
+                    Cout, Hout, Wout, KH, KW, stride, pads, dils, accumulate, 0, nullptr, (hipStream_t)stream);
+}
+
+// Conv2d backward-data: dx [B,Hin,Win,Cin] (+)= scatter(dy [B,Hout,Wout,Cout]); wp_t packed with K = Cout, N = Cin.
+extern "C" int cn_conv2d_bwd_data_bf16(const void* dy, long lddy, const void* wp_t, void* dx, long lddx, int B, int Cin,
+                                       int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, int dil,
+                                       int accumulate, void* stream) {
+  if (stride < 1) return CN_ERR_ARG;
+  const int Hout = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  const bf16_t* s = (const bf16_t*)dy;
+  const bf16_t* w = (const bf16_t*)wp_t;
+  return cnb_scatter(1, &s, lddy, &w, nullptr, &dx, lddx, B, Cout, Hout, Wout, Cin, Hin, Win, KH, KW, stride, &pad,
+                     &dil, accumulate, nullptr, (hipStream_t)stream);
+}
+
+extern "C" int cn_conv2d_bwd_data_grouped_bf16(int G, const void* const* dys, long lddy, const void* const* wps_t,
+                                               void* const* dxs, long lddx, int B, int Cin, int Hin, int Win, int Cout,
+                                               int KH, int KW, int stride, const int* pads, const int* dils,
+                                               int accumulate, void* stream) {
+  if (stride < 1 || G < 1 || G > CNB_MAX_GROUPS) return CN_ERR_ARG;
+  const int Hout = (Hin + 2 * pads[0] - dils[0] * (KH - 1) - 1) / stride + 1;
+  const int Wout = (Win + 2 * pads[0] - dils[0] * (KW - 1) - 1) / stride + 1;
+  return cnb_scatter(G, (const bf16_t* const*)dys, lddy, (const bf16_t* const*)wps_t, nullptr, dxs, lddx, B, Cout, Hout,
+                     Wout, Cin, Hin, Win, KH, KW, stride, pads, dils, accumulate, nullptr, (hipStream_t)stream);
+}
+
+// nn.ConvTranspose2d forward (convolution.py:45-68): y [B,Hout,Wout,Cout], Hout = (Hin-1)*s - 2*pad + K.
+extern "C" int cn_conv_transpose2d_fwd_bf16(const void* x, long ldx, const void* wp, const float* bias, void* y,
+                                            long ldy, int B, int Cin, int Hin, int Win, int Cout, int KH, int KW,
+                                            int stride, int pad, int accumulate, void* stream) {
+  const int Hout = (Hin - 1) * stride - 2 * pad + KH;
+  const int Wout = (Win - 1) * stride - 2 * pad + KW;
+  const bf16_t* s = (const bf16_t*)x;
+  const bf16_t* w = (const bf16_t*)wp;
+  const int dil = 1;
+  return cnb_scatter(1, &s, ldx, &w, &bias, &y, ldy, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride, &pad, &dil,
+                     accumulate, nullptr, (hipStream_t)stream);
+}
+
+// ConvTranspose2d backward-data: dx [B,Hin,Win,Cin] (+)= conv_stride_s(dy); wp_t packed with K = Cout, N = Cin.
+extern "C" int cn_conv_transpose2d_bwd_data_bf16(const void* dy, long lddy, const void* wp_t, void* dx, long lddx,
+                                                 int B, int Cin, int Hin, int Win, int Cout, int KH, int KW,
+                                                 int stride, int pad, int accumulate, void* stream) {
+  const int Hout = (Hin - 1) * stride - 2 * pad + KH;
+  const int Wout = (Win - 1) * stride - 2 * pad + KW;
+  const bf16_t* s = (const bf16_t*)dy;
+  const bf16_t* w = (const bf16_t*)wp_t;
+  const int dil = 1;
+  return cnb_gather(1, &s, lddy, &w, nullptr, &dx, lddx, 0, B, Cout, Hout, Wout, Cin, Hin, Win, KH, KW, stride, &pad,
+                    &dil, accumulate, 0, nullptr, (hipStream_t)stream);
+}

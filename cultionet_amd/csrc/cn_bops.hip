@@ -1,0 +1,544 @@
+// Streaming ops of the mixed-precision path on bf16 NHWC activations (gfx950, HBM/L2-bound): neighborhood attention
+// core, bilinear resize, slice copies / adds, and the layout+precision converters at the edges of the bf16 region.
+//
+// Reference ops: natten NeighborhoodAttention2D core (nn/modules/convolution.py:341-350; natten 0.17.1 semantics
+// restated in oracle/na2d_ref.py), F.interpolate(bilinear, align_corners=True) (nn/functional.py:72-81), torch.cat /
+// residual adds (nn/modules/unet_parts.py:700-760).
+#include "cn_bf16.h"
+
+// ------------------------------------------------------------------------------------------------------------
+// layout / precision converters
+// ------------------------------------------------------------------------------------------------------------
+// src f32 [B][C][HW] (batch stride sbs) -> dst bf16 [B*HW][Cpad] rows (ld), channels >= C zero-filled up to Cpad.
+__global__ __launch_bounds__(256) void cn_f32nchw_to_bf16nhwc_kernel(const float* __restrict__ src, long sbs,
+                                                                    bf16_t* __restrict__ dst, long ld, int C,
+                                                                    int Cpad, int HW) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * 64;
+  for (int c0 = 0; c0 < Cpad; c0 += 64) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+      const int c = i >> 6, p = i & 63;
+      tile[c][p] = (c0 + c < C && p0 + p < HW) ? src[b * sbs + (long)(c0 + c) * HW + p0 + p] : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 32; i += 256) {
+      const int p = i >> 5, c2 = (i & 31) * 2;
+      if (p0 + p < HW && c0 + c2 < Cpad)
+        *reinterpret_cast<unsigned*>(dst + ((long)b * HW + p0 + p) * ld + c0 + c2) =
+            cn_pack_bf16(tile[c2][p], tile[c2 + 1][p]);
+    }
+  }
+}
+
+// src bf16 [B*HW][>=C] rows (ld) -> dst f32 [B][C][HW] (batch stride dbs), (+)=.
+__global__ __launch_bounds__(256) void cn_bf16nhwc_to_f32nchw_kernel(const bf16_t* __restrict__ src, long ld,
+                                                                    float* __restrict__ dst, long dbs, int C, int HW,
+                                                                    int accumulate) {
+  __shared__ float tile[64][65];
+  const int b = blockIdx.y;
+  const int p0 = blockIdx.x * 64;
+  for (int c0 = 0; c0 < C; c0 += 64) {
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+      const int p = i >> 6, c = i & 63;
+      tile[c][p] = (c0 + c < C && p0 + p < HW) ? cn_bf16_to_f32(src[((long)b * HW + p0 + p) * ld + c0 + c]) : 0.f;
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 64 * 64; i += 256) {
+      const int c = i >> 6, p = i & 63;
+      if (c0 + c < C && p0 + p < HW) {
+        float* o = dst + b * dbs + (long)(c0 + c) * HW + p0 + p;
+        *o = accumulate ? *o + tile[c][p] : tile[c][p];
+      }
+    }
+  }
+}
+
+extern "C" int cn_convert_f32nchw_to_bf16nhwc(const float* src, long sbs, void* dst, long ld, int B, int C, int Cpad,
+                                              int HW, void* stream) {
+  if (B <= 0 || HW <= 0) return CN_OK;
+  if (Cpad < C || (Cpad & 1) || ld < Cpad) return CN_ERR_ARG;
+  hipLaunchKernelGGL(cn_f32nchw_to_bf16nhwc_kernel, dim3((HW + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, src, sbs,
+                     (bf16_t*)dst, ld, C, Cpad, HW);
+  return cn_check_launch();
+}
+
+extern "C" int cn_convert_bf16nhwc_to_f32nchw(const void* src, long ld, float* dst, long dbs, int B, int C, int HW,
+                                              int accumulate, void* stream) {
+  if (B <= 0 || HW <= 0) return CN_OK;
+  hipLaunchKernelGGL(cn_bf16nhwc_to_f32nchw_kernel, dim3((HW + 63) / 64, B), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, ld, dst, dbs, C, HW, accumulate);
+  return cn_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// slice copy / add / fill on [P][C] rows (C % 8 == 0): dst (+)= src ; dst = a + c ; fill
+// ------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void cn_bcopy_kernel(const bf16_t* __restrict__ a, long lda,
+                                                      const bf16_t* __restrict__ c, long ldc, bf16_t* __restrict__ d,
+                                                      long ldd, long P, int C8, int mode) {
+  const long n = P * C8;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long p = i / C8;
+    const int cg = (int)(i - p * C8);
+    float av[8];
+    cn_unpack8(*reinterpret_cast<const u32x4*>(a + p * lda + cg * 8), av);
+    if (mode != 0) {  // 1: d += a ; 2: d = a + c
+      float cv[8];
+      cn_unpack8(*reinterpret_cast<const u32x4*>((mode == 1 ? d + p * ldd : c + p * ldc) + cg * 8), cv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) av[j] += cv[j];
+      *reinterpret_cast<u32x4*>(d + p * ldd + cg * 8) = cn_pack8(av);
+    } else {
+      *reinterpret_cast<u32x4*>(d + p * ldd + cg * 8) = *reinterpret_cast<const u32x4*>(a + p * lda + cg * 8);
+    }
+  }
+}
+
+static inline unsigned bops_blocks(long n) {
+  long b = (n + 255) / 256;
+  return (unsigned)(b > 8192 ? 8192 : (b < 1 ? 1 : b));
+}
+
+extern "C" int cn_copy_bf16(const void* src, long lds_, void* dst, long ldd, long P, int C, int accumulate,
+                            void* stream) {
+  if (P <= 0 || C <= 0) return CN_OK;
+  if (C & 7) return CN_ERR_ARG;
+  hipLaunchKernelGGL(cn_bcopy_kernel, dim3(bops_blocks(P * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)src, lds_, nullptr, 0L, (bf16_t*)dst, ldd, P, C >> 3, accumulate ? 1 : 0);
+  return cn_check_launch();
+}
+
+extern "C" int cn_add_bf16(const void* a, long lda, const void* c, long ldc, void* dst, long ldd, long P, int C,
+                           void* stream) {
+  if (P <= 0 || C <= 0) return CN_OK;
+  if (C & 7) return CN_ERR_ARG;
+  hipLaunchKernelGGL(cn_bcopy_kernel, dim3(bops_blocks(P * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)a, lda, (const bf16_t*)c, ldc, (bf16_t*)dst, ldd, P, C >> 3, 2);
+  return cn_check_launch();
+}
+
+__global__ __launch_bounds__(256) void cn_bfill_kernel(bf16_t* __restrict__ d, long ldd, long P, int C8) {
+  const long n = P * C8;
+  const u32x4 z = {0u, 0u, 0u, 0u};
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long p = i / C8;
+    *reinterpret_cast<u32x4*>(d + p * ldd + (i - p * C8) * 8) = z;
+  }
+}
+
+extern "C" int cn_zero_bf16(void* dst, long ldd, long P, int C, void* stream) {
+  if (P <= 0 || C <= 0) return CN_OK;
+  if (C & 7) return CN_ERR_ARG;
+  hipLaunchKernelGGL(cn_bfill_kernel, dim3(bops_blocks(P * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dst,
+                     ldd, P, C >> 3);
+  return cn_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// bilinear resize, align_corners=True (ATen fp32 index math; weights fp32, data bf16)
+// ------------------------------------------------------------------------------------------------------------
+__device__ __forceinline__ void bbl_src(int o, float scale, int in_size, int& i0, int& i1, float& l1) {
+#pragma clang fp contract(off)
+  const float src = scale * (float)o;
+  i0 = (int)src;
+  if (i0 > in_size - 1) i0 = in_size - 1;
+  i1 = i0 + ((i0 < in_size - 1) ? 1 : 0);
+  l1 = src - i0;
+}
+
+__global__ __launch_bounds__(256) void cn_bbilinear_fwd_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                              bf16_t* __restrict__ y, long ldy, int B, int C8, int Hi,
+                                                              int Wi, int Ho, int Wo, float sh, float sw) {
+  const long n = (long)B * Ho * Wo * C8;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long po = i / C8;
+    const int cg = (int)(i - po * C8);
+    const int ox = (int)(po % Wo);
+    const long t = po / Wo;
+    const int oy = (int)(t % Ho);
+    const long b = t / Ho;
+    int y0, y1, x0, x1;
+    float ly, lx;
+    bbl_src(oy, sh, Hi, y0, y1, ly);
+    bbl_src(ox, sw, Wi, x0, x1, lx);
+    const bf16_t* xb = x + (b * Hi * Wi) * ldx + cg * 8;
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    cn_unpack8(*reinterpret_cast<const u32x4*>(xb + ((long)y0 * Wi + x0) * ldx), v00);
+    cn_unpack8(*reinterpret_cast<const u32x4*>(xb + ((long)y0 * Wi + x1) * ldx), v01);
+    cn_unpack8(*reinterpret_cast<const u32x4*>(xb + ((long)y1 * Wi + x0) * ldx), v10);
+    cn_unpack8(*reinterpret_cast<const u32x4*>(xb + ((long)y1 * Wi + x1) * ldx), v11);
+    const float hy = 1.f - ly, hx = 1.f - lx;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = hy * (hx * v00[j] + lx * v01[j]) + ly * (hx * v10[j] + lx * v11[j]);
+    *reinterpret_cast<u32x4*>(y + po * ldy + cg * 8) = cn_pack8(o);
+  }
+}
+
+// candidate output rows / columns reading input index i (<= 4 for resizes that shrink by less than 2x)
+__device__ __forceinline__ int bbl_candidates(int i, int in_size, int out_size, float scale, float inv_scale, int* idx,
+                                              float* wgt) {
+  int lo = (int)floorf((i - 1) * inv_scale) - 1, hi = (int)ceilf((i + 1) * inv_scale) + 1;
+  if (scale == 0.f) { lo = 0; hi = out_size - 1; }
+  lo = max(lo, 0);
+  hi = min(hi, out_size - 1);
+  int n = 0;
+#pragma unroll 1
+  for (int o = lo; o <= hi; ++o) {
+    int i0, i1; float l1;
+    bbl_src(o, scale, in_size, i0, i1, l1);
+    float w = 0.f;
+    if (i0 == i) w += 1.f - l1;
+    if (i1 == i) w += l1;
+    if (w != 0.f) {
+      if (n == 0) { idx[0] = o; wgt[0] = w; }
+      else if (n == 1) { idx[1] = o; wgt[1] = w; }
+      else if (n == 2) { idx[2] = o; wgt[2] = w; }
+      else if (n == 3) { idx[3] = o; wgt[3] = w; }
+      ++n;
+    }
+  }
+  return n;
+}
+
+// adjoint in gather form (deterministic): every input pixel sums the output pixels that read it
+__global__ __launch_bounds__(256) void cn_bbilinear_bwd_kernel(const bf16_t* __restrict__ dy, long lddy,
+                                                              bf16_t* __restrict__ dx, long lddx, int B, int C8,
+                                                              int Hi, int Wi, int Ho, int Wo, float sh, float sw,
+                                                              float inv_sh, float inv_sw, int accumulate) {
+  const long n = (long)B * Hi * Wi * C8;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long pi = i / C8;
+    const int cg = (int)(i - pi * C8);
+    const int ix = (int)(pi % Wi);
+    const long t = pi / Wi;
+    const int iy = (int)(t % Hi);
+    const long b = t / Hi;
+    int oyv[4] = {0, 0, 0, 0}, oxv[4] = {0, 0, 0, 0};
+    float wyv[4] = {0.f, 0.f, 0.f, 0.f}, wxv[4] = {0.f, 0.f, 0.f, 0.f};
+    const int ny = bbl_candidates(iy, Hi, Ho, sh, inv_sh, oyv, wyv);
+    const int nx = bbl_candidates(ix, Wi, Wo, sw, inv_sw, oxv, wxv);
+    const bf16_t* db = dy + (b * Ho * Wo) * lddy + cg * 8;
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (ny <= 4 && nx <= 4) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int l = 0; l < 4; ++l) {
+          const float w = wyv[k] * wxv[l];
+          if (w != 0.f) {
+            float v[8];
+            cn_unpack8(*reinterpret_cast<const u32x4*>(db + ((long)oyv[k] * Wo + oxv[l]) * lddy), v);
+#pragma unroll
+            for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+          }
+        }
+    } else {  // general (strong down-scaling): scan the candidate window
+      int oy_lo = (int)floorf((iy - 1) * inv_sh) - 1, oy_hi = (int)ceilf((iy + 1) * inv_sh) + 1;
+      int ox_lo = (int)floorf((ix - 1) * inv_sw) - 1, ox_hi = (int)ceilf((ix + 1) * inv_sw) + 1;
+      if (sh == 0.f) { oy_lo = 0; oy_hi = Ho - 1; }
+      if (sw == 0.f) { ox_lo = 0; ox_hi = Wo - 1; }
+      oy_lo = max(oy_lo, 0); oy_hi = min(oy_hi, Ho - 1);
+      ox_lo = max(ox_lo, 0); ox_hi = min(ox_hi, Wo - 1);
+      for (int oy = oy_lo; oy <= oy_hi; ++oy) {
+        int y0, y1; float ly;
+        bbl_src(oy, sh, Hi, y0, y1, ly);
+        float wy = 0.f;
+        if (y0 == iy) wy += 1.f - ly;
+        if (y1 == iy) wy += ly;
+        if (wy == 0.f) continue;
+        for (int ox = ox_lo; ox <= ox_hi; ++ox) {
+          int x0, x1; float lx;
+          bbl_src(ox, sw, Wi, x0, x1, lx);
+          float wx = 0.f;
+          if (x0 == ix) wx += 1.f - lx;
+          if (x1 == ix) wx += lx;
+          if (wx == 0.f) continue;
+          float v[8];
+          cn_unpack8(*reinterpret_cast<const u32x4*>(db + ((long)oy * Wo + ox) * lddy), v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += wy * wx * v[j];
+        }
+      }
+    }
+    bf16_t* o = dx + pi * lddx + cg * 8;
+    if (accumulate) {
+      float ov[8];
+      cn_unpack8(*reinterpret_cast<const u32x4*>(o), ov);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += ov[j];
+    }
+    *reinterpret_cast<u32x4*>(o) = cn_pack8(acc);
+  }
+}
+
+static inline float bbl_scale(int in_size, int out_size) {
+  return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
+}
+
+extern "C" int cn_bilinear_fwd_bf16(const void* x, long ldx, void* y, long ldy, int B, int C, int Hi, int Wi, int Ho,
+                                    int Wo, void* stream) {
+  if (B <= 0 || C <= 0) return CN_OK;
+  if (C & 7) return CN_ERR_ARG;
+  hipLaunchKernelGGL(cn_bbilinear_fwd_kernel, dim3(bops_blocks((long)B * Ho * Wo * (C >> 3))), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, B, C >> 3, Hi, Wi, Ho, Wo,
+                     bbl_scale(Hi, Ho), bbl_scale(Wi, Wo));
+  return cn_check_launch();
+}
+
+extern "C" int cn_bilinear_bwd_bf16(const void* dy, long lddy, void* dx, long lddx, int B, int C, int Hi, int Wi,
+                                    int Ho, int Wo, int accumulate, void* stream) {
+  if (B <= 0 || C <= 0) return CN_OK;
+  if (C & 7) return CN_ERR_ARG;
+  const float sh = bbl_scale(Hi, Ho), sw = bbl_scale(Wi, Wo);
+  hipLaunchKernelGGL(cn_bbilinear_bwd_kernel, dim3(bops_blocks((long)B * Hi * Wi * (C >> 3))), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, B, C >> 3, Hi, Wi, Ho, Wo, sh, sw,
+                     sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, accumulate);
+  return cn_check_launch();
+}
+
+// ------------------------------------------------------------------------------------------------------------
+// neighborhood attention core: qkv bf16 [B][H][W][3C] (channel = which*C + head*D + d), out bf16 [B][H][W][C];
+// attn / dattn fp32 [B][heads][9][H][W] (saved probabilities / dS scratch). One lane per (pixel, head), head fastest.
+// ------------------------------------------------------------------------------------------------------------
+#define NAB_K 3
+#define NAB_KK 9
+
+__device__ __forceinline__ int nab_window_start(int i, int len, int dil) {
+  if (dil <= 1) return max(i - 1, 0) + ((i + 1 >= len) ? (len - i - 2) : 0);
+  const int ni = i - dil;
+  if (ni < 0) return i % dil;
+  if (i + dil >= len) {
+    const int imodd = i % dil;
+    const int a = (len / dil) * dil;
+    const int b = len - a;
+    if (imodd < b) return len - b + imodd - 2 * dil;
+    return a + imodd - NAB_K * dil;
+  }
+  return ni;
+}
+
+template <int D>
+__device__ __forceinline__ void nab_load(const bf16_t* p, float* f) {
+  if (D == 4) {
+    const u32x2 v = *reinterpret_cast<const u32x2*>(p);
+    f[0] = cn_bf16_lo(v[0]); f[1] = cn_bf16_hi(v[0]); f[2] = cn_bf16_lo(v[1]); f[3] = cn_bf16_hi(v[1]);
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < D / 8; ++i) cn_unpack8(*reinterpret_cast<const u32x4*>(p + i * 8), f + i * 8);
+}
+template <int D>
+__device__ __forceinline__ void nab_store(bf16_t* p, const float* f) {
+  if (D == 4) {
+    const u32x2 v = {cn_pack_bf16(f[0], f[1]), cn_pack_bf16(f[2], f[3])};
+    *reinterpret_cast<u32x2*>(p) = v;
+    return;
+  }
+#pragma unroll
+  for (int i = 0; i < D / 8; ++i) *reinterpret_cast<u32x4*>(p + i * 8) = cn_pack8(f + i * 8);
+}
+
+template <int D>
+__global__ __launch_bounds__(256) void cn_bna_fwd_kernel(const bf16_t* __restrict__ qkv, long ldq,
+                                                        bf16_t* __restrict__ out, long ldo, float* __restrict__ attn,
+                                                        int B, int C, int heads, int H, int W, int dil, float scale) {
+  const int HW = H * W;
+  const long n = (long)B * HW * heads;
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= n) return;
+  const int h = (int)(i % heads);
+  const long bp = i / heads;
+  const int p = (int)(bp % HW);
+  const int b = (int)(bp / HW);
+  const int y = p / W, x = p - y * W;
+  const int sy = nab_window_start(y, H, dil), sx = nab_window_start(x, W, dil);
+  const bf16_t* base = qkv + ((long)b * HW) * ldq + h * D;
+  float q[D];
+  nab_load<D>(base + (long)p * ldq, q);
+  float lg[NAB_KK];
+#pragma unroll
+  for (int t = 0; t < NAB_KK; ++t) {
+    const int kp = (sy + (t / 3) * dil) * W + sx + (t % 3) * dil;
+    float kv[D];
+    nab_load<D>(base + (long)kp * ldq + C, kv);
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) s += q[d] * kv[d];
+    lg[t] = s * scale;
+  }
+  float mx = -INFINITY;
+#pragma unroll
+  for (int t = 0; t < NAB_KK; ++t) mx = fmaxf(mx, lg[t]);
+  float den = 0.f;
+#pragma unroll
+  for (int t = 0; t < NAB_KK; ++t) { lg[t] = expf(lg[t] - mx); den += lg[t]; }
+  const float inv = 1.0f / den;
+  float* ap = attn + ((long)(b * heads + h) * NAB_KK) * HW + p;
+  float o[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) o[d] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NAB_KK; ++t) {
+    lg[t] *= inv;
+    if (attn != nullptr) ap[(long)t * HW] = lg[t];
+    const int kp = (sy + (t / 3) * dil) * W + sx + (t % 3) * dil;
+    float vv[D];
+    nab_load<D>(base + (long)kp * ldq + 2 * C, vv);
+#pragma unroll
+    for (int d = 0; d < D; ++d) o[d] += lg[t] * vv[d];
+  }
+  nab_store<D>(out + ((long)b * HW + p) * ldo + h * D, o);
+}
+
+// query side: dP = dOut.v ; dS = P*(dP - sum P dP) (saved to dattn) ; dq = scale * sum dS*k
+template <int D>
+__global__ __launch_bounds__(256) void cn_bna_bwd_q_kernel(const bf16_t* __restrict__ qkv, long ldq,
+                                                          const bf16_t* __restrict__ dout, long ldo,
+                                                          const float* __restrict__ attn, float* __restrict__ dattn,
+                                                          bf16_t* __restrict__ dqkv, long lddq, int B, int C,
+                                                          int heads, int H, int W, int dil, float scale) {
+  const int HW = H * W;
+  const long n = (long)B * HW * heads;
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= n) return;
+  const int h = (int)(i % heads);
+  const long bp = i / heads;
+  const int p = (int)(bp % HW);
+  const int b = (int)(bp / HW);
+  const int y = p / W, x = p - y * W;
+  const int sy = nab_window_start(y, H, dil), sx = nab_window_start(x, W, dil);
+  const bf16_t* base = qkv + ((long)b * HW) * ldq + h * D;
+  float g[D];
+  nab_load<D>(dout + ((long)b * HW + p) * ldo + h * D, g);
+  const float* ap = attn + ((long)(b * heads + h) * NAB_KK) * HW + p;
+  float dp[NAB_KK], pr[NAB_KK];
+  float dot = 0.f;
+#pragma unroll
+  for (int t = 0; t < NAB_KK; ++t) {
+    const int kp = (sy + (t / 3) * dil) * W + sx + (t % 3) * dil;
+    float vv[D];
+    nab_load<D>(base + (long)kp * ldq + 2 * C, vv);
+    float s = 0.f;
+#pragma unroll
+    for (int d = 0; d < D; ++d) s += g[d] * vv[d];
+    dp[t] = s;
+    pr[t] = ap[(long)t * HW];
+    dot += pr[t] * s;
+  }
+  float* dap = dattn + ((long)(b * heads + h) * NAB_KK) * HW + p;
+  float dq[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) dq[d] = 0.f;
+#pragma unroll
+  for (int t = 0; t < NAB_KK; ++t) {
+    const float ds = pr[t] * (dp[t] - dot);
+    dap[(long)t * HW] = ds;
+    const int kp = (sy + (t / 3) * dil) * W + sx + (t % 3) * dil;
+    float kv[D];
+    nab_load<D>(base + (long)kp * ldq + C, kv);
+#pragma unroll
+    for (int d = 0; d < D; ++d) dq[d] += ds * kv[d];
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) dq[d] *= scale;
+  nab_store<D>(dqkv + ((long)b * HW + p) * lddq + h * D, dq);
+}
+
+// key side, gather form (deterministic): visit every query whose window contains this key pixel
+template <int D>
+__global__ __launch_bounds__(256) void cn_bna_bwd_kv_kernel(const bf16_t* __restrict__ qkv, long ldq,
+                                                           const bf16_t* __restrict__ dout, long ldo,
+                                                           const float* __restrict__ attn,
+                                                           const float* __restrict__ dattn,
+                                                           bf16_t* __restrict__ dqkv, long lddq, int B, int C,
+                                                           int heads, int H, int W, int dil, float scale) {
+  const int HW = H * W;
+  const long n = (long)B * HW * heads;
+  const long i = blockIdx.x * 256L + threadIdx.x;
+  if (i >= n) return;
+  const int h = (int)(i % heads);
+  const long bp = i / heads;
+  const int p = (int)(bp % HW);
+  const int b = (int)(bp / HW);
+  const int y = p / W, x = p - y * W;
+  const bf16_t* qb = qkv + ((long)b * HW) * ldq + h * D;
+  const bf16_t* gb = dout + ((long)b * HW) * ldo + h * D;
+  const float* ap = attn + ((long)(b * heads + h) * NAB_KK) * HW;
+  const float* dap = dattn + ((long)(b * heads + h) * NAB_KK) * HW;
+  float dk[D], dv[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) { dk[d] = 0.f; dv[d] = 0.f; }
+  for (int my = -2; my <= 2; ++my) {
+    const int qy = y + my * dil;
+    if (qy < 0 || qy >= H) continue;
+    const int offy = y - nab_window_start(qy, H, dil);
+    if (offy < 0 || offy > 2 * dil) continue;
+    const int ti = offy / dil;
+    for (int mx = -2; mx <= 2; ++mx) {
+      const int qx = x + mx * dil;
+      if (qx < 0 || qx >= W) continue;
+      const int offx = x - nab_window_start(qx, W, dil);
+      if (offx < 0 || offx > 2 * dil) continue;
+      const int t = ti * NAB_K + offx / dil;
+      const int qpix = qy * W + qx;
+      const float ds = dap[(long)t * HW + qpix];
+      const float pr = ap[(long)t * HW + qpix];
+      float qv[D], gv[D];
+      nab_load<D>(qb + (long)qpix * ldq, qv);
+      nab_load<D>(gb + (long)qpix * ldo, gv);
+#pragma unroll
+      for (int d = 0; d < D; ++d) { dk[d] += ds * qv[d]; dv[d] += pr * gv[d]; }
+    }
+  }
+#pragma unroll
+  for (int d = 0; d < D; ++d) dk[d] *= scale;
+  bf16_t* o = dqkv + ((long)b * HW + p) * lddq + h * D;
+  nab_store<D>(o + C, dk);
+  nab_store<D>(o + 2 * C, dv);
+}
+
+#define NAB_DISPATCH(D_, KERNEL, ...)                                                          \
+  switch (D_) {                                                                                \
+    case 4: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(256), 0, stream, __VA_ARGS__); break;  \
+    case 8: hipLaunchKernelGGL((KERNEL<8>), grid, dim3(256), 0, stream, __VA_ARGS__); break;  \
+    case 16: hipLaunchKernelGGL((KERNEL<16>), grid, dim3(256), 0, stream, __VA_ARGS__); break; \
+    case 32: hipLaunchKernelGGL((KERNEL<32>), grid, dim3(256), 0, stream, __VA_ARGS__); break; \
+    case 64: hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, stream, __VA_ARGS__); break; \
+    default: return CN_ERR_ARG;                                                                \
+  }
+
+extern "C" int cn_na2d_fwd_bf16(const void* qkv, long ldq, void* out, long ldo, float* attn, int B, int C, int heads,
+                                int H, int W, int kernel_size, int dilation, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (kernel_size != NAB_K || heads <= 0 || C % heads != 0) return CN_ERR_ARG;
+  if (kernel_size * dilation > H || kernel_size * dilation > W) return CN_ERR_ARG;
+  const int D = C / heads;
+  const float scale = 1.0f / sqrtf((float)D);
+  const long n = (long)B * H * W * heads;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  NAB_DISPATCH(D, cn_bna_fwd_kernel, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, attn, B, C, heads, H, W, dilation,
+               scale);
+  return cn_check_launch();
+}
+
+// dqkv bf16 [B][H][W][3C] fully overwritten; dattn: scratch of attn's size.
+extern "C" int cn_na2d_bwd_bf16(const void* qkv, long ldq, const void* dout, long ldo, const float* attn, float* dattn,
+                                void* dqkv, long lddq, int B, int C, int heads, int H, int W, int kernel_size,
+                                int dilation, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (kernel_size != NAB_K || heads <= 0 || C % heads != 0) return CN_ERR_ARG;
+  const int D = C / heads;
+  const float scale = 1.0f / sqrtf((float)D);
+  const long n = (long)B * H * W * heads;
+  const dim3 grid((unsigned)((n + 255) / 256));
+  NAB_DISPATCH(D, cn_bna_bwd_q_kernel, (const bf16_t*)qkv, ldq, (const bf16_t*)dout, ldo, attn, dattn, (bf16_t*)dqkv,
+               lddq, B, C, heads, H, W, dilation, scale);
+  NAB_DISPATCH(D, cn_bna_bwd_kv_kernel, (const bf16_t*)qkv, ldq, (const bf16_t*)dout, ldo, attn, dattn, (bf16_t*)dqkv,
+               lddq, B, C, heads, H, W, dilation, scale);
+  return cn_check_launch();
+}

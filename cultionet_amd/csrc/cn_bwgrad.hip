@@ -1,0 +1,315 @@
+// bf16 weight gradients for gfx950 (MI355X): v_mfma_f32_32x32x16_bf16 with the PIXELS as the contraction index.
+//
+// Weight gradients of nn.Conv2d / nn.ConvTranspose2d on the mixed-precision path (activations and activation
+// gradients bf16 NHWC, parameter gradients fp32 in the flat gradient buffer; reference: autograd of
+// /root/reference/src/cultionet/nn/modules/convolution.py:45-120 under precision="16-mixed", model.py:168-186).
+// Both layers are the same contraction over a pixel grid g:
+//     dW[cP][cQ][t] += sum_{b, g}  P[b][g][cP] * Q[b][g*s + off_t][cQ]
+//   Conv2d:           P = dy (cP = cout), Q = x  (cQ = cin),  off_t = k*dil - pad      -> dW laid out [Cout][Cin][T]
+//   ConvTranspose2d:  P = x  (cP = cin),  Q = dy (cQ = cout), off_t = k - pad          -> dW laid out [Cin][Cout][T]
+// i.e. dW index = (cP * CQ + cQ) * T + t in both cases.
+//
+// NHWC makes both operands pixel-major ([pixel][channel] rows in LDS), while an MFMA fragment wants 8 consecutive k
+// (= pixels) per lane: gfx950's transposing LDS read ds_read_b64_tr_b16 delivers exactly that (4 pixel rows x 16
+// channels per 16-lane group, column-major), and because every row of a transposed block is addressed by its own
+// lane, a tap is again just a row offset into the halo image -- no alignment constraints, no shifted copies.
+//
+// Block = 4 waves = 64 cP x 64 cQ x all T taps (wave = 32 x 32 x T, T*16 accumulator registers); it walks a
+// contiguous range of pixel tiles (split-K over tiles) and stores its partial [T][64][64] fp32 slice into the
+// workspace; cn_bwgrad_reduce_kernel sums the slices into dW (+=).
+#include "cn_bf16.h"
+#include "cn_profile.h"
+
+#define CNW_PITCH 192  // bytes per pixel row in LDS (64 channels = 128 B + 64 B pad): conflict-free transposed reads
+#define CNW_MAX_TAPS 9
+
+struct CnBWgGeom {
+  const bf16_t* P;
+  const bf16_t* Q;
+  long ldp, ldq;
+  int B, CP, CQ;
+  int Hg, Wg;      // pixel grid (= spatial size of P)
+  int Hq, Wq;      // spatial size of Q
+  int s;           // Q pixel = g*s + off
+  int T;
+  int doff[CNW_MAX_TAPS];  // LDS byte offset of each tap inside the Q halo image
+  int qy_off, qx_off;      // Q coordinate of halo pixel (0,0) relative to tile origin * s
+  int IH, IW;
+  int TH, TW;
+  int tiles_x, tiles_per_img, ntiles;
+  int nsplit, tiles_per_split;
+  int nbp, nbq;    // 64-channel blocks over cP / cQ
+  float* part;     // [nsplit][T][nbp*64][nbq*64]
+  int total;
+};
+
+__device__ __forceinline__ bf16x4 cnw_tr(const unsigned char* lds_addr) {
+  typedef short s4 __attribute__((ext_vector_type(4)));
+  return __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+      (__attribute__((address_space(3))) s4*)(const_cast<unsigned char*>(lds_addr)));
+}
+
+template <int T>
+__global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const CnBWgGeom g) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int wp = wid >> 1, wq = wid & 1;
+  int L;
+  {
+    const int lin = blockIdx.x;
+    const int per = (g.total + 7) >> 3;
+    L = (lin & 7) * per + (lin >> 3);
+    if (L >= g.total) return;
+  }
+  // L = (split * nbp + bp) * nbq + bq : the blocks of one split (same pixels) are neighbours on one XCD
+  const int bq = L % g.nbq;
+  const int bp = (L / g.nbq) % g.nbp;
+  const int split = L / (g.nbq * g.nbp);
+  const int npix = g.TH * g.TW;
+  const int IW = g.IW;
+  unsigned char* ldsP = lds;
+  unsigned char* ldsQ = lds + 128 * CNW_PITCH;
+
+  // transposed-read geometry: within a 16-lane group, lane 4q+p addresses row q, columns 4p..4p+3
+  const int g16 = lane >> 4;
+  const int rq = (lane & 15) >> 2, rp = lane & 3;
+  const int colb = (16 * (g16 & 1) + 4 * rp) * 2;  // byte offset of this lane's 4 columns inside a 32-channel tile
+  const int kh8 = 8 * (g16 >> 1);                   // k offset of the lane's half
+  // per k-step (16 pixels): grid pixel of row rq for the two reads (k = kh8 + rq, kh8 + 4 + rq)
+  int qrow[16];  // Q-image byte offsets of those pixels (tap offset added later), clamped for out-of-tile pixels
+#pragma unroll
+  for (int ks = 0; ks < 8; ++ks)
+#pragma unroll
+    for (int e = 0; e < 2; ++e) {
+      const int m = ks * 16 + kh8 + 4 * e + rq;
+      const int ty = m / g.TW, tx = m - ty * g.TW;
+      qrow[ks * 2 + e] = m < npix ? ((ty * g.s) * IW + tx * g.s) * CNW_PITCH : 0;
+    }
+  const int pcol = wp * 64 + colb, qcol = wq * 64 + colb;
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) acc[t][j] = 0.f;
+
+  const int t_begin = split * g.tiles_per_split;
+  const int t_end = t_begin + g.tiles_per_split < g.ntiles ? t_begin + g.tiles_per_split : g.ntiles;
+  const int cp0 = bp * 64, cq0 = bq * 64;
+  const int nq_pieces = g.IH * IW * 8;  // 16-byte pieces of the Q image (8 per pixel)
+#pragma unroll 1
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    const int b = tile / g.tiles_per_img;
+    const int tl = tile - b * g.tiles_per_img;
+    const int tyi = tl / g.tiles_x, txi = tl - tyi * g.tiles_x;
+    const int gy0 = tyi * g.TH, gx0 = txi * g.TW;
+    __syncthreads();  // previous tile's reads are done
+    // stage P: 128 pixels x 64 channels (zeros outside the tile / grid / channel range)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int q = tid + i * 256;
+      const int m = q >> 3, c8 = (q & 7) * 8;
+      const int ty = m / g.TW, tx = m - ty * g.TW;
+      const int gy = gy0 + ty, gx = gx0 + tx;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (m < npix && gy < g.Hg && gx < g.Wg && cp0 + c8 < g.CP)
+        v = *reinterpret_cast<const u32x4*>(g.P + (((long)b * g.Hg + gy) * g.Wg + gx) * g.ldp + cp0 + c8);
+      *reinterpret_cast<u32x4*>(ldsP + m * CNW_PITCH + c8 * 2) = v;
+    }
+    // stage Q: halo image
+    const int qy0 = gy0 * g.s + g.qy_off, qx0 = gx0 * g.s + g.qx_off;
+#pragma unroll 1
+    for (int q = tid; q < nq_pieces; q += 256) {
+      const int p = q >> 3, c8 = (q & 7) * 8;
+      const int hy = p / IW, hx = p - hy * IW;
+      const int iy = qy0 + hy, ix = qx0 + hx;
+      u32x4 v = {0u, 0u, 0u, 0u};
+      if (iy >= 0 && iy < g.Hq && ix >= 0 && ix < g.Wq && cq0 + c8 < g.CQ)
+        v = *reinterpret_cast<const u32x4*>(g.Q + (((long)b * g.Hq + iy) * g.Wq + ix) * g.ldq + cq0 + c8);
+      *reinterpret_cast<u32x4*>(ldsQ + p * CNW_PITCH + c8 * 2) = v;
+    }
+    __syncthreads();
+    const int ksteps = (npix + 15) >> 4;
+#pragma unroll
+    for (int ks = 0; ks < 8; ++ks) {
+      if (ks < ksteps) {
+        const int m0 = ks * 16 + kh8 + rq;
+        const bf16x4 pa = cnw_tr(ldsP + m0 * CNW_PITCH + pcol);
+        const bf16x4 pb = cnw_tr(ldsP + (m0 + 4) * CNW_PITCH + pcol);
+        const bf16x8 a = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3]};
+#pragma unroll
+        for (int t = 0; t < T; ++t) {
+          const bf16x4 qa = cnw_tr(ldsQ + qrow[ks * 2] + g.doff[t] + qcol);
+          const bf16x4 qb = cnw_tr(ldsQ + qrow[ks * 2 + 1] + g.doff[t] + qcol);
+          const bf16x8 bb = {qa[0], qa[1], qa[2], qa[3], qb[0], qb[1], qb[2], qb[3]};
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc[t], 0, 0, 0);
+        }
+      }
+    }
+  }
+  // partial slice: part[split][t][cP][cQ] (lanes contiguous along cQ)
+  const int r = lane & 31, h = lane >> 5;
+  const long CPp = (long)g.nbp * 64, CQp = (long)g.nbq * 64;
+  float* out = g.part + (long)split * T * CPp * CQp;
+#pragma unroll
+  for (int t = 0; t < T; ++t)
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      const int cp = cp0 + wp * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+      out[((long)t * CPp + cp) * CQp + cq0 + wq * 32 + r] = acc[t][j];
+    }
+}
+
+// dw[(cP*CQ + cQ)*T + t] += sum_split part[split][t][cP][cQ]
+__global__ __launch_bounds__(256) void cn_bwgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
+                                                              int nsplit, int T, int CP, int CQ, long CPp, long CQp) {
+  const long n = (long)CP * CQ * T;
+  const long slice = (long)T * CPp * CQp;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    // i = (t*CP + cp)*CQ + cq : reads coalesced along cq
+    const int cq = (int)(i % CQ);
+    const long r = i / CQ;
+    const int cp = (int)(r % CP);
+    const int t = (int)(r / CP);
+    const float* p = part + ((long)t * CPp + cp) * CQp + cq;
+    float s = 0.f;
+    for (int k = 0; k < nsplit; ++k) s += p[k * slice];
+    dw[((long)cp * CQ + cq) * T + t] += s;
+  }
+}
+
+static void cnw_pick_tile(int Hg, int Wg, int s, int span, int& TH, int& TW) {
+  static const int cand[][2] = {{5, 25}, {8, 16}, {4, 32}, {16, 8}, {2, 64}, {10, 12}, {6, 20}, {9, 14}, {11, 11},
+                                {13, 9}, {7, 18}, {1, 128}, {4, 16}, {8, 8}, {2, 32}, {4, 8}, {2, 16}};
+  double best = 1e300;
+  TH = 4; TW = 8;
+  for (auto& c : cand) {
+    const int th = c[0], tw = c[1];
+    const long ih = (long)(th - 1) * s + span + 1, iw = (long)(tw - 1) * s + span + 1;
+    if (ih * iw > 600) continue;
+    const long tiles = (long)((Hg + th - 1) / th) * ((Wg + tw - 1) / tw);
+    const double cost = (double)tiles * ((th * tw + 15) / 16) * 16.0 + 0.05 * tiles * ih * iw;
+    if (cost < best) { best = cost; TH = th; TW = tw; }
+  }
+}
+
+static int cnw_plan(CnBWgGeom& g, int KH, int KW, int pad, int dil) {
+  const int T = KH * KW;
+  if (T > CNW_MAX_TAPS || g.s < 1 || dil < 1) return CN_ERR_ARG;
+  g.T = T;
+  int mn_y = 0, mx_y = 0, mn_x = 0, mx_x = 0;
+  int dys[CNW_MAX_TAPS], dxs[CNW_MAX_TAPS];
+  for (int ky = 0; ky < KH; ++ky)
+    for (int kx = 0; kx < KW; ++kx) {
+      const int t = ky * KW + kx;
+      dys[t] = ky * dil - pad; dxs[t] = kx * dil - pad;
+      if (t == 0) { mn_y = mx_y = dys[t]; mn_x = mx_x = dxs[t]; }
+      mn_y = dys[t] < mn_y ? dys[t] : mn_y; mx_y = dys[t] > mx_y ? dys[t] : mx_y;
+      mn_x = dxs[t] < mn_x ? dxs[t] : mn_x; mx_x = dxs[t] > mx_x ? dxs[t] : mx_x;
+    }
+  const int span = (mx_y - mn_y) > (mx_x - mn_x) ? (mx_y - mn_y) : (mx_x - mn_x);
+  cnw_pick_tile(g.Hg, g.Wg, g.s, span, g.TH, g.TW);
+  g.qy_off = mn_y; g.qx_off = mn_x;
+  g.IH = (g.TH - 1) * g.s + (mx_y - mn_y) + 1;
+  g.IW = (g.TW - 1) * g.s + (mx_x - mn_x) + 1;
+  for (int t = 0; t < T; ++t) g.doff[t] = ((dys[t] - mn_y) * g.IW + (dxs[t] - mn_x)) * CNW_PITCH;
+  g.tiles_x = (g.Wg + g.TW - 1) / g.TW;
+  g.tiles_per_img = g.tiles_x * ((g.Hg + g.TH - 1) / g.TH);
+  g.ntiles = g.tiles_per_img * g.B;
+  g.nbp = (g.CP + 63) / 64;
+  g.nbq = (g.CQ + 63) / 64;
+  const int nb = g.nbp * g.nbq;
+  int nsplit = (512 + nb - 1) / nb;
+  if (nsplit > g.ntiles) nsplit = g.ntiles;
+  if (nsplit < 1) nsplit = 1;
+  g.tiles_per_split = (g.ntiles + nsplit - 1) / nsplit;
+  g.nsplit = (g.ntiles + g.tiles_per_split - 1) / g.tiles_per_split;
+  g.total = g.nsplit * nb;
+  return CN_OK;
+}
+
+static long cnw_ws_floats(const CnBWgGeom& g) { return (long)g.nsplit * g.T * g.nbp * 64 * g.nbq * 64; }
+
+static int cnw_run(CnBWgGeom& g, float* dw, float* ws, long ws_floats, hipStream_t stream) {
+  if (g.ntiles <= 0 || g.CP <= 0 || g.CQ <= 0) return CN_OK;
+  // shrink the split until the partial slices fit the workspace
+  while (cnw_ws_floats(g) > ws_floats && g.nsplit > 1) {
+    g.tiles_per_split *= 2;
+    g.nsplit = (g.ntiles + g.tiles_per_split - 1) / g.tiles_per_split;
+    g.total = g.nsplit * g.nbp * g.nbq;
+  }
+  if (ws == nullptr || cnw_ws_floats(g) > ws_floats) return CN_ERR_ARG;
+  g.part = ws;
+  const size_t shmem = (size_t)(128 + g.IH * g.IW) * CNW_PITCH;
+  if (shmem > 160 * 1024) return CN_ERR_LDS;
+  const dim3 grid(cn_xcd_grid(g.total)), block(256);
+  const double flops = 2.0 * g.B * (double)g.Hg * g.Wg * g.CP * g.CQ * g.T;
+  cn_prof_desc("bwgrad B%d %dx%d %dx%d T%d s%d split%d", g.B, g.Hg, g.Wg, g.CP, g.CQ, g.T, g.s, g.nsplit);
+  cn_prof_before(stream);
+#define CNW_GO(T_)                                                                                             \
+  do {                                                                                                         \
+    if (shmem > 64 * 1024)                                                                                     \
+      (void)hipFuncSetAttribute((const void*)cn_bwgrad_kernel<T_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                (int)shmem);                                                                   \
+    hipLaunchKernelGGL((cn_bwgrad_kernel<T_>), grid, block, shmem, stream, g);                                 \
+  } while (0)
+  switch (g.T) {
+    case 1: CNW_GO(1); break;
+    case 9: CNW_GO(9); break;
+    default: return CN_ERR_ARG;
+  }
+#undef CNW_GO
+  const long n = (long)g.CP * g.CQ * g.T;
+  const int rb = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  hipLaunchKernelGGL(cn_bwgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, g.part, dw, g.nsplit, g.T, g.CP, g.CQ,
+                     (long)g.nbp * 64, (long)g.nbq * 64);
+  cn_prof_after(stream, 5, flops);
+  return cn_check_launch();
+}
+
+// Scratch floats that always suffice for the weight gradient of one layer (partial slices of the pixel split).
+extern "C" long cn_bwgrad_workspace_floats(int B, int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride,
+                                           int pad, int dil, int transposed) {
+  CnBWgGeom g = {};
+  g.B = B;
+  if (!transposed) {
+    g.CP = Cout; g.CQ = Cin; g.s = stride;
+    g.Hg = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+    g.Wg = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  } else {
+    g.CP = Cin; g.CQ = Cout; g.s = stride; g.Hg = Hin; g.Wg = Win;
+  }
+  if (cnw_plan(g, KH, KW, pad, dil) != CN_OK) return -1;
+  return cnw_ws_floats(g);
+}
+
+// Conv2d: dw [Cout][Cin][KH][KW] (fp32) += ...; x bf16 NHWC [B,Hin,Win,Cin] (ldx), dy bf16 NHWC [B,Hout,Wout,Cout].
+extern "C" int cn_conv2d_bwd_weight_bf16(const void* x, long ldx, const void* dy, long lddy, float* dw, int B, int Cin,
+                                         int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, int dil,
+                                         float* ws, long ws_floats, void* stream) {
+  if (stride < 1) return CN_ERR_ARG;
+  CnBWgGeom g = {};
+  g.P = (const bf16_t*)dy; g.ldp = lddy; g.Q = (const bf16_t*)x; g.ldq = ldx;
+  g.B = B; g.CP = Cout; g.CQ = Cin; g.s = stride;
+  g.Hg = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  g.Wg = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  g.Hq = Hin; g.Wq = Win;
+  const int rc = cnw_plan(g, KH, KW, pad, dil);
+  if (rc != CN_OK) return rc;
+  return cnw_run(g, dw, ws, ws_floats, (hipStream_t)stream);
+}
+
+// ConvTranspose2d: dw [Cin][Cout][KH][KW] += ...; x [B,Hin,Win,Cin], dy [B,Hout,Wout,Cout], Hout = (Hin-1)*s - 2p + K.
+extern "C" int cn_conv_transpose2d_bwd_weight_bf16(const void* x, long ldx, const void* dy, long lddy, float* dw,
+                                                   int B, int Cin, int Hin, int Win, int Cout, int KH, int KW,
+                                                   int stride, int pad, float* ws, long ws_floats, void* stream) {
+  if (stride < 1) return CN_ERR_ARG;
+  CnBWgGeom g = {};
+  g.P = (const bf16_t*)x; g.ldp = ldx; g.Q = (const bf16_t*)dy; g.ldq = lddy;
+  g.B = B; g.CP = Cin; g.CQ = Cout; g.s = stride;
+  g.Hg = Hin; g.Wg = Win;
+  g.Hq = (Hin - 1) * stride - 2 * pad + KH; g.Wq = (Win - 1) * stride - 2 * pad + KW;
+  const int rc = cnw_plan(g, KH, KW, pad, 1);
+  if (rc != CN_OK) return rc;
+  return cnw_run(g, dw, ws, ws_floats, (hipStream_t)stream);
+}

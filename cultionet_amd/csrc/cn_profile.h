@@ -3,7 +3,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
-#define CN_PROF_KINDS 4  // 0 igemm<NT=128>  1 igemm<NT<=64>  2 wgrad<T=9>  3 wgrad<T=1>
+#define CN_PROF_KINDS 8  // 0 igemm<NT=128>  1 igemm<NT<=64>  2 wgrad<T=9>  3 wgrad<T=1>  4 bf16 conv  5 bf16 wgrad
 
 bool cn_prof_on();
 void cn_prof_before(hipStream_t stream);

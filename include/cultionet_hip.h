@@ -278,11 +278,104 @@ int cn_prepare_chips_f32(const void* x, int dtype, float* y, const float* mean, 
 int cn_predictions_to_u16(const float* dist, const float* edge, const float* crop, unsigned short* out, int B, int H,
                           int W, int pad_top, int pad_left, int h, int w, float scale, void* stream);
 
+
+/* ================================================================================================================
+ * bf16 mixed-precision path (BASELINE configs[2]; the reference's default precision="16-mixed", model.py:168-186).
+ * Activations and activation gradients: bfloat16, NHWC ([B][H][W][C] rows; `ld*` = elements between consecutive
+ * pixels, a multiple of 8, base pointers 16-byte aligned, so channel slices of a concat buffer are used in place).
+ * Parameters, statistics and parameter gradients: fp32. MFMA: v_mfma_f32_32x32x16_bf16 with fp32 accumulation.
+ * void* tensor arguments are bf16 device pointers.
+ * ================================================================================================================ */
+
+/* packed weights, MFMA-fragment order [tap][ceil(K/16)][ceil(N/32)][64 lanes][8]: element j of lane l is
+ * w[k = kstep*16 + 8*(l>>5) + j][n = ntile*32 + (l&31)] of tap t, zero beyond K / N. Strides as cn_pack_weights_f32. */
+long cn_bconv_packed_elems(int T, int K, int N);
+int cn_pack_weights_bf16(const float* w, void* wp, int T, int K, int N, long sk, long sn, long st, void* stream);
+/* descs: DEVICE array of 64-byte records {const float* w; void* wp; int T, K, N, KS, NT, pad; long sk, sn, st;} */
+int cn_pack_weights_batched_bf16(const void* descs, int n, void* stream);
+
+/* nn.Conv2d forward (convolution.py:71-120). out_kind 0: y bf16 NHWC (ldy); 1: y f32 NCHW with batch stride y_bs
+ * (the thin head convolutions hand over to the fp32 head kernels). stats (nullable; 2*Cout floats zeroed by the
+ * caller): per-channel sum and sum of squares of the fp32 results, for BatchNorm without a statistics pass. */
+int cn_conv2d_fwd_bf16(const void* x, long ldx, const void* wp, const float* bias /*nullable*/, void* y, long ldy,
+                       long y_bs, int B, int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride, int pad,
+                       int dil, int accumulate, int out_kind, float* stats /*nullable*/, void* stream);
+int cn_conv2d_fwd_grouped_bf16(int G, const void* const* xs, long ldx, const void* const* wps,
+                               const float* const* biases /*nullable*/, void* const* ys, long ldy, int B, int Cin,
+                               int Hin, int Win, int Cout, int KH, int KW, int stride, const int* pads,
+                               const int* dils, int accumulate, void* stream);
+int cn_conv2d_bwd_data_bf16(const void* dy, long lddy, const void* wp_t, void* dx, long lddx, int B, int Cin, int Hin,
+                            int Win, int Cout, int KH, int KW, int stride, int pad, int dil, int accumulate,
+                            void* stream);
+int cn_conv2d_bwd_data_grouped_bf16(int G, const void* const* dys, long lddy, const void* const* wps_t,
+                                    void* const* dxs, long lddx, int B, int Cin, int Hin, int Win, int Cout, int KH,
+                                    int KW, int stride, const int* pads, const int* dils, int accumulate,
+                                    void* stream);
+/* nn.ConvTranspose2d (convolution.py:45-68) */
+int cn_conv_transpose2d_fwd_bf16(const void* x, long ldx, const void* wp, const float* bias, void* y, long ldy, int B,
+                                 int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride, int pad,
+                                 int accumulate, void* stream);
+int cn_conv_transpose2d_bwd_data_bf16(const void* dy, long lddy, const void* wp_t, void* dx, long lddx, int B, int Cin,
+                                      int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, int accumulate,
+                                      void* stream);
+/* weight gradients: dw fp32 in the layer's own layout ([Cout][Cin][KH][KW] / [Cin][Cout][KH][KW]), ACCUMULATED.
+ * ws: fp32 scratch for the per-split partial slices; cn_bwgrad_workspace_floats(...) floats always suffice (the
+ * split shrinks to fit smaller buffers). */
+long cn_bwgrad_workspace_floats(int B, int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride, int pad,
+                                int dil, int transposed);
+int cn_conv2d_bwd_weight_bf16(const void* x, long ldx, const void* dy, long lddy, float* dw, int B, int Cin, int Hin,
+                              int Win, int Cout, int KH, int KW, int stride, int pad, int dil, float* ws,
+                              long ws_floats, void* stream);
+int cn_conv_transpose2d_bwd_weight_bf16(const void* x, long ldx, const void* dy, long lddy, float* dw, int B, int Cin,
+                                        int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, float* ws,
+                                        long ws_floats, void* stream);
+
+/* nn.BatchNorm2d (+SiLU, +residual) on [P = B*H*W][C] rows; C % 8 == 0. ws: cn_bn_workspace_floats_bf16(C) floats.
+ * conv_sums (nullable): the `stats` output of cn_conv2d_fwd_bf16. Backward ACCUMULATES dgamma / dbeta. */
+long cn_bn_workspace_floats_bf16(int C);
+int cn_bn_act_fwd_bf16(const void* x, long ldx, const float* gamma, const float* beta, float* running_mean,
+                       float* running_var, const void* res /*nullable*/, long ldr, void* y, long ldy, float* mean,
+                       float* rstd, float* ws, long P, int C, int training, float momentum, float eps, int act,
+                       const float* conv_sums /*nullable*/, void* stream);
+int cn_bn_act_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const float* mean, const float* rstd,
+                       const float* gamma, const float* beta, void* dx /*nullable*/, long lddx, float* dgamma,
+                       float* dbeta, float* ws, long P, int C, int training, int act, int accumulate_dx, void* stream);
+
+/* nn.LayerNorm over channels (rows of the NHWC image), + residual; statistics recomputed in backward.
+ * dw / db ACCUMULATED (fp32 atomics). */
+int cn_layernorm_c_fwd_bf16(const void* x, long ldx, const float* w, const float* b, const void* res /*nullable*/,
+                            long ldr, void* y, long ldy, long P, int C, float eps, void* stream);
+int cn_layernorm_c_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const float* w, void* dx, long lddx,
+                            float* dw, float* db, long P, int C, float eps, int accumulate_dx, void* stream);
+
+/* edges of the bf16 region: fp32 NCHW <-> bf16 NHWC (channels C..Cpad-1 zero-filled) */
+int cn_convert_f32nchw_to_bf16nhwc(const float* src, long sbs, void* dst, long ld, int B, int C, int Cpad, int HW,
+                                   void* stream);
+int cn_convert_bf16nhwc_to_f32nchw(const void* src, long ld, float* dst, long dbs, int B, int C, int HW,
+                                   int accumulate, void* stream);
+
+/* torch.cat / residual adds / fills on [P][C] row slices */
+int cn_copy_bf16(const void* src, long lds, void* dst, long ldd, long P, int C, int accumulate, void* stream);
+int cn_add_bf16(const void* a, long lda, const void* c, long ldc, void* dst, long ldd, long P, int C, void* stream);
+int cn_zero_bf16(void* dst, long ldd, long P, int C, void* stream);
+
+/* F.interpolate(bilinear, align_corners=True) */
+int cn_bilinear_fwd_bf16(const void* x, long ldx, void* y, long ldy, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                         void* stream);
+int cn_bilinear_bwd_bf16(const void* dy, long lddy, void* dx, long lddx, int B, int C, int Hi, int Wi, int Ho, int Wo,
+                         int accumulate, void* stream);
+
+/* NeighborhoodAttention2D core: qkv [B][H][W][3C], out [B][H][W][C]; attn / dattn fp32 [B][heads][9][H][W]. */
+int cn_na2d_fwd_bf16(const void* qkv, long ldq, void* out, long ldo, float* attn, int B, int C, int heads, int H, int W,
+                     int kernel_size, int dilation, void* stream);
+int cn_na2d_bwd_bf16(const void* qkv, long ldq, const void* dout, long ldo, const float* attn, float* dattn, void* dqkv,
+                     long lddq, int B, int C, int heads, int H, int W, int kernel_size, int dilation, void* stream);
+
 /* ---- diagnostics: per-launch HIP-event timing of the contraction kernels (bench.py roofline) ---
  * begin() starts recording event pairs around every implicit-GEMM / weight-gradient launch on the
- * launch stream; end() synchronises them and fills out[4][3] = {milliseconds, algorithmic flops,
- * launches} for kinds {igemm NT=128, igemm NT<=64, wgrad 3x3, wgrad 1x1}. Process-global, off by
- * default, not thread-safe. */
+ * launch stream; end() synchronises them and fills out[8][3] = {milliseconds, algorithmic flops,
+ * launches} for kinds {igemm NT=128, igemm NT<=64, wgrad 3x3, wgrad 1x1, bf16 conv, bf16 wgrad, -, -}.
+ * Process-global, off by default, single client, not thread-safe. */
 int cn_profile_begin(void);
 int cn_profile_end(double* out);
 

@@ -1,0 +1,371 @@
+"""Per-kernel parity of the bf16 NHWC mixed-precision entry points (through the C ABI) against plain PyTorch fp32 on
+the CPU evaluated on the SAME bf16-rounded inputs.
+
+Tolerances: the kernels accumulate in fp32 from bf16 operands, so against an fp32 evaluation of the rounded operands
+the only differences are the summation order and the final rounding of a bf16 OUTPUT (half an ulp = 2^-9 relative).
+bf16 outputs: |err| <= 6e-3 * max|ref| (+ tiny absolute); fp32 outputs (weight / parameter gradients, statistics):
+|err| <= 2e-3 * max|ref| (inputs are exact, only the order of ~1e5-term fp32 sums differs).
+"""
+import ctypes
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+BF = torch.bfloat16
+
+
+def _dev():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    return torch.device("cuda:0")
+
+
+def _s():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g) * scale
+
+
+def _r(t):  # round to bf16 and back
+    return t.to(BF).float()
+
+
+def _nhwc(t, ld=None):
+    """[B,C,H,W] fp32 CPU -> (logical NCHW view of a bf16 NHWC buffer on the GPU with pixel stride ld)."""
+    B, C, H, W = t.shape
+    ld = ld or C
+    buf = torch.zeros((B, H, W, ld), dtype=BF, device=_dev())
+    buf[..., :C] = t.permute(0, 2, 3, 1).to(BF).to(_dev())
+    return buf[..., :C].permute(0, 3, 1, 2)
+
+
+def _empty_nhwc(B, C, H, W, ld=None, fill=float("nan")):
+    ld = ld or C
+    buf = torch.full((B, H, W, ld), fill, dtype=BF, device=_dev())
+    return buf[..., :C].permute(0, 3, 1, 2)
+
+
+def _ld(t):
+    return t.stride(3)
+
+
+def _close(a, b, rel, what="", abs_=1e-6):
+    a = a.detach().float().cpu().double()
+    b = b.detach().float().cpu().double()
+    assert a.shape == b.shape, (what, a.shape, b.shape)
+    scale = float(b.abs().max())
+    err = float((a - b).abs().max())
+    assert err <= rel * scale + abs_, f"{what}: max err {err:.3e} > {rel * scale + abs_:.3e} (scale {scale:.3e})"
+
+
+def _pack(w, T, K, N, sk, sn, st):
+    from cultionet_amd import _lib
+
+    n = _lib.query("cn_bconv_packed_elems", T, K, N)
+    wp = torch.empty(n, dtype=BF, device=_dev())
+    _lib.call("cn_pack_weights_bf16", w.data_ptr(), wp.data_ptr(), T, K, N, sk, sn, st, _s())
+    return wp
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad, dil, bias
+    (2, 16, 20, 20, 32, 3, 1, 1, 1, False),
+    (2, 32, 25, 25, 64, 3, 1, 1, 1, True),
+    (1, 72, 13, 13, 128, 3, 1, 1, 1, False),
+    (2, 8, 28, 28, 16, 3, 2, 1, 1, False),     # pool conv (stride 2)
+    (1, 16, 25, 25, 32, 3, 2, 1, 1, False),    # odd size stride 2 -> 13
+    (2, 40, 14, 14, 128, 1, 1, 0, 1, True),    # 1x1 skip with bias
+    (2, 128, 13, 13, 256, 1, 1, 0, 1, False),
+    (2, 16, 28, 28, 16, 3, 1, 2, 2, False),    # true dilated conv
+    (1, 136, 9, 11, 140, 3, 1, 1, 1, True),    # ragged couts, non-square
+    (3, 24, 100, 100, 32, 3, 1, 1, 1, False),  # BASELINE spatial size
+    (2, 128, 50, 50, 128, 3, 1, 1, 1, False),
+    (2, 128, 100, 100, 384, 1, 1, 0, 1, True),  # qkv projection
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv2d_bf16(case):
+    from cultionet_amd import _lib
+
+    B, Cin, H, W, Cout, k, s, p, d, bias = case
+    T = k * k
+    w = _r(_rand(Cout, Cin, k, k, seed=2, scale=(Cin * T) ** -0.5))
+    b = _rand(Cout, seed=3) if bias else None
+    x = _r(_rand(B, Cin, H, W, seed=1))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, b, stride=s, padding=p, dilation=d)
+    dy = _r(_rand(*yr.shape, seed=4))
+    yr.backward(dy)
+    Ho, Wo = yr.shape[-2:]
+    dev = _dev()
+    wd = w.to(dev)
+    xg = _nhwc(x, ld=Cin + 8)
+    wp = _pack(wd, T, Cin, Cout, T, Cin * T, 1)
+    y = _empty_nhwc(B, Cout, Ho, Wo, ld=Cout + 16)
+    bd = b.to(dev) if bias else None
+    stats = torch.zeros(2 * Cout, device=dev)
+    _lib.call("cn_conv2d_fwd_bf16", xg.data_ptr(), _ld(xg), wp.data_ptr(), bd.data_ptr() if bias else None,
+              y.data_ptr(), _ld(y), 0, B, Cin, H, W, Cout, k, k, s, p, d, 0, 0, stats.data_ptr(), _s())
+    torch.cuda.synchronize()
+    _close(y, yr, 6e-3, "y")
+    _close(stats[:Cout], yr.detach().sum(dim=(0, 2, 3)), 2e-3, "stats sum", abs_=2e-3 * float(yr.abs().max()) * 10)
+    _close(stats[Cout:], (yr.detach() ** 2).sum(dim=(0, 2, 3)), 2e-3, "stats sumsq")
+    # f32 NCHW output (thin heads) and accumulate
+    y32 = torch.full((B, Cout, Ho, Wo), 1.0, device=dev)
+    _lib.call("cn_conv2d_fwd_bf16", xg.data_ptr(), _ld(xg), wp.data_ptr(), bd.data_ptr() if bias else None,
+              y32.data_ptr(), 0, Cout * Ho * Wo, B, Cin, H, W, Cout, k, k, s, p, d, 1, 1, None, _s())
+    _close(y32, yr + 1.0, 2e-3, "y f32 nchw (+=)")
+    # backward data
+    dyg = _nhwc(dy, ld=Cout + 8)
+    wpt = _pack(wd, T, Cout, Cin, Cin * T, T, 1)
+    dx = _empty_nhwc(B, Cin, H, W)
+    _lib.call("cn_conv2d_bwd_data_bf16", dyg.data_ptr(), _ld(dyg), wpt.data_ptr(), dx.data_ptr(), _ld(dx), B, Cin, H, W,
+              Cout, k, k, s, p, d, 0, _s())
+    _close(dx, xr.grad, 6e-3, "dx")
+    _lib.call("cn_conv2d_bwd_data_bf16", dyg.data_ptr(), _ld(dyg), wpt.data_ptr(), dx.data_ptr(), _ld(dx), B, Cin, H, W,
+              Cout, k, k, s, p, d, 1, _s())
+    _close(dx, 2 * _r(xr.grad), 1e-2, "dx (+=)")
+    # backward weight
+    nws = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, Cout, k, k, s, p, d, 0)
+    assert nws > 0
+    ws = torch.empty(nws, device=dev)
+    dw = torch.full((Cout, Cin, k, k), 0.5, device=dev)
+    _lib.call("cn_conv2d_bwd_weight_bf16", xg.data_ptr(), _ld(xg), dyg.data_ptr(), _ld(dyg), dw.data_ptr(), B, Cin, H, W,
+              Cout, k, k, s, p, d, ws.data_ptr(), nws, _s())
+    torch.cuda.synchronize()
+    _close(dw, wr.grad + 0.5, 2e-3, "dw")
+    # a much smaller workspace: the pixel split shrinks to fit
+    small = max(1, nws // 7)
+    need1 = (((Cout + 63) // 64) * 64) * (((Cin + 63) // 64) * 64) * T
+    small = max(small, need1)
+    ws2 = torch.empty(small, device=dev)
+    dw2 = torch.zeros((Cout, Cin, k, k), device=dev)
+    _lib.call("cn_conv2d_bwd_weight_bf16", xg.data_ptr(), _ld(xg), dyg.data_ptr(), _ld(dyg), dw2.data_ptr(), B, Cin, H,
+              W, Cout, k, k, s, p, d, ws2.data_ptr(), small, _s())
+    _close(dw2, wr.grad, 2e-3, "dw small ws")
+
+
+CONVT_CASES = [
+    # B, Cin, H, W, Cout, stride
+    (2, 16, 13, 13, 16, 2),
+    (2, 32, 25, 25, 32, 2),
+    (1, 128, 50, 50, 128, 2),   # BASELINE 50 -> 99
+    (2, 32, 7, 7, 24, 4),       # final_c style stride 4
+    (1, 128, 25, 25, 128, 4),   # 25 -> 97
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv_transpose2d_bf16(case):
+    from cultionet_amd import _lib
+
+    B, Cin, H, W, Cout, s = case
+    k, p, T = 3, 1, 9
+    w = _r(_rand(Cin, Cout, k, k, seed=2, scale=(Cin * T) ** -0.5))
+    b = _rand(Cout, seed=3)
+    x = _r(_rand(B, Cin, H, W, seed=1))
+    xr = x.clone().requires_grad_(True)
+    wr = w.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, b, stride=s, padding=p)
+    dy = _r(_rand(*yr.shape, seed=4))
+    yr.backward(dy)
+    Ho, Wo = yr.shape[-2:]
+    dev = _dev()
+    wd, bd = w.to(dev), b.to(dev)
+    xg = _nhwc(x)
+    wp = _pack(wd, T, Cin, Cout, Cout * T, T, 1)
+    y = _empty_nhwc(B, Cout, Ho, Wo)
+    _lib.call("cn_conv_transpose2d_fwd_bf16", xg.data_ptr(), _ld(xg), wp.data_ptr(), bd.data_ptr(), y.data_ptr(), _ld(y),
+              B, Cin, H, W, Cout, k, k, s, p, 0, _s())
+    _close(y, yr, 6e-3, "y")
+    dyg = _nhwc(dy)
+    wpt = _pack(wd, T, Cout, Cin, T, Cout * T, 1)
+    dx = _empty_nhwc(B, Cin, H, W)
+    _lib.call("cn_conv_transpose2d_bwd_data_bf16", dyg.data_ptr(), _ld(dyg), wpt.data_ptr(), dx.data_ptr(), _ld(dx), B,
+              Cin, H, W, Cout, k, k, s, p, 0, _s())
+    _close(dx, xr.grad, 6e-3, "dx")
+    nws = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, Cout, k, k, s, p, 1, 1)
+    ws = torch.empty(nws, device=dev)
+    dw = torch.zeros((Cin, Cout, k, k), device=dev)
+    _lib.call("cn_conv_transpose2d_bwd_weight_bf16", xg.data_ptr(), _ld(xg), dyg.data_ptr(), _ld(dyg), dw.data_ptr(), B,
+              Cin, H, W, Cout, k, k, s, p, ws.data_ptr(), nws, _s())
+    _close(dw, wr.grad, 2e-3, "dw")
+
+
+@pytest.mark.parametrize("shape,act,res,train", [((2, 16, 20, 20), 1, False, True), ((2, 128, 25, 25), 1, True, True),
+                                                  ((1, 480, 13, 13), 0, False, True), ((2, 32, 28, 28), 1, True, False),
+                                                  ((3, 64, 50, 50), 1, False, True), ((2, 8, 28, 28), 1, True, True)])
+def test_bn_act_bf16(shape, act, res, train):
+    from cultionet_amd import _lib
+
+    B, C, H, W = shape
+    P = B * H * W
+    x = _r(_rand(*shape, seed=1) * 1.5 + 0.3)
+    r = _r(_rand(*shape, seed=2)) if res else None
+    bn = torch.nn.BatchNorm2d(C)
+    with torch.no_grad():
+        bn.weight.copy_(1 + 0.1 * _rand(C, seed=3))
+        bn.bias.copy_(0.1 * _rand(C, seed=4))
+        bn.running_mean.copy_(0.2 * _rand(C, seed=5))
+        bn.running_var.copy_(1 + 0.1 * _rand(C, seed=6).abs())
+    bn.train(train)
+    rm0, rv0 = bn.running_mean.clone(), bn.running_var.clone()
+    xr = x.clone().requires_grad_(True)
+    z = bn(xr)
+    yr = F.silu(z) if act else z
+    if res:
+        yr = yr + r
+    dy = _r(_rand(*shape, seed=7))
+    yr.backward(dy)
+    dev = _dev()
+    xg = _nhwc(x, ld=C + 8)
+    rg = _nhwc(r, ld=C + 16) if res else None
+    y = _empty_nhwc(B, C, H, W)
+    gamma, beta = bn.weight.detach().to(dev), bn.bias.detach().to(dev)
+    rm, rv = rm0.to(dev), rv0.to(dev)
+    mean, rstd = torch.empty(C, device=dev), torch.empty(C, device=dev)
+    ws = torch.empty(_lib.query("cn_bn_workspace_floats_bf16", C), device=dev)
+    _lib.call("cn_bn_act_fwd_bf16", xg.data_ptr(), _ld(xg), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
+              rv.data_ptr(), rg.data_ptr() if res else None, _ld(rg) if res else 0, y.data_ptr(), _ld(y),
+              mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), P, C, 1 if train else 0, 0.1, bn.eps, act, None, _s())
+    _close(y, yr, 6e-3, "y")
+    if train:
+        _close(rm, bn.running_mean, 1e-4, "running_mean", abs_=1e-5)
+        _close(rv, bn.running_var, 1e-4, "running_var", abs_=1e-5)
+    dyg = _nhwc(dy)
+    dx = _empty_nhwc(B, C, H, W)
+    dg, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    _lib.call("cn_bn_act_bwd_bf16", xg.data_ptr(), _ld(xg), dyg.data_ptr(), _ld(dyg), mean.data_ptr(), rstd.data_ptr(),
+              gamma.data_ptr(), beta.data_ptr(), dx.data_ptr(), _ld(dx), dg.data_ptr(), db.data_ptr(), ws.data_ptr(), P,
+              C, 1 if train else 0, act, 0, _s())
+    _close(dx, xr.grad, 8e-3, "dx")
+    _close(dg, bn.weight.grad, 2e-3, "dgamma", abs_=1e-3)
+    _close(db, bn.bias.grad, 2e-3, "dbeta", abs_=1e-3)
+
+
+@pytest.mark.parametrize("shape,res", [((2, 32, 20, 20), False), ((2, 128, 25, 25), True), ((1, 8, 13, 13), True),
+                                       ((2, 256, 9, 9), False)])
+def test_layernorm_c_bf16(shape, res):
+    from cultionet_amd import _lib
+
+    B, C, H, W = shape
+    P = B * H * W
+    x = _r(_rand(*shape, seed=1) * 1.5 + 0.3)
+    r = _r(_rand(*shape, seed=2)) if res else None
+    ln = torch.nn.LayerNorm(C)
+    with torch.no_grad():
+        ln.weight.copy_(1 + 0.1 * _rand(C, seed=3))
+        ln.bias.copy_(0.1 * _rand(C, seed=4))
+    xr = x.clone().requires_grad_(True)
+    yr = ln(xr.permute(0, 2, 3, 1)).permute(0, 3, 1, 2)
+    if res:
+        yr = yr + r
+    dy = _r(_rand(*shape, seed=7))
+    yr.backward(dy)
+    dev = _dev()
+    xg = _nhwc(x, ld=C + 8)
+    rg = _nhwc(r) if res else None
+    y = _empty_nhwc(B, C, H, W)
+    w, b = ln.weight.detach().to(dev), ln.bias.detach().to(dev)
+    _lib.call("cn_layernorm_c_fwd_bf16", xg.data_ptr(), _ld(xg), w.data_ptr(), b.data_ptr(),
+              rg.data_ptr() if res else None, _ld(rg) if res else 0, y.data_ptr(), _ld(y), P, C, ln.eps, _s())
+    _close(y, yr, 6e-3, "y")
+    dyg = _nhwc(dy)
+    dx = _empty_nhwc(B, C, H, W)
+    dw, db = torch.zeros(C, device=dev), torch.zeros(C, device=dev)
+    _lib.call("cn_layernorm_c_bwd_bf16", xg.data_ptr(), _ld(xg), dyg.data_ptr(), _ld(dyg), w.data_ptr(), dx.data_ptr(),
+              _ld(dx), dw.data_ptr(), db.data_ptr(), P, C, ln.eps, 0, _s())
+    _close(dx, xr.grad, 8e-3, "dx")
+    _close(dw, ln.weight.grad, 2e-3, "dw", abs_=1e-3)
+    _close(db, ln.bias.grad, 2e-3, "db", abs_=1e-3)
+
+
+@pytest.mark.parametrize("shape,heads,dil", [((2, 32, 12, 12), 4, 1), ((1, 32, 14, 15), 4, 2), ((2, 32, 9, 9), 8, 1),
+                                             ((1, 128, 25, 25), 8, 1), ((2, 128, 20, 20), 4, 2)])
+def test_na2d_bf16(shape, heads, dil):
+    from cultionet_amd import _lib
+    from oracle import na2d_ref
+
+    B, C, H, W = shape
+    qkv = _r(_rand(B, 3 * C, H, W, seed=1))
+    D = C // heads
+    qr = qkv.clone().requires_grad_(True)
+    # oracle layout: q, k, v as [B, heads, H, W, D]
+    t = qr.view(B, 3, heads, D, H, W).permute(1, 0, 2, 4, 5, 3)
+    q, k_, v = t[0], t[1], t[2]
+    attn = na2d_ref.na2d_qk(q * (D ** -0.5), k_, 3, dil).softmax(dim=-1)
+    o = na2d_ref.na2d_av(attn, v, 3, dil)  # [B, heads, H, W, D]
+    outr = o.permute(0, 1, 4, 2, 3).reshape(B, C, H, W)
+    dy = _r(_rand(B, C, H, W, seed=2))
+    outr.backward(dy)
+    dev = _dev()
+    qg = _nhwc(qkv)
+    out = _empty_nhwc(B, C, H, W)
+    at = torch.empty((B, heads, 9, H, W), device=dev)
+    _lib.call("cn_na2d_fwd_bf16", qg.data_ptr(), _ld(qg), out.data_ptr(), _ld(out), at.data_ptr(), B, C, heads, H, W, 3,
+              dil, _s())
+    _close(out, outr, 6e-3, "out")
+    dyg = _nhwc(dy)
+    dq = _empty_nhwc(B, 3 * C, H, W)
+    dat = torch.empty_like(at)
+    _lib.call("cn_na2d_bwd_bf16", qg.data_ptr(), _ld(qg), dyg.data_ptr(), _ld(dyg), at.data_ptr(), dat.data_ptr(),
+              dq.data_ptr(), _ld(dq), B, C, heads, H, W, 3, dil, _s())
+    _close(dq, qr.grad, 8e-3, "dqkv")
+
+
+@pytest.mark.parametrize("case", [(2, 16, 13, 13, 14, 14), (1, 32, 49, 49, 50, 50), (2, 8, 97, 97, 100, 100),
+                                  (1, 8, 25, 25, 25, 25), (2, 16, 7, 9, 20, 23), (1, 8, 40, 40, 13, 17)])
+def test_bilinear_bf16(case):
+    from cultionet_amd import _lib
+
+    B, C, Hi, Wi, Ho, Wo = case
+    x = _r(_rand(B, C, Hi, Wi, seed=1))
+    xr = x.clone().requires_grad_(True)
+    yr = F.interpolate(xr, size=(Ho, Wo), mode="bilinear", align_corners=True)
+    dy = _r(_rand(B, C, Ho, Wo, seed=2))
+    yr.backward(dy)
+    xg = _nhwc(x, ld=C + 8)
+    y = _empty_nhwc(B, C, Ho, Wo, ld=C + 24)
+    _lib.call("cn_bilinear_fwd_bf16", xg.data_ptr(), _ld(xg), y.data_ptr(), _ld(y), B, C, Hi, Wi, Ho, Wo, _s())
+    _close(y, yr, 6e-3, "y")
+    dyg = _nhwc(dy)
+    dx = _empty_nhwc(B, C, Hi, Wi)
+    _lib.call("cn_bilinear_bwd_bf16", dyg.data_ptr(), _ld(dyg), dx.data_ptr(), _ld(dx), B, C, Hi, Wi, Ho, Wo, 0, _s())
+    _close(dx, xr.grad, 6e-3, "dx")
+
+
+def test_converters_and_slices_bf16():
+    from cultionet_amd import _lib
+
+    dev = _dev()
+    B, C, H, W = 2, 9, 13, 11
+    x = _rand(B, C, H, W, seed=1)
+    xd = x.to(dev)
+    buf = torch.full((B, H, W, 24), float("nan"), dtype=BF, device=dev)
+    _lib.call("cn_convert_f32nchw_to_bf16nhwc", xd.data_ptr(), C * H * W, buf.data_ptr(), 24, B, C, 16, H * W, _s())
+    got = buf[..., :16].float().cpu()
+    assert torch.equal(got[..., :C], _r(x).permute(0, 2, 3, 1))
+    assert torch.equal(got[..., C:], torch.zeros(B, H, W, 16 - C))
+    back = torch.full((B, C, H, W), 2.0, device=dev)
+    _lib.call("cn_convert_bf16nhwc_to_f32nchw", buf.data_ptr(), 24, back.data_ptr(), C * H * W, B, C, H * W, 1, _s())
+    assert torch.equal(back.cpu(), _r(x) + 2.0)
+    # slice copy / add / zero
+    a = _r(_rand(B, 16, H, W, seed=2))
+    c = _r(_rand(B, 16, H, W, seed=3))
+    ag, cg = _nhwc(a, ld=40), _nhwc(c)
+    d = _empty_nhwc(B, 16, H, W, ld=32, fill=0.0)
+    _lib.call("cn_copy_bf16", ag.data_ptr(), _ld(ag), d.data_ptr(), _ld(d), B * H * W, 16, 0, _s())
+    assert torch.equal(d.float().cpu(), a)
+    _lib.call("cn_copy_bf16", cg.data_ptr(), _ld(cg), d.data_ptr(), _ld(d), B * H * W, 16, 1, _s())
+    assert torch.equal(d.float().cpu(), _r(a + c))
+    _lib.call("cn_add_bf16", ag.data_ptr(), _ld(ag), cg.data_ptr(), _ld(cg), d.data_ptr(), _ld(d), B * H * W, 16, _s())
+    assert torch.equal(d.float().cpu(), _r(a + c))
+    _lib.call("cn_zero_bf16", d.data_ptr(), _ld(d), B * H * W, 16, _s())
+    assert float(d.float().abs().max()) == 0.0
