@@ -88,6 +88,7 @@ SIGNATURES = {
     "cn_bn_workspace_floats_bf16": [I],
     "cn_bn_act_fwd_bf16": [P, L, P, P, P, P, P, L, P, L, P, P, P, L, I, I, F, F, I, P, P],
     "cn_bn_act_bwd_bf16": [P, L, P, L, P, P, P, P, P, L, P, P, P, L, I, I, I, I, P],
+    "cn_channel_sum_bf16": [P, L, L, I, P, I, P, P],
     "cn_layernorm_c_fwd_bf16": [P, L, P, P, P, L, P, L, L, I, F, P],
     "cn_layernorm_c_bwd_bf16": [P, L, P, L, P, P, L, P, P, L, I, F, I, P],
     "cn_convert_f32nchw_to_bf16nhwc": [P, L, P, L, I, I, I, I, P],

@@ -22,7 +22,7 @@ class _TowerUNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, *params):
         store = model.param_store()
-        with E.using_store(store), E.recording(True) as tape:
+        with E.using_store(store), E.recording(True) as tape, E.mixed_precision(_autocast_bf16()):
             outs = model.forward_vars(model.input_var(x))
         ctx.model, ctx.tape, ctx.outs, ctx.store = model, tape, outs, store
         ctx.n_params = len(params)
@@ -42,12 +42,21 @@ class _TowerUNetFn(torch.autograd.Function):
         return (None, None) + pg
 
 
+def _autocast_bf16() -> bool:
+    """lightning.Trainer(precision="16-mixed" / "bf16-mixed") runs the step under torch.autocast: that selects the
+    bf16 MFMA path here (MI355X has no reason to prefer fp16; the GradScaler of "16-mixed" is harmless on it)."""
+    try:
+        return bool(torch.is_autocast_enabled("cuda")) and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
+    except Exception:  # pragma: no cover
+        return False
+
+
 def run_towerunet(model, x: torch.Tensor) -> T.Dict[str, torch.Tensor]:
     store = model.param_store()
     if torch.is_grad_enabled() and any(p.requires_grad for p in store.params):
         d, e, c = _TowerUNetFn.apply(model, x, *store.params)
         return {_KEYS[0]: d, _KEYS[1]: e, _KEYS[2]: c}
-    with E.using_store(store), E.recording(False):
+    with E.using_store(store), E.recording(False), E.mixed_precision(_autocast_bf16()):
         outs = model.forward_vars(model.input_var(x))
     return {k: outs[k].t for k in _KEYS}
 

@@ -82,7 +82,8 @@ class ConvBlock2d(nn.Module):
             h = E.bn_act(x, self.seq[0], E.ACT_SILU, training=self.training)
             y = E.conv2d(h, self.seq[2], self.stride, self.padding, self.dilation)
             return E.add(residual, y) if residual is not None else y
-        y = E.conv2d(x, self.seq[0], self.stride, self.padding, self.dilation)
+        # mixed precision: the conv epilogue hands BatchNorm its batch statistics (no statistics pass over y)
+        y = E.conv2d(x, self.seq[0], self.stride, self.padding, self.dilation, want_stats=self.training)
         return E.bn_act(y, self.seq[1], self.act, residual=residual, training=self.training)
 
 

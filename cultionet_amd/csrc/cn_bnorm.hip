@@ -390,3 +390,27 @@ extern "C" int cn_layernorm_c_bwd_bf16(const void* x, long ldx, const void* dy, 
                accumulate_dx);
   return cn_check_launch();
 }
+
+// bias gradients on the bf16 path: out[c] (+)= sum_p x[p][c]. ws: cn_bn_workspace_floats_bf16(C) floats.
+__global__ void cn_bsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out,
+                                        int accumulate) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s = 0.0;
+  for (int i = 0; i < nblk; ++i) s += part[((long)i * 2) * C + c];
+  out[c] = accumulate ? out[c] + (float)s : (float)s;
+}
+
+extern "C" int cn_channel_sum_bf16(const void* x, long ldx, long P, int C, float* out, int accumulate, float* ws,
+                                   void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (P <= 0 || C <= 0) return CN_OK;
+  if ((C & 7) || C > 2048) return CN_ERR_ARG;
+  int nblk;
+  long rows;
+  bbn_grid(P, C, nblk, rows);
+  hipLaunchKernelGGL((cn_bbn_partial_kernel<0>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr, 0L,
+                     nullptr, nullptr, nullptr, nullptr, P, C, 0, rows, ws);
+  hipLaunchKernelGGL(cn_bsum_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, ws, nblk, C, out, accumulate);
+  return cn_check_launch();
+}

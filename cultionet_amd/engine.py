@@ -34,9 +34,51 @@ def _stream() -> int:
 def _check(t: torch.Tensor) -> torch.Tensor:
     if not t.is_cuda:
         raise RuntimeError("cultionet_amd ops need device tensors (MI355X); there is no CPU fallback")
+    if t.dtype == torch.bfloat16:
+        # mixed-precision path: bf16 activations are NHWC (logical shape [B,C,H,W], channel stride 1)
+        if t.dim() != 4 or (t.shape[1] > 1 and t.stride(1) != 1) or t.stride(3) % 8 or t.data_ptr() % 16:
+            raise RuntimeError("bf16 activations must be NHWC views (channels innermost, 16-byte aligned slices)")
+        return t
     if t.dtype != torch.float32:
-        raise RuntimeError(f"fp32 tensor expected, got {t.dtype}")
+        raise RuntimeError(f"fp32 (or bf16 NHWC) tensor expected, got {t.dtype}")
     return t
+
+
+def is16(t: torch.Tensor) -> bool:
+    return t.dtype == torch.bfloat16
+
+
+def ld(t: torch.Tensor) -> int:
+    """Pixel stride (elements) of a bf16 NHWC activation held as a logical [B,C,H,W] view."""
+    return t.stride(3)
+
+
+def _dense16(t: torch.Tensor) -> bool:
+    """Pixels of all images form ONE run of rows with stride ld (kernels take P = B*H*W rows)."""
+    B, _, H, W = t.shape
+    l = t.stride(3)
+    return (W == 1 or True) and (H == 1 or t.stride(2) == W * l) and (B == 1 or t.stride(0) == H * W * l)
+
+
+class mixed_precision:
+    """Context manager: run the TowerUNet body (encoder .. tower heads) in bf16 NHWC with fp32 accumulation,
+    statistics and parameters -- the reference's precision="16-mixed" (model.py:168-186) on MI355X MFMA."""
+
+    def __init__(self, enabled: bool = True):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.prev = getattr(_state, "bf16", False)
+        _state.bf16 = self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        _state.bf16 = self.prev
+        return False
+
+
+def bf16_enabled() -> bool:
+    return bool(getattr(_state, "bf16", False))
 
 
 def bstride(t: torch.Tensor) -> int:
@@ -56,13 +98,14 @@ def _dense_inner(t: torch.Tensor) -> bool:
 class Var:
     """A device buffer and (during training) its gradient buffer."""
 
-    __slots__ = ("t", "grad", "req", "parent")
+    __slots__ = ("t", "grad", "req", "parent", "stats")
 
     def __init__(self, t: torch.Tensor, req: bool = False):
         self.t = t
         self.grad: T.Optional[torch.Tensor] = None
         self.req = req
         self.parent: T.Optional[T.Tuple["Var", int, int]] = None  # channel slice [c0, c1) of another Var
+        self.stats: T.Optional[torch.Tensor] = None  # bf16 conv outputs: per-channel {sum, sumsq} from the epilogue
 
     @property
     def shape(self):
@@ -127,11 +170,14 @@ def grad_buffer(v: Var) -> T.Tuple[torch.Tensor, int]:
             # a channel slice writes straight into its parent's gradient (zero-filled once, then accumulated)
             pv, c0, c1 = v.parent
             if pv.grad is None:
-                pv.grad = torch.empty(pv.t.shape, dtype=torch.float32, device=pv.t.device)
-                _lib.call("cn_fill_f32", pv.grad.data_ptr(), pv.grad.numel(), 0.0, _stream())
+                pv.grad = _new(tuple(pv.t.shape), pv.t)
+                if is16(pv.t):
+                    _lib.call("cn_zero_bf16", pv.grad.data_ptr(), ld(pv.grad), _rows(pv.grad), pv.grad.shape[1], _stream())
+                else:
+                    _lib.call("cn_fill_f32", pv.grad.data_ptr(), pv.grad.numel(), 0.0, _stream())
             v.grad = pv.grad[:, c0:c1]
             return v.grad, 1
-        v.grad = torch.empty(v.t.shape, dtype=torch.float32, device=v.t.device)
+        v.grad = _new(tuple(v.t.shape), v.t)
         return v.grad, 0
     return v.grad, 1
 
@@ -145,6 +191,9 @@ def give_grad(v: Var, g: torch.Tensor) -> None:
         return
     if v.grad is None:
         grad_buffer(v)
+    if is16(g):
+        _lib.call("cn_copy_bf16", g.data_ptr(), ld(g), v.grad.data_ptr(), ld(v.grad), _rows(g), g.shape[1], 1, _stream())
+        return
     B = g.shape[0]
     n = g[0].numel()
     _lib.call("cn_copy_f32", g.data_ptr(), bstride(g), v.grad.data_ptr(), bstride(v.grad), B, n, 1, _stream())
@@ -188,6 +237,8 @@ class ParamStore:
         self._base = self.flat.data_ptr()
         self._packs: T.List[T.Tuple] = []      # (PackedWeight, attr, dst tensor, w ptr, T, K, N, sk, sn, st)
         self._pack_table: T.Optional[torch.Tensor] = None
+        self._packs16: T.List[T.Tuple] = []    # the same for the bf16 MFMA-fragment copies
+        self._pack_table16: T.Optional[torch.Tensor] = None
 
     def owns(self, module: torch.nn.Module) -> bool:
         lo, hi = self._base, self._base + self.numel * 4
@@ -231,8 +282,25 @@ class ParamStore:
         self._packs.append((pw, attr, dst, w.data_ptr(), T_, K, N, sk, sn, st))
         self._pack_table = None
 
+    def register_pack16(self, pw, attr: str, dst: torch.Tensor, w: torch.Tensor, T_: int, K: int, N: int, sk: int,
+                        sn: int, st: int) -> None:
+        self._packs16.append((pw, attr, dst, w.data_ptr(), T_, K, N, sk, sn, st))
+        self._pack_table16 = None
+
     def repack_all(self) -> None:
-        """Refresh every registered packed weight copy with ONE launch (after the parameters changed)."""
+        """Refresh every registered packed weight copy with ONE launch per precision (after the parameters changed)."""
+        if self._packs16:
+            if self._pack_table16 is None:
+                import struct
+
+                buf = bytearray()
+                for (_pw, _attr, dst, wptr, T_, K, N, sk, sn, st) in self._packs16:
+                    buf += struct.pack("<QQiiiiiiqqq", wptr, dst.data_ptr(), T_, K, N, (K + 15) // 16, (N + 31) // 32, 0,
+                                       sk, sn, st)
+                self._pack_table16 = torch.frombuffer(buf, dtype=torch.uint8).clone().to(self.flat.device)
+            _lib.call("cn_pack_weights_batched_bf16", self._pack_table16.data_ptr(), len(self._packs16), _stream())
+            for (pw, _attr, _dst, *_rest) in self._packs16:
+                pw.version = self.version
         if not self._packs:
             return
         if self._pack_table is None:
@@ -302,11 +370,13 @@ def pgrad(p: torch.nn.Parameter) -> torch.Tensor:
 class PackedWeight:
     """Packed copies of one weight tensor for the implicit-GEMM kernels (forward / bwd-data)."""
 
-    __slots__ = ("fwd", "bwd", "version", "store_id")
+    __slots__ = ("fwd", "bwd", "fwd16", "bwd16", "version", "store_id")
 
     def __init__(self):
         self.fwd = None
         self.bwd = None
+        self.fwd16 = None  # bf16 MFMA-fragment copies (mixed-precision path)
+        self.bwd16 = None
         self.version = -1
         self.store_id = 0
 
@@ -326,16 +396,24 @@ def _sync_packs(pw: "PackedWeight") -> None:
     """Bring all registered packed weights up to date if the parameters changed since the last pack."""
     st = current_store()
     if pw.store_id != id(st):  # parameters were re-flattened into a new store: drop copies of the old one
-        pw.fwd = pw.bwd = None
+        pw.fwd = pw.bwd = pw.fwd16 = pw.bwd16 = None
         pw.store_id = id(st)
     if pw.version != st.version:
-        if pw.fwd is None and pw.bwd is None:
+        if pw.fwd is None and pw.bwd is None and pw.fwd16 is None and pw.bwd16 is None:
             pw.version = st.version
         else:
             st.repack_all()
 
 
-def packed_conv(mod, need_bwd: bool) -> PackedWeight:
+def _pack16(pw: "PackedWeight", attr: str, w: torch.Tensor, T_: int, K: int, N: int, sk: int, sn: int,
+            st: int) -> torch.Tensor:
+    out = torch.empty(_lib.query("cn_bconv_packed_elems", T_, K, N), dtype=torch.bfloat16, device=w.device)
+    _lib.call("cn_pack_weights_bf16", w.data_ptr(), out.data_ptr(), T_, K, N, sk, sn, st, _stream())
+    current_store().register_pack16(pw, attr, out, w, T_, K, N, sk, sn, st)
+    return out
+
+
+def packed_conv(mod, need_bwd: bool, bf16: bool = False) -> PackedWeight:
     """Packed weights of an nn.Conv2d / nn.Linear-like module (weight [Cout][Cin][KH][KW])."""
     pw = mod.__dict__.get("_cn_packed")
     if pw is None:
@@ -345,6 +423,12 @@ def packed_conv(mod, need_bwd: bool) -> PackedWeight:
     w = mod.weight
     cout, cin = w.shape[0], w.shape[1]
     taps = int(w[0, 0].numel()) if w.dim() > 2 else 1
+    if bf16:
+        if pw.fwd16 is None:
+            pw.fwd16 = _pack16(pw, "fwd16", w, taps, cin, cout, taps, cin * taps, 1)
+        if need_bwd and pw.bwd16 is None:
+            pw.bwd16 = _pack16(pw, "bwd16", w, taps, cout, cin, cin * taps, taps, 1)
+        return pw
     if pw.fwd is None:
         pw.fwd = _pack(pw, "fwd", w, taps, cin, cout, taps, cin * taps, 1)
     if need_bwd and pw.bwd is None:
@@ -352,7 +436,7 @@ def packed_conv(mod, need_bwd: bool) -> PackedWeight:
     return pw
 
 
-def packed_convT(mod, need_bwd: bool) -> PackedWeight:
+def packed_convT(mod, need_bwd: bool, bf16: bool = False) -> PackedWeight:
     """Packed weights of an nn.ConvTranspose2d (weight [Cin][Cout][KH][KW])."""
     pw = mod.__dict__.get("_cn_packed")
     if pw is None:
@@ -362,6 +446,12 @@ def packed_convT(mod, need_bwd: bool) -> PackedWeight:
     w = mod.weight
     cin, cout = w.shape[0], w.shape[1]
     taps = int(w[0, 0].numel())
+    if bf16:
+        if pw.fwd16 is None:
+            pw.fwd16 = _pack16(pw, "fwd16", w, taps, cin, cout, cout * taps, taps, 1)
+        if need_bwd and pw.bwd16 is None:
+            pw.bwd16 = _pack16(pw, "bwd16", w, taps, cout, cin, taps, cout * taps, 1)
+        return pw
     if pw.fwd is None:
         pw.fwd = _pack(pw, "fwd", w, taps, cin, cout, cout * taps, taps, 1)
     if need_bwd and pw.bwd is None:
@@ -374,7 +464,19 @@ def packed_convT(mod, need_bwd: bool) -> PackedWeight:
 # ---------------------------------------------------------------------------
 
 def _new(shape, like: torch.Tensor) -> torch.Tensor:
+    if like.dtype == torch.bfloat16 and len(shape) == 4:
+        B, C, H, W = shape
+        return torch.empty((B, H, W, C), dtype=torch.bfloat16, device=like.device).permute(0, 3, 1, 2)
     return torch.empty(shape, dtype=torch.float32, device=like.device)
+
+
+def new_buffer(shape, like: torch.Tensor) -> torch.Tensor:
+    """An activation buffer of logical shape [B,C,H,W] in ``like``'s precision / layout (fp32 NCHW or bf16 NHWC)."""
+    return _new(tuple(shape), like)
+
+
+def _rows(t: torch.Tensor) -> int:
+    return t.shape[0] * t.shape[2] * t.shape[3]
 
 
 _WS_FLOATS = 16 << 20  # persistent weight-gradient scratch (64 MB): aligned operand copies + partial dW slices
@@ -398,10 +500,13 @@ def _pad_ws(*tensors: torch.Tensor) -> T.Tuple[T.Optional[int], int]:
     return ws.data_ptr(), ws.numel()
 
 
-def conv2d(x: Var, mod, stride: int = 1, padding: int = 0, dilation: int = 1, out: T.Optional[torch.Tensor] = None) -> Var:
+def conv2d(x: Var, mod, stride: int = 1, padding: int = 0, dilation: int = 1, out: T.Optional[torch.Tensor] = None,
+           want_stats: bool = False) -> Var:
     """nn.Conv2d forward (+ tape node for bwd-data, bwd-weight, bias grad)."""
     tape = current_tape()
     xt = _check(x.t)
+    if is16(xt):
+        return _conv2d_bf16(x, mod, stride, padding, dilation, out, want_stats)
     B, Cin, H, W = xt.shape
     w = mod.weight
     Cout = w.shape[0]
@@ -449,6 +554,8 @@ def conv2d_group(xs: T.Sequence[Var], mods: T.Sequence, paddings: T.Sequence[int
     tape = current_tape()
     G = len(mods)
     xts = [_check(x.t) for x in xs]
+    if is16(xts[0]):  # mixed precision: conv by conv (each with BatchNorm statistics from its epilogue)
+        return [_conv2d_bf16(x, m, stride, p, d, None, tape.enabled) for x, m, p, d in zip(xs, mods, paddings, dilations)]
     B, Cin, H, W = xts[0].shape
     w0 = mods[0].weight
     Cout, KH, KW = w0.shape[0], w0.shape[2], w0.shape[3]
@@ -540,6 +647,8 @@ def conv_transpose2d(x: Var, mod, stride: int, padding: int) -> Var:
     """nn.ConvTranspose2d forward (k x k, stride s, padding p, with bias)."""
     tape = current_tape()
     xt = _check(x.t)
+    if is16(xt):
+        return _conv_transpose2d_bf16(x, mod, stride, padding)
     B, Cin, H, W = xt.shape
     w = mod.weight
     Cout, KH, KW = w.shape[1], w.shape[2], w.shape[3]
@@ -643,6 +752,10 @@ def bn_act(x: Var, bn, act: int, residual: T.Optional[Var] = None, channels: T.O
     """y = act(batch_norm(x)) (+ residual). x viewed as [B][C][L] with C = ``channels`` (BatchNorm3d: L = T*H*W)."""
     tape = current_tape()
     xt = _check(x.t)
+    if is16(xt):
+        if channels is not None and channels != xt.shape[1]:
+            raise NotImplementedError("BatchNorm3d views are fp32-only (PreTimeReduction runs in fp32)")
+        return _bn_act_bf16(x, bn, act, residual, training, out)
     B = xt.shape[0]
     C = channels if channels is not None else xt.shape[1]
     L = int(xt[0].numel()) // C
@@ -700,13 +813,21 @@ def bn_act_group(xs: T.Sequence[Var], bns: T.Sequence, act: int, residual: T.Opt
     tape = current_tape()
     G = len(xs)
     xts = [_check(x.t) for x in xs]
+    if residual is not None and not sum_outputs:
+        raise ValueError("bn_act_group: a residual needs sum_outputs=True")
+    if is16(xts[0]):  # mixed precision: branch by branch; the ResUNet-a sum rides along as the residual
+        if not sum_outputs:
+            return [_bn_act_bf16(x, bn, act, None, training, outs[i] if outs is not None else None)
+                    for i, (x, bn) in enumerate(zip(xs, bns))]
+        acc = residual
+        for x, bn in zip(xs, bns):
+            acc = _bn_act_bf16(x, bn, act, acc, training, None)
+        return acc
     B, C = xts[0].shape[0], xts[0].shape[1]
     L = int(xts[0][0].numel()) // C
     for t in xts:
         if tuple(t.shape) != tuple(xts[0].shape) or bstride(t) != bstride(xts[0]):
             raise ValueError("bn_act_group: inputs must have the same shape and strides")
-    if residual is not None and not sum_outputs:
-        raise ValueError("bn_act_group: a residual needs sum_outputs=True")
     dev = xts[0].device
     use_batch = training or any(bn.running_mean is None for bn in bns)
     tab = lambda ptrs: (ctypes.c_void_p * G)(*ptrs)
@@ -772,6 +893,8 @@ def layer_norm_c(x: Var, ln, residual: T.Optional[Var] = None) -> Var:
     """nn.LayerNorm over the channel axis of an NCHW buffer (+ residual)."""
     tape = current_tape()
     xt = _check(x.t)
+    if is16(xt):
+        return _layer_norm_c_bf16(x, ln, residual)
     B, C = xt.shape[0], xt.shape[1]
     L = int(xt[0, 0].numel())
     y = _new(xt.shape, xt)
@@ -808,6 +931,10 @@ def na2d(qkv: Var, heads: int, kernel_size: int, dilation: int, attn_drop: float
     """Neighborhood attention core on a [B, 3C, H, W] qkv buffer -> [B, C, H, W]."""
     tape = current_tape()
     qt = _check(qkv.t)
+    if is16(qt):
+        if attn_drop > 0.0:
+            raise NotImplementedError("attention dropout on the bf16 path")
+        return _na2d_bf16(qkv, heads, kernel_size, dilation)
     B, C3, H, W = qt.shape
     C = C3 // 3
     out = _new((B, C, H, W), qt)
@@ -847,6 +974,8 @@ def spatial_channel_attention(skip: Var, out: Var, mod) -> Var:
     ``mod``: the host mirror with .channel_attention.fc1/.fc2 (Conv2d 1x1 pairs), .spatial_attention.conv, .gamma."""
     tape = current_tape()
     st, ot = _check(skip.t), _check(out.t)
+    if is16(st):
+        raise NotImplementedError("attention_weights='spatial_channel' has no bf16 kernel (fp32 only)")
     B, C, H, W = st.shape
     L = H * W
     Ch = C // 2
@@ -928,6 +1057,8 @@ def resize_bilinear(x: Var, size: T.Tuple[int, int], out: T.Optional[torch.Tenso
     Ho, Wo = int(size[0]), int(size[1])
     if (Hi, Wi) == (Ho, Wo) and out is None:
         return x
+    if is16(xt):
+        return _resize_bilinear_bf16(x, (Ho, Wo), out)
     y = out if out is not None else _new((B, C, Ho, Wo), xt)
     _lib.call("cn_bilinear_fwd_f32", xt.data_ptr(), bstride(xt), y.data_ptr(), bstride(y), B, C, Hi, Wi, Ho, Wo,
               _stream())
@@ -965,7 +1096,8 @@ def join_channels(parts: T.Sequence[Var], buf: torch.Tensor) -> Var:
     c0 = 0
     for p in parts:
         c = p.t.shape[1]
-        if p.t.data_ptr() != buf[:, c0:c0 + c].data_ptr() or (buf.shape[0] > 1 and bstride(p.t) != bstride(buf)):
+        if p.t.data_ptr() != buf[:, c0:c0 + c].data_ptr() or \
+                (not is16(buf) and buf.shape[0] > 1 and bstride(p.t) != bstride(buf)):
             raise RuntimeError("join_channels: parts must be the channel slices of buf, in order")
         c0 += c
     yv = Var(buf, tape.enabled)
@@ -993,6 +1125,8 @@ def thin_conv3x3(x: Var, mods: T.Sequence, grouped: bool, dilation: int = 1,
     Output [B, len(mods)*CP, H, W] (channel = g*CP + c)."""
     tape = current_tape()
     xt = _check(x.t)
+    if is16(xt):
+        return _thin_conv3x3_bf16(x, mods, grouped, dilation, out)
     B, Cx, H, W = xt.shape
     n = len(mods)
     w0 = mods[0].weight
@@ -1054,6 +1188,12 @@ def cat_channels(parts: T.Sequence[Var], buf: T.Optional[torch.Tensor] = None) -
     for p in parts:
         c = p.t.shape[1]
         dst = y[:, off:off + c]
+        if is16(y):
+            if p.t.data_ptr() != dst.data_ptr():
+                _lib.call("cn_copy_bf16", _check(p.t).data_ptr(), ld(p.t), dst.data_ptr(), ld(y), B * H * W, c, 0,
+                          _stream())
+            off += c
+            continue
         in_place = p.t.data_ptr() == dst.data_ptr() and (B == 1 or bstride(p.t) == bstride(y))
         if not in_place:
             _lib.call("cn_copy_f32", p.t.data_ptr(), bstride(p.t), dst.data_ptr(), bstride(y), B, c * H * W, 0,
@@ -1083,8 +1223,12 @@ def add(a: Var, b: Var) -> Var:
     B = at.shape[0]
     n = int(at[0].numel())
     y = _new(at.shape, at)
-    _lib.call("cn_add_f32", at.data_ptr(), bstride(at), bt.data_ptr(), bstride(bt), y.data_ptr(), bstride(y), B, n,
-              _stream())
+    if is16(at):
+        _lib.call("cn_add_bf16", at.data_ptr(), ld(at), bt.data_ptr(), ld(bt), y.data_ptr(), ld(y), _rows(at),
+                  at.shape[1], _stream())
+    else:
+        _lib.call("cn_add_f32", at.data_ptr(), bstride(at), bt.data_ptr(), bstride(bt), y.data_ptr(), bstride(y), B, n,
+                  _stream())
     yv = Var(y, tape.enabled)
     if tape.enabled:
 
@@ -1096,7 +1240,12 @@ def add(a: Var, b: Var) -> Var:
             if b.req:
                 if b.grad is None:  # never let two Vars alias one gradient buffer
                     cp = _new(dy.shape, dy)
-                    _lib.call("cn_copy_f32", dy.data_ptr(), bstride(dy), cp.data_ptr(), bstride(cp), B, n, 0, _stream())
+                    if is16(dy):
+                        _lib.call("cn_copy_bf16", dy.data_ptr(), ld(dy), cp.data_ptr(), ld(cp), _rows(dy), dy.shape[1],
+                                  0, _stream())
+                    else:
+                        _lib.call("cn_copy_f32", dy.data_ptr(), bstride(dy), cp.data_ptr(), bstride(cp), B, n, 0,
+                                  _stream())
                     b.grad = cp
                 else:
                     give_grad(b, dy)
@@ -1227,6 +1376,8 @@ def dropout(x: Var, p: float, channelwise: bool, training: bool) -> Var:
         return x
     tape = current_tape()
     xt = _check(x.t)
+    if is16(xt):
+        raise NotImplementedError("dropout > 0 has no bf16 kernel yet (train mixed precision with dropout=0.0)")
     B, C = xt.shape[0], xt.shape[1]
     L = int(xt[0, 0].numel())
     seed = _next_seed()
@@ -1253,6 +1404,8 @@ def adaptive_max_pool2d(x: Var, size: T.Tuple[int, int]) -> Var:
     """F.adaptive_max_pool2d(x, output_size=size)."""
     tape = current_tape()
     xt = _check(x.t)
+    if is16(xt):
+        raise NotImplementedError("pool_by_max has no bf16 kernel (fp32 only)")
     B, C, Hi, Wi = xt.shape
     Ho, Wo = int(size[0]), int(size[1])
     y = _new((B, C, Ho, Wo), xt)
@@ -1272,4 +1425,325 @@ def adaptive_max_pool2d(x: Var, size: T.Tuple[int, int]) -> Var:
             yv.grad = None
 
         tape.add(bwd)
+    return yv
+
+
+# ---------------------------------------------------------------------------
+# mixed-precision (bf16 NHWC) op bodies: activations / activation gradients bf16, parameters + statistics fp32
+# ---------------------------------------------------------------------------
+_WS16_MAX_FLOATS = 96 << 20  # cap of the weight-gradient scratch (384 MB); the pixel split shrinks to fit
+
+
+def _ws16(need: int, dev: torch.device) -> T.Tuple[int, int]:
+    """(pointer, floats) of the persistent fp32 scratch of the bf16 kernels on the current stream's device."""
+    need = int(min(max(need, 1 << 20), _WS16_MAX_FLOATS))
+    pool = getattr(_state, "ws16_pool", None)
+    if pool is None:
+        pool = _state.ws16_pool = {}
+    ws = pool.get(dev)
+    if ws is None or ws.numel() < need:
+        ws = pool[dev] = torch.empty(need, dtype=torch.float32, device=dev)
+    return ws.data_ptr(), ws.numel()
+
+
+def _bn_ws16(C: int, dev: torch.device) -> int:
+    return _ws16(_lib.query("cn_bn_workspace_floats_bf16", C), dev)[0]
+
+
+def to_bf16(x: Var) -> Var:
+    """fp32 NCHW -> bf16 NHWC at the entry of the mixed-precision region (gradient converted back)."""
+    tape = current_tape()
+    xt = _check(x.t)
+    if is16(xt):
+        return x
+    B, C, H, W = xt.shape
+    y = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=xt.device).permute(0, 3, 1, 2)
+    if C % 8:
+        raise RuntimeError("the bf16 region needs channel counts that are multiples of 8")
+    _lib.call("cn_convert_f32nchw_to_bf16nhwc", xt.data_ptr(), bstride(xt), y.data_ptr(), ld(y), B, C, C, H * W,
+              _stream())
+    yv = Var(y, tape.enabled and x.req)
+    if tape.enabled and x.req:
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            dx, acc = grad_buffer(x)
+            _lib.call("cn_convert_bf16nhwc_to_f32nchw", dy.data_ptr(), ld(dy), dx.data_ptr(), bstride(dx), B, C, H * W,
+                      acc, _stream())
+            yv.grad = None
+
+        tape.add(bwd)
+    return yv
+
+
+def _conv2d_bf16(x: Var, mod, stride: int, padding: int, dilation: int, out: T.Optional[torch.Tensor],
+                 want_stats: bool) -> Var:
+    tape = current_tape()
+    xt = x.t
+    B, Cin, H, W = xt.shape
+    w = mod.weight
+    Cout = w.shape[0]
+    KH, KW = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+    Ho = (H + 2 * padding - dilation * (KH - 1) - 1) // stride + 1
+    Wo = (W + 2 * padding - dilation * (KW - 1) - 1) // stride + 1
+    pw = packed_conv(mod, tape.enabled and x.req, bf16=True)
+    y = _check(out) if out is not None else _new((B, Cout, Ho, Wo), xt)
+    bias = mod.bias
+    stats = torch.zeros(2 * Cout, dtype=torch.float32, device=xt.device) if want_stats else None
+    _lib.call("cn_conv2d_fwd_bf16", xt.data_ptr(), ld(xt), pw.fwd16.data_ptr(),
+              bias.data_ptr() if bias is not None else None, y.data_ptr(), ld(y), 0, B, Cin, H, W, Cout, KH, KW, stride,
+              padding, dilation, 0, 0, stats.data_ptr() if stats is not None else None, _stream())
+    yv = Var(y, tape.enabled)
+    yv.stats = stats
+    if tape.enabled:
+        store = current_store()
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            s = _stream()
+            need = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, 0)
+            wsp, wsn = _ws16(need, xt.device)
+            _lib.call("cn_conv2d_bwd_weight_bf16", xt.data_ptr(), ld(xt), dy.data_ptr(), ld(dy),
+                      store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, wsp, wsn, s)
+            if bias is not None:
+                _lib.call("cn_channel_sum_bf16", dy.data_ptr(), ld(dy), B * Ho * Wo, Cout,
+                          store.grad_of(bias).data_ptr(), 1, _bn_ws16(Cout, xt.device), s)
+            if x.req:
+                dx, acc = grad_buffer(x)
+                _lib.call("cn_conv2d_bwd_data_bf16", dy.data_ptr(), ld(dy), pw.bwd16.data_ptr(), dx.data_ptr(), ld(dx),
+                          B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, acc, s)
+            yv.grad = None
+
+        tape.add(bwd, (w, bias))
+    return yv
+
+
+def _conv_transpose2d_bf16(x: Var, mod, stride: int, padding: int) -> Var:
+    tape = current_tape()
+    xt = x.t
+    B, Cin, H, W = xt.shape
+    w = mod.weight
+    Cout, KH, KW = w.shape[1], w.shape[2], w.shape[3]
+    Ho = (H - 1) * stride - 2 * padding + KH
+    Wo = (W - 1) * stride - 2 * padding + KW
+    pw = packed_convT(mod, tape.enabled and x.req, bf16=True)
+    y = _new((B, Cout, Ho, Wo), xt)
+    bias = mod.bias
+    _lib.call("cn_conv_transpose2d_fwd_bf16", xt.data_ptr(), ld(xt), pw.fwd16.data_ptr(),
+              bias.data_ptr() if bias is not None else None, y.data_ptr(), ld(y), B, Cin, H, W, Cout, KH, KW, stride,
+              padding, 0, _stream())
+    yv = Var(y, tape.enabled)
+    if tape.enabled:
+        store = current_store()
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            s = _stream()
+            need = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, Cout, KH, KW, stride, padding, 1, 1)
+            wsp, wsn = _ws16(need, xt.device)
+            _lib.call("cn_conv_transpose2d_bwd_weight_bf16", xt.data_ptr(), ld(xt), dy.data_ptr(), ld(dy),
+                      store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, wsp, wsn, s)
+            if bias is not None:
+                _lib.call("cn_channel_sum_bf16", dy.data_ptr(), ld(dy), B * Ho * Wo, Cout,
+                          store.grad_of(bias).data_ptr(), 1, _bn_ws16(Cout, xt.device), s)
+            if x.req:
+                dx, acc = grad_buffer(x)
+                _lib.call("cn_conv_transpose2d_bwd_data_bf16", dy.data_ptr(), ld(dy), pw.bwd16.data_ptr(),
+                          dx.data_ptr(), ld(dx), B, Cin, H, W, Cout, KH, KW, stride, padding, acc, s)
+            yv.grad = None
+
+        tape.add(bwd, (w, bias))
+    return yv
+
+
+def _bn_act_bf16(x: Var, bn, act: int, residual: T.Optional[Var], training: bool,
+                 out: T.Optional[torch.Tensor]) -> Var:
+    tape = current_tape()
+    xt = x.t
+    B, C, H, W = xt.shape
+    P = B * H * W
+    dev = xt.device
+    y = _check(out) if out is not None else _new(xt.shape, xt)
+    mean = torch.empty(C, dtype=torch.float32, device=dev)
+    rstd = torch.empty(C, dtype=torch.float32, device=dev)
+    rt = _check(residual.t) if residual is not None else None
+    use_batch = training or (bn.running_mean is None)
+    sums = x.stats if use_batch else None
+    _lib.call("cn_bn_act_fwd_bf16", xt.data_ptr(), ld(xt), bn.weight.data_ptr(), bn.bias.data_ptr(),
+              bn.running_mean.data_ptr() if bn.running_mean is not None else None,
+              bn.running_var.data_ptr() if bn.running_var is not None else None,
+              rt.data_ptr() if rt is not None else None, ld(rt) if rt is not None else 0, y.data_ptr(), ld(y),
+              mean.data_ptr(), rstd.data_ptr(), _bn_ws16(C, dev), P, C, 1 if use_batch else 0, _bn_momentum(bn),
+              float(bn.eps), act, sums.data_ptr() if sums is not None else None, _stream())
+    yv = Var(y, tape.enabled)
+    if tape.enabled:
+        store = current_store()
+        gamma, beta = bn.weight, bn.bias
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            if residual is not None:
+                give_grad(residual, dy)
+            if x.req:
+                dx, acc = grad_buffer(x)
+                dxp, dxl = dx.data_ptr(), ld(dx)
+            else:
+                dxp, dxl, acc = None, 0, 0
+            _lib.call("cn_bn_act_bwd_bf16", xt.data_ptr(), ld(xt), dy.data_ptr(), ld(dy), mean.data_ptr(),
+                      rstd.data_ptr(), gamma.data_ptr(), beta.data_ptr(), dxp, dxl, store.grad_of(gamma).data_ptr(),
+                      store.grad_of(beta).data_ptr(), _bn_ws16(C, dev), P, C, 1 if use_batch else 0, act, acc, _stream())
+            yv.grad = None
+
+        tape.add(bwd, (gamma, beta))
+    return yv
+
+
+def _layer_norm_c_bf16(x: Var, ln, residual: T.Optional[Var]) -> Var:
+    tape = current_tape()
+    xt = x.t
+    B, C, H, W = xt.shape
+    P = B * H * W
+    y = _new(xt.shape, xt)
+    rt = _check(residual.t) if residual is not None else None
+    _lib.call("cn_layernorm_c_fwd_bf16", xt.data_ptr(), ld(xt), ln.weight.data_ptr(), ln.bias.data_ptr(),
+              rt.data_ptr() if rt is not None else None, ld(rt) if rt is not None else 0, y.data_ptr(), ld(y), P, C,
+              float(ln.eps), _stream())
+    yv = Var(y, tape.enabled)
+    if tape.enabled:
+        store = current_store()
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            if residual is not None:
+                give_grad(residual, dy)
+            dx, acc = grad_buffer(x)
+            _lib.call("cn_layernorm_c_bwd_bf16", xt.data_ptr(), ld(xt), dy.data_ptr(), ld(dy), ln.weight.data_ptr(),
+                      dx.data_ptr(), ld(dx), store.grad_of(ln.weight).data_ptr(), store.grad_of(ln.bias).data_ptr(), P, C,
+                      float(ln.eps), acc, _stream())
+            yv.grad = None
+
+        tape.add(bwd, (ln.weight, ln.bias))
+    return yv
+
+
+def _na2d_bf16(qkv: Var, heads: int, kernel_size: int, dilation: int) -> Var:
+    tape = current_tape()
+    qt = qkv.t
+    B, C3, H, W = qt.shape
+    C = C3 // 3
+    out = _new((B, C, H, W), qt)
+    attn = torch.empty((B, heads, kernel_size * kernel_size, H, W), dtype=torch.float32, device=qt.device)
+    _lib.call("cn_na2d_fwd_bf16", qt.data_ptr(), ld(qt), out.data_ptr(), ld(out), attn.data_ptr(), B, C, heads, H, W,
+              kernel_size, dilation, _stream())
+    ov = Var(out, tape.enabled)
+    if tape.enabled:
+
+        def bwd():
+            do = ov.grad
+            if do is None:
+                return
+            dattn = torch.empty_like(attn)
+            dq = _new(qt.shape, qt)
+            _lib.call("cn_na2d_bwd_bf16", qt.data_ptr(), ld(qt), do.data_ptr(), ld(do), attn.data_ptr(),
+                      dattn.data_ptr(), dq.data_ptr(), ld(dq), B, C, heads, H, W, kernel_size, dilation, _stream())
+            if qkv.grad is None and qkv.parent is None:
+                qkv.grad = dq
+            else:  # pragma: no cover - qkv has a single consumer in TowerUNet
+                give_grad(qkv, dq)
+            ov.grad = None
+
+        tape.add(bwd)
+    return ov
+
+
+def _resize_bilinear_bf16(x: Var, size: T.Tuple[int, int], out: T.Optional[torch.Tensor]) -> Var:
+    tape = current_tape()
+    xt = x.t
+    B, C, Hi, Wi = xt.shape
+    Ho, Wo = size
+    y = _check(out) if out is not None else _new((B, C, Ho, Wo), xt)
+    if (Hi, Wi) == (Ho, Wo):
+        _lib.call("cn_copy_bf16", xt.data_ptr(), ld(xt), y.data_ptr(), ld(y), B * Ho * Wo, C, 0, _stream())
+    else:
+        _lib.call("cn_bilinear_fwd_bf16", xt.data_ptr(), ld(xt), y.data_ptr(), ld(y), B, C, Hi, Wi, Ho, Wo, _stream())
+    yv = Var(y, tape.enabled and x.req)
+    if tape.enabled and x.req:
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            if (Hi, Wi) == (Ho, Wo):
+                give_grad(x, dy)
+            else:
+                dx, acc = grad_buffer(x)
+                _lib.call("cn_bilinear_bwd_bf16", dy.data_ptr(), ld(dy), dx.data_ptr(), ld(dx), B, C, Hi, Wi, Ho, Wo, acc,
+                          _stream())
+            yv.grad = None
+
+        tape.add(bwd)
+    return yv
+
+
+def _thin_conv3x3_bf16(x: Var, mods: T.Sequence, grouped: bool, dilation: int, out: T.Optional[torch.Tensor]) -> Var:
+    """The first head convolutions (128 -> 3, three streams) on a bf16 tower output: the MFMA kernel with an fp32
+    NCHW epilogue, so everything downstream of it (9 / 3 / 1-channel head tensors) stays on the fp32 head kernels."""
+    if grouped:
+        raise NotImplementedError("grouped thin convolutions read the fp32 head tensors, never bf16")
+    tape = current_tape()
+    xt = x.t
+    B, Cin, H, W = xt.shape
+    n = len(mods)
+    CP = mods[0].weight.shape[0]
+    y = out if out is not None else torch.empty((B, n * CP, H, W), dtype=torch.float32, device=xt.device)
+    if y.dtype != torch.float32 or not y.is_contiguous():
+        raise RuntimeError("thin_conv3x3 (bf16 input) writes a dense fp32 NCHW tensor")
+    HW = H * W
+    pws = [packed_conv(m, tape.enabled and x.req, bf16=True) for m in mods]
+    for i, (m, pw) in enumerate(zip(mods, pws)):
+        yi = y[:, i * CP:(i + 1) * CP]
+        _lib.call("cn_conv2d_fwd_bf16", xt.data_ptr(), ld(xt), pw.fwd16.data_ptr(),
+                  m.bias.data_ptr() if m.bias is not None else None, yi.data_ptr(), 0, n * CP * HW, B, Cin, H, W, CP, 3,
+                  3, 1, dilation, dilation, 0, 1, None, _stream())
+    yv = Var(y, tape.enabled)
+    if tape.enabled:
+        store = current_store()
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            s = _stream()
+            cp8 = (CP + 7) // 8 * 8
+            need = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, CP, 3, 3, 1, dilation, dilation, 0)
+            wsp, wsn = _ws16(need, xt.device)
+            first = True
+            for i, (m, pw) in enumerate(zip(mods, pws)):
+                dyi = dy[:, i * CP:(i + 1) * CP]
+                d16 = torch.empty((B, H, W, cp8), dtype=torch.bfloat16, device=xt.device)
+                _lib.call("cn_convert_f32nchw_to_bf16nhwc", dyi.data_ptr(), bstride(dy), d16.data_ptr(), cp8, B, CP,
+                          cp8, HW, s)
+                _lib.call("cn_conv2d_bwd_weight_bf16", xt.data_ptr(), ld(xt), d16.data_ptr(), cp8,
+                          store.grad_of(m.weight).data_ptr(), B, Cin, H, W, CP, 3, 3, 1, dilation, dilation, wsp, wsn, s)
+                if m.bias is not None:
+                    _lib.call("cn_channel_sum_f32", dyi.data_ptr(), bstride(dy), B, CP, HW,
+                              store.grad_of(m.bias).data_ptr(), 1, s)
+                if x.req:
+                    dx, acc = grad_buffer(x)
+                    _lib.call("cn_conv2d_bwd_data_bf16", d16.data_ptr(), cp8, pw.bwd16.data_ptr(), dx.data_ptr(),
+                              ld(dx), B, Cin, H, W, CP, 3, 3, 1, dilation, dilation, acc if first else 1, s)
+                    first = False
+            yv.grad = None
+
+        tape.add(bwd, tuple(m.weight for m in mods) + tuple(m.bias for m in mods if m.bias is not None))
     return yv

@@ -296,7 +296,7 @@ class HipTrainer:
 
     def __init__(self, lit: CultionetLitModel, gradient_clip_val: T.Optional[float] = 1.0,
                  lr_fn: T.Optional[T.Callable[[int], T.Union[float, T.Tuple[float, float]]]] = None, comm=None,
-                 total_steps: T.Optional[int] = None):
+                 total_steps: T.Optional[int] = None, precision: str = "32-true"):
         self.lit = lit
         self.model = lit.cultionet_model.mask_model
         self.store = self.model.param_store()
@@ -318,6 +318,11 @@ class HipTrainer:
         self.lr_fn = lr_fn
         self.step_count = 0
         self.comm = comm
+        # lightning.Trainer(precision=...) of the reference (model.py:168-186; default "16-mixed"): on MI355X the
+        # mixed mode is bf16 activations + fp32 master weights / statistics / accumulation (no loss scaling needed)
+        if precision not in ("32-true", "32", "bf16-mixed", "16-mixed"):
+            raise ValueError(f"unsupported precision {precision!r}")
+        self.bf16 = precision in ("bf16-mixed", "16-mixed")
         if lit.optimizer != "AdamW":
             raise NotImplementedError("the fused HIP optimizer implements AdamW (the reference default)")
         if comm is not None:
@@ -334,7 +339,7 @@ class HipTrainer:
         kind = E.LOSS_KINDS[str(lit.loss_name)]
         s = E._stream()
         _lib.call("cn_fill_f32", self.total.data_ptr(), 1, 0.0, s)
-        with E.using_store(store), E.recording(True) as tape:
+        with E.using_store(store), E.recording(True) as tape, E.mixed_precision(self.bf16):
             outs = self.model.forward_vars(self.model.input_var(batch.x))
             for key, kw in lit._loss_terms(batch):
                 E.tanimoto_loss(outs[key], loss_kind=kind, weight=1.0 / 3.0, total=self.total, **kw)

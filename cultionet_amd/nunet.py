@@ -85,7 +85,10 @@ class PreTimeReduction(nn.Module):
     def forward(self, x: E.Var) -> E.Var:
         x3 = self.conv3(x)
         s = self.conv5(x, residual=x3)  # x3 + x5 fused into conv5's last BN+SiLU
-        return E.layer_norm_c(s, self.layer_norm[1])
+        y = E.layer_norm_c(s, self.layer_norm[1])
+        # mixed precision: the time reduction (0.1 % of the FLOPs, fp32 input chips) stays fp32; its output enters the
+        # bf16 NHWC region here and the tower heads leave it again (engine._thin_conv3x3_bf16)
+        return E.to_bf16(y) if E.bf16_enabled() else y
 
 
 class TowerUNet(nn.Module):

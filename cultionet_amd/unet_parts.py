@@ -250,7 +250,7 @@ class TowerUNetBlock(nn.Module):
         if tower_down is not None:
             cs.append(tower_down.shape[1])
         B = decode_side.shape[0]
-        buf = torch.empty((B, sum(cs), size[0], size[1]), dtype=torch.float32, device=decode_side.t.device)
+        buf = E.new_buffer((B, sum(cs), size[0], size[1]), decode_side.t)
         offs = [sum(cs[:i]) for i in range(len(cs))]
         sl = lambda i: buf[:, offs[i]:offs[i] + cs[i]]
         parts = [backbone_side, self.backbone_down_conv(backbone_down, size=size, out=sl(1)), decode_side,

@@ -341,6 +341,9 @@ int cn_bn_act_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const
                        const float* gamma, const float* beta, void* dx /*nullable*/, long lddx, float* dgamma,
                        float* dbeta, float* ws, long P, int C, int training, int act, int accumulate_dx, void* stream);
 
+/* bias gradients: out[c] (+)= sum_p x[p][c]; ws: cn_bn_workspace_floats_bf16(C) floats */
+int cn_channel_sum_bf16(const void* x, long ldx, long P, int C, float* out, int accumulate, float* ws, void* stream);
+
 /* nn.LayerNorm over channels (rows of the NHWC image), + residual; statistics recomputed in backward.
  * dw / db ACCUMULATED (fp32 atomics). */
 int cn_layernorm_c_fwd_bf16(const void* x, long ldx, const float* w, const float* b, const void* res /*nullable*/,

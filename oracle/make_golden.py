@@ -30,7 +30,13 @@ def _ref_model(ns, hidden, in_channels=3, in_time=12, **kw):
     return m
 
 
-def _train_case(ns, hidden, B, H, W, with_mask, seed=7, stages=False, loss_name="TanimotoComplementLoss", **kw):
+def _train_case(ns, hidden, B, H, W, with_mask, seed=7, stages=False, loss_name="TanimotoComplementLoss",
+                autocast=False, **kw):
+    """autocast=True: the same step under torch.autocast("cpu", dtype=torch.bfloat16) -- what
+    lightning.Trainer(precision="bf16-mixed") wraps around training_step (the reference's default is the fp16
+    flavour "16-mixed", model.py:168-186; CPU autocast has no fp16, and bf16 is the MI355X-native choice)."""
+    import contextlib
+
     m = _ref_model(ns, hidden, loss_name=loss_name, **kw)
     m.train()
     x, y, bdist = O.seeded_batch(B, height=H, width=W, seed=seed, with_mask=with_mask)
@@ -51,14 +57,28 @@ def _train_case(ns, hidden, B, H, W, with_mask, seed=7, stages=False, loss_name=
 
         for name in ("pre_unet", "encoder", "decoder", "tower_fusion"):
             hooks.append(getattr(tu, name).register_forward_hook(grab(name)))
-    pred = m(batch)
-    loss, rep = m.calc_loss(batch, pred)
+    ctx = torch.autocast("cpu", dtype=torch.bfloat16) if autocast else contextlib.nullcontext()
+    if autocast:
+        # torch 2.10 CPU (oneDNN) corrupts the heap in the bf16 backward of nn.Conv3d(3, C, (10,1,1)) at 100x100
+        # ("double free or corruption"; 50x50 and smaller are fine), so PreTimeReduction -- 0.1 % of the FLOPs -- is
+        # evaluated in fp32 inside the autocast region. The HIP mixed-precision path makes the same choice.
+        pre = m.cultionet_model.mask_model.pre_unet
+        inner = pre.forward
+
+        def fp32_forward(*a, **k):
+            with torch.autocast("cpu", enabled=False):
+                return inner(*a, **k)
+
+        pre.forward = fp32_forward
+    with ctx:
+        pred = m(batch)
+        loss, rep = m.calc_loss(batch, pred)
     loss.backward()
     for h in hooks:
         h.remove()
     out = dict(rec)
     for k in ("distance", "edge", "crop"):
-        out[k] = pred[k].detach().numpy()
+        out[k] = pred[k].detach().float().numpy()
     out["loss"] = np.float64(loss.item())
     for k, v in rep.items():
         out[k] = np.float64(v.item())
@@ -68,7 +88,7 @@ def _train_case(ns, hidden, B, H, W, with_mask, seed=7, stages=False, loss_name=
         norms.append(float(p.grad.double().norm()))
     out["grad_names"] = np.array(names)
     out["grad_norms"] = np.array(norms, dtype=np.float64)
-    out["margin"] = np.float64(min(float((pred[k] - 0.5).abs().min()) for k in ("distance", "edge", "crop")))
+    out["margin"] = np.float64(min(float((pred[k].float() - 0.5).abs().min()) for k in ("distance", "edge", "crop")))
     # running statistics after one train-mode forward (BN momentum path)
     sd = m.state_dict()
     k0 = next(k for k in sd if "tower_fusion.tower_a.res_conv" in k and k.endswith("running_mean"))[:-len("running_mean")]
@@ -125,6 +145,18 @@ def main():
         np.savez_compressed(path, **d)
         print(name, os.path.getsize(path) // 1024, "KiB", "loss" in d and d["loss"])
 
+    if "--bf16-only" in sys.argv:
+        # mixed-precision fixtures (BASELINE configs[2]): the reference under CPU bf16 autocast, plus the fp32 run of
+        # the SAME case so the tests can state the tolerance relative to the reference's own bf16 deviation
+        for name, args, kw in (("h8_b2_28", (8, 2, 28, 28, True), {}),
+                               ("h32_b1_100", (32, 1, 100, 100, False), {}),
+                               ("h32_b4_100", (32, 4, 100, 100, True), {})):
+            a = _train_case(ns, *args, autocast=True, **kw)
+            f = _train_case(ns, *args, autocast=False, **kw)
+            for k in ("distance", "edge", "crop", "loss", "dloss", "eloss", "closs", "grad_norms"):
+                a["fp32_" + k] = f[k]
+            save(f"train_bf16_{name}.npz", a)
+        return
     if "--variants-only" in sys.argv:
         save("train_h8_b2_28_poolmax.npz", _train_case(ns, 8, 2, 28, 28, True, pool_by_max=True))
         save("train_h8_b2_28_res.npz", _train_case(ns, 8, 2, 28, 28, False, res_block_type="res", attention_weights=None))
