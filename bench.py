@@ -4,13 +4,17 @@
 
 A "step" is one pass of the hot path over one synthetic batch already resident in HBM:
 forward + Tanimoto loss + backward + global-norm clip + AdamW, all in the hand-written HIP kernels
-(cultionet_amd.lightning.HipTrainer). Workload at N=1 = BASELINE configs[1]: TowerUNet fp32,
-hidden 32, batch 8 of [3,12,100,100] chips. N > 1 shards chips over ranks (weak scaling, per-GPU batch
-fixed) with one bucketed RCCL all-reduce of the flat gradient overlapped with the backward tape.
+(cultionet_amd.lightning.HipTrainer). Default workload = BASELINE configs[1]: TowerUNet fp32, hidden 32, batch 8 of
+[3,12,100,100] chips. `--dtype bf16 --batch 32` = BASELINE configs[2] (mixed precision: bf16 NHWC activations, fp32
+master weights / statistics / accumulation). N > 1 shards chips over ranks (weak scaling, per-GPU batch fixed) with one
+bucketed RCCL all-reduce of the flat gradient overlapped with the backward tape.
 
-Rank 0 prints ONE JSON line; `roofline` is the dominant kernel's algorithmic FLOP/s from HIP events
-recorded on the launch stream inside the timed region; `cpu_baseline` is the CPU oracle (a port of the
-reference's PyTorch-CPU path) timed on this box's host cores on a bounded sample (rank 0, N=1 only).
+Rank 0 prints ONE JSON line. `roofline` is the dominant kernel's algorithmic FLOP/s from HIP events recorded on the
+launch stream inside the timed region (`kernel` = the real rocprof kernel name, `family` = its template family);
+`cpu_baseline` is the CPU oracle (a port of the reference's PyTorch-CPU path) timed on this box's host cores on a
+bounded sample (rank 0, N=1 only); `loss_delta_vs_cpu` compares the step-1 loss of both legs (identical key-seeded
+weights and batch); `roofline.streaming` = GB/s of the HBM-bound BatchNorm / LayerNorm / bilinear entry points from a
+short separate pass after the timed region; `predict` = BASELINE configs[4] (large-tile eval pixels/s, GPU and CPU).
 """
 from __future__ import annotations
 
@@ -26,9 +30,11 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 FWD_GFLOP_PER_CHIP = {32: 64.88, 64: 258.0}  # forward 2*MAC FLOPs at [1,3,12,100,100]
-PEAK_F32_MFMA_TFLOPS = 157.3                 # MI355X_MICROARCH.md: f32-input MFMA == f32 vector peak
-KIND_NAMES = ["cn_conv_igemm_kernel<NT=128>", "cn_conv_igemm_kernel<NT<=64>", "cn_wgrad_kernel<3x3>",
-              "cn_wgrad_kernel<1x1>"]
+PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak; bf16 dense MFMA
+PEAK_HBM_GBS = 8000.0
+FAMILY = {0: "cn_conv_igemm*/cn_conv1x1 <NT=128>", 1: "cn_conv_igemm* <NT<=64>", 2: "cn_wgrad* <3x3>",
+          3: "cn_wgrad* <1x1>", 4: "cn_bconv_kernel (bf16)", 5: "cn_bwgrad_kernel (bf16)"}
+PMC_FILE = "profiles/r01_pmc_traffic.json"
 
 
 def parse():
@@ -36,20 +42,17 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--batch", type=int, default=8, help="chips per GPU")
+    ap.add_argument("--batch", type=int, default=None, help="chips per GPU (default 8 for f32, 32 for bf16)")
     ap.add_argument("--hidden", type=int, default=32)
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the streaming-kernel pass and the predict block")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = best of the documented sweep (16)")
     return ap.parse_args()
 
 
-def cpu_baseline(batch: int, hidden: int, steps: int, threads: int = 0):
-    """The oracle (port of the reference CPU path) timed on the host cores: fwd + loss + bwd + AdamW."""
-    import torch
-
-    from oracle import towerunet_oracle as O
-
+def _cpu_threads(threads: int) -> int:
     avail = os.cpu_count() or 1
     try:
         avail = len(os.sched_getaffinity(0))
@@ -58,7 +61,17 @@ def cpu_baseline(batch: int, hidden: int, steps: int, threads: int = 0):
     # Thread count: the best of a sweep on the GPU box's host (2 x EPYC 9575F, 256 logical CPUs), batch 8:
     # 4 thr 2.1, 8 thr 2.8, 16 thr 3.3-3.5, 24 thr 3.0, 32 thr 2.8, 64 thr 1.6, 128 thr 0.74, 256 thr 0.03 chips/s
     # (oneDNN scales poorly on these small 100x100 chips); `cores` reports the threads actually used.
-    cores = min(threads, avail) if threads else min(16, avail)
+    return min(threads, avail) if threads else min(16, avail)
+
+
+def cpu_baseline(batch: int, hidden: int, steps: int, threads: int = 0):
+    """The oracle (port of the reference CPU path) timed on the host cores: fwd + loss + bwd + clip + AdamW (fp32).
+    Returns (record, loss of the first step)."""
+    import torch
+
+    from oracle import towerunet_oracle as O
+
+    cores = _cpu_threads(threads)
     torch.set_num_threads(cores)
     m = O.TowerUNet(3, 12, hidden_channels=hidden)
     m.load_state_dict(O.seeded_state_dict(m.state_dict()))
@@ -72,9 +85,9 @@ def cpu_baseline(batch: int, hidden: int, steps: int, threads: int = 0):
         loss.backward()
         torch.nn.utils.clip_grad_norm_(m.parameters(), 1.0)
         opt.step()
-        return float(loss)
+        return float(loss.detach())
 
-    step()  # warm-up (oneDNN primitive creation)
+    first = step()  # warm-up (oneDNN primitive creation); also the step-1 loss both legs share
     t0 = time.perf_counter()
     for _ in range(steps):
         step()
@@ -86,27 +99,15 @@ def cpu_baseline(batch: int, hidden: int, steps: int, threads: int = 0):
         "kind": "port",
         "sample": f"{steps} train steps (1 warm-up discarded) of batch {batch} x [3,12,100,100], hidden {hidden}, "
                   f"fp32, torch {torch.__version__} CPU, {cores} threads",
-    }
-
-
-# rocprof kernel-name prefixes behind each profiled kind (template instantiations of one kernel family)
-KIND_PATTERNS = {
-    0: ("cn_conv_igemm_vec_kernel<4, 1,", "cn_conv_igemm_vec_kernel<2, 2,", "cn_conv_igemm_kernel<2, 2,",
-        "cn_conv1x1_kernel<"),
-    1: ("cn_conv_igemm_vec_kernel<1,", "cn_conv_igemm_kernel<1,"),
-    2: ("cn_wgrad_vec_kernel<9,", "cn_wgrad_kernel<9>"),
-    3: ("cn_wgrad_vec_kernel<1,", "cn_wgrad_kernel<1>"),
-}
+    }, first
 
 
 def pmc_traffic(prefixes):
-    """HBM-side bytes per launch of a kernel family, from the committed PMC passes of THIS command
-    (profiles/r01_pmc_traffic.json: FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate rocprofv3 --pmc runs,
-    tools/pmc_traffic.py). PMC counters cannot be collected from inside the timed run, so the figure is read
-    from that file; None if it is absent."""
-    path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "profiles", "r01_pmc_traffic.json")
+    """HBM-side bytes per launch of a kernel family from the COMMITTED PMC passes of the default command
+    (FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate rocprofv3 --pmc runs, tools/pmc_traffic.py). PMC counters cannot be
+    collected inside the timed run: this is a constant read from that file, labelled as such in the JSON."""
     try:
-        with open(path) as f:
+        with open(os.path.join(ROOT, PMC_FILE)) as f:
             kernels = json.load(f)["kernels"]
     except (OSError, ValueError, KeyError):
         return None
@@ -116,6 +117,124 @@ def pmc_traffic(prefixes):
             tot += v["hbm_bytes_per_launch"] * v["launches"]
             n += v["launches"]
     return tot / n if n else None
+
+
+def streaming_pass(trainer, batch, steps: int = 2):
+    """GB/s of the BatchNorm / LayerNorm / bilinear entry points: every call of those ops is bracketed by HIP events
+    on the launch stream (torch's current stream) in a short pass AFTER the timed region (so the timed step is not
+    perturbed). Algorithmic bytes: elements x passes x element size (BN fwd: stats read + apply read + write = 3;
+    BN bwd: 2 reads x 2 passes + dx write = 5; LN fwd 2, bwd 3 (x, dy, dx); bilinear: input + output once)."""
+    import torch
+
+    from cultionet_amd import _lib
+
+    orig = _lib.call
+    recs = []
+    # argument positions (0-based, after the name): see include/cultionet_hip.h
+    def elems(name, a):
+        if name in ("cn_bn_act_fwd_f32",):
+            return a[13] * a[14] * a[15], 4, 3 if a[16] else 2
+        if name in ("cn_bn_act_bwd_f32",):
+            return a[14] * a[15] * a[16], 4, 5
+        if name in ("cn_bn_act_group_fwd_f32",):
+            return a[0] * a[14] * a[15] * a[16], 4, 3
+        if name in ("cn_bn_act_group_bwd_f32",):
+            return a[0] * a[15] * a[16] * a[17], 4, 5
+        if name == "cn_layernorm_c_fwd_f32":
+            return a[10] * a[11] * a[12], 4, 2
+        if name == "cn_layernorm_c_bwd_f32":
+            return a[11] * a[12] * a[13], 4, 3
+        if name == "cn_bilinear_fwd_f32":
+            return a[4] * a[5] * (a[6] * a[7] + a[8] * a[9]), 4, 1
+        if name == "cn_bilinear_bwd_f32":
+            return a[4] * a[5] * (a[6] * a[7] + a[8] * a[9]), 4, 1
+        if name == "cn_bn_act_fwd_bf16":
+            return a[13] * a[14], 2, (2 if a[19] is not None else 3) if a[15] else 2
+        if name == "cn_bn_act_bwd_bf16":
+            return a[13] * a[14], 2, 5
+        if name == "cn_layernorm_c_fwd_bf16":
+            return a[8] * a[9], 2, 2
+        if name == "cn_layernorm_c_bwd_bf16":
+            return a[9] * a[10], 2, 3
+        if name in ("cn_bilinear_fwd_bf16", "cn_bilinear_bwd_bf16"):
+            return a[4] * a[5] * (a[6] * a[7] + a[8] * a[9]), 2, 1
+        return None
+
+    def hooked(name, *a):
+        e = elems(name, a)
+        if e is None:
+            return orig(name, *a)
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+        rc = orig(name, *a)
+        ev1.record()
+        recs.append((name, e[0] * e[1] * e[2], ev0, ev1))
+        return rc
+
+    _lib.call = hooked
+    try:
+        for _ in range(steps):
+            trainer.training_step(batch)
+        torch.cuda.synchronize()
+    finally:
+        _lib.call = orig
+    agg = {}
+    for name, nbytes, e0, e1 in recs:
+        ms = e0.elapsed_time(e1)
+        a = agg.setdefault(name, [0.0, 0.0, 0])
+        a[0] += ms
+        a[1] += nbytes
+        a[2] += 1
+    out = {}
+    for name, (ms, nbytes, n) in sorted(agg.items(), key=lambda kv: -kv[1][0]):
+        gbs = nbytes / (ms * 1e-3) / 1e9 if ms > 0 else 0.0
+        out[name] = {"ms_per_step": ms / steps, "calls_per_step": n / steps, "GB/s": gbs,
+                     "frac_of_hbm_peak": gbs / PEAK_HBM_GBS}
+    return out
+
+
+def predict_block(dev, hidden: int, cpu: bool, threads: int):
+    """BASELINE configs[4]: eval forward of one [1,4,25,256,256] tile, pixels/s on the GPU and on the host CPU."""
+    import torch
+
+    from cultionet_amd import synthetic as S
+    from cultionet_amd.lightning import CultionetLitModel
+
+    lit = CultionetLitModel(in_channels=4, in_time=25, hidden_channels=hidden, dropout=0.0)
+    model = lit.cultionet_model.mask_model
+    model.load_state_dict(S.seeded_state_dict(model.state_dict()))
+    lit = lit.to(dev).eval()
+    x, _, _ = S.seeded_batch(1, channels=4, time=25, height=256, width=256, seed=11)
+    xd = x.to(dev)
+    with torch.no_grad():
+        for _ in range(2):
+            model(xd)
+        torch.cuda.synchronize()
+        n = 10
+        t0 = time.perf_counter()
+        for _ in range(n):
+            model(xd)
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / n
+    out = {"workload": f"eval forward [1,4,25,256,256], hidden {hidden}, fp32 (BASELINE configs[4])",
+           "ms_per_tile": dt * 1e3, "value": 256 * 256 / dt, "unit": "pixels/s"}
+    if cpu:
+        from oracle import towerunet_oracle as O
+
+        cores = _cpu_threads(threads)
+        torch.set_num_threads(cores)
+        m = O.TowerUNet(4, 25, hidden_channels=hidden)
+        m.load_state_dict(O.seeded_state_dict(m.state_dict()))
+        m.eval()
+        with torch.no_grad():
+            m(x)
+            t0 = time.perf_counter()
+            m(x)
+            m(x)
+            dtc = (time.perf_counter() - t0) / 2
+        out["cpu_baseline"] = {"value": 256 * 256 / dtc, "unit": "pixels/s", "cores": cores, "kind": "port",
+                               "sample": "2 eval forwards of the same tile (1 warm-up discarded)"}
+    return out
 
 
 def main():
@@ -132,6 +251,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     comm = None
+    rccl_ranks = 0
     use_dist = world > 1 or os.environ.get("CN_FORCE_COMM") == "1"  # CN_FORCE_COMM: exercise RCCL with one rank
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -144,6 +264,7 @@ def main():
         from cultionet_amd.ddp import GradientAllReduce
 
         comm = GradientAllReduce(world_size=world)
+        rccl_ranks = dist.get_world_size()  # what the process group really initialised
 
     from cultionet_amd import _lib
     from cultionet_amd.data import Data
@@ -151,7 +272,9 @@ def main():
     from cultionet_amd import synthetic as O
 
     _lib.load()
-    B, hidden = args.batch, args.hidden
+    bf16 = args.dtype == "bf16"
+    B = args.batch if args.batch is not None else (32 if bf16 else 8)
+    hidden = args.hidden
     lit = CultionetLitModel(in_channels=3, in_time=12, hidden_channels=hidden, dropout=0.0)
     model = lit.cultionet_model.mask_model
     model.load_state_dict(O.seeded_state_dict(model.state_dict()))
@@ -159,16 +282,26 @@ def main():
     x, y, bdist = O.seeded_batch(B, seed=7 + rank)
     batch = Data(x=x.to(dev), y=y.to(dev), bdist=bdist.to(dev), lon=torch.zeros(B, device=dev),
                  lat=torch.zeros(B, device=dev))
-    trainer = HipTrainer(lit, gradient_clip_val=1.0, comm=comm)
+    trainer = HipTrainer(lit, gradient_clip_val=1.0, comm=comm, precision="bf16-mixed" if bf16 else "32-true")
 
     def sync():
         if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(args.warmup):
-        trainer.training_step(batch)
+    first_loss = None
+    for i in range(args.warmup):
+        l = trainer.training_step(batch)
+        if i == 0:
+            first_loss = float(l.item())  # loss at the key-seeded initial weights (compared with the CPU leg)
     sync()
+    launches = [0]
+    orig_call = _lib.call
+
+    def counting(name, *a):
+        launches[0] += 1
+        return orig_call(name, *a)
+
     _lib.call("cn_profile_begin")
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -178,6 +311,15 @@ def main():
     prof = (ctypes.c_double * 24)()
     _lib.call("cn_profile_end", prof)
     loss_val = float(loss.item())
+    if first_loss is None:
+        first_loss = loss_val if args.steps == 1 else None
+    # C-ABI calls per step (each launches 1-3 kernels), counted on one extra untimed step
+    _lib.call = counting
+    try:
+        trainer.training_step(batch)
+    finally:
+        _lib.call = orig_call
+    torch.cuda.synchronize()
 
     t = torch.tensor([dt], dtype=torch.float64, device=dev)
     if use_dist:
@@ -187,11 +329,28 @@ def main():
     if rank == 0:
         chips = world * B * args.steps
         value = chips / dt
-        kinds = [(prof[3 * k], prof[3 * k + 1], prof[3 * k + 2]) for k in range(4)]
-        dom = max(range(4), key=lambda k: kinds[k][0])
-        ms, flops, launches = kinds[dom]
+        peak = PEAK_TFLOPS[args.dtype]
+        kinds = [(prof[3 * k], prof[3 * k + 1], prof[3 * k + 2]) for k in range(8)]
+        # dominant kernel = the top entry of the per-kernel-name aggregation (real rocprof names)
+        name_buf = ctypes.create_string_buffer(96)
+        top3 = (ctypes.c_double * 3)()
+        nk = _lib.query("cn_profile_top", 0, name_buf, 96, top3)
+        by_kernel = {}
+        for r in range(min(nk, 8)):
+            nb = ctypes.create_string_buffer(96)
+            o3 = (ctypes.c_double * 3)()
+            _lib.query("cn_profile_top", r, nb, 96, o3)
+            by_kernel[nb.value.decode()] = {
+                "ms_per_step": o3[0] / args.steps, "tflops": (o3[1] / (o3[0] * 1e-3) / 1e12) if o3[0] else 0.0,
+                "launches_per_step": o3[2] / args.steps}
+        top_name = name_buf.value.decode() if nk > 0 else ""
+        ms, flops, nl = top3[0], top3[1], top3[2]
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
+        dom = max(range(8), key=lambda k: kinds[k][0])
         train_gflop = 3.0 * FWD_GFLOP_PER_CHIP.get(hidden, 0.0)
+        traffic = None
+        if not bf16 and (hidden, B) == (32, 8) and top_name.startswith("cn_conv_igemm_vec_kernel<4, 1,"):
+            traffic = pmc_traffic(("cn_conv_igemm_vec_kernel<4, 1,",))
         out = {
             "metric": "train_chips_per_sec",
             "value": value,
@@ -203,36 +362,54 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic",
             "config": {
                 "workload": f"TowerUNet train step (fwd + Tanimoto + bwd + clip + AdamW), hidden {hidden}, "
-                            f"per-GPU batch {B} x [3,12,100,100] fp32 (BASELINE configs[1])",
+                            f"per-GPU batch {B} x [3,12,100,100] "
+                            + ("bf16 mixed precision (BASELINE configs[2])" if bf16 else "fp32 (BASELINE configs[1])"),
                 "global_batch": world * B,
                 "parallelism": f"dp{world}" if world > 1 else "single",
+                "rccl_ranks": rccl_ranks,
                 "loss": loss_val,
+                "abi_calls_per_step": launches[0],
             },
             "roofline": {
                 "bound": "mfma",
-                "kernel": KIND_NAMES[dom],
+                "kernel": top_name,
                 "achieved": achieved,
-                "peak": PEAK_F32_MFMA_TFLOPS,
+                "peak": peak,
                 "unit": "TFLOP/s",
-                "frac": achieved / PEAK_F32_MFMA_TFLOPS,
-                # the committed PMC passes are of the default workload (hidden 32, batch 8)
-                "traffic": pmc_traffic(KIND_PATTERNS[dom]) if (hidden, B) == (32, 8) else None,
-                "avg_launch_us": ms * 1e3 / launches if launches else None,
-                "launches_per_step": launches / args.steps,
+                "frac": achieved / peak,
+                "traffic": traffic,
+                "traffic_source": (f"{PMC_FILE} (committed rocprofv3 --pmc passes of this command; not measured in "
+                                   "this run)") if traffic is not None else None,
+                "avg_launch_us": ms * 1e3 / nl if nl else None,
+                "launches_per_step": nl / args.steps,
                 "share_of_step_time": ms * 1e-3 / dt,
-                "by_kernel": {KIND_NAMES[k]: {"ms_per_step": kinds[k][0] / args.steps,
-                                             "tflops": (kinds[k][1] / (kinds[k][0] * 1e-3) / 1e12) if kinds[k][0] else 0.0,
-                                             "launches_per_step": kinds[k][2] / args.steps} for k in range(4)},
+                "by_kernel": by_kernel,
+                "family": {FAMILY[k]: {"ms_per_step": kinds[k][0] / args.steps,
+                                       "tflops": (kinds[k][1] / (kinds[k][0] * 1e-3) / 1e12) if kinds[k][0] else 0.0,
+                                       "frac": ((kinds[k][1] / (kinds[k][0] * 1e-3) / 1e12) / peak) if kinds[k][0] else 0.0,
+                                       "launches_per_step": kinds[k][2] / args.steps}
+                           for k in range(6) if kinds[k][2] > 0},
+                "dominant_family": FAMILY.get(dom),
                 "end_to_end_tflops": value * train_gflop / 1e3,
-                "end_to_end_frac": value * train_gflop / 1e3 / PEAK_F32_MFMA_TFLOPS,
+                "end_to_end_frac": value * train_gflop / 1e3 / peak,
             },
         }
+        if world == 1 and not args.no_extras:
+            out["roofline"]["streaming"] = streaming_pass(trainer, batch)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(B, hidden, args.cpu_steps, args.cpu_threads)
+            out["cpu_baseline"], cpu_first = cpu_baseline(B, hidden, args.cpu_steps, args.cpu_threads)
+            if first_loss is not None:
+                out["loss_delta_vs_cpu"] = {"hip_step1_loss": first_loss, "cpu_step1_loss": cpu_first,
+                                            "abs_delta": abs(first_loss - cpu_first),
+                                            "tolerance": 5e-4 if bf16 else 1e-4}
+        if world == 1 and not args.no_extras and not bf16:
+            del trainer, batch
+            torch.cuda.empty_cache()
+            out["predict"] = predict_block(dev, hidden, not args.no_cpu_baseline, args.cpu_threads)
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

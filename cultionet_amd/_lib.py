@@ -102,6 +102,7 @@ SIGNATURES = {
     "cn_na2d_bwd_bf16": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, P],
     "cn_profile_begin": [],
     "cn_profile_end": [P],
+    "cn_profile_top": [I, P, I, P],
 }
 
 ERRORS = {-1: "CN_ERR_ARG (invalid argument / unsupported shape)", -2: "CN_ERR_LAUNCH (HIP launch failed)",

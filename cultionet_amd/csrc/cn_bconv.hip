@@ -416,6 +416,7 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
   if (np > 10) return CN_ERR_LDS;
   const size_t shmem = (size_t)max_pix * CNB_PITCH;
   const dim3 grid(cn_xcd_grid(total)), block(256);
+  cn_prof_name("cn_bconv_kernel<%d, %d>", WN, np <= 4 ? 4 : 10);
   cn_prof_desc("bconv B%d %dx%d %d->%d cls%d taps%d s%d/%d", g.B, g.Hin, g.Win, g.Cin, g.Cout, g.ncls, g.cls[0].ntaps,
                g.is, g.os);
   cn_prof_before(stream);

@@ -244,6 +244,7 @@ static int cnw_run(CnBWgGeom& g, float* dw, float* ws, long ws_floats, hipStream
   if (shmem > 160 * 1024) return CN_ERR_LDS;
   const dim3 grid(cn_xcd_grid(g.total)), block(256);
   const double flops = 2.0 * g.B * (double)g.Hg * g.Wg * g.CP * g.CQ * g.T;
+  cn_prof_name("cn_bwgrad_kernel<%d>", g.T);
   cn_prof_desc("bwgrad B%d %dx%d %dx%d T%d s%d split%d", g.B, g.Hg, g.Wg, g.CP, g.CQ, g.T, g.s, g.nsplit);
   cn_prof_before(stream);
 #define CNW_GO(T_)                                                                                             \
@@ -259,11 +260,11 @@ static int cnw_run(CnBWgGeom& g, float* dw, float* ws, long ws_floats, hipStream
     default: return CN_ERR_ARG;
   }
 #undef CNW_GO
+  cn_prof_after(stream, 5, flops);  // the contraction kernel alone
   const long n = (long)g.CP * g.CQ * g.T;
   const int rb = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
   hipLaunchKernelGGL(cn_bwgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, g.part, dw, g.nsplit, g.T, g.CP, g.CQ,
                      (long)g.nbp * 64, (long)g.nbq * 64);
-  cn_prof_after(stream, 5, flops);
   return cn_check_launch();
 }
 

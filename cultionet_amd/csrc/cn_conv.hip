@@ -585,6 +585,7 @@ static int cn_launch_igemm_v(const float* x, const float* wp, const float* bias,
   g.grid_y = (g.Cout + NT - 1) / NT;
   g.splits = splits < 1 ? 1 : splits;
   dim3 grid(cn_xcd_grid((long)g.grid_x * g.grid_y * g.splits));
+  cn_prof_name("cn_conv_igemm_vec_kernel<%d, %d, %d, %d, %d>", WAVES_N, TN, TM, NV, RP);
   cn_prof_desc("igemm_vec<%d,%d,%d,%d,%d> G%d B%d %d->%d %dx%d->%dx%d taps%d cls%d is%d os%d grid%dx%dx%d", WAVES_N, TN,
                TM, NV, RP, g.G, g.B, g.Cin, g.Cout, g.Hin, g.Win, g.Hout, g.Wout, max_taps, g.ncls, g.is, g.os,
                total_tiles, (g.Cout + NT - 1) / NT, splits);
@@ -612,6 +613,7 @@ static int cn_launch_igemm_t(const float* x, const float* wp, const float* bias,
   g.grid_y = (g.Cout + NT - 1) / NT;
   g.splits = splits < 1 ? 1 : splits;
   dim3 grid(cn_xcd_grid((long)g.grid_x * g.grid_y * g.splits));
+  cn_prof_name("cn_conv_igemm_kernel<%d, %d, %d>", WAVES_N, TN, NI_T);
   cn_prof_desc("igemm_dw<%d,%d,%d> G%d B%d %d->%d %dx%d->%dx%d taps%d cls%d is%d os%d grid%dx%dx%d", WAVES_N, TN, NI_T,
                g.G, g.B, g.Cin, g.Cout, g.Hin, g.Win, g.Hout, g.Wout, max_taps, g.ncls, g.is, g.os, total_tiles,
                (g.Cout + NT - 1) / NT, splits);
@@ -1019,6 +1021,7 @@ static int cn_conv1x1_launch(const float* x, long xbs, const float* wp, const fl
   g.tiles_per_img = use160 ? (HW + 159) / 160 : (HW + 127) / 128;
   g.grid_x = B * g.tiles_per_img;
   const double flops = 2.0 * B * HW * (double)Cout * Cin;
+  cn_prof_name("cn_conv1x1_kernel<%d>", use160 ? 5 : 4);
   cn_prof_desc("gemm1x1<%d> B%d %d->%d HW%d grid%dx%d", use160 ? 5 : 4, B, Cin, Cout, HW, g.grid_x, g.grid_y);
   cn_prof_before(stream);
   if (use160)

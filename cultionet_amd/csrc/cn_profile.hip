@@ -3,13 +3,18 @@
 #include <cstdarg>
 #include <cstdio>
 #include <cstdlib>
+#include <cstring>
+#include <algorithm>
 #include <vector>
 
 #include "cn_common.h"
 
 namespace {
-struct Rec { hipEvent_t a, b; int kind; double flops; char desc[96]; };
+struct Rec { hipEvent_t a, b; int kind; double flops; char desc[96]; char name[64]; };
+struct Agg { char name[64]; double ms, flops, launches; };
 char g_desc[96] = {0};
+char g_name[64] = {0};
+std::vector<Agg> g_aggs;  // per kernel name, filled by cn_profile_end, sorted by time
 bool g_on = false;
 std::vector<Rec> g_recs;
 std::vector<hipEvent_t> g_pool;
@@ -34,6 +39,14 @@ void cn_prof_desc(const char* fmt, ...) {
   va_end(ap);
 }
 
+void cn_prof_name(const char* fmt, ...) {
+  if (!g_on) return;
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_name, sizeof(g_name), fmt, ap);
+  va_end(ap);
+}
+
 void cn_prof_before(hipStream_t stream) {
   if (!g_on) return;
   g_pending = get_event();
@@ -44,9 +57,11 @@ void cn_prof_after(hipStream_t stream, int kind, double flops) {
   if (!g_on || g_pending == nullptr) return;
   hipEvent_t b = get_event();
   (void)hipEventRecord(b, stream);
-  Rec r = {g_pending, b, kind, flops, {0}};
+  Rec r = {g_pending, b, kind, flops, {0}, {0}};
   snprintf(r.desc, sizeof(r.desc), "%s", g_desc);
+  snprintf(r.name, sizeof(r.name), "%s", g_name);
   g_desc[0] = 0;
+  g_name[0] = 0;
   g_recs.push_back(r);
   g_pending = nullptr;
 }
@@ -61,6 +76,7 @@ extern "C" int cn_profile_begin(void) {
 extern "C" int cn_profile_end(double* out) {
   g_on = false;
   for (int i = 0; i < CN_PROF_KINDS * 3; ++i) out[i] = 0.0;
+  g_aggs.clear();
   const char* dump = getenv("CN_PROF_DUMP");
   FILE* df = dump ? fopen(dump, "a") : nullptr;
   for (auto& r : g_recs) {
@@ -70,11 +86,33 @@ extern "C" int cn_profile_end(double* out) {
     out[r.kind * 3 + 0] += ms;
     out[r.kind * 3 + 1] += r.flops;
     out[r.kind * 3 + 2] += 1.0;
+    {
+      size_t i = 0;
+      for (; i < g_aggs.size(); ++i)
+        if (strncmp(g_aggs[i].name, r.name, sizeof(r.name)) == 0) break;
+      if (i == g_aggs.size()) {
+        Agg a = {{0}, 0.0, 0.0, 0.0};
+        snprintf(a.name, sizeof(a.name), "%s", r.name);
+        g_aggs.push_back(a);
+      }
+      g_aggs[i].ms += ms; g_aggs[i].flops += r.flops; g_aggs[i].launches += 1.0;
+    }
     if (df) fprintf(df, "%d\t%s\t%.3f\t%.0f\n", r.kind, r.desc, ms * 1e3, r.flops);
     g_pool.push_back(r.a);
     g_pool.push_back(r.b);
   }
   if (df) fclose(df);
   g_recs.clear();
+  std::sort(g_aggs.begin(), g_aggs.end(), [](const Agg& a, const Agg& b) { return a.ms > b.ms; });
   return CN_OK;
+}
+
+// After cn_profile_end: the rank-th kernel by total time (rocprof-style name) and its {ms, flops, launches}.
+// Returns the number of distinct kernels recorded (rank >= that: outputs untouched).
+extern "C" int cn_profile_top(int rank, char* name_out, int cap, double* out) {
+  if (rank >= 0 && rank < (int)g_aggs.size() && name_out != nullptr && cap > 0) {
+    snprintf(name_out, (size_t)cap, "%s", g_aggs[rank].name);
+    out[0] = g_aggs[rank].ms; out[1] = g_aggs[rank].flops; out[2] = g_aggs[rank].launches;
+  }
+  return (int)g_aggs.size();
 }

@@ -572,6 +572,7 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
     g.mq_lo = lo;
     g.mq_hi = hi;
   }
+  cn_prof_name("cn_wgrad_vec_kernel<%d, %d>", T, g.s == 1 ? 1 : 2);
   cn_prof_desc("wgrad_vec<%d> G%d N%d A%d %dx%d Bc%d %dx%d s%d grid%dx%dx%d nbuf%d", T, g.G, g.N, g.A, g.Hs, g.Ws, g.Bc,
                g.Hb, g.Wb, g.s, gx, gy, splits, g.nbuf);
   g.spg = splits;
@@ -653,6 +654,7 @@ static int cn_wgrad_launch_t(const float* S, const float* Bg, float* dW, CnWgrad
                               160 * 1024);
     attr_set = true;
   }
+  cn_prof_name("cn_wgrad_kernel<%d>", T);
   cn_prof_desc("wgrad_dw<%d> N%d A%d %dx%d Bc%d %dx%d s%d grid%dx%dx%d", T, g.N, g.A, g.Hs, g.Ws, g.Bc, g.Hb, g.Wb, g.s,
                gx, gy, splits);
   g.grid_x = gx; g.grid_y = gy; g.grid_z = splits;

@@ -381,6 +381,10 @@ int cn_na2d_bwd_bf16(const void* qkv, long ldq, const void* dout, long ldo, cons
  * Process-global, off by default, single client, not thread-safe. */
 int cn_profile_begin(void);
 int cn_profile_end(double* out);
+/* after cn_profile_end: the rank-th recorded kernel by total time (rocprof-style name, e.g.
+ * "cn_conv_igemm_vec_kernel<4, 1, 5, 1, 1>") with out[3] = {milliseconds, algorithmic flops, launches};
+ * returns the number of distinct kernels recorded. */
+int cn_profile_top(int rank, char* name_out, int cap, double* out);
 
 #ifdef __cplusplus
 }
