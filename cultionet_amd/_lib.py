@@ -86,7 +86,8 @@ SIGNATURES = {
     "cn_conv2d_bwd_weight_bf16": [P, L, P, L, P, I, I, I, I, I, I, I, I, I, I, P, L, P],
     "cn_conv_transpose2d_bwd_weight_bf16": [P, L, P, L, P, I, I, I, I, I, I, I, I, I, P, L, P],
     "cn_bn_workspace_floats_bf16": [I],
-    "cn_bn_act_fwd_bf16": [P, L, P, P, P, P, P, L, P, L, P, P, P, L, I, I, F, F, I, P, P],
+    "cn_conv2d_stats_rows_bf16": [I, I, I, I, I, I, I, I, I],
+    "cn_bn_act_fwd_bf16": [P, L, P, P, P, P, P, L, P, L, P, P, P, L, I, I, F, F, I, P, I, P],
     "cn_bn_act_bwd_bf16": [P, L, P, L, P, P, P, P, P, L, P, P, P, L, I, I, I, I, P],
     "cn_channel_sum_bf16": [P, L, L, I, P, I, P, P],
     "cn_layernorm_c_fwd_bf16": [P, L, P, P, P, L, P, L, L, I, F, P],

@@ -58,7 +58,9 @@ struct CnBGeom {
   int accumulate;
   int total;      // logical blocks
   int ncls;
-  float* stats;   // nullable: per-cout {sum, sum of squares} of the fp32 results (2 * Cout floats, atomically added)
+  float* stats;   // nullable: per pixel tile {sum, sum of squares}[Cout] of the fp32 results, rows [tile][2][Cout]
+                  // (plain stores, one row per tile: same-address float atomics serialise at ~200 ns each and
+                  // 2560 tiles x 4 waves of them made a 128->128 conv at 100x100 nine times slower)
   CnBClass cls[CNB_MAX_CLASSES];
 };
 
@@ -70,7 +72,8 @@ template <int WN, int NP>
 __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int WM = 4 / WN;   // waves along the pixel columns
-  constexpr int MPW = WN;      // 32-pixel columns per wave (4 columns per block)
+  constexpr int MPW = 4;       // 32-pixel columns per wave: every weight fragment (one 16-byte global load per
+                               // lane) feeds 4 MFMAs; the block tile is 32 * 4 * WM pixels x 32 * WN couts
   const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
   const int r = lane & 31, h = lane >> 5;
   const int wn = wid % WN, wm = wid / WN;
@@ -103,20 +106,19 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
 
   // ---- staging descriptors: piece q = 16 bytes (8 channels) of one halo pixel ----
   const bf16_t* __restrict__ xg = g.x[grp];
-  long goff[NP];
-  int lw[NP];
+  int gpix[NP];  // input pixel index (b, iy, ix) of piece tid + i*256, -1 outside the image / past the image
   const int npieces = k.IH * IW * 4;
   const int iy0 = gy0 * g.is + k.iy_off, ix0 = gx0 * g.is + k.ix_off;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int q = tid + i * 256;
-    const int p = q >> 2, s = q & 3;
+    const int p = q >> 2;
     const int hy = p / IW, hx = p - hy * IW;
     const int iy = iy0 + hy, ix = ix0 + hx;
     const bool ok = q < npieces && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
-    goff[i] = ok ? (((long)b * g.Hin + iy) * g.Win + ix) * g.ldx + s * 8 : -1;
-    lw[i] = q < npieces ? p * CNB_PITCH + s * 16 : -1;
+    gpix[i] = ok ? (b * g.Hin + iy) * g.Win + ix : -1;
   }
+  const int s8 = (tid & 3) * 8;  // channel offset of this thread's pieces inside a chunk (256 % 4 == 0)
 
   // ---- this wave's pixel columns: LDS base of each lane's pixel ----
   int pbase[MPW];
@@ -135,53 +137,112 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
 
   const int nchunks = (g.KS + 1) >> 1;
   const int ntaps = k.ntaps;
+  // tap tables live in one VGPR each (lane t holds tap t) and are fetched with v_readlane: a scalar load inside the
+  // tap loop would need s_waitcnt lgkmcnt(0), which also drains the LDS reads deliberately kept in flight
+  const int doff_v = lane < CNB_MAX_TAPS ? k.doff[lane < CNB_MAX_TAPS ? lane : 0] : 0;
+  const int wt_v = lane < CNB_MAX_TAPS ? k.wt[lane < CNB_MAX_TAPS ? lane : 0] : 0;
   const bf16x8* __restrict__ wfrag = reinterpret_cast<const bf16x8*>(g.wp[grp]);
-  // fragment index of (tap, kstep): ((wt * KS + kstep) * NT + ntile) * 64 + lane
-  auto afrag = [&](int t, int kstep) -> bf16x8 {
+  // weight fragments of linear step s = chunk * ntaps + tap: ((wt * KS + kstep) * NT + ntile) * 64 + lane
+  const int nsteps = nchunks * ntaps;
+  auto afrag = [&](int s, int half) -> bf16x8 {
     bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (!n_live || kstep >= g.KS) return z;
-    return wfrag[((long)(k.wt[t] * g.KS + kstep) * g.NT + ntile) * 64 + lane];
+    if (!n_live || s >= nsteps) return z;
+    const int ch = s / ntaps, t = s - ch * ntaps;
+    const int kstep = ch * 2 + half;
+    if (kstep >= g.KS) return z;
+    const int wt = __builtin_amdgcn_readlane(wt_v, t);
+    return wfrag[((long)(wt * g.KS + kstep) * g.NT + ntile) * 64 + lane];
   };
 
   if (ntaps > 0) {
+    // 3-deep ring of weight fragments (global loads in flight across two whole taps = 16 MFMAs)
     bf16x8 a0 = afrag(0, 0), a1 = afrag(0, 1);
+    bf16x8 b0 = afrag(1, 0), b1 = afrag(1, 1);
+    bf16x8 c0 = afrag(2, 0), c1 = afrag(2, 1);
+    int step = 0;
 #pragma unroll 1
     for (int ch = 0; ch < nchunks; ++ch) {
-      const int c0 = ch * 32;
-      // stage the halo image of this 32-channel chunk
-      u32x4 sv[NP];
+      const int cc = ch * 32;
+      // stage the halo image of this 32-channel chunk (NP > 5: in two halves to bound the registers in flight)
+      constexpr int H1 = NP > 5 ? 5 : NP;
+      {
+        u32x4 sv[H1];
 #pragma unroll
-      for (int i = 0; i < NP; ++i) {
-        const int s8 = ((tid + i * 256) & 3) * 8;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (goff[i] >= 0 && c0 + s8 < g.Cin) v = *reinterpret_cast<const u32x4*>(xg + goff[i] + c0);
-        sv[i] = v;
+        for (int i = 0; i < H1; ++i) {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (gpix[i] >= 0 && cc + s8 < g.Cin) v = *reinterpret_cast<const u32x4*>(xg + (long)gpix[i] * g.ldx + s8 + cc);
+          sv[i] = v;
+        }
+        __syncthreads();  // the previous chunk's reads are done
+#pragma unroll
+        for (int i = 0; i < H1; ++i) {
+          const int q = tid + i * 256;
+          if (q < npieces) *reinterpret_cast<u32x4*>(lds + (q >> 2) * CNB_PITCH + (q & 3) * 16) = sv[i];
+        }
       }
-      __syncthreads();  // the previous chunk's reads are done
+      if (NP > H1) {
+        u32x4 sv[NP - H1 > 0 ? NP - H1 : 1];
 #pragma unroll
-      for (int i = 0; i < NP; ++i)
-        if (lw[i] >= 0) *reinterpret_cast<u32x4*>(lds + lw[i]) = sv[i];
+        for (int i = H1; i < NP; ++i) {
+          u32x4 v = {0u, 0u, 0u, 0u};
+          if (gpix[i] >= 0 && cc + s8 < g.Cin) v = *reinterpret_cast<const u32x4*>(xg + (long)gpix[i] * g.ldx + s8 + cc);
+          sv[i - H1] = v;
+        }
+#pragma unroll
+        for (int i = H1; i < NP; ++i) {
+          const int q = tid + i * 256;
+          if (q < npieces) *reinterpret_cast<u32x4*>(lds + (q >> 2) * CNB_PITCH + (q & 3) * 16) = sv[i - H1];
+        }
+      }
       __syncthreads();
+      // Taps are software-pipelined by hand: the 8 pixel fragments of tap t+1 are read from LDS (into the other
+      // register set) BEFORE the 8 MFMAs of tap t issue, so LDS latency hides behind matrix work. Left to itself
+      // the compiler funnels every fragment through one register quad: read, wait, MFMA, read, wait, ...
+      bf16x8 X[2 * MPW], Y[2 * MPW];
+#define CNB_READ(BUF, T_)                                                                          \
+  {                                                                                                \
+    const int toff_ = __builtin_amdgcn_readlane(doff_v, T_);                                       \
+    _Pragma("unroll") for (int i = 0; i < MPW; ++i) {                                              \
+      BUF[i] = *reinterpret_cast<const bf16x8*>(lds + pbase[i] + toff_);                           \
+      BUF[MPW + i] = *reinterpret_cast<const bf16x8*>(lds + pbase[i] + toff_ + 32);                \
+    }                                                                                              \
+  }
+#define CNB_MMA(BUF)                                                                               \
+  {                                                                                                \
+    _Pragma("unroll") for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(a0, BUF[i], acc[i]);         \
+    _Pragma("unroll") for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(a1, BUF[MPW + i], acc[i]);   \
+  }
+#define CNB_ROTATE()                                                                               \
+  {                                                                                                \
+    a0 = b0; a1 = b1; b0 = c0; b1 = c1; c0 = n0; c1 = n1;                                          \
+    ++step;                                                                                        \
+  }
+      CNB_READ(X, 0);
+      int t = 0;
 #pragma unroll 1
-      for (int t = 0; t < ntaps; ++t) {
-        // prefetch the next tap's weight fragments (next chunk's first tap at the end of this one)
-        const int tn = t + 1 < ntaps ? t + 1 : 0;
-        const int chn = t + 1 < ntaps ? ch : ch + 1;
-        const bf16x8 n0 = afrag(tn, chn * 2), n1 = afrag(tn, chn * 2 + 1);
-        const int toff = k.doff[t];
-#pragma unroll
-        for (int i = 0; i < MPW; ++i) {
-          const bf16x8 b0 = *reinterpret_cast<const bf16x8*>(lds + pbase[i] + toff);
-          acc[i] = cnb_mfma(a0, b0, acc[i]);
+      while (true) {
+        {
+          const bf16x8 n0 = afrag(step + 3, 0), n1 = afrag(step + 3, 1);
+          if (t + 1 < ntaps) CNB_READ(Y, t + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          CNB_MMA(X);
+          __builtin_amdgcn_sched_barrier(0);
+          CNB_ROTATE();
         }
-#pragma unroll
-        for (int i = 0; i < MPW; ++i) {
-          const bf16x8 b1 = *reinterpret_cast<const bf16x8*>(lds + pbase[i] + toff + 32);
-          acc[i] = cnb_mfma(a1, b1, acc[i]);
+        if (++t >= ntaps) break;
+        {
+          const bf16x8 n0 = afrag(step + 3, 0), n1 = afrag(step + 3, 1);
+          if (t + 1 < ntaps) CNB_READ(X, t + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          CNB_MMA(Y);
+          __builtin_amdgcn_sched_barrier(0);
+          CNB_ROTATE();
         }
-        a0 = n0;
-        a1 = n1;
+        if (++t >= ntaps) break;
       }
+#undef CNB_READ
+#undef CNB_MMA
+#undef CNB_ROTATE
     }
   }
 
@@ -265,8 +326,14 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
       }
       const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * h;
       if (r == 0 && n < g.Cout) {
-        atomicAdd(g.stats + n, a);
-        atomicAdd(g.stats + g.Cout + n, c);
+        float* row = g.stats + (long)tile * 2 * g.Cout;
+        if (WM == 1) {  // this wave saw every pixel of the tile
+          row[n] = a;
+          row[g.Cout + n] = c;
+        } else {        // WM waves share a cout tile: few adders per address, rows zeroed by the launcher
+          atomicAdd(row + n, a);
+          atomicAdd(row + g.Cout + n, c);
+        }
       }
     }
   }
@@ -350,20 +417,23 @@ extern "C" int cn_pack_weights_bf16(const float* w, void* wp, int T, int K, int 
 // ------------------------------------------------------------------------------------------------------------
 static inline int cnb_floordiv(int a, int b) { return (a >= 0) ? a / b : -((-a + b - 1) / b); }
 
-// Pixel tile (TH x TW <= 128) for a logical grid: exact covers first (5x25 covers 100, 50 and 25 exactly).
-static void cnb_pick_tile(int Hg, int Wg, int is, int span, int& TH, int& TW) {
+// Pixel tile (TH x TW <= max_pix = 128 / 256 / 512 for WN = 4 / 2 / 1) for a logical grid: exact covers first
+// (5x25, 10x25 and 20x25 cover 100, 50 and 25 exactly).
+static void cnb_pick_tile(int Hg, int Wg, int is, int span, int max_pix, int& TH, int& TW) {
   static const int cand[][2] = {{5, 25}, {8, 16}, {4, 32}, {16, 8}, {2, 64}, {10, 12}, {6, 20}, {9, 14}, {11, 11},
-                                {13, 9}, {7, 18}, {3, 42}, {1, 128}, {4, 16}, {8, 8}, {2, 32}, {4, 8}, {2, 16}};
+                                {13, 9}, {7, 18}, {3, 42}, {1, 128}, {4, 16}, {8, 8}, {2, 32}, {4, 8}, {2, 16},
+                                {10, 25}, {16, 16}, {8, 32}, {13, 19}, {12, 21}, {14, 18}, {4, 64},
+                                {20, 25}, {16, 32}, {22, 23}, {13, 39}, {8, 64}, {32, 16}};
   double best = 1e300;
-  TH = 8; TW = 16;
+  TH = 4; TW = 8;
   for (auto& c : cand) {
     const int th = c[0], tw = c[1];
+    if (th * tw > max_pix) continue;
     const long ih = (long)(th - 1) * is + span + 1, iw = (long)(tw - 1) * is + span + 1;
     if (ih * iw > 640) continue;  // staging budget: 10 pieces per thread, 51 KB of LDS
     const long tiles = (long)((Hg + th - 1) / th) * ((Wg + tw - 1) / tw);
-    // cost ~ MFMA columns issued (tiles * ceil(pixels/32)) with a small penalty for halo bytes
-    const double cols = (double)tiles * ((th * tw + 31) / 32);
-    const double cost = cols * 32.0 + 0.05 * tiles * ih * iw;
+    // cost ~ MFMA columns issued (every block runs all max_pix / 32 columns) with a small penalty for halo bytes
+    const double cost = (double)tiles * max_pix + 0.05 * tiles * ih * iw;
     if (cost < best) { best = cost; TH = th; TW = tw; }
   }
 }
@@ -387,10 +457,10 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
     // stash the spans for the second pass
     k.IH = mx_y - mn_y; k.IW = mx_x - mn_x;
   }
-  cnb_pick_tile(Hg, Wg, g.is, span, g.TH, g.TW);
   g.KS = (g.Cin + 15) / 16;
   g.NT = (g.Cout + 31) / 32;
   const int WN = g.NT >= 4 ? 4 : (g.NT >= 2 ? 2 : 1);
+  cnb_pick_tile(Hg, Wg, g.is, span, 128 * (4 / WN), g.TH, g.TW);
   g.nblk_n = (g.NT + WN - 1) / WN;
   long total = 0;
   int max_pix = 0;
@@ -416,6 +486,12 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
   if (np > 10) return CN_ERR_LDS;
   const size_t shmem = (size_t)max_pix * CNB_PITCH;
   const dim3 grid(cn_xcd_grid(total)), block(256);
+  if (g.stats != nullptr) {
+    if (g.ncls != 1) return CN_ERR_ARG;
+    if (WN != 4 &&
+        hipMemsetAsync(g.stats, 0, sizeof(float) * 2 * g.Cout * (size_t)g.cls[0].tiles_per_img * g.B, stream) != hipSuccess)
+      return CN_ERR_LAUNCH;
+  }
   cn_prof_name("cn_bconv_kernel<%d, %d>", WN, np <= 4 ? 4 : 10);
   cn_prof_desc("bconv B%d %dx%d %d->%d cls%d taps%d s%d/%d", g.B, g.Hin, g.Win, g.Cin, g.Cout, g.ncls, g.cls[0].ntaps,
                g.is, g.os);
@@ -513,6 +589,21 @@ static int cnb_scatter(int G, const bf16_t* const* srcs, long lds_, const bf16_t
   g.ncls = nc;
   if (nc == 0) return CN_OK;
   return cnb_launch(g, G, stream, 2.0 * B * macs * Csrc * Cdst);
+}
+
+// Rows of the per-tile BatchNorm statistics cn_conv2d_fwd_bf16 writes ([rows][2][Cout] floats; no zero-fill needed).
+extern "C" int cn_conv2d_stats_rows_bf16(int B, int Hin, int Win, int Cout, int KH, int KW, int stride, int pad,
+                                         int dil) {
+  if (stride < 1 || dil < 1) return -1;
+  const int Hout = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  if (Hout <= 0 || Wout <= 0) return 0;
+  const int NT = (Cout + 31) / 32;
+  const int WN = NT >= 4 ? 4 : (NT >= 2 ? 2 : 1);
+  int TH, TW;
+  const int span = dil * ((KH > KW ? KH : KW) - 1);
+  cnb_pick_tile(Hout, Wout, stride, span, 128 * (4 / WN), TH, TW);
+  return B * ((Hout + TH - 1) / TH) * ((Wout + TW - 1) / TW);
 }
 
 // ---- C ABI ---------------------------------------------------------------------------------------------------

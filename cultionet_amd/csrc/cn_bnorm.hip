@@ -72,25 +72,38 @@ __global__ __launch_bounds__(256) void cn_bbn_partial_kernel(const bf16_t* __res
   }
 }
 
+// Per-channel fp64 combine of the per-block partial sums: 16 lanes share a channel (16 channels per 256-thread
+// block), each walks every 16th block, then a shuffle tree. (One thread per channel walking 512 partials serially
+// took 80 us for a 128-channel layer.)
+__device__ __forceinline__ void bbn_combine(const float* __restrict__ part, int nblk, int C, int c, int sub, double& s,
+                                            double& ss) {
+  s = 0.0; ss = 0.0;
+  if (c < C)
+    for (int i = sub; i < nblk; i += 16) { s += part[((long)i * 2) * C + c]; ss += part[((long)i * 2 + 1) * C + c]; }
+#pragma unroll
+  for (int off = 8; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); ss += __shfl_xor(ss, off, 64); }
+}
+
 // Forward finalize: batch mean / rstd (fp64 combine), running-statistics update (momentum, unbiased variance).
-// sums (nullable): {sum, sumsq}[C] produced by the convolution's epilogue instead of `part`.
-__global__ void cn_bbn_finalize_fwd_kernel(const float* __restrict__ part, int nblk, const float* __restrict__ sums,
-                                           int C, double count, float eps, float momentum,
-                                           float* __restrict__ running_mean, float* __restrict__ running_var,
-                                           float* __restrict__ mean, float* __restrict__ rstd, int training) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
+// `part` rows come from the statistics pass or straight from the convolution's epilogue (one row per pixel tile).
+__global__ __launch_bounds__(256) void cn_bbn_finalize_fwd_kernel(const float* __restrict__ part, int nblk, int C,
+                                                                 double count,
+                                                                 float eps, float momentum,
+                                                                 float* __restrict__ running_mean,
+                                                                 float* __restrict__ running_var,
+                                                                 float* __restrict__ mean, float* __restrict__ rstd,
+                                                                 int training) {
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
   if (!training) {
-    mean[c] = running_mean[c];
-    rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+    if (c < C && sub == 0) {
+      mean[c] = running_mean[c];
+      rstd[c] = 1.0f / sqrtf(running_var[c] + eps);
+    }
     return;
   }
   double s = 0.0, ss = 0.0;
-  if (sums != nullptr) {
-    s = sums[c]; ss = sums[C + c];
-  } else {
-    for (int i = 0; i < nblk; ++i) { s += part[((long)i * 2) * C + c]; ss += part[((long)i * 2 + 1) * C + c]; }
-  }
+  bbn_combine(part, nblk, C, c, sub, s, ss);
+  if (c >= C || sub != 0) return;
   const double md = s / count;
   double var = ss / count - md * md;
   if (var < 0.0) var = 0.0;
@@ -104,13 +117,14 @@ __global__ void cn_bbn_finalize_fwd_kernel(const float* __restrict__ part, int n
 }
 
 // Backward finalize: coef = {mean(dz), mean(dz*xhat)}; dgamma += sum dz*xhat, dbeta += sum dz.
-__global__ void cn_bbn_finalize_bwd_kernel(const float* __restrict__ part, int nblk, int C, double count,
-                                           float* __restrict__ coef, float* __restrict__ dgamma,
-                                           float* __restrict__ dbeta, int training) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < nblk; ++i) { s1 += part[((long)i * 2) * C + c]; s2 += part[((long)i * 2 + 1) * C + c]; }
+__global__ __launch_bounds__(256) void cn_bbn_finalize_bwd_kernel(const float* __restrict__ part, int nblk, int C,
+                                                                 double count, float* __restrict__ coef,
+                                                                 float* __restrict__ dgamma,
+                                                                 float* __restrict__ dbeta, int training) {
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  double s1, s2;
+  bbn_combine(part, nblk, C, c, sub, s1, s2);
+  if (c >= C || sub != 0) return;
   coef[c] = training ? (float)(s1 / count) : 0.f;
   coef[C + c] = training ? (float)(s2 / count) : 0.f;
   dgamma[c] += (float)s2;
@@ -198,12 +212,12 @@ extern "C" long cn_bn_workspace_floats_bf16(int C) { return (long)BBN_MAX_BLOCKS
 
 // y = act(bn(x)) (+ res). x, res, y: bf16 [P][C] rows with pixel strides; C % 8 == 0, C <= 2048.
 // training: batch statistics (saved to mean / rstd, running stats updated); else running statistics.
-// conv_sums (nullable, training only): {sum, sum of squares}[C] from cn_conv2d_fwd_bf16's epilogue -- skips the
-// statistics pass over x.
+// conv_sums (nullable, training only): conv_rows rows of {sum, sum of squares}[C] from cn_conv2d_fwd_bf16's epilogue
+// -- skips the statistics pass over x.
 extern "C" int cn_bn_act_fwd_bf16(const void* x, long ldx, const float* gamma, const float* beta, float* running_mean,
                                   float* running_var, const void* res, long ldr, void* y, long ldy, float* mean,
                                   float* rstd, float* ws, long P, int C, int training, float momentum, float eps,
-                                  int act, const float* conv_sums, void* stream_) {
+                                  int act, const float* conv_sums, int conv_rows, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (P <= 0 || C <= 0) return CN_OK;
   if ((C & 7) || C > 2048) return CN_ERR_ARG;
@@ -211,11 +225,13 @@ extern "C" int cn_bn_act_fwd_bf16(const void* x, long ldx, const float* gamma, c
   int nblk;
   long rows;
   bbn_grid(P, C, nblk, rows);
-  if (training && conv_sums == nullptr)
+  if (training && !(conv_sums != nullptr && conv_rows > 0))
     hipLaunchKernelGGL((cn_bbn_partial_kernel<0>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr,
                        0L, nullptr, nullptr, nullptr, nullptr, P, C, act, rows, ws);
-  hipLaunchKernelGGL(cn_bbn_finalize_fwd_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, ws, nblk, conv_sums, C,
-                     (double)P, eps, momentum, running_mean, running_var, mean, rstd, training);
+  const bool fused = training && conv_sums != nullptr && conv_rows > 0;
+  hipLaunchKernelGGL(cn_bbn_finalize_fwd_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, fused ? conv_sums : ws,
+                     fused ? conv_rows : nblk, C, (double)P, eps, momentum, running_mean, running_var, mean, rstd,
+                     training);
   hipLaunchKernelGGL((cn_bbn_apply_kernel<0>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr, 0L,
                      mean, rstd, gamma, beta, nullptr, (const bf16_t*)res, ldr, (bf16_t*)y, ldy, P, C, act, 0, rows);
   return cn_check_launch();
@@ -235,7 +251,7 @@ extern "C" int cn_bn_act_bwd_bf16(const void* x, long ldx, const void* dy, long 
   float* coef = ws + (long)BBN_MAX_BLOCKS * 2 * C;
   hipLaunchKernelGGL((cn_bbn_partial_kernel<1>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx,
                      (const bf16_t*)dy, lddy, mean, rstd, gamma, beta, P, C, act, rows, ws);
-  hipLaunchKernelGGL(cn_bbn_finalize_bwd_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, ws, nblk, C, (double)P,
+  hipLaunchKernelGGL(cn_bbn_finalize_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, ws, nblk, C, (double)P,
                      coef, dgamma, dbeta, training);
   if (dx != nullptr)
     hipLaunchKernelGGL((cn_bbn_apply_kernel<1>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx,
@@ -392,12 +408,12 @@ extern "C" int cn_layernorm_c_bwd_bf16(const void* x, long ldx, const void* dy, 
 }
 
 // bias gradients on the bf16 path: out[c] (+)= sum_p x[p][c]. ws: cn_bn_workspace_floats_bf16(C) floats.
-__global__ void cn_bsum_finalize_kernel(const float* __restrict__ part, int nblk, int C, float* __restrict__ out,
-                                        int accumulate) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  double s = 0.0;
-  for (int i = 0; i < nblk; ++i) s += part[((long)i * 2) * C + c];
+__global__ __launch_bounds__(256) void cn_bsum_finalize_kernel(const float* __restrict__ part, int nblk, int C,
+                                                              float* __restrict__ out, int accumulate) {
+  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  double s, ss;
+  bbn_combine(part, nblk, C, c, sub, s, ss);
+  if (c >= C || sub != 0) return;
   out[c] = accumulate ? out[c] + (float)s : (float)s;
 }
 
@@ -411,6 +427,6 @@ extern "C" int cn_channel_sum_bf16(const void* x, long ldx, long P, int C, float
   bbn_grid(P, C, nblk, rows);
   hipLaunchKernelGGL((cn_bbn_partial_kernel<0>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr, 0L,
                      nullptr, nullptr, nullptr, nullptr, P, C, 0, rows, ws);
-  hipLaunchKernelGGL(cn_bsum_finalize_kernel, dim3((C + 127) / 128), dim3(128), 0, stream, ws, nblk, C, out, accumulate);
+  hipLaunchKernelGGL(cn_bsum_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, ws, nblk, C, out, accumulate);
   return cn_check_launch();
 }

@@ -219,7 +219,10 @@ static int cnw_plan(CnBWgGeom& g, int KH, int KW, int pad, int dil) {
   g.nbp = (g.CP + 63) / 64;
   g.nbq = (g.CQ + 63) / 64;
   const int nb = g.nbp * g.nbq;
-  int nsplit = (512 + nb - 1) / nb;
+  // T = 9 keeps 144 accumulator registers per wave: one block per CU => one full round of 256 blocks; the 1x1
+  // kernel runs two blocks per CU
+  const int want = T > 4 ? 256 : 512;
+  int nsplit = (want + nb - 1) / nb;
   if (nsplit > g.ntiles) nsplit = g.ntiles;
   if (nsplit < 1) nsplit = 1;
   g.tiles_per_split = (g.ntiles + nsplit - 1) / nsplit;

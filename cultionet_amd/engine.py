@@ -1491,7 +1491,10 @@ def _conv2d_bf16(x: Var, mod, stride: int, padding: int, dilation: int, out: T.O
     pw = packed_conv(mod, tape.enabled and x.req, bf16=True)
     y = _check(out) if out is not None else _new((B, Cout, Ho, Wo), xt)
     bias = mod.bias
-    stats = torch.zeros(2 * Cout, dtype=torch.float32, device=xt.device) if want_stats else None
+    stats = None
+    if want_stats:  # one row of {sum, sumsq}[Cout] per pixel tile, written by the conv epilogue (no zero-fill)
+        rows = _lib.query("cn_conv2d_stats_rows_bf16", B, H, W, Cout, KH, KW, stride, padding, dilation)
+        stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=xt.device)
     _lib.call("cn_conv2d_fwd_bf16", xt.data_ptr(), ld(xt), pw.fwd16.data_ptr(),
               bias.data_ptr() if bias is not None else None, y.data_ptr(), ld(y), 0, B, Cin, H, W, Cout, KH, KW, stride,
               padding, dilation, 0, 0, stats.data_ptr() if stats is not None else None, _stream())
@@ -1580,7 +1583,8 @@ def _bn_act_bf16(x: Var, bn, act: int, residual: T.Optional[Var], training: bool
               bn.running_var.data_ptr() if bn.running_var is not None else None,
               rt.data_ptr() if rt is not None else None, ld(rt) if rt is not None else 0, y.data_ptr(), ld(y),
               mean.data_ptr(), rstd.data_ptr(), _bn_ws16(C, dev), P, C, 1 if use_batch else 0, _bn_momentum(bn),
-              float(bn.eps), act, sums.data_ptr() if sums is not None else None, _stream())
+              float(bn.eps), act, sums.data_ptr() if sums is not None else None,
+              sums.shape[0] if sums is not None else 0, _stream())
     yv = Var(y, tape.enabled)
     if tape.enabled:
         store = current_store()

@@ -295,8 +295,10 @@ int cn_pack_weights_bf16(const float* w, void* wp, int T, int K, int N, long sk,
 int cn_pack_weights_batched_bf16(const void* descs, int n, void* stream);
 
 /* nn.Conv2d forward (convolution.py:71-120). out_kind 0: y bf16 NHWC (ldy); 1: y f32 NCHW with batch stride y_bs
- * (the thin head convolutions hand over to the fp32 head kernels). stats (nullable; 2*Cout floats zeroed by the
- * caller): per-channel sum and sum of squares of the fp32 results, for BatchNorm without a statistics pass. */
+ * (the thin head convolutions hand over to the fp32 head kernels). stats (nullable): cn_conv2d_stats_rows_bf16(...)
+ * rows of [2][Cout] floats, one per pixel tile, receive the sum and sum of squares of the fp32 results (plain stores,
+ * no zero-fill needed): BatchNorm statistics without a pass over y (cn_bn_act_fwd_bf16 combines the rows). */
+int cn_conv2d_stats_rows_bf16(int B, int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, int dil);
 int cn_conv2d_fwd_bf16(const void* x, long ldx, const void* wp, const float* bias /*nullable*/, void* y, long ldy,
                        long y_bs, int B, int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride, int pad,
                        int dil, int accumulate, int out_kind, float* stats /*nullable*/, void* stream);
@@ -331,12 +333,12 @@ int cn_conv_transpose2d_bwd_weight_bf16(const void* x, long ldx, const void* dy,
                                         long ws_floats, void* stream);
 
 /* nn.BatchNorm2d (+SiLU, +residual) on [P = B*H*W][C] rows; C % 8 == 0. ws: cn_bn_workspace_floats_bf16(C) floats.
- * conv_sums (nullable): the `stats` output of cn_conv2d_fwd_bf16. Backward ACCUMULATES dgamma / dbeta. */
+ * conv_sums (nullable) / conv_rows: the `stats` rows of cn_conv2d_fwd_bf16. Backward ACCUMULATES dgamma / dbeta. */
 long cn_bn_workspace_floats_bf16(int C);
 int cn_bn_act_fwd_bf16(const void* x, long ldx, const float* gamma, const float* beta, float* running_mean,
                        float* running_var, const void* res /*nullable*/, long ldr, void* y, long ldy, float* mean,
                        float* rstd, float* ws, long P, int C, int training, float momentum, float eps, int act,
-                       const float* conv_sums /*nullable*/, void* stream);
+                       const float* conv_sums /*nullable*/, int conv_rows, void* stream);
 int cn_bn_act_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const float* mean, const float* rstd,
                        const float* gamma, const float* beta, void* dx /*nullable*/, long lddx, float* dgamma,
                        float* dbeta, float* ws, long P, int C, int training, int act, int accumulate_dx, void* stream);

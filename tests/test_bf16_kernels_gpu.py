@@ -110,13 +110,14 @@ def test_conv2d_bf16(case):
     wp = _pack(wd, T, Cin, Cout, T, Cin * T, 1)
     y = _empty_nhwc(B, Cout, Ho, Wo, ld=Cout + 16)
     bd = b.to(dev) if bias else None
-    stats = torch.zeros(2 * Cout, device=dev)
+    rows = _lib.query("cn_conv2d_stats_rows_bf16", B, H, W, Cout, k, k, s, p, d)
+    stats = torch.full((rows, 2, Cout), float("nan"), device=dev)
     _lib.call("cn_conv2d_fwd_bf16", xg.data_ptr(), _ld(xg), wp.data_ptr(), bd.data_ptr() if bias else None,
               y.data_ptr(), _ld(y), 0, B, Cin, H, W, Cout, k, k, s, p, d, 0, 0, stats.data_ptr(), _s())
     torch.cuda.synchronize()
     _close(y, yr, 6e-3, "y")
-    _close(stats[:Cout], yr.detach().sum(dim=(0, 2, 3)), 2e-3, "stats sum", abs_=2e-3 * float(yr.abs().max()) * 10)
-    _close(stats[Cout:], (yr.detach() ** 2).sum(dim=(0, 2, 3)), 2e-3, "stats sumsq")
+    _close(stats[:, 0].sum(0), yr.detach().sum(dim=(0, 2, 3)), 2e-3, "stats sum", abs_=2e-3 * float(yr.abs().max()) * 10)
+    _close(stats[:, 1].sum(0), (yr.detach() ** 2).sum(dim=(0, 2, 3)), 2e-3, "stats sumsq")
     # f32 NCHW output (thin heads) and accumulate
     y32 = torch.full((B, Cout, Ho, Wo), 1.0, device=dev)
     _lib.call("cn_conv2d_fwd_bf16", xg.data_ptr(), _ld(xg), wp.data_ptr(), bd.data_ptr() if bias else None,
@@ -234,7 +235,7 @@ def test_bn_act_bf16(shape, act, res, train):
     ws = torch.empty(_lib.query("cn_bn_workspace_floats_bf16", C), device=dev)
     _lib.call("cn_bn_act_fwd_bf16", xg.data_ptr(), _ld(xg), gamma.data_ptr(), beta.data_ptr(), rm.data_ptr(),
               rv.data_ptr(), rg.data_ptr() if res else None, _ld(rg) if res else 0, y.data_ptr(), _ld(y),
-              mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), P, C, 1 if train else 0, 0.1, bn.eps, act, None, _s())
+              mean.data_ptr(), rstd.data_ptr(), ws.data_ptr(), P, C, 1 if train else 0, 0.1, bn.eps, act, None, 0, _s())
     _close(y, yr, 6e-3, "y")
     if train:
         _close(rm, bn.running_mean, 1e-4, "running_mean", abs_=1e-5)
