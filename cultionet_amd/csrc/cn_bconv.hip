@@ -26,7 +26,6 @@
 #define CNB_MAX_TAPS 9
 #define CNB_MAX_CLASSES 16
 #define CNB_MAX_GROUPS 4
-#define CNB_PITCH 80  // bytes per halo pixel in LDS: 64 B of channels + 16 B pad => conflict-free ds_read_b128
 
 struct CnBClass {
   int ntaps;
@@ -68,13 +67,24 @@ __device__ __forceinline__ f32x16 cnb_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
 }
 
-template <int WN, int NP>
+// KSC = 16-channel k-steps per staged chunk (2 / 4 / 8 => 32 / 64 / 128 channels per LDS image): fewer, longer
+// chunks mean fewer barrier + staging phases per MFMA (a 1x1 conv has only one tap per chunk to amortise them over).
+template <int KSC>
+struct CnbPitch { static constexpr int value = KSC * 32 + 16; };  // bytes per halo pixel: channels + 16 B pad
+                                                                  // (5, 9, 17 sixteen-byte slots: coprime with 16)
+
+template <int WN, int NP, int KSC>
 __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int WM = 4 / WN;   // waves along the pixel columns
   constexpr int MPW = 4;       // 32-pixel columns per wave: every weight fragment (one 16-byte global load per
                                // lane) feeds 4 MFMAs; the block tile is 32 * 4 * WM pixels x 32 * WN couts
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  constexpr int PITCH = CnbPitch<KSC>::value;
+  constexpr int PPP = KSC * 2;  // 16-byte pieces per pixel
+  constexpr int KPAIRS = KSC / 2;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: keeps the weight-fragment
+                                                             // offsets in SGPRs (no waterfall loops around buffer loads)
   const int r = lane & 31, h = lane >> 5;
   const int wn = wid % WN, wm = wid / WN;
 
@@ -107,18 +117,18 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
   // ---- staging descriptors: piece q = 16 bytes (8 channels) of one halo pixel ----
   const bf16_t* __restrict__ xg = g.x[grp];
   int gpix[NP];  // input pixel index (b, iy, ix) of piece tid + i*256, -1 outside the image / past the image
-  const int npieces = k.IH * IW * 4;
+  const int npieces = k.IH * IW * PPP;
   const int iy0 = gy0 * g.is + k.iy_off, ix0 = gx0 * g.is + k.ix_off;
 #pragma unroll
   for (int i = 0; i < NP; ++i) {
     const int q = tid + i * 256;
-    const int p = q >> 2;
+    const int p = q / PPP;
     const int hy = p / IW, hx = p - hy * IW;
     const int iy = iy0 + hy, ix = ix0 + hx;
     const bool ok = q < npieces && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
     gpix[i] = ok ? (b * g.Hin + iy) * g.Win + ix : -1;
   }
-  const int s8 = (tid & 3) * 8;  // channel offset of this thread's pieces inside a chunk (256 % 4 == 0)
+  const int s8 = (tid % PPP) * 8;  // channel offset of this thread's pieces inside a chunk (256 % PPP == 0)
 
   // ---- this wave's pixel columns: LDS base of each lane's pixel ----
   int pbase[MPW];
@@ -126,7 +136,7 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
   for (int i = 0; i < MPW; ++i) {
     const int m = (wm + i * WM) * 32 + r;
     const int ty = m / g.TW, tx = m - ty * g.TW;
-    pbase[i] = m < npix ? ((ty * g.is) * IW + tx * g.is) * CNB_PITCH + h * 16 : h * 16;
+    pbase[i] = m < npix ? ((ty * g.is) * IW + tx * g.is) * PITCH + h * 16 : h * 16;
   }
 
   f32x16 acc[MPW];
@@ -135,126 +145,140 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
-  const int nchunks = (g.KS + 1) >> 1;
+  const int KS = g.KS, NT = g.NT;
+  const int nchunks = (KS + KSC - 1) / KSC;
   const int ntaps = k.ntaps;
   // tap tables live in one VGPR each (lane t holds tap t) and are fetched with v_readlane: a scalar load inside the
   // tap loop would need s_waitcnt lgkmcnt(0), which also drains the LDS reads deliberately kept in flight
   const int doff_v = lane < CNB_MAX_TAPS ? k.doff[lane < CNB_MAX_TAPS ? lane : 0] : 0;
   const int wt_v = lane < CNB_MAX_TAPS ? k.wt[lane < CNB_MAX_TAPS ? lane : 0] : 0;
-  const bf16x8* __restrict__ wfrag = reinterpret_cast<const bf16x8*>(g.wp[grp]);
-  // weight fragments of linear step s = chunk * ntaps + tap: ((wt * KS + kstep) * NT + ntile) * 64 + lane
-  const int nsteps = nchunks * ntaps;
-  auto afrag = [&](int s, int half) -> bf16x8 {
-    bf16x8 z = {0, 0, 0, 0, 0, 0, 0, 0};
-    if (!n_live || s >= nsteps) return z;
-    const int ch = s / ntaps, t = s - ch * ntaps;
-    const int kstep = ch * 2 + half;
-    if (kstep >= g.KS) return z;
-    const int wt = __builtin_amdgcn_readlane(wt_v, t);
-    return wfrag[((long)(wt * g.KS + kstep) * g.NT + ntile) * 64 + lane];
-  };
+  const int spc = ntaps * KPAIRS;     // steps per chunk: (tap, k-pair)
+  const int nsteps = nchunks * spc;
 
   if (ntaps > 0) {
-    // 3-deep ring of weight fragments (global loads in flight across two whole taps = 16 MFMAs)
-    bf16x8 a0 = afrag(0, 0), a1 = afrag(0, 1);
-    bf16x8 b0 = afrag(1, 0), b1 = afrag(1, 1);
-    bf16x8 c0 = afrag(2, 0), c1 = afrag(2, 1);
-    int step = 0;
-#pragma unroll 1
-    for (int ch = 0; ch < nchunks; ++ch) {
-      const int cc = ch * 32;
-      // stage the halo image of this 32-channel chunk (NP > 5: in two halves to bound the registers in flight)
-      constexpr int H1 = NP > 5 ? 5 : NP;
-      {
-        u32x4 sv[H1];
-#pragma unroll
-        for (int i = 0; i < H1; ++i) {
-          u32x4 v = {0u, 0u, 0u, 0u};
-          if (gpix[i] >= 0 && cc + s8 < g.Cin) v = *reinterpret_cast<const u32x4*>(xg + (long)gpix[i] * g.ldx + s8 + cc);
-          sv[i] = v;
-        }
-        __syncthreads();  // the previous chunk's reads are done
-#pragma unroll
-        for (int i = 0; i < H1; ++i) {
-          const int q = tid + i * 256;
-          if (q < npieces) *reinterpret_cast<u32x4*>(lds + (q >> 2) * CNB_PITCH + (q & 3) * 16) = sv[i];
-        }
+    // Weight fragments: buffer loads with the whole fragment address in SGPRs (one VMEM instruction, no per-lane
+    // address arithmetic): byte offset of (tap, kstep) = ((wt * KS + kstep) * NT + ntile) * 1024, + lane * 16.
+    // Out-of-range k-steps (Cin not a multiple of the chunk) and dead cout tiles are CLAMPED to valid fragments
+    // instead of masked: the pixel image holds zeros for channels >= Cin, and dead tiles never store.
+    const unsigned long long wbase = reinterpret_cast<unsigned long long>(g.wp[grp]);
+    const unsigned wlo = __builtin_amdgcn_readfirstlane((unsigned)wbase);
+    const unsigned whi = __builtin_amdgcn_readfirstlane((unsigned)(wbase >> 32));
+    const __amdgpu_buffer_rsrc_t wrsrc = __builtin_amdgcn_make_buffer_rsrc(
+        reinterpret_cast<bf16_t*>(((unsigned long long)whi << 32) | wlo), 0, 0x7fffffff, 0x00020000);
+    const int lane16 = lane * 16;
+    const int nt_c = n_live ? ntile : NT - 1;
+    // step (ch, t, kp): k-steps ch*KSC + 2*kp and + 1
+    auto wload = [&](int ch, int t, int kp, int half) -> bf16x8 {
+      int ks = ch * KSC + kp * 2 + half;
+      ks = ks < KS ? ks : KS - 1;
+      const int wt = __builtin_amdgcn_readlane(wt_v, t);
+      const int soff = ((wt * KS + ks) * NT + nt_c) * 1024;
+      // Inline asm on purpose: hipcc waits vmcnt(0) for compiler-visible loads carried around a loop, i.e. for the
+      // fragments issued a few instructions earlier (a full L2 round trip per 8 MFMAs). These loads are waited for by
+      // hand with a COUNTED s_waitcnt (CNB_WAIT_A) that leaves the other register set's two loads in flight.
+      u32x4 v;
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(lane16), "s"(wrsrc), "s"(soff) : "memory");
+      return __builtin_bit_cast(bf16x8, v);
+    };
+    // The loop walks the linear step sequence (chunk, tap, k-pair), two steps per iteration with static register
+    // names: pixel fragments of step s+1 are read from LDS into the OTHER set (X / Y) before the 8 MFMAs of step s
+    // issue, and each set's weight fragments are re-loaded for step s+2 right after its MFMAs have issued. Left to
+    // itself the compiler funnels every fragment through one register quad (read, wait, MFMA, read, wait, ...).
+    bf16x8 X[2 * MPW], Y[2 * MPW];
+    bf16x8 ax0, ax1, ay0, ay1;
+    int ch = 0, t = 0, kp = 0;      // current step
+    int ch2 = 0, t2 = 0, kp2 = 0;   // two steps ahead (weight prefetch)
+    auto adv = [&](int& c_, int& t_, int& k_) {
+      if (KPAIRS > 1) {
+        if (++k_ < KPAIRS) return;
+        k_ = 0;
       }
-      if (NP > H1) {
-        u32x4 sv[NP - H1 > 0 ? NP - H1 : 1];
-#pragma unroll
-        for (int i = H1; i < NP; ++i) {
-          u32x4 v = {0u, 0u, 0u, 0u};
-          if (gpix[i] >= 0 && cc + s8 < g.Cin) v = *reinterpret_cast<const u32x4*>(xg + (long)gpix[i] * g.ldx + s8 + cc);
-          sv[i - H1] = v;
-        }
-#pragma unroll
-        for (int i = H1; i < NP; ++i) {
-          const int q = tid + i * 256;
-          if (q < npieces) *reinterpret_cast<u32x4*>(lds + (q >> 2) * CNB_PITCH + (q & 3) * 16) = sv[i - H1];
-        }
-      }
-      __syncthreads();
-      // Taps are software-pipelined by hand: the 8 pixel fragments of tap t+1 are read from LDS (into the other
-      // register set) BEFORE the 8 MFMAs of tap t issue, so LDS latency hides behind matrix work. Left to itself
-      // the compiler funnels every fragment through one register quad: read, wait, MFMA, read, wait, ...
-      bf16x8 X[2 * MPW], Y[2 * MPW];
-#define CNB_READ(BUF, T_)                                                                          \
+      if (++t_ == ntaps) { t_ = 0; ++c_; }
+    };
+    ax0 = wload(0, 0, 0, 0); ax1 = wload(0, 0, 0, 1);
+    adv(ch2, t2, kp2);
+    {
+      const int cq = ch2 < nchunks ? ch2 : nchunks - 1;
+      ay0 = wload(cq, t2, kp2, 0); ay1 = wload(cq, t2, kp2, 1);
+    }
+    adv(ch2, t2, kp2);
+
+    // chunk staging, register-prefetched: the global loads of chunk c+1 are issued right after chunk c's image has
+    // been written, and stay in flight while chunk c is multiplied
+    u32x4 sv[NP];
+#define CNB_FETCH(CH_)                                                                                  \
+  {                                                                                                     \
+    const int cc = (CH_) * (KSC * 16);                                                                  \
+    _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                    \
+      u32x4 v = {0u, 0u, 0u, 0u};                                                                       \
+      if (gpix[i] >= 0 && cc + s8 < g.Cin)                                                              \
+        v = *reinterpret_cast<const u32x4*>(xg + (long)gpix[i] * g.ldx + s8 + cc);                      \
+      sv[i] = v;                                                                                        \
+    }                                                                                                   \
+  }
+#define CNB_STAGE()                                                                                     \
+  {                                                                                                     \
+    __syncthreads(); /* the previous chunk's reads are done */                                          \
+    _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                    \
+      const int q = tid + i * 256;                                                                      \
+      if (q < npieces) *reinterpret_cast<u32x4*>(lds + (q / PPP) * PITCH + (q % PPP) * 16) = sv[i];     \
+    }                                                                                                   \
+    __syncthreads();                                                                                    \
+    if (ch + 1 < nchunks) CNB_FETCH(ch + 1);                                                            \
+  }
+#define CNB_READ(BUF, T_, KP_)                                                                     \
   {                                                                                                \
-    const int toff_ = __builtin_amdgcn_readlane(doff_v, T_);                                       \
+    const int toff_ = __builtin_amdgcn_readlane(doff_v, T_) + (KP_) * 64;                          \
     _Pragma("unroll") for (int i = 0; i < MPW; ++i) {                                              \
       BUF[i] = *reinterpret_cast<const bf16x8*>(lds + pbase[i] + toff_);                           \
       BUF[MPW + i] = *reinterpret_cast<const bf16x8*>(lds + pbase[i] + toff_ + 32);                \
     }                                                                                              \
   }
-#define CNB_MMA(BUF)                                                                               \
+#define CNB_HALF(CUR, OTH, A0, A1)                                                                 \
   {                                                                                                \
-    _Pragma("unroll") for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(a0, BUF[i], acc[i]);         \
-    _Pragma("unroll") for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(a1, BUF[MPW + i], acc[i]);   \
+    if (t == 0 && kp == 0) {                                                                       \
+      CNB_STAGE();                                                                                 \
+      CNB_READ(CUR, 0, 0);                                                                         \
+    }                                                                                              \
+    {                                                                                              \
+      int tn = t, kn = kp, cn = 0;                                                                 \
+      adv(cn, tn, kn);                                                                             \
+      if (cn == 0) CNB_READ(OTH, tn, kn);                                                          \
+    }                                                                                              \
+    /* weight fragments of this step: everything but the two newest loads (the other set's) has landed */ \
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                               \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    _Pragma("unroll") for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(A0, CUR[i], acc[i]);         \
+    _Pragma("unroll") for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(A1, CUR[MPW + i], acc[i]);   \
+    __builtin_amdgcn_sched_barrier(0);                                                             \
+    {                                                                                              \
+      const int cq = ch2 < nchunks ? ch2 : nchunks - 1;                                            \
+      A0 = wload(cq, t2, kp2, 0);                                                                  \
+      A1 = wload(cq, t2, kp2, 1);                                                                  \
+    }                                                                                              \
+    adv(ch2, t2, kp2);                                                                             \
+    adv(ch, t, kp);                                                                                \
   }
-#define CNB_ROTATE()                                                                               \
-  {                                                                                                \
-    a0 = b0; a1 = b1; b0 = c0; b1 = c1; c0 = n0; c1 = n1;                                          \
-    ++step;                                                                                        \
-  }
-      CNB_READ(X, 0);
-      int t = 0;
+    CNB_FETCH(0);
 #pragma unroll 1
-      while (true) {
-        {
-          const bf16x8 n0 = afrag(step + 3, 0), n1 = afrag(step + 3, 1);
-          if (t + 1 < ntaps) CNB_READ(Y, t + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          CNB_MMA(X);
-          __builtin_amdgcn_sched_barrier(0);
-          CNB_ROTATE();
-        }
-        if (++t >= ntaps) break;
-        {
-          const bf16x8 n0 = afrag(step + 3, 0), n1 = afrag(step + 3, 1);
-          if (t + 1 < ntaps) CNB_READ(X, t + 1);
-          __builtin_amdgcn_sched_barrier(0);
-          CNB_MMA(Y);
-          __builtin_amdgcn_sched_barrier(0);
-          CNB_ROTATE();
-        }
-        if (++t >= ntaps) break;
-      }
-#undef CNB_READ
-#undef CNB_MMA
-#undef CNB_ROTATE
+    for (int s = 0; s < nsteps; s += 2) {
+      CNB_HALF(X, Y, ax0, ax1);
+      if (s + 1 < nsteps) CNB_HALF(Y, X, ay0, ay1);
     }
+#undef CNB_FETCH
+#undef CNB_STAGE
+#undef CNB_READ
+#undef CNB_HALF
   }
 
   // ---- epilogue: lane = pixel, registers = 4 groups of 4 consecutive couts ----
-  if (!n_live) return;
   const float* __restrict__ bias = g.bias[grp];
   const int n0 = ntile * 32;
   float bsum[16];
 #pragma unroll
   for (int j = 0; j < 16; ++j) {
     const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * h;
-    bsum[j] = (bias != nullptr && n < g.Cout) ? bias[n] : 0.f;
+    bsum[j] = (bias != nullptr && n_live && n < g.Cout) ? bias[n] : 0.f;
   }
   float s1[16], s2[16];
   if (g.stats != nullptr) {
@@ -266,7 +290,7 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
     const int m = (wm + i * WM) * 32 + r;
     const int ty = m / g.TW, tx = m - ty * g.TW;
     const int gy = gy0 + ty, gx = gx0 + tx;
-    const bool ok = m < npix && gy < k.Hg && gx < k.Wg;
+    const bool ok = n_live && m < npix && gy < k.Hg && gx < k.Wg;
     const int oy = gy * g.os + k.oy0, ox = gx * g.os + k.ox0;
     if (g.stats != nullptr) {
 #pragma unroll
@@ -276,33 +300,51 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
         s2[j] += v * v;
       }
     }
-    if (!ok) continue;
     if (g.out_kind == 0) {
-      bf16_t* yp = reinterpret_cast<bf16_t*>(g.y[grp]) + (((long)b * g.Hout + oy) * g.Wout + ox) * g.ldy + n0 + 4 * h;
+      bf16_t* yp = reinterpret_cast<bf16_t*>(g.y[grp]) + (((long)b * g.Hout + oy) * g.Wout + ox) * g.ldy + n0;
+      if ((g.Cout & 7) == 0) {
+        // A pixel's 32 couts are split over its two half-wave lanes in 4-cout groups (lane i: 8q..8q+3, lane i+32:
+        // 8q+4..8q+7). v_permlane32_swap trades group q of the upper half for group q+1 of the lower half, so every
+        // lane ends up with 8 CONSECUTIVE couts: two 16-byte stores per pixel column instead of four 8-byte ones.
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        const int n = n0 + 8 * q + 4 * h;
-        if (n >= g.Cout) continue;
-        float v0 = acc[i][4 * q] + bsum[4 * q], v1 = acc[i][4 * q + 1] + bsum[4 * q + 1];
-        float v2 = acc[i][4 * q + 2] + bsum[4 * q + 2], v3 = acc[i][4 * q + 3] + bsum[4 * q + 3];
-        if (n + 3 < g.Cout) {
-          u32x2* dst = reinterpret_cast<u32x2*>(yp + 8 * q);
+        for (int q = 0; q < 4; q += 2) {
+          unsigned a0 = cn_pack_bf16(acc[i][4 * q] + bsum[4 * q], acc[i][4 * q + 1] + bsum[4 * q + 1]);
+          unsigned a1 = cn_pack_bf16(acc[i][4 * q + 2] + bsum[4 * q + 2], acc[i][4 * q + 3] + bsum[4 * q + 3]);
+          unsigned b0 = cn_pack_bf16(acc[i][4 * q + 4] + bsum[4 * q + 4], acc[i][4 * q + 5] + bsum[4 * q + 5]);
+          unsigned b1 = cn_pack_bf16(acc[i][4 * q + 6] + bsum[4 * q + 6], acc[i][4 * q + 7] + bsum[4 * q + 7]);
+          const auto sw0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+          const auto sw1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+          const int n = n0 + 8 * (q + h);
+          if (!ok || n >= g.Cout) continue;
+          u32x4* dst = reinterpret_cast<u32x4*>(yp + 8 * (q + h));
+          u32x4 pk = {sw0[0], sw1[0], sw0[1], sw1[1]};
           if (g.accumulate) {
-            const u32x2 o = *dst;
-            v0 += cn_bf16_lo(o[0]); v1 += cn_bf16_hi(o[0]); v2 += cn_bf16_lo(o[1]); v3 += cn_bf16_hi(o[1]);
+            float ov[8], nv[8];
+            cn_unpack8(*dst, ov);
+            cn_unpack8(pk, nv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) nv[e] += ov[e];
+            pk = cn_pack8(nv);
           }
-          u32x2 pk = {cn_pack_bf16(v0, v1), cn_pack_bf16(v2, v3)};
           *dst = pk;
-        } else {  // ragged cout tail
-          const float vv[4] = {v0, v1, v2, v3};
-          for (int e = 0; e < 4 && n + e < g.Cout; ++e) {
-            float v = vv[e];
-            if (g.accumulate) v += cn_bf16_to_f32(yp[8 * q + e]);
-            yp[8 * q + e] = cn_f32_to_bf16(v);
-          }
+        }
+        continue;
+      }
+      if (!ok) continue;
+      yp += 4 * h;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {  // ragged couts: element-wise
+        const int n = n0 + 8 * q + 4 * h;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          if (n + e >= g.Cout) continue;
+          float v = acc[i][4 * q + e] + bsum[4 * q + e];
+          if (g.accumulate) v += cn_bf16_to_f32(yp[8 * q + e]);
+          yp[8 * q + e] = cn_f32_to_bf16(v);
         }
       }
     } else {
+      if (!ok) continue;
       float* yp = reinterpret_cast<float*>(g.y[grp]) + (long)b * g.y_bs + (long)oy * g.Wout + ox;
       const long cs = (long)g.Hout * g.Wout;
 #pragma unroll
@@ -315,26 +357,26 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
     }
   }
   if (g.stats != nullptr) {
-    // per-cout sums over this wave's pixels: reduce the 32 lanes of each half, then one atomic per cout
+    // Per-cout sums over this wave's pixels = sums over the LANES of 32 values per lane: transposed through LDS
+    // (each lane writes its 32 partials as one padded row, then sums ONE column over its half-wave's 32 rows): ~100
+    // instructions per wave instead of 160 cross-lane shuffles + 160 adds.
+    __syncthreads();  // every wave is done with the pixel image
+    float* red = reinterpret_cast<float*>(lds) + wid * (64 * 33);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      float a = s1[j], c = s2[j];
+      red[lane * 33 + j] = s1[j];
+      red[lane * 33 + 16 + j] = s2[j];
+    }
+    const int jj = lane & 31, hh = lane >> 5;
+    float tot = 0.f;
 #pragma unroll
-      for (int off = 16; off > 0; off >>= 1) {
-        a += __shfl_xor(a, off, 64);
-        c += __shfl_xor(c, off, 64);
-      }
-      const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * h;
-      if (r == 0 && n < g.Cout) {
-        float* row = g.stats + (long)tile * 2 * g.Cout;
-        if (WM == 1) {  // this wave saw every pixel of the tile
-          row[n] = a;
-          row[g.Cout + n] = c;
-        } else {        // WM waves share a cout tile: few adders per address, rows zeroed by the launcher
-          atomicAdd(row + n, a);
-          atomicAdd(row + g.Cout + n, c);
-        }
-      }
+    for (int rr = 0; rr < 32; ++rr) tot += red[(hh * 32 + rr) * 33 + jj];
+    const int j = jj & 15;
+    const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * hh;
+    if (n_live && n < g.Cout) {
+      float* row = g.stats + (long)tile * 2 * g.Cout + (jj >= 16 ? g.Cout : 0) + n;
+      if (WM == 1) *row = tot;   // this wave saw every pixel of the tile
+      else atomicAdd(row, tot);  // WM waves share a cout tile: few adders per address, rows zeroed by the launcher
     }
   }
 }
@@ -462,29 +504,47 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
   const int WN = g.NT >= 4 ? 4 : (g.NT >= 2 ? 2 : 1);
   cnb_pick_tile(Hg, Wg, g.is, span, 128 * (4 / WN), g.TH, g.TW);
   g.nblk_n = (g.NT + WN - 1) / WN;
-  long total = 0;
-  int max_pix = 0;
+  // halo sizes, then the chunk depth: as many 16-channel k-steps per staged image as the staging budget allows
+  // (10 pieces of 16 bytes per thread), 1x1 launches preferring the deepest (one tap per chunk to amortise the
+  // barrier + staging phase over), 3x3 launches 64 channels
+  int max_pix = 0, max_taps = 0;
   for (int c = 0; c < g.ncls; ++c) {
     CnBClass& k = g.cls[c];
     const int sy = k.IH, sx = k.IW;
     k.IH = (g.TH - 1) * g.is + sy + 1;
     k.IW = (g.TW - 1) * g.is + sx + 1;
+    max_pix = k.IH * k.IW > max_pix ? k.IH * k.IW : max_pix;
+    max_taps = k.ntaps > max_taps ? k.ntaps : max_taps;
+  }
+  int KSC = 2;
+  {
+    const int pref[3] = {max_taps <= 1 ? 8 : 4, max_taps <= 1 ? 4 : 2, 2};
+    for (int i = 0; i < 3; ++i) {
+      const int c = pref[i];
+      if (c > 2 && c / 2 >= g.KS) continue;  // deeper than the input is wide
+      if (((long)max_pix * c * 2 + 255) / 256 <= 10) { KSC = c; break; }
+    }
+  }
+  const int pitch = KSC * 32 + 16;
+  const int np = (int)(((long)max_pix * KSC * 2 + 255) / 256);
+  if (np > 10) return CN_ERR_LDS;
+  long total = 0;
+  for (int c = 0; c < g.ncls; ++c) {
+    CnBClass& k = g.cls[c];
     for (int t = 0; t < k.ntaps; ++t) {
       const int dy = k.doff[t] >> 16, dx = (short)(k.doff[t] & 0xffff);
-      k.doff[t] = ((dy - k.iy_off) * k.IW + (dx - k.ix_off)) * CNB_PITCH;
+      k.doff[t] = ((dy - k.iy_off) * k.IW + (dx - k.ix_off)) * pitch;
     }
     k.tiles_x = (k.Wg + g.TW - 1) / g.TW;
     k.tiles_per_img = k.tiles_x * ((k.Hg + g.TH - 1) / g.TH);
     k.block_begin = (int)total;
     total += (long)k.tiles_per_img * g.B * g.nblk_n;
-    max_pix = k.IH * k.IW > max_pix ? k.IH * k.IW : max_pix;
   }
   if (total <= 0) return CN_OK;
   if (total > 0x7fffff00L) return CN_ERR_ARG;
   g.total = (int)total;
-  const int np = (max_pix * 4 + 255) / 256;
-  if (np > 10) return CN_ERR_LDS;
-  const size_t shmem = (size_t)max_pix * CNB_PITCH;
+  size_t shmem = (size_t)max_pix * pitch;
+  if (g.stats != nullptr && shmem < 4 * 64 * 33 * sizeof(float)) shmem = 4 * 64 * 33 * sizeof(float);
   const dim3 grid(cn_xcd_grid(total)), block(256);
   if (g.stats != nullptr) {
     if (g.ncls != 1) return CN_ERR_ARG;
@@ -492,17 +552,31 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
         hipMemsetAsync(g.stats, 0, sizeof(float) * 2 * g.Cout * (size_t)g.cls[0].tiles_per_img * g.B, stream) != hipSuccess)
       return CN_ERR_LAUNCH;
   }
-  cn_prof_name("cn_bconv_kernel<%d, %d>", WN, np <= 4 ? 4 : 10);
+  const int NPv = np <= 4 ? 4 : (np <= 6 ? 6 : 10);
+  cn_prof_name("cn_bconv_kernel<%d, %d, %d>", WN, (KSC == 2 ? NPv : (KSC == 4 ? (NPv <= 6 ? 6 : 10) : 10)), KSC);
   cn_prof_desc("bconv B%d %dx%d %d->%d cls%d taps%d s%d/%d", g.B, g.Hin, g.Win, g.Cin, g.Cout, g.ncls, g.cls[0].ntaps,
                g.is, g.os);
   cn_prof_before(stream);
-#define CNB_GO(WN_, NP_) hipLaunchKernelGGL((cn_bconv_kernel<WN_, NP_>), grid, block, shmem, stream, g)
-  if (np <= 4) {
-    if (WN == 4) CNB_GO(4, 4); else if (WN == 2) CNB_GO(2, 4); else CNB_GO(1, 4);
+#define CNB_GO3(WN_, NP_, KSC_)                                                                                  \
+  do {                                                                                                           \
+    if (shmem > 64 * 1024)                                                                                       \
+      (void)hipFuncSetAttribute((const void*)cn_bconv_kernel<WN_, NP_, KSC_>,                                    \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                         \
+    hipLaunchKernelGGL((cn_bconv_kernel<WN_, NP_, KSC_>), grid, block, shmem, stream, g);                        \
+  } while (0)
+#define CNB_GO(NP_, KSC_)                                                                                        \
+  do {                                                                                                           \
+    if (WN == 4) CNB_GO3(4, NP_, KSC_); else if (WN == 2) CNB_GO3(2, NP_, KSC_); else CNB_GO3(1, NP_, KSC_);     \
+  } while (0)
+  if (KSC == 2) {
+    if (NPv == 4) CNB_GO(4, 2); else if (NPv == 6) CNB_GO(6, 2); else CNB_GO(10, 2);
+  } else if (KSC == 4) {
+    if (NPv <= 6) CNB_GO(6, 4); else CNB_GO(10, 4);
   } else {
-    if (WN == 4) CNB_GO(4, 10); else if (WN == 2) CNB_GO(2, 10); else CNB_GO(1, 10);
+    CNB_GO(10, 8);
   }
 #undef CNB_GO
+#undef CNB_GO3
   cn_prof_after(stream, 4, flops);
   return cn_check_launch();
 }
