@@ -49,10 +49,13 @@ __device__ __forceinline__ bf16x4 cnw_tr(const unsigned char* lds_addr) {
       (__attribute__((address_space(3))) s4*)(const_cast<unsigned char*>(lds_addr)));
 }
 
-template <int T>
+// NQ = 16-byte pieces of the Q halo image per thread that are register-prefetched (0: synchronous staging loop for
+// large halos, e.g. strided layers).
+template <int T, int NQ>
 __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const CnBWgGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  const int tid = threadIdx.x, lane = tid & 63, wid = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wp = wid >> 1, wq = wid & 1;
   int L;
   {
@@ -75,17 +78,21 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
   const int rq = (lane & 15) >> 2, rp = lane & 3;
   const int colb = (16 * (g16 & 1) + 4 * rp) * 2;  // byte offset of this lane's 4 columns inside a 32-channel tile
   const int kh8 = 8 * (g16 >> 1);                   // k offset of the lane's half
-  // per k-step (16 pixels): grid pixel of row rq for the two reads (k = kh8 + rq, kh8 + 4 + rq)
-  int qrow[16];  // Q-image byte offsets of those pixels (tap offset added later), clamped for out-of-tile pixels
+  // per k-step (16 pixels): Q-image byte offset of the lane's row for the two reads (k = kh8 + rq, kh8 + 4 + rq),
+  // column offset folded in; out-of-tile pixels are clamped (their P rows are zero)
+  int qrow[16];
 #pragma unroll
   for (int ks = 0; ks < 8; ++ks)
 #pragma unroll
     for (int e = 0; e < 2; ++e) {
       const int m = ks * 16 + kh8 + 4 * e + rq;
       const int ty = m / g.TW, tx = m - ty * g.TW;
-      qrow[ks * 2 + e] = m < npix ? ((ty * g.s) * IW + tx * g.s) * CNW_PITCH : 0;
+      qrow[ks * 2 + e] = (m < npix ? ((ty * g.s) * IW + tx * g.s) * CNW_PITCH : 0) + wq * 64 + colb + 128 * CNW_PITCH;
     }
-  const int pcol = wp * 64 + colb, qcol = wq * 64 + colb;
+  const int prow0 = (kh8 + rq) * CNW_PITCH + wp * 64 + colb;
+  int doff[T];
+#pragma unroll
+  for (int t = 0; t < T; ++t) doff[t] = g.doff[t];
 
   f32x16 acc[T];
 #pragma unroll
@@ -97,56 +104,125 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
   const int t_end = t_begin + g.tiles_per_split < g.ntiles ? t_begin + g.tiles_per_split : g.ntiles;
   const int cp0 = bp * 64, cq0 = bq * 64;
   const int nq_pieces = g.IH * IW * 8;  // 16-byte pieces of the Q image (8 per pixel)
-#pragma unroll 1
-  for (int tile = t_begin; tile < t_end; ++tile) {
+  const int ksteps = (npix + 15) >> 4;
+
+  // per-thread staging descriptors (tile independent): P piece i = pixel (tid + 256 i) / 8, Q piece likewise
+  constexpr int NQR = NQ > 0 ? NQ : 1;
+  int pm[4], pty[4], ptx[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pm[i] = (tid + i * 256) >> 3;
+    pty[i] = pm[i] / g.TW;
+    ptx[i] = pm[i] - pty[i] * g.TW;
+  }
+  const int c8 = (tid & 7) * 8;
+  int qhy[NQR], qhx[NQR];
+  if (NQ > 0) {
+#pragma unroll
+    for (int i = 0; i < NQR; ++i) {
+      const int p = (tid + i * 256) >> 3;
+      qhy[i] = p / IW;
+      qhx[i] = p - qhy[i] * IW;
+    }
+  }
+  u32x4 pv[4], qv[NQR];
+  auto fetch = [&](int tile) {
     const int b = tile / g.tiles_per_img;
     const int tl = tile - b * g.tiles_per_img;
     const int tyi = tl / g.tiles_x, txi = tl - tyi * g.tiles_x;
     const int gy0 = tyi * g.TH, gx0 = txi * g.TW;
-    __syncthreads();  // previous tile's reads are done
-    // stage P: 128 pixels x 64 channels (zeros outside the tile / grid / channel range)
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int q = tid + i * 256;
-      const int m = q >> 3, c8 = (q & 7) * 8;
-      const int ty = m / g.TW, tx = m - ty * g.TW;
-      const int gy = gy0 + ty, gx = gx0 + tx;
+      const int gy = gy0 + pty[i], gx = gx0 + ptx[i];
       u32x4 v = {0u, 0u, 0u, 0u};
-      if (m < npix && gy < g.Hg && gx < g.Wg && cp0 + c8 < g.CP)
+      if (pm[i] < npix && gy < g.Hg && gx < g.Wg && cp0 + c8 < g.CP)
         v = *reinterpret_cast<const u32x4*>(g.P + (((long)b * g.Hg + gy) * g.Wg + gx) * g.ldp + cp0 + c8);
-      *reinterpret_cast<u32x4*>(ldsP + m * CNW_PITCH + c8 * 2) = v;
+      pv[i] = v;
     }
-    // stage Q: halo image
-    const int qy0 = gy0 * g.s + g.qy_off, qx0 = gx0 * g.s + g.qx_off;
+    if (NQ > 0) {
+      const int qy0 = gy0 * g.s + g.qy_off, qx0 = gx0 * g.s + g.qx_off;
+#pragma unroll
+      for (int i = 0; i < NQR; ++i) {
+        const int iy = qy0 + qhy[i], ix = qx0 + qhx[i];
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (tid + i * 256 < nq_pieces && iy >= 0 && iy < g.Hq && ix >= 0 && ix < g.Wq && cq0 + c8 < g.CQ)
+          v = *reinterpret_cast<const u32x4*>(g.Q + (((long)b * g.Hq + iy) * g.Wq + ix) * g.ldq + cq0 + c8);
+        qv[i] = v;
+      }
+    }
+  };
+  auto store = [&](int tile) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(ldsP + pm[i] * CNW_PITCH + c8 * 2) = pv[i];
+    if (NQ > 0) {
+#pragma unroll
+      for (int i = 0; i < NQR; ++i)
+        if (tid + i * 256 < nq_pieces)
+          *reinterpret_cast<u32x4*>(ldsQ + ((tid + i * 256) >> 3) * CNW_PITCH + c8 * 2) = qv[i];
+    } else {  // large halo: synchronous loop
+      const int b = tile / g.tiles_per_img;
+      const int tl = tile - b * g.tiles_per_img;
+      const int tyi = tl / g.tiles_x, txi = tl - tyi * g.tiles_x;
+      const int qy0 = tyi * g.TH * g.s + g.qy_off, qx0 = txi * g.TW * g.s + g.qx_off;
 #pragma unroll 1
-    for (int q = tid; q < nq_pieces; q += 256) {
-      const int p = q >> 3, c8 = (q & 7) * 8;
-      const int hy = p / IW, hx = p - hy * IW;
-      const int iy = qy0 + hy, ix = qx0 + hx;
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (iy >= 0 && iy < g.Hq && ix >= 0 && ix < g.Wq && cq0 + c8 < g.CQ)
-        v = *reinterpret_cast<const u32x4*>(g.Q + (((long)b * g.Hq + iy) * g.Wq + ix) * g.ldq + cq0 + c8);
-      *reinterpret_cast<u32x4*>(ldsQ + p * CNW_PITCH + c8 * 2) = v;
+      for (int q = tid; q < nq_pieces; q += 256) {
+        const int p = q >> 3;
+        const int hy = p / IW, hx = p - hy * IW;
+        const int iy = qy0 + hy, ix = qx0 + hx;
+        u32x4 v = {0u, 0u, 0u, 0u};
+        if (iy >= 0 && iy < g.Hq && ix >= 0 && ix < g.Wq && cq0 + c8 < g.CQ)
+          v = *reinterpret_cast<const u32x4*>(g.Q + (((long)b * g.Hq + iy) * g.Wq + ix) * g.ldq + cq0 + c8);
+        *reinterpret_cast<u32x4*>(ldsQ + p * CNW_PITCH + c8 * 2) = v;
+      }
     }
+  };
+
+  // k-steps are software-pipelined by hand over two static fragment sets: the 2 + 2T transposed reads of k-step
+  // ks+1 are issued before the T MFMAs of k-step ks (the compiler alone keeps one read pair ahead, which exposes
+  // the LDS latency in front of every MFMA: one wave per SIMD has nothing else to run)
+#define CNW_READ(A_, B_, KS_)                                                                   \
+  {                                                                                             \
+    const bf16x4 pa_ = cnw_tr(lds + prow0 + (KS_) * 16 * CNW_PITCH);                            \
+    const bf16x4 pb_ = cnw_tr(lds + prow0 + ((KS_) * 16 + 4) * CNW_PITCH);                      \
+    A_ = bf16x8{pa_[0], pa_[1], pa_[2], pa_[3], pb_[0], pb_[1], pb_[2], pb_[3]};                \
+    _Pragma("unroll") for (int t = 0; t < T; ++t) {                                             \
+      const bf16x4 qa_ = cnw_tr(lds + qrow[(KS_) * 2] + doff[t]);                               \
+      const bf16x4 qb_ = cnw_tr(lds + qrow[(KS_) * 2 + 1] + doff[t]);                           \
+      B_[t] = bf16x8{qa_[0], qa_[1], qa_[2], qa_[3], qb_[0], qb_[1], qb_[2], qb_[3]};           \
+    }                                                                                           \
+  }
+#define CNW_MMA(A_, B_)                                                                         \
+  {                                                                                             \
+    _Pragma("unroll") for (int t = 0; t < T; ++t)                                               \
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_[t], acc[t], 0, 0, 0);           \
+  }
+  bf16x8 AX, AY, BX[T], BY[T];
+  if (t_begin < t_end) fetch(t_begin);
+#pragma unroll 1
+  for (int tile = t_begin; tile < t_end; ++tile) {
+    __syncthreads();  // previous tile's reads are done
+    store(tile);
     __syncthreads();
-    const int ksteps = (npix + 15) >> 4;
+    if (tile + 1 < t_end) fetch(tile + 1);  // next tile's global loads fly while this one is multiplied
+    CNW_READ(AX, BX, 0);
 #pragma unroll
-    for (int ks = 0; ks < 8; ++ks) {
+    for (int ks = 0; ks < 8; ks += 2) {
       if (ks < ksteps) {
-        const int m0 = ks * 16 + kh8 + rq;
-        const bf16x4 pa = cnw_tr(ldsP + m0 * CNW_PITCH + pcol);
-        const bf16x4 pb = cnw_tr(ldsP + (m0 + 4) * CNW_PITCH + pcol);
-        const bf16x8 a = {pa[0], pa[1], pa[2], pa[3], pb[0], pb[1], pb[2], pb[3]};
-#pragma unroll
-        for (int t = 0; t < T; ++t) {
-          const bf16x4 qa = cnw_tr(ldsQ + qrow[ks * 2] + g.doff[t] + qcol);
-          const bf16x4 qb = cnw_tr(ldsQ + qrow[ks * 2 + 1] + g.doff[t] + qcol);
-          const bf16x8 bb = {qa[0], qa[1], qa[2], qa[3], qb[0], qb[1], qb[2], qb[3]};
-          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, bb, acc[t], 0, 0, 0);
-        }
+        if (ks + 1 < ksteps) CNW_READ(AY, BY, ks + 1);
+        __builtin_amdgcn_sched_barrier(0);
+        CNW_MMA(AX, BX);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      if (ks + 1 < ksteps) {
+        if (ks + 2 < ksteps) CNW_READ(AX, BX, ks + 2);
+        __builtin_amdgcn_sched_barrier(0);
+        CNW_MMA(AY, BY);
+        __builtin_amdgcn_sched_barrier(0);
       }
     }
   }
+#undef CNW_READ
+#undef CNW_MMA
   // partial slice: part[split][t][cP][cQ] (lanes contiguous along cQ)
   const int r = lane & 31, h = lane >> 5;
   const long CPp = (long)g.nbp * 64, CQp = (long)g.nbq * 64;
@@ -247,19 +323,20 @@ static int cnw_run(CnBWgGeom& g, float* dw, float* ws, long ws_floats, hipStream
   if (shmem > 160 * 1024) return CN_ERR_LDS;
   const dim3 grid(cn_xcd_grid(g.total)), block(256);
   const double flops = 2.0 * g.B * (double)g.Hg * g.Wg * g.CP * g.CQ * g.T;
-  cn_prof_name("cn_bwgrad_kernel<%d>", g.T);
+  cn_prof_name("cn_bwgrad_kernel<%d, %d>", g.T, (g.IH * g.IW * 8 + 255) / 256 <= 8 ? (g.T == 1 && (g.IH * g.IW * 8 + 255) / 256 <= 4 ? 4 : 8) : 0);
   cn_prof_desc("bwgrad B%d %dx%d %dx%d T%d s%d split%d", g.B, g.Hg, g.Wg, g.CP, g.CQ, g.T, g.s, g.nsplit);
   cn_prof_before(stream);
-#define CNW_GO(T_)                                                                                             \
+  const int nq = (g.IH * g.IW * 8 + 255) / 256;  // Q pieces per thread: <= 8 are register-prefetched
+#define CNW_GO(T_, NQ_)                                                                                        \
   do {                                                                                                         \
     if (shmem > 64 * 1024)                                                                                     \
-      (void)hipFuncSetAttribute((const void*)cn_bwgrad_kernel<T_>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                (int)shmem);                                                                   \
-    hipLaunchKernelGGL((cn_bwgrad_kernel<T_>), grid, block, shmem, stream, g);                                 \
+      (void)hipFuncSetAttribute((const void*)cn_bwgrad_kernel<T_, NQ_>,                                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                       \
+    hipLaunchKernelGGL((cn_bwgrad_kernel<T_, NQ_>), grid, block, shmem, stream, g);                            \
   } while (0)
   switch (g.T) {
-    case 1: CNW_GO(1); break;
-    case 9: CNW_GO(9); break;
+    case 1: if (nq <= 4) CNW_GO(1, 4); else if (nq <= 8) CNW_GO(1, 8); else CNW_GO(1, 0); break;
+    case 9: if (nq <= 8) CNW_GO(9, 8); else CNW_GO(9, 0); break;
     default: return CN_ERR_ARG;
   }
 #undef CNW_GO
