@@ -78,8 +78,19 @@ __global__ __launch_bounds__(256) void cn_bbn_partial_kernel(const bf16_t* __res
 __device__ __forceinline__ void bbn_combine(const float* __restrict__ part, int nblk, int C, int c, int sub, double& s,
                                             double& ss) {
   s = 0.0; ss = 0.0;
-  if (c < C)
-    for (int i = sub; i < nblk; i += 16) { s += part[((long)i * 2) * C + c]; ss += part[((long)i * 2 + 1) * C + c]; }
+  if (c < C) {
+    // four independent chains: the rows of one channel are C floats apart, every load is its own cache line
+    double s1 = 0.0, q1 = 0.0, s2 = 0.0, q2 = 0.0, s3 = 0.0, q3 = 0.0;
+    int i = sub;
+    for (; i + 48 < nblk; i += 64) {
+      s += part[((long)i * 2) * C + c]; ss += part[((long)i * 2 + 1) * C + c];
+      s1 += part[((long)(i + 16) * 2) * C + c]; q1 += part[((long)(i + 16) * 2 + 1) * C + c];
+      s2 += part[((long)(i + 32) * 2) * C + c]; q2 += part[((long)(i + 32) * 2 + 1) * C + c];
+      s3 += part[((long)(i + 48) * 2) * C + c]; q3 += part[((long)(i + 48) * 2 + 1) * C + c];
+    }
+    for (; i < nblk; i += 16) { s += part[((long)i * 2) * C + c]; ss += part[((long)i * 2 + 1) * C + c]; }
+    s += s1 + s2 + s3; ss += q1 + q2 + q3;
+  }
 #pragma unroll
   for (int off = 8; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); ss += __shfl_xor(ss, off, 64); }
 }

@@ -1699,55 +1699,82 @@ def _resize_bilinear_bf16(x: Var, size: T.Tuple[int, int], out: T.Optional[torch
     return yv
 
 
+class _ThinPack16:
+    """Concatenated copy [n*CP][Cin][3][3] of the n thin head weights + its bf16 fragment packs (refreshed when the
+    parameters change): the three head streams of a tower run as ONE 128 -> 9 convolution, one 9 -> 128 backward-data
+    and one weight-gradient launch instead of three each."""
+
+    __slots__ = ("wcat", "dwcat", "fwd16", "bwd16", "version", "store_id")
+
+    def __init__(self):
+        self.wcat = self.dwcat = self.fwd16 = self.bwd16 = None
+        self.version = -1
+        self.store_id = 0
+
+
 def _thin_conv3x3_bf16(x: Var, mods: T.Sequence, grouped: bool, dilation: int, out: T.Optional[torch.Tensor]) -> Var:
     """The first head convolutions (128 -> 3, three streams) on a bf16 tower output: the MFMA kernel with an fp32
     NCHW epilogue, so everything downstream of it (9 / 3 / 1-channel head tensors) stays on the fp32 head kernels."""
     if grouped:
         raise NotImplementedError("grouped thin convolutions read the fp32 head tensors, never bf16")
+    if any(m.bias is not None for m in mods):
+        raise NotImplementedError("thin head convolutions on the bf16 path are bias-free (ConvBlock2d)")
     tape = current_tape()
     xt = x.t
     B, Cin, H, W = xt.shape
     n = len(mods)
     CP = mods[0].weight.shape[0]
-    y = out if out is not None else torch.empty((B, n * CP, H, W), dtype=torch.float32, device=xt.device)
+    CPt = n * CP
+    y = out if out is not None else torch.empty((B, CPt, H, W), dtype=torch.float32, device=xt.device)
     if y.dtype != torch.float32 or not y.is_contiguous():
         raise RuntimeError("thin_conv3x3 (bf16 input) writes a dense fp32 NCHW tensor")
     HW = H * W
-    pws = [packed_conv(m, tape.enabled and x.req, bf16=True) for m in mods]
-    for i, (m, pw) in enumerate(zip(mods, pws)):
-        yi = y[:, i * CP:(i + 1) * CP]
-        _lib.call("cn_conv2d_fwd_bf16", xt.data_ptr(), ld(xt), pw.fwd16.data_ptr(),
-                  m.bias.data_ptr() if m.bias is not None else None, yi.data_ptr(), 0, n * CP * HW, B, Cin, H, W, CP, 3,
-                  3, 1, dilation, dilation, 0, 1, None, _stream())
+    store = current_store()
+    store.refresh()
+    tw = mods[0].__dict__.get("_cn_thin16")
+    if tw is None or tw.store_id != id(store):
+        tw = _ThinPack16()
+        tw.store_id = id(store)
+        tw.wcat = torch.empty((CPt, Cin, 3, 3), dtype=torch.float32, device=xt.device)
+        tw.dwcat = torch.empty_like(tw.wcat)
+        tw.fwd16 = torch.empty(_lib.query("cn_bconv_packed_elems", 9, Cin, CPt), dtype=torch.bfloat16, device=xt.device)
+        tw.bwd16 = torch.empty(_lib.query("cn_bconv_packed_elems", 9, CPt, Cin), dtype=torch.bfloat16, device=xt.device)
+        mods[0].__dict__["_cn_thin16"] = tw
+    if tw.version != store.version:
+        s = _stream()
+        per = CP * Cin * 9
+        for i, m in enumerate(mods):
+            _lib.call("cn_copy_f32", m.weight.data_ptr(), per, tw.wcat[i * CP].data_ptr(), per, 1, per, 0, s)
+        _lib.call("cn_pack_weights_bf16", tw.wcat.data_ptr(), tw.fwd16.data_ptr(), 9, Cin, CPt, 9, Cin * 9, 1, s)
+        _lib.call("cn_pack_weights_bf16", tw.wcat.data_ptr(), tw.bwd16.data_ptr(), 9, CPt, Cin, Cin * 9, 9, 1, s)
+        tw.version = store.version
+    _lib.call("cn_conv2d_fwd_bf16", xt.data_ptr(), ld(xt), tw.fwd16.data_ptr(), None, y.data_ptr(), 0, CPt * HW, B, Cin,
+              H, W, CPt, 3, 3, 1, dilation, dilation, 0, 1, None, _stream())
     yv = Var(y, tape.enabled)
     if tape.enabled:
-        store = current_store()
 
         def bwd():
             dy = yv.grad
             if dy is None:
                 return
             s = _stream()
-            cp8 = (CP + 7) // 8 * 8
-            need = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, CP, 3, 3, 1, dilation, dilation, 0)
+            cp8 = (CPt + 7) // 8 * 8
+            d16 = torch.empty((B, H, W, cp8), dtype=torch.bfloat16, device=xt.device)
+            _lib.call("cn_convert_f32nchw_to_bf16nhwc", dy.data_ptr(), bstride(dy), d16.data_ptr(), cp8, B, CPt, cp8, HW, s)
+            need = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, CPt, 3, 3, 1, dilation, dilation, 0)
             wsp, wsn = _ws16(need, xt.device)
-            first = True
-            for i, (m, pw) in enumerate(zip(mods, pws)):
-                dyi = dy[:, i * CP:(i + 1) * CP]
-                d16 = torch.empty((B, H, W, cp8), dtype=torch.bfloat16, device=xt.device)
-                _lib.call("cn_convert_f32nchw_to_bf16nhwc", dyi.data_ptr(), bstride(dy), d16.data_ptr(), cp8, B, CP,
-                          cp8, HW, s)
-                _lib.call("cn_conv2d_bwd_weight_bf16", xt.data_ptr(), ld(xt), d16.data_ptr(), cp8,
-                          store.grad_of(m.weight).data_ptr(), B, Cin, H, W, CP, 3, 3, 1, dilation, dilation, wsp, wsn, s)
-                if m.bias is not None:
-                    _lib.call("cn_channel_sum_f32", dyi.data_ptr(), bstride(dy), B, CP, HW,
-                              store.grad_of(m.bias).data_ptr(), 1, s)
-                if x.req:
-                    dx, acc = grad_buffer(x)
-                    _lib.call("cn_conv2d_bwd_data_bf16", d16.data_ptr(), cp8, pw.bwd16.data_ptr(), dx.data_ptr(),
-                              ld(dx), B, Cin, H, W, CP, 3, 3, 1, dilation, dilation, acc if first else 1, s)
-                    first = False
+            _lib.call("cn_fill_f32", tw.dwcat.data_ptr(), tw.dwcat.numel(), 0.0, s)
+            _lib.call("cn_conv2d_bwd_weight_bf16", xt.data_ptr(), ld(xt), d16.data_ptr(), cp8, tw.dwcat.data_ptr(), B, Cin,
+                      H, W, CPt, 3, 3, 1, dilation, dilation, wsp, wsn, s)
+            per = CP * Cin * 9
+            for i, m in enumerate(mods):
+                _lib.call("cn_copy_f32", tw.dwcat[i * CP].data_ptr(), per, store.grad_of(m.weight).data_ptr(), per, 1,
+                          per, 1, s)
+            if x.req:
+                dx, acc = grad_buffer(x)
+                _lib.call("cn_conv2d_bwd_data_bf16", d16.data_ptr(), cp8, tw.bwd16.data_ptr(), dx.data_ptr(), ld(dx), B,
+                          Cin, H, W, CPt, 3, 3, 1, dilation, dilation, acc, s)
             yv.grad = None
 
-        tape.add(bwd, tuple(m.weight for m in mods) + tuple(m.bias for m in mods if m.bias is not None))
+        tape.add(bwd, tuple(m.weight for m in mods))
     return yv
