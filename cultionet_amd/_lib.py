@@ -66,6 +66,7 @@ SIGNATURES = {
     "cn_final_combine_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, F, P],
     "cn_tanimoto_fwd_f32": [P, L, P, P, P, I, I, I, I, I, L, I, F, I, P, P, P, F, P, P],
     "cn_tanimoto_bwd_f32": [P, L, P, P, P, I, I, I, I, I, L, P, F, P, L, I, P],
+    "cn_eval_metrics_f32": [P, P, P, P, P, I, F, L, P, P, P, P],
     "cn_grad_sumsq_f32": [P, L, P, P],
     "cn_adamw_step_f32": [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P],
     "cn_pack_timeconv_f32": [P, P, I, I, I, I, I, P],
@@ -101,6 +102,8 @@ SIGNATURES = {
     "cn_bilinear_bwd_bf16": [P, L, P, L, I, I, I, I, I, I, I, P],
     "cn_na2d_fwd_bf16": [P, L, P, L, P, I, I, I, I, I, I, I, P],
     "cn_na2d_bwd_bf16": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, P],
+    "cn_window_chips_f32": [P, I, P, P, I, I, I, I, I, I, I, P, P, F, F, F, P],
+    "cn_stitch_predictions_u16": [P, P, P, P, P, I, I, I, I, I, I, F, P],
     "cn_profile_begin": [],
     "cn_profile_end": [P],
     "cn_profile_top": [I, P, I, P],

@@ -190,3 +190,76 @@ extern "C" int cn_tanimoto_bwd_f32(const float* pred, long pbs, const float* tar
                      accumulate);
   return cn_check_launch();
 }
+
+// ---------------------------------------------------------------------------------------------------------------
+// Validation metrics of _shared_eval_step (/root/reference/src/cultionet/models/lightning.py:374-481): one pass over
+// the three probability maps builds the masked regression sums and the two 2x2 confusion matrices; a one-thread
+// finalize turns them into what the reference gets from torchmetrics:
+//   MeanAbsoluteError / MeanSquaredError of distance vs bdist over valid pixels,
+//   FBetaScore(task="multiclass", num_classes=2, beta=2) -- micro-averaged, i.e. accuracy -- and
+//   MatthewsCorrCoef(task="multiclass", num_classes=2) of thresholded edge / crop labels,
+//   score = loss + (1-edge_f) + (1-crop_f) + mae + (1-max(edge_mcc,0)) + (1-max(crop_mcc,0)).
+// Valid pixels: labels != -1 (get_true_labels, lightning.py:161-207; all pixels when no -1 is present).
+// counts[11] = {n, sum|d|, sum d^2, edge tp, fp, fn, tn, crop tp, fp, fn, tn}
+__global__ __launch_bounds__(256) void cn_eval_counts_kernel(const float* __restrict__ dist, const float* __restrict__ edge,
+                                                            const float* __restrict__ crop,
+                                                            const float* __restrict__ bdist,
+                                                            const long long* __restrict__ lab, int klass, float thresh,
+                                                            long n, double* __restrict__ counts) {
+  __shared__ double scratch[4];
+  double a[11];
+#pragma unroll
+  for (int k = 0; k < 11; ++k) a[k] = 0.0;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long long y = lab[i];
+    if (y == -1) continue;
+    const float d = dist[i] - bdist[i];
+    a[0] += 1.0;
+    a[1] += fabsf(d);
+    a[2] += (double)d * d;
+    const bool te = y == klass, tc = y > 0 && y < klass;
+    const bool pe = edge[i] > thresh, pc = crop[i] > thresh;
+    a[3 + (pe ? (te ? 0 : 1) : (te ? 2 : 3))] += 1.0;
+    a[7 + (pc ? (tc ? 0 : 1) : (tc ? 2 : 3))] += 1.0;
+  }
+#pragma unroll
+  for (int k = 0; k < 11; ++k) {
+    const double s = cn_block_sum<double, 256>(a[k], scratch);
+    if (threadIdx.x == 0 && s != 0.0) atomicAdd(counts + k, s);
+  }
+}
+
+__device__ __forceinline__ double ev_mcc(double tp, double fp, double fn, double tn) {
+  const double den = (tp + fp) * (tp + fn) * (tn + fp) * (tn + fn);
+  return den > 0.0 ? (tp * tn - fp * fn) / sqrt(den) : 0.0;  // torchmetrics: 0 when a marginal is empty
+}
+
+// out[7] = {dist_mae, dist_mse, edge_f, crop_f, edge_mcc, crop_mcc, score}
+__global__ void cn_eval_finalize_kernel(const double* __restrict__ c, const float* __restrict__ loss,
+                                        float* __restrict__ out) {
+  const double n = c[0] > 0.0 ? c[0] : 1.0;
+  const double mae = c[1] / n, mse = c[2] / n;
+  const double ef = (c[3] + c[6]) / n, cf = (c[7] + c[10]) / n;
+  const double em = ev_mcc(c[3], c[4], c[5], c[6]), cm = ev_mcc(c[7], c[8], c[9], c[10]);
+  out[0] = (float)mae; out[1] = (float)mse; out[2] = (float)ef; out[3] = (float)cf;
+  out[4] = (float)em; out[5] = (float)cm;
+  out[6] = (float)((double)loss[0] + (1.0 - ef) + (1.0 - cf) + mae + (1.0 - (em > 0.0 ? em : 0.0)) +
+                   (1.0 - (cm > 0.0 ? cm : 0.0)));
+}
+
+// dist / edge / crop: dense [B][1][H][W] fp32 probabilities; bdist [B][H][W]; labels int64 [B][H][W]; loss: 1 float
+// (device); counts: 11 doubles of scratch; out: 7 floats (device).
+extern "C" int cn_eval_metrics_f32(const float* dist, const float* edge, const float* crop, const float* bdist,
+                                   const long long* labels, int klass, float thresh, long n, const float* loss,
+                                   double* counts, float* out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (hipMemsetAsync(counts, 0, 11 * sizeof(double), stream) != hipSuccess) return CN_ERR_LAUNCH;
+  if (n > 0) {
+    long nb = (n + 255) / 256;
+    if (nb > 1024) nb = 1024;
+    hipLaunchKernelGGL(cn_eval_counts_kernel, dim3((unsigned)nb), dim3(256), 0, stream, dist, edge, crop, bdist, labels,
+                       klass, thresh, n, counts);
+  }
+  hipLaunchKernelGGL(cn_eval_finalize_kernel, dim3(1), dim3(1), 0, stream, counts, loss, out);
+  return cn_check_launch();
+}

@@ -68,3 +68,26 @@ class Data:
     @property
     def width(self) -> int:
         return self.x.shape[4]
+
+
+def collate_fn(data_list: "list[Data]") -> Data:
+    """Concatenate samples into one batch (the DataLoader collate of /root/reference/src/cultionet/data/utils.py:
+    55-68): tensors and arrays are concatenated along their first axis, lists are chained, None stays None."""
+    first = data_list[0]
+    out = {}
+    for key in first.to_dict().keys():
+        v0 = getattr(first, key)
+        if v0 is None:
+            out[key] = None
+        elif isinstance(v0, torch.Tensor):
+            out[key] = torch.cat([getattr(d, key) for d in data_list])
+        elif isinstance(v0, np.ndarray):
+            out[key] = np.concatenate([getattr(d, key) for d in data_list])
+        elif isinstance(v0, list):
+            merged = []
+            for d in data_list:
+                merged = merged + getattr(d, key)
+            out[key] = merged
+        else:
+            raise TypeError(f"collate_fn: unsupported attribute type {type(v0)} for {key!r}")
+    return Data(**out)

@@ -91,6 +91,29 @@ class LightningModuleMixin(_Base):
     def cultionet_model(self) -> CultioNet:
         return getattr(self, self.model_attr)
 
+    # ---- device-side input prologue ----------------------------------------------------------
+    def set_norm_values(self, mean: T.Optional[torch.Tensor], std: T.Optional[torch.Tensor]) -> None:
+        """Per-channel z-score statistics (NormValues, utils/normalize.py:63-82) applied by the device prologue."""
+        self._norm_mean, self._norm_std = mean, std
+
+    def on_after_batch_transfer(self, batch: Data, dataloader_idx: int = 0) -> Data:
+        """Lightning hook, called once the batch is on the GPU. A batch whose ``x`` is still RAW (integer
+        reflectances, as stored by the reference's .pt files) is scaled / clipped / z-scored here by one HIP pass
+        (cn_prepare_chips_f32) instead of per sample on the CPU in EdgeDataset.get (data/datasets.py:443-446):
+        collate the raw samples with cultionet_amd.data.collate_fn and let the device do the arithmetic. Float
+        batches (already prepared upstream) pass through untouched."""
+        x = getattr(batch, "x", None)
+        if x is None or not x.is_cuda or x.dtype == torch.float32:
+            return batch
+        from .edges import SCALE_FACTOR, prepare_chips
+
+        batch.x = prepare_chips(x, getattr(self, "_norm_mean", None), getattr(self, "_norm_std", None))
+        bd = getattr(batch, "bdist", None)
+        if bd is not None and bd.dtype != torch.float32:
+            B = bd.shape[0]
+            batch.bdist = prepare_chips(bd.reshape(B, 1, 1, *bd.shape[1:])).reshape(bd.shape)
+        return batch
+
     def predict_step(self, batch: Data, batch_idx: int = None) -> T.Dict[str, torch.Tensor]:
         return self.forward(batch, batch_idx=batch_idx)
 
@@ -149,24 +172,110 @@ class LightningModuleMixin(_Base):
         self.log("loss", loss, on_step=False, on_epoch=True, prog_bar=True, batch_size=batch.num_samples)
         return loss
 
-    def validation_step(self, batch: Data, batch_idx: int = None) -> dict:
+    def probas_to_labels(self, x: torch.Tensor, thresh: float = 0.5) -> torch.Tensor:
+        """lightning.py:126-136."""
+        if x.shape[1] == 1:
+            return x.gt(thresh).squeeze(dim=1).long()
+        return x.argmax(dim=1).long()
+
+    def _shared_eval_step(self, batch: Data, batch_idx: int = None) -> dict:
+        """lightning.py:374-481: loss + the torchmetrics scores, computed on the device by ONE fused kernel
+        (masked MAE / MSE, two 2x2 confusion matrices, micro F-beta = accuracy, MCC, checkpoint score): no
+        torchmetrics round trips, no masked_select copies, no host sync."""
+        from . import _lib
+
         with torch.no_grad():
             predictions = self(batch)
-            loss, report = self.calc_loss(batch, predictions)
-        metrics = {"vloss": loss, **{f"v{k}": v for k, v in report.items()}}
-        self.log_dict(metrics, on_step=False, on_epoch=True, prog_bar=True)
+            loss, loss_report = self.calc_loss(batch, predictions)
+            dist = predictions[InferenceNames.DISTANCE].float().contiguous()
+            edge = predictions[InferenceNames.EDGE].float().contiguous()
+            crop = predictions[InferenceNames.CROP].float().contiguous()
+            if edge.shape[1] != 1 or crop.shape[1] != 1:
+                raise NotImplementedError("the fused metrics kernel covers single-channel edge / crop maps")
+            y = batch.y if batch.y.dtype == torch.int64 else batch.y.long()
+            y = y.contiguous()
+            bdist = batch.bdist.float().contiguous()
+            dev = dist.device
+            counts = torch.empty(11, dtype=torch.float64, device=dev)
+            out = torch.empty(7, dtype=torch.float32, device=dev)
+            lossd = loss.detach().float().reshape(1).contiguous()
+            _lib.call("cn_eval_metrics_f32", dist.data_ptr(), edge.data_ptr(), crop.data_ptr(), bdist.data_ptr(),
+                      y.data_ptr(), int(self.edge_class), 0.5, y.numel(), lossd.data_ptr(), counts.data_ptr(),
+                      out.data_ptr(), E._stream())
+        metrics = {
+            "loss": loss,
+            "dist_mae": out[0],
+            "dist_mse": out[1],
+            "edge_f1": out[2],
+            "crop_f1": out[3],
+            "edge_mcc": out[4],
+            "crop_mcc": out[5],
+            "score": out[6],
+        }
+        metrics.update(loss_report)
         return metrics
 
+    def validation_step(self, batch: Data, batch_idx: int = None) -> dict:
+        """lightning.py:483-508 (``val_score`` is what callbacks.py:246 checkpoints on)."""
+        eval_metrics = self._shared_eval_step(batch, batch_idx)
+        metrics = {
+            "vef1": eval_metrics["edge_f1"],
+            "vcf1": eval_metrics["crop_f1"],
+            "vmae": eval_metrics["dist_mae"],
+            "val_score": eval_metrics["score"],
+            "val_loss": eval_metrics["loss"],
+            "val_dloss": eval_metrics["dloss"],
+            "val_eloss": eval_metrics["eloss"],
+            "val_closs": eval_metrics["closs"],
+        }
+        self.log_dict(metrics, on_step=False, on_epoch=True, prog_bar=True, batch_size=batch.num_samples)
+        if self.save_batch_val_metrics:
+            self._save_batch_metrics(metrics, getattr(self, "current_epoch", 0), batch)
+        return metrics
+
+    def _save_batch_metrics(self, metrics: T.Dict[str, torch.Tensor], epoch: int, batch: Data) -> None:
+        """lightning.py:510-533: appends the batch metrics to <logger.save_dir>/batch_metrics.parquet."""
+        import pandas as pd
+
+        trainer = getattr(self, "trainer", None)
+        if trainer is not None and getattr(trainer, "sanity_checking", False):
+            return
+        logger = getattr(self, "logger", None)
+        save_dir = getattr(logger, "save_dir", None) if logger is not None else None
+        if save_dir is None:
+            return
+        ids = list(getattr(batch, "train_id", []) or [])
+        write_metrics = {"epoch": [epoch] * len(ids), "train_ids": ids}
+        for k, v in metrics.items():
+            write_metrics[k] = [float(v)] * len(ids)
+        metrics_file = Path(save_dir) / "batch_metrics.parquet"
+        df = pd.DataFrame(write_metrics)
+        if metrics_file.is_file():
+            df = pd.concat((pd.read_parquet(metrics_file), df), axis=0)
+        df.to_parquet(metrics_file)
+
     def test_step(self, batch: Data, batch_idx: int = None) -> dict:
-        with torch.no_grad():
-            predictions = self(batch)
-            loss, report = self.calc_loss(batch, predictions)
-        metrics = {"tloss": loss, **{f"t{k}": v for k, v in report.items()}}
+        """lightning.py:535-560. Upstream also reads ``edge_dice`` / ``crop_dice`` / ``edge_jaccard`` / ``crop_jaccard``
+        there, keys its _shared_eval_step never produces (a KeyError in the reference): the keys that exist are
+        logged."""
+        eval_metrics = self._shared_eval_step(batch, batch_idx)
+        metrics = {
+            "test_loss": eval_metrics["loss"],
+            "tmae": eval_metrics["dist_mae"],
+            "tmse": eval_metrics["dist_mse"],
+            "tef1": eval_metrics["edge_f1"],
+            "tcf1": eval_metrics["crop_f1"],
+            "temcc": eval_metrics["edge_mcc"],
+            "tcmcc": eval_metrics["crop_mcc"],
+            "test_score": eval_metrics["score"],
+        }
         self.log_dict(metrics, on_step=False, on_epoch=True, prog_bar=True)
         return metrics
 
     def configure_scorer(self):
-        """lightning.py:562-577 (torchmetrics scorers; validation bookkeeping is out of scope)."""
+        """lightning.py:562-577. The four torchmetrics scorers (MAE, MSE, micro F-beta(2), MCC) are evaluated by the
+        fused HIP metrics kernel in _shared_eval_step; the attributes are kept (torchmetrics objects when that package
+        is installed) for code that reaches for them."""
         try:
             import torchmetrics  # type: ignore
 
@@ -224,6 +333,106 @@ class LightningModuleMixin(_Base):
             "lr_scheduler": {"scheduler": model_lr_scheduler, "name": "lr_sch", "monitor": "val_score",
                              "interval": interval, "frequency": 1},
         }
+
+
+class CultionetLitTransferModel(LightningModuleMixin):
+    """lightning.py:686-818: transfer learning on a pretrained CultionetLitModel checkpoint.
+
+    ``finetune``: "all" trains everything; "fc" freezes the network and unfreezes the ``mask_model.final_*`` heads;
+    anything else (the default None) freezes the network and REPLACES final_a / final_b / final_c / final_combine by
+    freshly initialised, trainable heads. Frozen parameters keep ``requires_grad=False`` (torch optimizers skip them);
+    the HIP tape still writes their gradient slices, which nothing reads.
+    """
+
+    def __init__(
+        self,
+        pretrained_ckpt_file: T.Union[Path, str],
+        in_channels: int,
+        in_time: int,
+        hidden_channels: int = 64,
+        model_type: str = ModelTypes.TOWERUNET,
+        dropout: float = 0.2,
+        activation_type: str = "SiLU",
+        dilations: T.Union[int, T.Sequence[int]] = None,
+        res_block_type: str = ResBlockTypes.RESA,
+        attention_weights: str = AttentionTypes.NATTEN,
+        optimizer: str = "AdamW",
+        loss_name: str = LossTypes.TANIMOTO_COMPLEMENT,
+        learning_rate: float = 0.01,
+        lr_scheduler: str = LearningRateSchedulers.ONE_CYCLE_LR,
+        steplr_step_size: int = 5,
+        weight_decay: float = 1e-3,
+        eps: float = 1e-4,
+        ckpt_name: str = "last_transfer",
+        model_name: str = "cultionet_transfer",
+        pool_by_max: bool = False,
+        batchnorm_first: bool = False,
+        class_counts: T.Optional[torch.Tensor] = None,
+        edge_class: T.Optional[int] = None,
+        scale_pos_weight: bool = False,
+        save_batch_val_metrics: bool = False,
+        finetune: T.Optional[str] = None,
+    ):
+        super().__init__()
+        self.save_hyperparameters()
+        from .nunet import init_conv_weights
+        from .unet_parts import TowerUNetFinal, TowerUNetFinalCombine
+
+        self.optimizer = optimizer
+        self.loss_name = loss_name
+        self.learning_rate = learning_rate
+        self.lr_scheduler = lr_scheduler
+        self.steplr_step_size = steplr_step_size
+        self.weight_decay = weight_decay
+        self.eps = eps
+        self.ckpt_name = ckpt_name
+        self.model_name = model_name
+        self.in_time = in_time
+        self.class_counts = class_counts
+        self.scale_pos_weight = scale_pos_weight
+        self.save_batch_val_metrics = save_batch_val_metrics
+        self.finetune = finetune
+        self.edge_class = edge_class if edge_class is not None else 2
+
+        cultionet_model = CultionetLitModel.load_from_checkpoint(
+            checkpoint_path=str(pretrained_ckpt_file)).cultionet_model
+        if self.finetune != "all":
+            self.freeze(cultionet_model)
+            if self.finetune == "fc":
+                for name, param in cultionet_model.named_parameters():
+                    if name.startswith("mask_model.final_"):
+                        param.requires_grad = True
+            else:
+                mm = cultionet_model.mask_model
+                for attr, factor in (("final_a", 0), ("final_b", 2), ("final_c", 4)):
+                    old = getattr(mm, attr)
+                    new = TowerUNetFinal(in_channels=old.in_channels, num_classes=old.num_classes,
+                                         activation_type=activation_type, resample_factor=factor)
+                    new.apply(init_conv_weights)
+                    setattr(mm, attr, new)
+                fc = mm.final_combine
+                new_fc = TowerUNetFinalCombine(num_classes=fc.num_classes, edge_activation=fc.edge_activation,
+                                               mask_activation=fc.mask_activation)
+                new_fc.apply(init_conv_weights)
+                mm.final_combine = new_fc
+                mm.__dict__["_cn_store"] = None  # modules were replaced: re-flatten the parameters on next use
+        self.model_attr = f"{model_name}_{model_type}"
+        setattr(self, self.model_attr, cultionet_model)
+        self.configure_loss()
+        self.configure_scorer()
+
+    @property
+    def is_transfer_model(self) -> bool:
+        return True
+
+    def freeze(self, layer):
+        for param in layer.parameters():
+            param.requires_grad = False
+
+    def unfreeze(self, layer):
+        for param in layer.parameters():
+            param.requires_grad = True
+        return layer
 
 
 class CultionetLitModel(LightningModuleMixin):
@@ -325,6 +534,9 @@ class HipTrainer:
         self.bf16 = precision in ("bf16-mixed", "16-mixed")
         if lit.optimizer != "AdamW":
             raise NotImplementedError("the fused HIP optimizer implements AdamW (the reference default)")
+        if any(not p.requires_grad for p in self.store.params):
+            raise NotImplementedError("frozen parameters (CultionetLitTransferModel): the fused optimizer updates the "
+                                      "whole flat buffer; train transfer models through the drop-in (torch optimizer) mode")
         if comm is not None:
             # torch DDP (the reference's strategy="ddp", model.py:101,184) broadcasts rank 0's parameters and buffers
             # at construction; dropout masks must differ per rank (each rank draws its own torch RNG stream upstream)

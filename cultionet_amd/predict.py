@@ -1,0 +1,78 @@
+"""Sliding-window scene prediction on the device (BASELINE configs[4]).
+
+The reference predicts a scene by (a) cutting it into ``window_size`` chunks grown by ``padding`` on every side with
+zero fill at the scene border and zero-filled to ``window_size + 2*padding`` squares
+(/root/reference/src/cultionet/data/create.py:176-212, data/store.py:69-100), one ``.pt`` file per window; (b)
+``EdgeDataset.get`` scaling each window (x/10000, clip(1e-9, 1), optional z-score; data/datasets.py:443-488,
+utils/normalize.py:63-82); (c) ``predict_step``; (d) ``LightningGTiffWriter.write_on_batch_end`` slicing the padding
+off, x10000, clip, and writing the window into the GeoTIFF (callbacks.py:176-227), one window at a time through
+Python, numpy and a file lock.
+
+Here the raw scene stays resident in HBM in its stored integer type; every batch of windows is cut + scaled + z-scored
+by ONE kernel (cn_window_chips_f32), run through the HIP eval forward, and stitched into the uint16 [3, H, W] mosaic
+by ONE kernel (cn_stitch_predictions_u16). File IO (GeoTIFF) stays with the caller.
+"""
+from __future__ import annotations
+
+import typing as T
+
+import torch
+
+from . import _lib
+from .edges import _DTYPES, SCALE_FACTOR
+from .engine import _stream
+
+
+def window_origins(height: int, width: int, window_size: int) -> T.List[T.Tuple[int, int]]:
+    """Row-major window origins (row_off, col_off): the chunk grid of data/create.py:176-182."""
+    return [(r, c) for r in range(0, height, window_size) for c in range(0, width, window_size)]
+
+
+class SlidingWindowPredictor:
+    """``predict_scene(scene)``: raw [C, T, H, W] scene (f32 / i32 / i16 / u16, on the GPU) -> uint16 [3, H, W]
+    (distance, edge, crop) x 10000, exactly the bands LightningGTiffWriter writes."""
+
+    def __init__(self, lit, window_size: int = 100, padding: int = 5, batch_size: int = 8,
+                 mean: T.Optional[torch.Tensor] = None, std: T.Optional[torch.Tensor] = None,
+                 scale: float = 1.0 / SCALE_FACTOR, lo: float = 1e-9, hi: float = 1.0):
+        if window_size <= 0 or padding < 0 or batch_size <= 0:
+            raise ValueError("window_size, batch_size must be positive and padding non-negative")
+        self.lit = lit
+        self.ws, self.pad, self.bs = int(window_size), int(padding), int(batch_size)
+        self.mean, self.std = mean, std
+        self.scale, self.lo, self.hi = float(scale), float(lo), float(hi)
+
+    @torch.no_grad()
+    def predict_scene(self, scene: torch.Tensor) -> torch.Tensor:
+        if not scene.is_cuda:
+            raise RuntimeError("predict_scene needs the scene on the GPU (there is no CPU fallback)")
+        if scene.dim() != 4 or scene.dtype not in _DTYPES:
+            raise ValueError("scene must be [C, T, H, W] of dtype f32 / i32 / i16 / u16")
+        scene = scene.contiguous()
+        C, Tn, H, W = scene.shape
+        dev = scene.device
+        S = self.ws + 2 * self.pad
+        origins = window_origins(H, W, self.ws)
+        rc = torch.tensor(origins, dtype=torch.int32).to(dev)
+        out = torch.zeros((3, H, W), dtype=torch.uint16, device=dev)
+        f32 = lambda t: t.to(device=dev, dtype=torch.float32).reshape(-1).contiguous() if t is not None else None
+        mean, std = f32(self.mean), f32(self.std)
+        if mean is not None and mean.numel() != C:
+            raise ValueError("mean / std must hold one value per channel")
+        was_training = self.lit.training
+        self.lit.eval()
+        try:
+            for i in range(0, len(origins), self.bs):
+                n = min(self.bs, len(origins) - i)
+                x = torch.empty((n, C, Tn, S, S), dtype=torch.float32, device=dev)
+                _lib.call("cn_window_chips_f32", scene.data_ptr(), _DTYPES[scene.dtype], x.data_ptr(),
+                          rc[i:i + n].data_ptr(), n, C, Tn, H, W, S, self.pad,
+                          mean.data_ptr() if mean is not None else None, std.data_ptr() if std is not None else None,
+                          self.scale, self.lo, self.hi, _stream())
+                pred = self.lit.cultionet_model.mask_model(x)
+                d, e, c = (pred[k].float().contiguous() for k in ("distance", "edge", "crop"))
+                _lib.call("cn_stitch_predictions_u16", d.data_ptr(), e.data_ptr(), c.data_ptr(), out.data_ptr(),
+                          rc[i:i + n].data_ptr(), n, S, self.pad, self.ws, H, W, float(SCALE_FACTOR), _stream())
+        finally:
+            self.lit.train(was_training)
+        return out

@@ -40,6 +40,7 @@ class TowerUNetFinalCombine(nn.Module):
         super().__init__()
         if num_classes != 1 or not edge_activation or not mask_activation:
             raise NotImplementedError("the fused final-combine kernel covers num_classes=1 with both activations")
+        self.num_classes, self.edge_activation, self.mask_activation = num_classes, edge_activation, mask_activation
         self.final_dist = nn.Sequential(nn.Conv2d(1, 1, kernel_size=1, padding=0), nn.Sigmoid())
         self.dist_gamma1 = nn.Parameter(torch.ones(1, requires_grad=True))
         self.dist_gamma2 = nn.Parameter(torch.ones(1, requires_grad=True))

@@ -262,6 +262,15 @@ int cn_tanimoto_bwd_f32(const float* pred, long pbs, const float* target_f, cons
                         int target_mode, int mask_mode, int klass, int B, int C, long HW, const float* coef,
                         float upstream, float* dpred, long dbs, int accumulate, void* stream);
 
+/* ---- validation metrics of _shared_eval_step (models/lightning.py:374-481): masked MAE / MSE of the distance map,
+ * micro F-beta (= accuracy, torchmetrics FBetaScore(task="multiclass", num_classes=2)) and MatthewsCorrCoef of the
+ * thresholded edge / crop maps, and the checkpoint score. dist / edge / crop dense [B][1][H][W] fp32, n = B*H*W;
+ * valid pixels: labels != -1; loss: 1 device float. counts: 11 doubles scratch.
+ * out[7] = {dist_mae, dist_mse, edge_f, crop_f, edge_mcc, crop_mcc, score}. */
+int cn_eval_metrics_f32(const float* dist, const float* edge, const float* crop, const float* bdist,
+                        const long long* labels, int klass, float thresh, long n, const float* loss, double* counts,
+                        float* out, void* stream);
+
 /* ---- torch.optim.AdamW + clip_grad_norm_ (models/lightning.py:622-629, model.py:84,173) ------
  * one flat buffer each for params, grads, exp_avg, exp_avg_sq. sumsq nullable (no clipping). */
 int cn_grad_sumsq_f32(const float* g, long n, double* out, void* stream);
@@ -277,6 +286,16 @@ int cn_prepare_chips_f32(const void* x, int dtype, float* y, const float* mean, 
                          float scale, float lo, float hi, void* stream);
 int cn_predictions_to_u16(const float* dist, const float* edge, const float* crop, unsigned short* out, int B, int H,
                           int W, int pad_top, int pad_left, int h, int w, float scale, void* stream);
+/* sliding-window predict (BASELINE configs[4]; data/create.py:176-212, data/store.py:69-100, callbacks.py:176-227):
+ * window_chips: window n = crop [r0-pad, r0-pad+S) x [c0-pad, c0-pad+S) of the zero-extended scene [C*T][H][W]
+ *   (stored dtype as prepare), scaled / clipped / z-scored into fp32 [nwin][C*T][S][S]; win_rc: DEVICE int [nwin][2].
+ * stitch: out u16 [3][H][W] <- window interiors (padding dropped, x scale, clip, cast), clipped at the scene edge. */
+int cn_window_chips_f32(const void* scene, int dtype, float* out, const int* win_rc, int nwin, int C, int T, int H, int W,
+                        int S, int pad, const float* mean, const float* stdv, float scale, float lo, float hi,
+                        void* stream);
+int cn_stitch_predictions_u16(const float* dist, const float* edge, const float* crop, unsigned short* out,
+                              const int* win_rc, int nwin, int S, int pad, int ws, int H, int W, float scale,
+                              void* stream);
 
 
 /* ================================================================================================================

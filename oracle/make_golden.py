@@ -145,6 +145,26 @@ def main():
         np.savez_compressed(path, **d)
         print(name, os.path.getsize(path) // 1024, "KiB", "loss" in d and d["loss"])
 
+    if "--h64-only" in sys.argv:
+        # the CLI default width (scripts/args.yml:220-226: hidden_channels 64)
+        save("train_h64_b1_100.npz", _train_case(ns, 64, 1, 100, 100, True))
+        return
+    if "--metrics-only" in sys.argv:
+        # validation metrics: the reference's own validation_step (eval mode, no_grad, as Lightning
+        # calls it) with the torchmetrics scorers of oracle/metrics_ref.py (or a real torchmetrics when importable)
+        for name, mask in (("val_h8_b2_28_masked", True), ("val_h8_b2_28", False)):
+            m = _ref_model(ns, 8)
+            xc, yc, bc = O.seeded_batch(2, height=28, width=28, seed=1011)
+            cal = ns.Data(x=xc, y=yc, bdist=bc, lon=torch.zeros(2), lat=torch.zeros(2))
+            calibrate_bn(m, lambda: m(cal))
+            x, y, bdist = O.seeded_batch(2, height=28, width=28, seed=11, with_mask=mask)
+            batch = ns.Data(x=x, y=y, bdist=bdist, lon=torch.zeros(2), lat=torch.zeros(2))
+            with torch.no_grad():
+                met = m.validation_step(batch)
+            out = {k: np.float64(float(v)) for k, v in met.items()}
+            out["meta"] = np.array([8, 2, 28, 28, int(mask), 11])
+            save(name + ".npz", out)
+        return
     if "--bf16-only" in sys.argv:
         # mixed-precision fixtures (BASELINE configs[2]): the reference under CPU bf16 autocast, plus the fp32 run of
         # the SAME case so the tests can state the tolerance relative to the reference's own bf16 deviation

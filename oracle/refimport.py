@@ -61,17 +61,24 @@ def import_reference():
     lightning.LightningModule = LightningModule
     sys.modules["lightning"] = lightning
 
-    tm = types.ModuleType("torchmetrics")
+    try:  # a real torchmetrics pins the validation metrics; absent here => the restatement in oracle/metrics_ref.py
+        import torchmetrics  # noqa: F401
+    except Exception:
+        from . import metrics_ref
 
-    class _Metric(nn.Module):
-        def __init__(self, *a, **k):
-            super().__init__()
+        tm = types.ModuleType("torchmetrics")
+        for name in ("MeanAbsoluteError", "MeanSquaredError", "FBetaScore", "MatthewsCorrCoef"):
+            setattr(tm, name, getattr(metrics_ref, name))
+        sys.modules["torchmetrics"] = tm
 
-    for name in ("MeanAbsoluteError", "MeanSquaredError", "FBetaScore", "MatthewsCorrCoef"):
-        setattr(tm, name, _Metric)
-    sys.modules["torchmetrics"] = tm
+    # natten: the REAL package pins NA2D whenever it is importable (it is not, in this image); otherwise the stub
+    # below routes the reference to our restatement (the only non-torch arithmetic on the path)
+    try:
+        import natten as _real_natten  # noqa: F401
 
-    # natten stub -> our restatement (the only non-torch arithmetic on the path)
+        have_natten = hasattr(_real_natten, "NeighborhoodAttention2D")
+    except Exception:
+        have_natten = False
     natten = types.ModuleType("natten")
     natten.NeighborhoodAttention2D = na2d_ref.NeighborhoodAttention2D
     nf = types.ModuleType("natten.functional")
@@ -79,8 +86,9 @@ def import_reference():
     nf.na2d_qk = na2d_ref.na2d_qk
     nf.na2d_av = na2d_ref.na2d_av
     natten.functional = nf
-    sys.modules["natten"] = natten
-    sys.modules["natten.functional"] = nf
+    if not have_natten:
+        sys.modules["natten"] = natten
+        sys.modules["natten.functional"] = nf
 
     # cultionet.data stub: the in-memory contract of data/data.py:51-139
     data_mod = types.ModuleType("cultionet.data")

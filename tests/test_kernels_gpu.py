@@ -235,7 +235,9 @@ def test_layer_norm_c(shape, res):
 
 
 @pytest.mark.parametrize("B,C,heads,H,W,dil", [(2, 32, 4, 14, 14, 1), (1, 32, 4, 28, 28, 2), (2, 128, 8, 25, 25, 1),
-                                               (1, 128, 4, 50, 50, 2), (1, 16, 8, 7, 9, 2)])
+                                               (1, 128, 4, 50, 50, 2), (1, 16, 8, 7, 9, 2),
+                                               (8, 128, 4, 100, 100, 2),   # BASELINE configs[1]: tower a / up_au
+                                               (8, 128, 4, 50, 50, 1), (8, 128, 8, 25, 25, 1)])
 def test_na2d(B, C, heads, H, W, dil):
     from cultionet_amd import engine as E
     from oracle import na2d_ref as N

@@ -51,6 +51,7 @@ def _check_outputs(pred, g):
     ("train_h8_b2_28_res", {"res_block_type": "res", "attention_weights": None}),
     ("train_h8_b2_28_bnfirst", {"batchnorm_first": True}),
     ("train_h8_b2_28_sca", {"attention_weights": "spatial_channel"}),
+    ("train_h64_b1_100", {}),   # hidden_channels=64: the CLI default (scripts/args.yml:220-226)
 ])
 def test_native_train_step_matches_reference(golden_dir, name, kw):
     from cultionet_amd.lightning import HipTrainer
@@ -216,3 +217,31 @@ def test_dropin_torch_optimizer_step_refreshes_packed_weights(golden_dir):
     assert abs(losses[1] - rlosses[1]) <= 5e-4, (losses, rlosses)  # one AdamW step apart: not bitwise, but the same weights
     assert abs(losses[2] - rlosses[2]) <= 2e-3, (losses, rlosses)
     assert abs(losses[1] - losses[0]) > 1e-3  # the step did change the loss (a stale pack would hide in this gap)
+
+
+def test_batch32_fp32_matches_oracle():
+    """Per-GPU batch 32 in fp32 (the batch of BASELINE configs[2]/[3]) against the CPU oracle on the same seeded
+    weights / inputs: probability maps and loss to 1e-4, gradient norms to 2e-3 relative."""
+    from cultionet_amd.data import Data
+    from cultionet_amd.lightning import HipTrainer
+    from oracle import towerunet_oracle as O
+    from oracle.selfcheck import build_pair
+
+    torch.set_num_threads(min(32, os.cpu_count() or 8))
+    lit, ref = build_pair(hidden=32, device="cuda:0")
+    lit.train()
+    ref.train()
+    B = 32
+    x, y, bdist = O.seeded_batch(B, seed=21, with_mask=True)
+    pred = ref(x)
+    loss_ref, _ = O.calc_loss(pred, y, bdist)
+    loss_ref.backward()
+    batch = Data(x=x.cuda(), y=y.cuda(), bdist=bdist.cuda())
+    trainer = HipTrainer(lit)
+    loss = trainer.forward_backward(batch)
+    torch.cuda.synchronize()
+    assert abs(float(loss.item()) - float(loss_ref.detach())) <= TOL
+    model = lit.cultionet_model.mask_model
+    for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
+        a, b_ = float(trainer.store.grad_of(p).double().norm()), float(pr.grad.double().norm())
+        assert abs(a - b_) <= 2e-3 * max(1e-3, abs(b_)) + 1e-6, n

@@ -1,0 +1,66 @@
+"""SURVEY 8(f)-2/3 and BASELINE configs[4]: collate + device prologue, and sliding-window scene prediction against the
+CPU restatement oracle/predict_ref.py (the reference's predict path needs the GIS stack: restatement-checked)."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _pair(hidden=8, C=3, Tn=12):
+    from oracle.make_golden import calibrate_bn
+    from oracle.selfcheck import build_pair
+    from oracle import towerunet_oracle as O
+
+    lit, ref = build_pair(hidden=hidden, in_channels=C, in_time=Tn)
+    xc, _, _ = O.seeded_batch(2, channels=C, time=Tn, height=28, width=28, seed=77)
+    calibrate_bn(ref, lambda: ref(xc))
+    lit.cultionet_model.mask_model.load_state_dict(ref.state_dict())
+    return lit, ref
+
+
+@pytest.mark.parametrize("H,W,ws,pad", [(70, 95, 40, 4), (64, 64, 32, 6), (50, 41, 64, 5)])
+def test_sliding_window_predict_matches_restatement(H, W, ws, pad):
+    from cultionet_amd.predict import SlidingWindowPredictor
+    from oracle import predict_ref
+
+    lit, ref = _pair()
+    g = torch.Generator().manual_seed(H * 131 + W)
+    scene = torch.randint(0, 9000, (3, 12, H, W), generator=g, dtype=torch.int32).to(torch.int16)
+    mean = torch.tensor([0.31, 0.28, 0.35])
+    std = torch.tensor([0.21, 0.19, 0.24])
+    want = predict_ref.predict_scene(ref, scene.numpy().astype(np.float64), ws, pad, mean.numpy(), std.numpy())
+    pred = SlidingWindowPredictor(lit, window_size=ws, padding=pad, batch_size=3, mean=mean, std=std)
+    got = pred.predict_scene(scene.cuda()).cpu().numpy().astype(np.int64)
+    d = np.abs(got - want.astype(np.int64))
+    # probabilities agree to ~1e-5 (x10000 = 0.1 count): a count flips only when a value straddles an integer
+    assert d.max() <= 2, d.max()
+    assert (d > 0).mean() <= 0.05, (d > 0).mean()
+    assert got.shape == (3, H, W) and got.max() <= 10000
+
+
+def test_collate_and_device_prologue():
+    from cultionet_amd.data import Data, collate_fn
+    from cultionet_amd.lightning import CultionetLitModel
+
+    g = torch.Generator().manual_seed(3)
+    samples = []
+    for i in range(3):
+        samples.append(Data(x=torch.randint(0, 9000, (1, 3, 12, 20, 20), generator=g, dtype=torch.int32),
+                            y=torch.randint(-1, 3, (1, 20, 20), generator=g),
+                            bdist=torch.randint(0, 10000, (1, 20, 20), generator=g, dtype=torch.int32),
+                            train_id=[f"s{i}"], lon=torch.zeros(1), extra=None, arr=np.array([i])))
+    batch = collate_fn(samples)
+    assert batch.x.shape == (3, 3, 12, 20, 20) and batch.train_id == ["s0", "s1", "s2"] and batch.extra is None
+    assert np.array_equal(batch.arr, np.array([0, 1, 2])) and batch.num_samples == 3
+    lit = CultionetLitModel(in_channels=3, in_time=12, hidden_channels=8, dropout=0.0).to("cuda:0")
+    mean, std = torch.tensor([0.3, 0.25, 0.4]), torch.tensor([0.2, 0.15, 0.3])
+    lit.set_norm_values(mean, std)
+    dev = batch.to("cuda:0")
+    out = lit.on_after_batch_transfer(dev)
+    want = ((batch.x.float() / 10000.0).clip(1e-9, 1) - mean.view(1, 3, 1, 1, 1)) / std.view(1, 3, 1, 1, 1)
+    assert (out.x.cpu() - want).abs().max() <= 1e-6
+    wb = (batch.bdist.float() / 10000.0).clip(1e-9, 1)
+    assert (out.bdist.cpu() - wb).abs().max() <= 1e-7
+    pred = lit.eval()(out)  # the prepared batch feeds the forward
+    assert pred["distance"].shape == (3, 1, 20, 20)
