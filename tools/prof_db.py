@@ -6,7 +6,7 @@ c = sqlite3.connect(sys.argv[1])
 n = int(sys.argv[2]) if len(sys.argv) > 2 else 40
 rows = c.execute("select name, total_calls, total_duration, average, percentage from top_kernels").fetchall()
 tot = sum(r[2] for r in rows)
-print(f"total kernel time {tot / 1e3:.1f} ms over {sum(r[1] for r in rows)} launches")
+print(f"total kernel time {tot / 1e3:.1f} ms over {sum(r[1] for r in rows)} launches", file=sys.stderr)
 if "--csv" in sys.argv:
     print('"Name","Calls","TotalDurationNs","AverageNs","Percentage"')
     for r in rows:
