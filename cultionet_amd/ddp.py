@@ -21,6 +21,8 @@ import typing as T
 import torch
 import torch.distributed as dist
 
+from . import engine as _engine
+
 
 def plan_buckets(offsets: T.Sequence[int], sizes: T.Sequence[int], ready_node: T.Sequence[int], total: int,
                  bucket_elems: int) -> T.List[T.Tuple[int, int, int]]:
@@ -98,8 +100,13 @@ class GradientAllReduce:
         for k in range(len(nodes) - 1, -1, -1):
             nodes[k]()
             nodes[k] = None
-            for lo, hi in by_node.get(k, ()):
+            ready = by_node.get(k, ())
+            if ready and on_gpu:
+                _engine.join_side_stream()  # weight gradients run on the engine's side stream
+            for lo, hi in ready:
                 works.append(self._launch(flat[lo:hi], on_gpu))
+        if on_gpu:
+            _engine.join_side_stream()
         for lo, hi, r in plan:  # buckets whose ready index lies outside the tape (no nodes recorded)
             if r >= len(nodes) or r < 0:
                 works.append(self._launch(flat[lo:hi], on_gpu))

@@ -133,6 +133,68 @@ class Tape:
         nodes, self.nodes = self.nodes, []
         while nodes:
             nodes.pop()()
+        join_side_stream()
+
+
+# ---------------------------------------------------------------------------
+# weight gradients on a side stream
+# ---------------------------------------------------------------------------
+# In backward only dx feeds the next node; dW (and bias gradients) are needed by the optimizer alone. Their launches
+# go to a second HIP stream that waits for the node's dy, so the launch-shaped layers of the coarse levels (25x25,
+# 13x13: a fraction of the 256 CUs each) run beside the dx chain instead of in front of it. The main stream joins
+# the side stream once, before the gradient exchange / optimizer. CN_OVERLAP_WGRAD=0 keeps everything on one stream.
+_OVERLAP_WGRAD = os.environ.get("CN_OVERLAP_WGRAD", "1") == "1"
+_side_streams: T.Dict[T.Any, T.Dict[str, T.Any]] = {}
+
+
+def _side_state(dev) -> T.Dict[str, T.Any]:
+    st = _side_streams.get(dev)
+    if st is None:
+        st = {"stream": torch.cuda.Stream(device=dev), "event": torch.cuda.Event(), "dirty": False}
+        _side_streams[dev] = st
+    return st
+
+
+class side_stream:
+    """Context manager: enqueue the enclosed launches on the side stream, ordered after everything enqueued so far on
+    the current stream. ``tensors`` are the buffers those launches read (kept from being recycled by the caching
+    allocator until the side stream has passed them)."""
+
+    def __init__(self, *tensors: torch.Tensor):
+        self.tensors = tensors
+        self.ctx = None
+
+    def __enter__(self):
+        if not _OVERLAP_WGRAD:
+            return self
+        main = torch.cuda.current_stream()
+        st = _side_state(main.device)
+        st["event"].record(main)
+        st["stream"].wait_event(st["event"])
+        st["dirty"] = True
+        self.st = st
+        self.ctx = torch.cuda.stream(st["stream"])
+        self.ctx.__enter__()
+        return self
+
+    def __exit__(self, *exc):
+        if self.ctx is not None:
+            self.ctx.__exit__(*exc)
+            for t in self.tensors:
+                if t is not None:
+                    t.record_stream(self.st["stream"])
+        return False
+
+
+def join_side_stream() -> None:
+    """Make the current stream wait for every weight-gradient launch issued so far."""
+    if not torch.cuda.is_available():
+        return
+    main = torch.cuda.current_stream()
+    st = _side_streams.get(main.device)
+    if st is not None and st["dirty"]:
+        main.wait_stream(st["stream"])
+        st["dirty"] = False
 
 
 def current_tape() -> Tape:
@@ -496,6 +558,8 @@ def _pad_ws(*tensors: torch.Tensor) -> T.Tuple[T.Optional[int], int]:
         pool = _state.ws_pool = {}
     ws = pool.get(dev)
     if ws is None or ws.numel() < need:
+        if ws is not None:  # growing: the old buffer may still be read by launches in flight on the side stream
+            torch.cuda.synchronize(dev)
         ws = pool[dev] = torch.empty(need, dtype=torch.float32, device=dev)
     return ws.data_ptr(), ws.numel()
 
@@ -527,17 +591,19 @@ def conv2d(x: Var, mod, stride: int = 1, padding: int = 0, dilation: int = 1, ou
             dy = yv.grad
             if dy is None:
                 return
-            s = _stream()
-            wsp, wsn = _pad_ws(xt, dy)
-            _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
-                      store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, wsp, wsn, s)
-            if bias is not None:
-                _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Ho * Wo,
-                          store.grad_of(bias).data_ptr(), 1, s)
+            with side_stream(xt, dy):
+                s = _stream()
+                wsp, wsn = _pad_ws(xt, dy)
+                _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
+                          store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, wsp, wsn,
+                          s)
+                if bias is not None:
+                    _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Ho * Wo,
+                              store.grad_of(bias).data_ptr(), 1, s)
             if x.req:
                 dx, acc = grad_buffer(x)
                 _lib.call("cn_conv2d_bwd_data_f32", dy.data_ptr(), bstride(dy), pw.bwd.data_ptr(), dx.data_ptr(),
-                          bstride(dx), B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, acc, s)
+                          bstride(dx), B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, acc, _stream())
             yv.grad = None
 
         tape.add(bwd, (w, bias))
@@ -582,30 +648,32 @@ def conv2d_group(xs: T.Sequence[Var], mods: T.Sequence, paddings: T.Sequence[int
         store = current_store()
 
         def bwd():
-            s = _stream()
             live = [i for i in range(G) if yvs[i].grad is not None]
             grouped_w = (len(live) == G and len(set(paddings)) == 1 and len(set(dilations)) == 1
                          and len({bstride(yvs[i].grad) for i in live}) == 1)
-            if grouped_w:  # one launch for the G weight gradients
-                wsp, wsn = _pad_ws(*([xts[i] for i in range(G)] + [yvs[i].grad for i in range(G)]))
-                _lib.call("cn_conv2d_bwd_weight_grouped_f32", G, tab([t.data_ptr() for t in xts]), bstride(xts[0]),
-                          tab([yvs[i].grad.data_ptr() for i in range(G)]), bstride(yvs[0].grad),
-                          tab([store.grad_of(m.weight).data_ptr() for m in mods]), B, Cin, H, W, Cout, KH, KW, stride,
-                          paddings[0], dilations[0], wsp, wsn, s)
-            for i in live:
-                dy, m, xt = yvs[i].grad, mods[i], xts[i]
-                if grouped_w:
+            with side_stream(*(list(xts) + [yvs[i].grad for i in live])):
+                s = _stream()
+                if grouped_w:  # one launch for the G weight gradients
+                    wsp, wsn = _pad_ws(*([xts[i] for i in range(G)] + [yvs[i].grad for i in range(G)]))
+                    _lib.call("cn_conv2d_bwd_weight_grouped_f32", G, tab([t.data_ptr() for t in xts]), bstride(xts[0]),
+                              tab([yvs[i].grad.data_ptr() for i in range(G)]), bstride(yvs[0].grad),
+                              tab([store.grad_of(m.weight).data_ptr() for m in mods]), B, Cin, H, W, Cout, KH, KW,
+                              stride, paddings[0], dilations[0], wsp, wsn, s)
+                for i in live:
+                    dy, m, xt = yvs[i].grad, mods[i], xts[i]
+                    if grouped_w:
+                        if has_bias:
+                            _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Ho * Wo,
+                                      store.grad_of(m.bias).data_ptr(), 1, s)
+                        continue
+                    wsp, wsn = _pad_ws(xt, dy)
+                    _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
+                              store.grad_of(m.weight).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, paddings[i],
+                              dilations[i], wsp, wsn, s)
                     if has_bias:
                         _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Ho * Wo,
                                   store.grad_of(m.bias).data_ptr(), 1, s)
-                    continue
-                wsp, wsn = _pad_ws(xt, dy)
-                _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
-                          store.grad_of(m.weight).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, paddings[i],
-                          dilations[i], wsp, wsn, s)
-                if has_bias:
-                    _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Ho * Wo,
-                              store.grad_of(m.bias).data_ptr(), 1, s)
+            s = _stream()
             todo = [i for i in live if xs[i].req]
             if todo:
                 bufs = []
@@ -668,17 +736,18 @@ def conv_transpose2d(x: Var, mod, stride: int, padding: int) -> Var:
             dy = yv.grad
             if dy is None:
                 return
-            s = _stream()
-            wsp, wsn = _pad_ws(xt, dy)
-            _lib.call("cn_conv_transpose2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
-                      store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, wsp, wsn, s)
-            if bias is not None:
-                _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Ho * Wo,
-                          store.grad_of(bias).data_ptr(), 1, s)
+            with side_stream(xt, dy):
+                s = _stream()
+                wsp, wsn = _pad_ws(xt, dy)
+                _lib.call("cn_conv_transpose2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
+                          store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, wsp, wsn, s)
+                if bias is not None:
+                    _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Ho * Wo,
+                              store.grad_of(bias).data_ptr(), 1, s)
             if x.req:
                 dx, acc = grad_buffer(x)
                 _lib.call("cn_conv_transpose2d_bwd_data_f32", dy.data_ptr(), bstride(dy), pw.bwd.data_ptr(),
-                          dx.data_ptr(), bstride(dx), B, Cin, H, W, Cout, KH, KW, stride, padding, acc, s)
+                          dx.data_ptr(), bstride(dx), B, Cin, H, W, Cout, KH, KW, stride, padding, acc, _stream())
             yv.grad = None
 
         tape.add(bwd, (w, bias))
@@ -720,11 +789,14 @@ def time_conv(x: Var, mod, tin: int) -> Var:
             dy = yv.grad
             if dy is None:
                 return
+            with side_stream(xt, dy):
+                s = _stream()
+                dwexp = torch.zeros(Cout * tout * CT, dtype=torch.float32, device=xt.device)
+                _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
+                          dwexp.data_ptr(), B, CT, H, W, Cout * tout, 1, 1, 1, 0, 1, None, 0, s)
+                _lib.call("cn_fold_timeconv_grad_f32", dwexp.data_ptr(), store.grad_of(w).data_ptr(), Cout, Cin, tin, k,
+                          s)
             s = _stream()
-            dwexp = torch.zeros(Cout * tout * CT, dtype=torch.float32, device=xt.device)
-            _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
-                      dwexp.data_ptr(), B, CT, H, W, Cout * tout, 1, 1, 1, 0, 1, None, 0, s)
-            _lib.call("cn_fold_timeconv_grad_f32", dwexp.data_ptr(), store.grad_of(w).data_ptr(), Cout, Cin, tin, k, s)
             if x.req:
                 dx, acc = grad_buffer(x)
                 _lib.call("cn_conv2d_bwd_data_f32", dy.data_ptr(), bstride(dy), pw.bwd.data_ptr(), dx.data_ptr(),
@@ -1154,15 +1226,17 @@ def thin_conv3x3(x: Var, mods: T.Sequence, grouped: bool, dilation: int = 1,
             dy = yv.grad
             if dy is None:
                 return
+            with side_stream(xt, dy):
+                s = _stream()
+                dwtab = _ptr_table([store.grad_of(w).data_ptr() for w in ws])
+                _lib.call("cn_thin_conv3x3_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
+                          dwtab, B, Cin, H, W, n, CP, g, dilation, s)
+                if has_bias:
+                    for i, b in enumerate(bs):
+                        dyi = dy[:, i * CP:(i + 1) * CP]
+                        _lib.call("cn_channel_sum_f32", dyi.data_ptr(), bstride(dy), B, CP, H * W,
+                                  store.grad_of(b).data_ptr(), 1, s)
             s = _stream()
-            dwtab = _ptr_table([store.grad_of(w).data_ptr() for w in ws])
-            _lib.call("cn_thin_conv3x3_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy), dwtab,
-                      B, Cin, H, W, n, CP, g, dilation, s)
-            if has_bias:
-                for i, b in enumerate(bs):
-                    dyi = dy[:, i * CP:(i + 1) * CP]
-                    _lib.call("cn_channel_sum_f32", dyi.data_ptr(), bstride(dy), B, CP, H * W,
-                              store.grad_of(b).data_ptr(), 1, s)
             if x.req:
                 dx, acc = grad_buffer(x)
                 _lib.call("cn_thin_conv3x3_bwd_data_f32", dy.data_ptr(), bstride(dy), wtab, dx.data_ptr(), bstride(dx),
@@ -1434,20 +1508,24 @@ def adaptive_max_pool2d(x: Var, size: T.Tuple[int, int]) -> Var:
 _WS16_MAX_FLOATS = 96 << 20  # cap of the weight-gradient scratch (384 MB); the pixel split shrinks to fit
 
 
-def _ws16(need: int, dev: torch.device) -> T.Tuple[int, int]:
-    """(pointer, floats) of the persistent fp32 scratch of the bf16 kernels on the current stream's device."""
+def _ws16(need: int, dev: torch.device, pool_name: str = "wgrad") -> T.Tuple[int, int]:
+    """(pointer, floats) of a persistent fp32 scratch of the bf16 kernels. One buffer per (device, purpose): the
+    weight-gradient slices live on the side stream, BatchNorm partial sums on the main stream."""
     need = int(min(max(need, 1 << 20), _WS16_MAX_FLOATS))
     pool = getattr(_state, "ws16_pool", None)
     if pool is None:
         pool = _state.ws16_pool = {}
-    ws = pool.get(dev)
+    key = (dev, pool_name)
+    ws = pool.get(key)
     if ws is None or ws.numel() < need:
-        ws = pool[dev] = torch.empty(need, dtype=torch.float32, device=dev)
+        if ws is not None:  # growing: the old buffer may still be in use by launches in flight on either stream
+            torch.cuda.synchronize(dev)
+        ws = pool[key] = torch.empty(need, dtype=torch.float32, device=dev)
     return ws.data_ptr(), ws.numel()
 
 
-def _bn_ws16(C: int, dev: torch.device) -> int:
-    return _ws16(_lib.query("cn_bn_workspace_floats_bf16", C), dev)[0]
+def _bn_ws16(C: int, dev: torch.device, pool_name: str = "bn") -> int:
+    return _ws16(_lib.query("cn_bn_workspace_floats_bf16", C), dev, pool_name)[0]
 
 
 def to_bf16(x: Var) -> Var:
@@ -1507,18 +1585,20 @@ def _conv2d_bf16(x: Var, mod, stride: int, padding: int, dilation: int, out: T.O
             dy = yv.grad
             if dy is None:
                 return
-            s = _stream()
-            need = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, 0)
-            wsp, wsn = _ws16(need, xt.device)
-            _lib.call("cn_conv2d_bwd_weight_bf16", xt.data_ptr(), ld(xt), dy.data_ptr(), ld(dy),
-                      store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, wsp, wsn, s)
-            if bias is not None:
-                _lib.call("cn_channel_sum_bf16", dy.data_ptr(), ld(dy), B * Ho * Wo, Cout,
-                          store.grad_of(bias).data_ptr(), 1, _bn_ws16(Cout, xt.device), s)
+            with side_stream(xt, dy):
+                s = _stream()
+                need = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, 0)
+                wsp, wsn = _ws16(need, xt.device)
+                _lib.call("cn_conv2d_bwd_weight_bf16", xt.data_ptr(), ld(xt), dy.data_ptr(), ld(dy),
+                          store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, wsp, wsn,
+                          s)
+                if bias is not None:
+                    _lib.call("cn_channel_sum_bf16", dy.data_ptr(), ld(dy), B * Ho * Wo, Cout,
+                              store.grad_of(bias).data_ptr(), 1, _bn_ws16(Cout, xt.device, "side"), s)
             if x.req:
                 dx, acc = grad_buffer(x)
                 _lib.call("cn_conv2d_bwd_data_bf16", dy.data_ptr(), ld(dy), pw.bwd16.data_ptr(), dx.data_ptr(), ld(dx),
-                          B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, acc, s)
+                          B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, acc, _stream())
             yv.grad = None
 
         tape.add(bwd, (w, bias))
@@ -1547,18 +1627,19 @@ def _conv_transpose2d_bf16(x: Var, mod, stride: int, padding: int) -> Var:
             dy = yv.grad
             if dy is None:
                 return
-            s = _stream()
-            need = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, Cout, KH, KW, stride, padding, 1, 1)
-            wsp, wsn = _ws16(need, xt.device)
-            _lib.call("cn_conv_transpose2d_bwd_weight_bf16", xt.data_ptr(), ld(xt), dy.data_ptr(), ld(dy),
-                      store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, wsp, wsn, s)
-            if bias is not None:
-                _lib.call("cn_channel_sum_bf16", dy.data_ptr(), ld(dy), B * Ho * Wo, Cout,
-                          store.grad_of(bias).data_ptr(), 1, _bn_ws16(Cout, xt.device), s)
+            with side_stream(xt, dy):
+                s = _stream()
+                need = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, Cout, KH, KW, stride, padding, 1, 1)
+                wsp, wsn = _ws16(need, xt.device)
+                _lib.call("cn_conv_transpose2d_bwd_weight_bf16", xt.data_ptr(), ld(xt), dy.data_ptr(), ld(dy),
+                          store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, wsp, wsn, s)
+                if bias is not None:
+                    _lib.call("cn_channel_sum_bf16", dy.data_ptr(), ld(dy), B * Ho * Wo, Cout,
+                              store.grad_of(bias).data_ptr(), 1, _bn_ws16(Cout, xt.device, "side"), s)
             if x.req:
                 dx, acc = grad_buffer(x)
                 _lib.call("cn_conv_transpose2d_bwd_data_bf16", dy.data_ptr(), ld(dy), pw.bwd16.data_ptr(),
-                          dx.data_ptr(), ld(dx), B, Cin, H, W, Cout, KH, KW, stride, padding, acc, s)
+                          dx.data_ptr(), ld(dx), B, Cin, H, W, Cout, KH, KW, stride, padding, acc, _stream())
             yv.grad = None
 
         tape.add(bwd, (w, bias))
@@ -1761,15 +1842,17 @@ def _thin_conv3x3_bf16(x: Var, mods: T.Sequence, grouped: bool, dilation: int, o
             cp8 = (CPt + 7) // 8 * 8
             d16 = torch.empty((B, H, W, cp8), dtype=torch.bfloat16, device=xt.device)
             _lib.call("cn_convert_f32nchw_to_bf16nhwc", dy.data_ptr(), bstride(dy), d16.data_ptr(), cp8, B, CPt, cp8, HW, s)
-            need = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, CPt, 3, 3, 1, dilation, dilation, 0)
-            wsp, wsn = _ws16(need, xt.device)
-            _lib.call("cn_fill_f32", tw.dwcat.data_ptr(), tw.dwcat.numel(), 0.0, s)
-            _lib.call("cn_conv2d_bwd_weight_bf16", xt.data_ptr(), ld(xt), d16.data_ptr(), cp8, tw.dwcat.data_ptr(), B, Cin,
-                      H, W, CPt, 3, 3, 1, dilation, dilation, wsp, wsn, s)
-            per = CP * Cin * 9
-            for i, m in enumerate(mods):
-                _lib.call("cn_copy_f32", tw.dwcat[i * CP].data_ptr(), per, store.grad_of(m.weight).data_ptr(), per, 1,
-                          per, 1, s)
+            with side_stream(xt, d16):
+                ss = _stream()
+                need = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, CPt, 3, 3, 1, dilation, dilation, 0)
+                wsp, wsn = _ws16(need, xt.device)
+                _lib.call("cn_fill_f32", tw.dwcat.data_ptr(), tw.dwcat.numel(), 0.0, ss)
+                _lib.call("cn_conv2d_bwd_weight_bf16", xt.data_ptr(), ld(xt), d16.data_ptr(), cp8, tw.dwcat.data_ptr(), B,
+                          Cin, H, W, CPt, 3, 3, 1, dilation, dilation, wsp, wsn, ss)
+                per = CP * Cin * 9
+                for i, m in enumerate(mods):
+                    _lib.call("cn_copy_f32", tw.dwcat[i * CP].data_ptr(), per, store.grad_of(m.weight).data_ptr(), per,
+                              1, per, 1, ss)
             if x.req:
                 dx, acc = grad_buffer(x)
                 _lib.call("cn_conv2d_bwd_data_bf16", d16.data_ptr(), cp8, tw.bwd16.data_ptr(), dx.data_ptr(), ld(dx), B,
