@@ -28,7 +28,10 @@ _state = threading.local()
 
 
 def _stream() -> int:
-    return torch.cuda.current_stream().cuda_stream
+    """HIP stream handle the next launch goes to: the side stream inside a ``side_stream`` block, else torch's
+    current stream."""
+    ov = getattr(_state, "stream_override", None)
+    return ov if ov is not None else torch.cuda.current_stream().cuda_stream
 
 
 def _check(t: torch.Tensor) -> torch.Tensor:
@@ -173,13 +176,17 @@ class side_stream:
         st["stream"].wait_event(st["event"])
         st["dirty"] = True
         self.st = st
-        self.ctx = torch.cuda.stream(st["stream"])
-        self.ctx.__enter__()
+        # launches go through the C ABI with an explicit stream handle: redirect _stream() instead of switching torch's
+        # current stream (a torch.cuda.stream() context costs ~15 us of host time per layer). torch allocations made
+        # inside the block still belong to the main stream: nothing inside may rely on a torch op (fills go through
+        # cn_fill_f32 on the side stream).
+        self.ctx = True
+        _state.stream_override = st["stream"].cuda_stream
         return self
 
     def __exit__(self, *exc):
         if self.ctx is not None:
-            self.ctx.__exit__(*exc)
+            _state.stream_override = None
             for t in self.tensors:
                 if t is not None:
                     t.record_stream(self.st["stream"])
@@ -791,11 +798,14 @@ def time_conv(x: Var, mod, tin: int) -> Var:
                 return
             with side_stream(xt, dy):
                 s = _stream()
-                dwexp = torch.zeros(Cout * tout * CT, dtype=torch.float32, device=xt.device)
+                dwexp = torch.empty(Cout * tout * CT, dtype=torch.float32, device=xt.device)
+                _lib.call("cn_fill_f32", dwexp.data_ptr(), dwexp.numel(), 0.0, s)
                 _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
                           dwexp.data_ptr(), B, CT, H, W, Cout * tout, 1, 1, 1, 0, 1, None, 0, s)
                 _lib.call("cn_fold_timeconv_grad_f32", dwexp.data_ptr(), store.grad_of(w).data_ptr(), Cout, Cin, tin, k,
                           s)
+                if _OVERLAP_WGRAD:
+                    dwexp.record_stream(_side_state(xt.device)["stream"])
             s = _stream()
             if x.req:
                 dx, acc = grad_buffer(x)
