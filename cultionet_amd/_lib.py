@@ -11,7 +11,7 @@ import os
 from ctypes import c_double, c_float, c_int, c_long, c_ulonglong, c_void_p
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libcultionet_hip.so")
+LIB_PATH = os.environ.get("CN_LIB_PATH") or os.path.join(_HERE, "csrc", "libcultionet_hip.so")  # CN_LIB_PATH: diagnostic builds
 
 P = c_void_p  # device pointers are passed as integers (tensor.data_ptr())
 I, L, F, U64 = c_int, c_long, c_float, c_ulonglong

@@ -38,6 +38,7 @@ struct CnBClass {
   int iy_off, ix_off;      // input coordinate of halo pixel (0,0) relative to (tile origin * is)
   int IH, IW;              // halo image size in pixels
   int grp;
+  unsigned mgIW;           // ceil(2^32 / IW): x / IW == umulhi(x, mgIW) for x < 65536 (0 when IW == 1)
 };
 
 struct CnBGeom {
@@ -50,6 +51,7 @@ struct CnBGeom {
   int B, Cin, Hin, Win, Cout, Hout, Wout;
   int is, os;
   int TH, TW;
+  unsigned mgTW;  // ceil(2^32 / TW) (0 when TW == 1)
   int KS;         // 16-channel k-steps (ceil(Cin / 16))
   int NT;         // 32-cout tiles (ceil(Cout / 32))
   int nblk_n;     // cout blocks (of 32*WN) per pixel tile
@@ -62,6 +64,22 @@ struct CnBGeom {
                   // 2560 tiles x 4 waves of them made a 128->128 conv at 100x100 nine times slower)
   CnBClass cls[CNB_MAX_CLASSES];
 };
+
+// Diagnostic build (-DCNB_STAMP): s_memtime stamps of one wave of two blocks, read back with cn_bconv_read_stamps
+// (tools/bconv_stamps.py). Never compiled into the shipped library.
+#ifdef CNB_STAMP
+__device__ unsigned long long cnb_stamps[2 * 128];
+#define CNB_ST(i) do { if (do_stamp) cnb_stamps[stamp_slot * 128 + (i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int cn_bconv_read_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(cnb_stamps), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -2;
+}
+#else
+#define CNB_ST(i) do { } while (0)
+#endif
+
+// x / d for 0 <= x < 65536 with mg = ceil(2^32 / d) precomputed on the host (two instructions instead of ~40)
+__device__ __forceinline__ int cnb_div(int x, unsigned mg) { return mg ? (int)__umulhi((unsigned)x, mg) : x; }
+static inline unsigned cnb_magic(int d) { return d <= 1 ? 0u : (unsigned)((0x100000000ull + d - 1) / d); }
 
 __device__ __forceinline__ f32x16 cnb_mfma(bf16x8 a, bf16x8 b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, c, 0, 0, 0);
@@ -96,6 +114,12 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
     L = (lin & 7) * per + (lin >> 3);
     if (L >= g.total) return;
   }
+#ifdef CNB_STAMP
+  const bool do_stamp = (L == 0 || L == g.total / 2) && tid == 0;
+  const int stamp_slot = L == 0 ? 0 : 1;
+  int stamp_i = 8;
+#endif
+  CNB_ST(0);
   int ci = 0;
 #pragma unroll 1
   for (int c = 1; c < g.ncls; ++c)
@@ -123,7 +147,7 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
   for (int i = 0; i < NP; ++i) {
     const int q = tid + i * 256;
     const int p = q / PPP;
-    const int hy = p / IW, hx = p - hy * IW;
+    const int hy = cnb_div(p, k.mgIW), hx = p - hy * IW;
     const int iy = iy0 + hy, ix = ix0 + hx;
     const bool ok = q < npieces && iy >= 0 && iy < g.Hin && ix >= 0 && ix < g.Win;
     gpix[i] = ok ? (b * g.Hin + iy) * g.Win + ix : -1;
@@ -135,7 +159,7 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
 #pragma unroll
   for (int i = 0; i < MPW; ++i) {
     const int m = (wm + i * WM) * 32 + r;
-    const int ty = m / g.TW, tx = m - ty * g.TW;
+    const int ty = cnb_div(m, g.mgTW), tx = m - ty * g.TW;
     pbase[i] = m < npix ? ((ty * g.is) * IW + tx * g.is) * PITCH + h * 16 : h * 16;
   }
 
@@ -155,6 +179,7 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
   const int spc = ntaps * KPAIRS;     // steps per chunk: (tap, k-pair)
   const int nsteps = nchunks * spc;
 
+  CNB_ST(1);
   if (ntaps > 0) {
     // Weight fragments: buffer loads with the whole fragment address in SGPRs (one VMEM instruction, no per-lane
     // address arithmetic): byte offset of (tap, kstep) = ((wt * KS + kstep) * NT + ntile) * 1024, + lane * 16.
@@ -218,12 +243,16 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
   }
 #define CNB_STAGE()                                                                                     \
   {                                                                                                     \
+    CNB_ST(100 + ch * 4);                                                                               \
     __syncthreads(); /* the previous chunk's reads are done */                                          \
+    CNB_ST(101 + ch * 4);                                                                               \
     _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                    \
       const int q = tid + i * 256;                                                                      \
       if (q < npieces) *reinterpret_cast<u32x4*>(lds + (q / PPP) * PITCH + (q % PPP) * 16) = sv[i];     \
     }                                                                                                   \
+    CNB_ST(102 + ch * 4);                                                                               \
     __syncthreads();                                                                                    \
+    CNB_ST(103 + ch * 4);                                                                               \
     if (ch + 1 < nchunks) CNB_FETCH(ch + 1);                                                            \
   }
 #define CNB_READ(BUF, T_, KP_)                                                                     \
@@ -258,7 +287,14 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
     }                                                                                              \
     adv(ch2, t2, kp2);                                                                             \
     adv(ch, t, kp);                                                                                \
+    CNB_STEP_STAMP();                                                                              \
   }
+#ifdef CNB_STAMP
+#define CNB_STEP_STAMP() do { if (stamp_i < 96) { CNB_ST(stamp_i); ++stamp_i; } } while (0)
+#else
+#define CNB_STEP_STAMP() do { } while (0)
+#endif
+    CNB_ST(2);
     CNB_FETCH(0);
 #pragma unroll 1
     for (int s = 0; s < nsteps; s += 2) {
@@ -272,6 +308,7 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
   }
 
   // ---- epilogue: lane = pixel, registers = 4 groups of 4 consecutive couts ----
+  CNB_ST(3);
   const float* __restrict__ bias = g.bias[grp];
   const int n0 = ntile * 32;
   float bsum[16];
@@ -288,7 +325,7 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
 #pragma unroll
   for (int i = 0; i < MPW; ++i) {
     const int m = (wm + i * WM) * 32 + r;
-    const int ty = m / g.TW, tx = m - ty * g.TW;
+    const int ty = cnb_div(m, g.mgTW), tx = m - ty * g.TW;
     const int gy = gy0 + ty, gx = gx0 + tx;
     const bool ok = n_live && m < npix && gy < k.Hg && gx < k.Wg;
     const int oy = gy * g.os + k.oy0, ox = gx * g.os + k.ox0;
@@ -356,6 +393,7 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
       }
     }
   }
+  CNB_ST(4);
   if (g.stats != nullptr) {
     // Per-cout sums over this wave's pixels = sums over the LANES of 32 values per lane: transposed through LDS
     // (each lane writes its 32 partials as one padded row, then sums ONE column over its half-wave's 32 rows): ~100
@@ -379,6 +417,7 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
       else atomicAdd(row, tot);  // WM waves share a cout tile: few adders per address, rows zeroed by the launcher
     }
   }
+  CNB_ST(5);
 }
 
 // ------------------------------------------------------------------------------------------------------------
@@ -526,6 +565,8 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
     }
   }
   const int pitch = KSC * 32 + 16;
+  g.mgTW = cnb_magic(g.TW);
+  for (int c = 0; c < g.ncls; ++c) g.cls[c].mgIW = cnb_magic(g.cls[c].IW);
   const int np = (int)(((long)max_pix * KSC * 2 + 255) / 256);
   if (np > 10) return CN_ERR_LDS;
   long total = 0;
