@@ -91,8 +91,11 @@ template <int KSC>
 struct CnbPitch { static constexpr int value = KSC * 32 + 16; };  // bytes per halo pixel: channels + 16 B pad
                                                                   // (5, 9, 17 sixteen-byte slots: coprime with 16)
 
+// Three blocks per CU (<= 168 VGPRs): measured against the two-blocks variant that double-buffered the pixel
+// fragments and register-prefetched the staging (209-237 VGPRs), thread-level parallelism wins on every 3x3 shape
+// (128->128 @100^2: 767 -> 842 TFLOP/s, @50^2: 531 -> 647): while one block stages or stores, two others multiply.
 template <int WN, int NP, int KSC>
-__global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
+__global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int WM = 4 / WN;   // waves along the pixel columns
   constexpr int MPW = 4;       // 32-pixel columns per wave: every weight fragment (one 16-byte global load per
@@ -206,10 +209,10 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
       return __builtin_bit_cast(bf16x8, v);
     };
     // The loop walks the linear step sequence (chunk, tap, k-pair), two steps per iteration with static register
-    // names: pixel fragments of step s+1 are read from LDS into the OTHER set (X / Y) before the 8 MFMAs of step s
-    // issue, and each set's weight fragments are re-loaded for step s+2 right after its MFMAs have issued. Left to
-    // itself the compiler funnels every fragment through one register quad (read, wait, MFMA, read, wait, ...).
-    bf16x8 X[2 * MPW], Y[2 * MPW];
+    // names for the two weight-fragment sets (each re-loaded for step s+2 right after its MFMAs have issued). The 8
+    // pixel fragments of a step are read from LDS in one batch (8 distinct register quads, so the 8 MFMAs wait with
+    // counted lgkmcnt instead of read, wait, MFMA, read, wait, ... through one quad as the compiler schedules it).
+    bf16x8 X[2 * MPW];
     bf16x8 ax0, ax1, ay0, ay1;
     int ch = 0, t = 0, kp = 0;      // current step
     int ch2 = 0, t2 = 0, kp2 = 0;   // two steps ahead (weight prefetch)
@@ -228,32 +231,34 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
     }
     adv(ch2, t2, kp2);
 
-    // chunk staging, register-prefetched: the global loads of chunk c+1 are issued right after chunk c's image has
-    // been written, and stay in flight while chunk c is multiplied
-    u32x4 sv[NP];
-#define CNB_FETCH(CH_)                                                                                  \
+    // chunk staging: global -> registers -> padded LDS image, in at most two phases of five 16-byte pieces per thread
+    // (bounds the registers in flight); the other two blocks of the CU multiply meanwhile
+#define CNB_PHASE(I0, I1)                                                                               \
   {                                                                                                     \
-    const int cc = (CH_) * (KSC * 16);                                                                  \
-    _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                    \
+    u32x4 sv[(I1) - (I0) > 0 ? (I1) - (I0) : 1];                                                        \
+    _Pragma("unroll") for (int i = (I0); i < (I1); ++i) {                                               \
       u32x4 v = {0u, 0u, 0u, 0u};                                                                       \
       if (gpix[i] >= 0 && cc + s8 < g.Cin)                                                              \
         v = *reinterpret_cast<const u32x4*>(xg + (long)gpix[i] * g.ldx + s8 + cc);                      \
-      sv[i] = v;                                                                                        \
+      sv[i - (I0)] = v;                                                                                 \
+    }                                                                                                   \
+    if ((I0) == 0) __syncthreads(); /* the previous chunk's reads are done */                           \
+    _Pragma("unroll") for (int i = (I0); i < (I1); ++i) {                                               \
+      const int q = tid + i * 256;                                                                      \
+      if (q < npieces) *reinterpret_cast<u32x4*>(lds + (q / PPP) * PITCH + (q % PPP) * 16) = sv[i - (I0)]; \
     }                                                                                                   \
   }
 #define CNB_STAGE()                                                                                     \
   {                                                                                                     \
+    const int cc = ch * (KSC * 16);                                                                     \
+    constexpr int H1 = NP > 5 ? 5 : NP;                                                                 \
     CNB_ST(100 + ch * 4);                                                                               \
-    __syncthreads(); /* the previous chunk's reads are done */                                          \
+    CNB_PHASE(0, H1);                                                                                   \
     CNB_ST(101 + ch * 4);                                                                               \
-    _Pragma("unroll") for (int i = 0; i < NP; ++i) {                                                    \
-      const int q = tid + i * 256;                                                                      \
-      if (q < npieces) *reinterpret_cast<u32x4*>(lds + (q / PPP) * PITCH + (q % PPP) * 16) = sv[i];     \
-    }                                                                                                   \
+    if (NP > H1) CNB_PHASE(H1, NP);                                                                     \
     CNB_ST(102 + ch * 4);                                                                               \
     __syncthreads();                                                                                    \
     CNB_ST(103 + ch * 4);                                                                               \
-    if (ch + 1 < nchunks) CNB_FETCH(ch + 1);                                                            \
   }
 #define CNB_READ(BUF, T_, KP_)                                                                     \
   {                                                                                                \
@@ -265,15 +270,8 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
   }
 #define CNB_HALF(CUR, OTH, A0, A1)                                                                 \
   {                                                                                                \
-    if (t == 0 && kp == 0) {                                                                       \
-      CNB_STAGE();                                                                                 \
-      CNB_READ(CUR, 0, 0);                                                                         \
-    }                                                                                              \
-    {                                                                                              \
-      int tn = t, kn = kp, cn = 0;                                                                 \
-      adv(cn, tn, kn);                                                                             \
-      if (cn == 0) CNB_READ(OTH, tn, kn);                                                          \
-    }                                                                                              \
+    if (t == 0 && kp == 0) CNB_STAGE();                                                            \
+    CNB_READ(CUR, t, kp);                                                                          \
     /* weight fragments of this step: everything but the two newest loads (the other set's) has landed */ \
     asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                               \
     __builtin_amdgcn_sched_barrier(0);                                                             \
@@ -295,13 +293,12 @@ __global__ __launch_bounds__(256, 2) void cn_bconv_kernel(const CnBGeom g) {
 #define CNB_STEP_STAMP() do { } while (0)
 #endif
     CNB_ST(2);
-    CNB_FETCH(0);
 #pragma unroll 1
     for (int s = 0; s < nsteps; s += 2) {
-      CNB_HALF(X, Y, ax0, ax1);
-      if (s + 1 < nsteps) CNB_HALF(Y, X, ay0, ay1);
+      CNB_HALF(X, X, ax0, ax1);
+      if (s + 1 < nsteps) CNB_HALF(X, X, ay0, ay1);
     }
-#undef CNB_FETCH
+#undef CNB_PHASE
 #undef CNB_STAGE
 #undef CNB_READ
 #undef CNB_HALF
