@@ -51,7 +51,7 @@ __device__ __forceinline__ bf16x4 cnw_tr(const unsigned char* lds_addr) {
 
 // NQ = 16-byte pieces of the Q halo image per thread that are register-prefetched (0: synchronous staging loop for
 // large halos, e.g. strided layers).
-template <int T, int NQ>
+template <int T, int NQ, bool FULL>
 __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const CnBWgGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -205,19 +205,49 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
     __syncthreads();
     if (tile + 1 < t_end) fetch(tile + 1);  // next tile's global loads fly while this one is multiplied
     CNW_READ(AX, BX, 0);
+    if (FULL) {
+      // Full tiles (8 k-steps, no conditionals => one basic block per k-step): the transposed reads and address adds
+      // of k-step ks+1 are INTERLEAVED with the MFMAs of k-step ks, two reads + two VALU in each MFMA's 32-cycle
+      // shadow.  One wave per SIMD has nobody to hide behind: a phase-separated order leaves the matrix pipe idle for
+      // the ~300 cycles of read issue per k-step.
+#define CNW_INTERLEAVE()                                                 \
+  {                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < T; ++i_) {                   \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* MFMA */      \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); /* DS read */   \
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0); /* VALU */      \
+    }                                                                    \
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                   \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                   \
+  }
 #pragma unroll
-    for (int ks = 0; ks < 8; ks += 2) {
-      if (ks < ksteps) {
-        if (ks + 1 < ksteps) CNW_READ(AY, BY, ks + 1);
+      for (int ks = 0; ks < 8; ks += 2) {
         __builtin_amdgcn_sched_barrier(0);
+        CNW_READ(AY, BY, ks + 1);
         CNW_MMA(AX, BX);
+        CNW_INTERLEAVE();
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 2 < 8) CNW_READ(AX, BX, ks + 2);
+        CNW_MMA(AY, BY);
+        if (ks + 2 < 8) CNW_INTERLEAVE();
         __builtin_amdgcn_sched_barrier(0);
       }
-      if (ks + 1 < ksteps) {
-        if (ks + 2 < ksteps) CNW_READ(AX, BX, ks + 2);
-        __builtin_amdgcn_sched_barrier(0);
-        CNW_MMA(AY, BY);
-        __builtin_amdgcn_sched_barrier(0);
+#undef CNW_INTERLEAVE
+    } else {
+#pragma unroll
+      for (int ks = 0; ks < 8; ks += 2) {
+        if (ks < ksteps) {
+          if (ks + 1 < ksteps) CNW_READ(AY, BY, ks + 1);
+          __builtin_amdgcn_sched_barrier(0);
+          CNW_MMA(AX, BX);
+          __builtin_amdgcn_sched_barrier(0);
+        }
+        if (ks + 1 < ksteps) {
+          if (ks + 2 < ksteps) CNW_READ(AX, BX, ks + 2);
+          __builtin_amdgcn_sched_barrier(0);
+          CNW_MMA(AY, BY);
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
     }
   }
@@ -237,20 +267,38 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
 }
 
 // dw[(cP*CQ + cQ)*T + t] += sum_split part[split][t][cP][cQ]
+// 64 outputs per block (consecutive cq: coalesced slice reads), the splits dealt over the block's 4 waves with 4
+// independent loads in flight per thread, combined through LDS.
 __global__ __launch_bounds__(256) void cn_bwgrad_reduce_kernel(const float* __restrict__ part, float* __restrict__ dw,
                                                               int nsplit, int T, int CP, int CQ, long CPp, long CQp) {
+  __shared__ float red[4][64];
   const long n = (long)CP * CQ * T;
   const long slice = (long)T * CPp * CQp;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    // i = (t*CP + cp)*CQ + cq : reads coalesced along cq
-    const int cq = (int)(i % CQ);
-    const long r = i / CQ;
-    const int cp = (int)(r % CP);
-    const int t = (int)(r / CP);
-    const float* p = part + ((long)t * CPp + cp) * CQp + cq;
-    float s = 0.f;
-    for (int k = 0; k < nsplit; ++k) s += p[k * slice];
-    dw[((long)cp * CQ + cq) * T + t] += s;
+  const int lane = threadIdx.x & 63, kg = threadIdx.x >> 6;
+  for (long i0 = blockIdx.x * 64L; i0 < n; i0 += (long)gridDim.x * 64) {
+    const long i = i0 + lane;  // i = (t*CP + cp)*CQ + cq
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f, s3 = 0.f;
+    int cq = 0, cp = 0, t = 0;
+    if (i < n) {
+      cq = (int)(i % CQ);
+      const long r = i / CQ;
+      cp = (int)(r % CP);
+      t = (int)(r / CP);
+      const float* p = part + ((long)t * CPp + cp) * CQp + cq;
+      int k = kg;
+      for (; k + 12 < nsplit; k += 16) {
+        s0 += p[k * slice];
+        s1 += p[(k + 4) * slice];
+        s2 += p[(k + 8) * slice];
+        s3 += p[(k + 12) * slice];
+      }
+      for (; k < nsplit; k += 4) s0 += p[k * slice];
+    }
+    red[kg][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (kg == 0 && i < n)
+      dw[((long)cp * CQ + cq) * T + t] += (red[0][lane] + red[1][lane]) + (red[2][lane] + red[3][lane]);
+    __syncthreads();
   }
 }
 
@@ -327,12 +375,17 @@ static int cnw_run(CnBWgGeom& g, float* dw, float* ws, long ws_floats, hipStream
   cn_prof_desc("bwgrad B%d %dx%d %dx%d T%d s%d split%d", g.B, g.Hg, g.Wg, g.CP, g.CQ, g.T, g.s, g.nsplit);
   cn_prof_before(stream);
   const int nq = (g.IH * g.IW * 8 + 255) / 256;  // Q pieces per thread: <= 8 are register-prefetched
-#define CNW_GO(T_, NQ_)                                                                                        \
+#define CNW_GO1(T_, NQ_, F_)                                                                                   \
   do {                                                                                                         \
     if (shmem > 64 * 1024)                                                                                     \
-      (void)hipFuncSetAttribute((const void*)cn_bwgrad_kernel<T_, NQ_>,                                        \
+      (void)hipFuncSetAttribute((const void*)cn_bwgrad_kernel<T_, NQ_, F_>,                                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                       \
-    hipLaunchKernelGGL((cn_bwgrad_kernel<T_, NQ_>), grid, block, shmem, stream, g);                            \
+    hipLaunchKernelGGL((cn_bwgrad_kernel<T_, NQ_, F_>), grid, block, shmem, stream, g);                        \
+  } while (0)
+  const bool full = g.TH * g.TW > 112;  // all 8 k-steps of 16 pixels are live
+#define CNW_GO(T_, NQ_)                                                                                        \
+  do {                                                                                                         \
+    if (full) CNW_GO1(T_, NQ_, true); else CNW_GO1(T_, NQ_, false);                                            \
   } while (0)
   switch (g.T) {
     case 1: if (nq <= 4) CNW_GO(1, 4); else if (nq <= 8) CNW_GO(1, 8); else CNW_GO(1, 0); break;
@@ -340,9 +393,10 @@ static int cnw_run(CnBWgGeom& g, float* dw, float* ws, long ws_floats, hipStream
     default: return CN_ERR_ARG;
   }
 #undef CNW_GO
+#undef CNW_GO1
   cn_prof_after(stream, 5, flops);  // the contraction kernel alone
   const long n = (long)g.CP * g.CQ * g.T;
-  const int rb = (int)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048);
+  const int rb = (int)((n + 63) / 64 < 8192 ? (n + 63) / 64 : 8192);
   hipLaunchKernelGGL(cn_bwgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, g.part, dw, g.nsplit, g.T, g.CP, g.CQ,
                      (long)g.nbp * 64, (long)g.nbq * 64);
   return cn_check_launch();
