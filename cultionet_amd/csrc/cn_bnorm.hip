@@ -41,15 +41,16 @@ __global__ __launch_bounds__(256) void cn_bbn_partial_kernel(const bf16_t* __res
   const long p0 = blockIdx.x * rows_per_block;
   const long p1 = p0 + rows_per_block < P ? p0 + rows_per_block : P;
   if (live) {
-    for (long p = p0 + row; p < p1; p += R) {
+    // two pixels per iteration: both 16-byte loads (four in MODE 1) are in flight before either is consumed
+    auto accum = [&](const u32x4& xr, const u32x4& dr) {
       float xv[8];
-      cn_unpack8(*reinterpret_cast<const u32x4*>(x + p * ldx + cg * 8), xv);
+      cn_unpack8(xr, xv);
       if (MODE == 0) {
 #pragma unroll
         for (int j = 0; j < 8; ++j) { a1[j] += xv[j]; a2[j] += xv[j] * xv[j]; }
       } else {
         float dv[8];
-        cn_unpack8(*reinterpret_cast<const u32x4*>(dy + p * lddy + cg * 8), dv);
+        cn_unpack8(dr, dv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float xh = (xv[j] - m[j]) * rs[j];
@@ -59,6 +60,25 @@ __global__ __launch_bounds__(256) void cn_bbn_partial_kernel(const bf16_t* __res
           a2[j] += dz * xh;
         }
       }
+    };
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    long p = p0 + row;
+    for (; p + R < p1; p += 2 * R) {
+      const u32x4 xa = *reinterpret_cast<const u32x4*>(x + p * ldx + cg * 8);
+      const u32x4 xb = *reinterpret_cast<const u32x4*>(x + (p + R) * ldx + cg * 8);
+      u32x4 da = z4, db = z4;
+      if (MODE == 1) {
+        da = *reinterpret_cast<const u32x4*>(dy + p * lddy + cg * 8);
+        db = *reinterpret_cast<const u32x4*>(dy + (p + R) * lddy + cg * 8);
+      }
+      accum(xa, da);
+      accum(xb, db);
+    }
+    if (p < p1) {
+      const u32x4 xa = *reinterpret_cast<const u32x4*>(x + p * ldx + cg * 8);
+      u32x4 da = z4;
+      if (MODE == 1) da = *reinterpret_cast<const u32x4*>(dy + p * lddy + cg * 8);
+      accum(xa, da);
     }
   }
 #pragma unroll
@@ -72,27 +92,28 @@ __global__ __launch_bounds__(256) void cn_bbn_partial_kernel(const bf16_t* __res
   }
 }
 
-// Per-channel fp64 combine of the per-block partial sums: 16 lanes share a channel (16 channels per 256-thread
-// block), each walks every 16th block, then a shuffle tree. (One thread per channel walking 512 partials serially
-// took 80 us for a 128-channel layer.)
+// Per-channel fp64 combine of the partial-sum rows: one WAVE per channel (4 channels per 256-thread block), lane l
+// walks rows l, l+64, ... in four independent chains, then a shuffle tree. Rows come from the statistics pass
+// (<= 512) or from the convolution epilogue (one per pixel tile: 2560 at batch 32 x 100^2), so the serial depth is what
+// matters: 16 lanes per channel took 17.5 us for 2560 rows, one thread per channel 80 us for 512.
+#define BBN_FIN_CH 4  // channels per finalize block
 __device__ __forceinline__ void bbn_combine(const float* __restrict__ part, int nblk, int C, int c, int sub, double& s,
                                             double& ss) {
   s = 0.0; ss = 0.0;
   if (c < C) {
-    // four independent chains: the rows of one channel are C floats apart, every load is its own cache line
     double s1 = 0.0, q1 = 0.0, s2 = 0.0, q2 = 0.0, s3 = 0.0, q3 = 0.0;
     int i = sub;
-    for (; i + 48 < nblk; i += 64) {
+    for (; i + 192 < nblk; i += 256) {
       s += part[((long)i * 2) * C + c]; ss += part[((long)i * 2 + 1) * C + c];
-      s1 += part[((long)(i + 16) * 2) * C + c]; q1 += part[((long)(i + 16) * 2 + 1) * C + c];
-      s2 += part[((long)(i + 32) * 2) * C + c]; q2 += part[((long)(i + 32) * 2 + 1) * C + c];
-      s3 += part[((long)(i + 48) * 2) * C + c]; q3 += part[((long)(i + 48) * 2 + 1) * C + c];
+      s1 += part[((long)(i + 64) * 2) * C + c]; q1 += part[((long)(i + 64) * 2 + 1) * C + c];
+      s2 += part[((long)(i + 128) * 2) * C + c]; q2 += part[((long)(i + 128) * 2 + 1) * C + c];
+      s3 += part[((long)(i + 192) * 2) * C + c]; q3 += part[((long)(i + 192) * 2 + 1) * C + c];
     }
-    for (; i < nblk; i += 16) { s += part[((long)i * 2) * C + c]; ss += part[((long)i * 2 + 1) * C + c]; }
+    for (; i < nblk; i += 64) { s += part[((long)i * 2) * C + c]; ss += part[((long)i * 2 + 1) * C + c]; }
     s += s1 + s2 + s3; ss += q1 + q2 + q3;
   }
 #pragma unroll
-  for (int off = 8; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); ss += __shfl_xor(ss, off, 64); }
+  for (int off = 32; off > 0; off >>= 1) { s += __shfl_xor(s, off, 64); ss += __shfl_xor(ss, off, 64); }
 }
 
 // Forward finalize: batch mean / rstd (fp64 combine), running-statistics update (momentum, unbiased variance).
@@ -104,7 +125,7 @@ __global__ __launch_bounds__(256) void cn_bbn_finalize_fwd_kernel(const float* _
                                                                  float* __restrict__ running_var,
                                                                  float* __restrict__ mean, float* __restrict__ rstd,
                                                                  int training) {
-  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  const int c = blockIdx.x * BBN_FIN_CH + (threadIdx.x >> 6), sub = threadIdx.x & 63;
   if (!training) {
     if (c < C && sub == 0) {
       mean[c] = running_mean[c];
@@ -132,7 +153,7 @@ __global__ __launch_bounds__(256) void cn_bbn_finalize_bwd_kernel(const float* _
                                                                  double count, float* __restrict__ coef,
                                                                  float* __restrict__ dgamma,
                                                                  float* __restrict__ dbeta, int training) {
-  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  const int c = blockIdx.x * BBN_FIN_CH + (threadIdx.x >> 6), sub = threadIdx.x & 63;
   double s1, s2;
   bbn_combine(part, nblk, C, c, sub, s1, s2);
   if (c >= C || sub != 0) return;
@@ -171,9 +192,10 @@ __global__ __launch_bounds__(256) void cn_bbn_apply_kernel(const bf16_t* __restr
   }
   const long p0 = blockIdx.x * rows_per_block;
   const long p1 = p0 + rows_per_block < P ? p0 + rows_per_block : P;
-  for (long p = p0 + row; p < p1; p += R) {
+  const u32x4 z4 = {0u, 0u, 0u, 0u};
+  auto body = [&](long p, const u32x4& xr, const u32x4& ar, const u32x4& br) {
     float xv[8], o[8];
-    cn_unpack8(*reinterpret_cast<const u32x4*>(x + p * ldx + cg * 8), xv);
+    cn_unpack8(xr, xv);
     if (MODE == 0) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
@@ -183,13 +205,13 @@ __global__ __launch_bounds__(256) void cn_bbn_apply_kernel(const bf16_t* __restr
       }
       if (res != nullptr) {
         float rv[8];
-        cn_unpack8(*reinterpret_cast<const u32x4*>(res + p * ldr + cg * 8), rv);
+        cn_unpack8(ar, rv);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] += rv[j];
       }
     } else {
       float dv[8];
-      cn_unpack8(*reinterpret_cast<const u32x4*>(dy + p * lddy + cg * 8), dv);
+      cn_unpack8(ar, dv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
         const float xh = (xv[j] - m[j]) * rs[j];
@@ -199,13 +221,47 @@ __global__ __launch_bounds__(256) void cn_bbn_apply_kernel(const bf16_t* __restr
       }
       if (accumulate) {
         float ov[8];
-        cn_unpack8(*reinterpret_cast<const u32x4*>(y + p * ldy + cg * 8), ov);
+        cn_unpack8(br, ov);
 #pragma unroll
         for (int j = 0; j < 8; ++j) o[j] += ov[j];
       }
     }
     *reinterpret_cast<u32x4*>(y + p * ldy + cg * 8) = cn_pack8(o);
+  };
+  // second operand: residual (MODE 0) or dy (MODE 1); third: the dx being accumulated into
+  auto ld2 = [&](long p) -> u32x4 {
+    if (MODE == 0) return res != nullptr ? *reinterpret_cast<const u32x4*>(res + p * ldr + cg * 8) : z4;
+    return *reinterpret_cast<const u32x4*>(dy + p * lddy + cg * 8);
+  };
+  auto ld3 = [&](long p) -> u32x4 {
+    return (MODE == 1 && accumulate) ? *reinterpret_cast<const u32x4*>(y + p * ldy + cg * 8) : z4;
+  };
+  long p = p0 + row;
+  for (; p + R < p1; p += 2 * R) {  // two pixels per iteration: all loads issued before the first is consumed
+    const u32x4 xa = *reinterpret_cast<const u32x4*>(x + p * ldx + cg * 8);
+    const u32x4 xb = *reinterpret_cast<const u32x4*>(x + (p + R) * ldx + cg * 8);
+    const u32x4 aa = ld2(p), ab = ld2(p + R);
+    const u32x4 ba = ld3(p), bb = ld3(p + R);
+    body(p, xa, aa, ba);
+    body(p + R, xb, ab, bb);
   }
+  if (p < p1) {
+    const u32x4 xa = *reinterpret_cast<const u32x4*>(x + p * ldx + cg * 8);
+    const u32x4 aa = ld2(p);
+    const u32x4 ba = ld3(p);
+    body(p, xa, aa, ba);
+  }
+}
+
+// grid of the apply passes: no per-block output rows, so many more (smaller) blocks than the statistics passes
+static inline void bbn_apply_grid(long P, int C, int& nblk, long& rows) {
+  const int R = 256 / (C >> 3);
+  long want = (P + (long)R * 4 - 1) / ((long)R * 4);  // >= 4 row-iterations per block
+  if (want > 4096) want = 4096;
+  if (want < 1) want = 1;
+  rows = (P + want - 1) / want;
+  rows = (rows + R - 1) / R * R;
+  nblk = (int)((P + rows - 1) / rows);
 }
 
 static inline void bbn_grid(long P, int C, int& nblk, long& rows) {
@@ -240,11 +296,14 @@ extern "C" int cn_bn_act_fwd_bf16(const void* x, long ldx, const float* gamma, c
     hipLaunchKernelGGL((cn_bbn_partial_kernel<0>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr,
                        0L, nullptr, nullptr, nullptr, nullptr, P, C, act, rows, ws);
   const bool fused = training && conv_sums != nullptr && conv_rows > 0;
-  hipLaunchKernelGGL(cn_bbn_finalize_fwd_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, fused ? conv_sums : ws,
+  hipLaunchKernelGGL(cn_bbn_finalize_fwd_kernel, dim3((C + BBN_FIN_CH - 1) / BBN_FIN_CH), dim3(256), 0, stream, fused ? conv_sums : ws,
                      fused ? conv_rows : nblk, C, (double)P, eps, momentum, running_mean, running_var, mean, rstd,
                      training);
-  hipLaunchKernelGGL((cn_bbn_apply_kernel<0>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr, 0L,
-                     mean, rstd, gamma, beta, nullptr, (const bf16_t*)res, ldr, (bf16_t*)y, ldy, P, C, act, 0, rows);
+  int ablk;
+  long arows;
+  bbn_apply_grid(P, C, ablk, arows);
+  hipLaunchKernelGGL((cn_bbn_apply_kernel<0>), dim3(ablk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr, 0L,
+                     mean, rstd, gamma, beta, nullptr, (const bf16_t*)res, ldr, (bf16_t*)y, ldy, P, C, act, 0, arows);
   return cn_check_launch();
 }
 
@@ -262,12 +321,16 @@ extern "C" int cn_bn_act_bwd_bf16(const void* x, long ldx, const void* dy, long 
   float* coef = ws + (long)BBN_MAX_BLOCKS * 2 * C;
   hipLaunchKernelGGL((cn_bbn_partial_kernel<1>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx,
                      (const bf16_t*)dy, lddy, mean, rstd, gamma, beta, P, C, act, rows, ws);
-  hipLaunchKernelGGL(cn_bbn_finalize_bwd_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, ws, nblk, C, (double)P,
+  hipLaunchKernelGGL(cn_bbn_finalize_bwd_kernel, dim3((C + BBN_FIN_CH - 1) / BBN_FIN_CH), dim3(256), 0, stream, ws, nblk, C, (double)P,
                      coef, dgamma, dbeta, training);
-  if (dx != nullptr)
-    hipLaunchKernelGGL((cn_bbn_apply_kernel<1>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx,
+  if (dx != nullptr) {
+    int ablk;
+    long arows;
+    bbn_apply_grid(P, C, ablk, arows);
+    hipLaunchKernelGGL((cn_bbn_apply_kernel<1>), dim3(ablk), dim3(256), 0, stream, (const bf16_t*)x, ldx,
                        (const bf16_t*)dy, lddy, mean, rstd, gamma, beta, coef, nullptr, 0L, (bf16_t*)dx, lddx, P, C,
-                       act, accumulate_dx, rows);
+                       act, accumulate_dx, arows);
+  }
   return cn_check_launch();
 }
 
@@ -421,7 +484,7 @@ extern "C" int cn_layernorm_c_bwd_bf16(const void* x, long ldx, const void* dy, 
 // bias gradients on the bf16 path: out[c] (+)= sum_p x[p][c]. ws: cn_bn_workspace_floats_bf16(C) floats.
 __global__ __launch_bounds__(256) void cn_bsum_finalize_kernel(const float* __restrict__ part, int nblk, int C,
                                                               float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * 16 + (threadIdx.x >> 4), sub = threadIdx.x & 15;
+  const int c = blockIdx.x * BBN_FIN_CH + (threadIdx.x >> 6), sub = threadIdx.x & 63;
   double s, ss;
   bbn_combine(part, nblk, C, c, sub, s, ss);
   if (c >= C || sub != 0) return;
@@ -438,6 +501,6 @@ extern "C" int cn_channel_sum_bf16(const void* x, long ldx, long P, int C, float
   bbn_grid(P, C, nblk, rows);
   hipLaunchKernelGGL((cn_bbn_partial_kernel<0>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr, 0L,
                      nullptr, nullptr, nullptr, nullptr, P, C, 0, rows, ws);
-  hipLaunchKernelGGL(cn_bsum_finalize_kernel, dim3((C + 15) / 16), dim3(256), 0, stream, ws, nblk, C, out, accumulate);
+  hipLaunchKernelGGL(cn_bsum_finalize_kernel, dim3((C + BBN_FIN_CH - 1) / BBN_FIN_CH), dim3(256), 0, stream, ws, nblk, C, out, accumulate);
   return cn_check_launch();
 }

@@ -76,25 +76,68 @@ extern "C" int cn_convert_bf16nhwc_to_f32nchw(const void* src, long ld, float* d
 // ------------------------------------------------------------------------------------------------------------
 // slice copy / add / fill on [P][C] rows (C % 8 == 0): dst (+)= src ; dst = a + c ; fill
 // ------------------------------------------------------------------------------------------------------------
+// IDX = int when the piece count fits 31 bits (one 32-bit division per piece instead of a 64-bit one); two pieces
+// per iteration so that every lane has 2-4 independent 16-byte loads in flight.
+template <typename IDX>
 __global__ __launch_bounds__(256) void cn_bcopy_kernel(const bf16_t* __restrict__ a, long lda,
                                                       const bf16_t* __restrict__ c, long ldc, bf16_t* __restrict__ d,
                                                       long ldd, long P, int C8, int mode) {
-  const long n = P * C8;
-  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
-    const long p = i / C8;
-    const int cg = (int)(i - p * C8);
-    float av[8];
-    cn_unpack8(*reinterpret_cast<const u32x4*>(a + p * lda + cg * 8), av);
+  const IDX n = (IDX)(P * C8);
+  const IDX stride = (IDX)gridDim.x * 256;
+  auto one = [&](IDX i, const bf16_t*& pa, const bf16_t*& pc, bf16_t*& pd) {
+    const IDX p = i / (IDX)C8;
+    const int cg = (int)(i - p * (IDX)C8);
+    pa = a + (long)p * lda + cg * 8;
+    pd = d + (long)p * ldd + cg * 8;
+    pc = mode == 1 ? pd : (mode == 2 ? c + (long)p * ldc + cg * 8 : nullptr);
+  };
+  auto fin = [&](const u32x4& ar, const u32x4& cr, bf16_t* pd) {
     if (mode != 0) {  // 1: d += a ; 2: d = a + c
-      float cv[8];
-      cn_unpack8(*reinterpret_cast<const u32x4*>((mode == 1 ? d + p * ldd : c + p * ldc) + cg * 8), cv);
+      float av[8], cv[8];
+      cn_unpack8(ar, av);
+      cn_unpack8(cr, cv);
 #pragma unroll
       for (int j = 0; j < 8; ++j) av[j] += cv[j];
-      *reinterpret_cast<u32x4*>(d + p * ldd + cg * 8) = cn_pack8(av);
+      *reinterpret_cast<u32x4*>(pd) = cn_pack8(av);
     } else {
-      *reinterpret_cast<u32x4*>(d + p * ldd + cg * 8) = *reinterpret_cast<const u32x4*>(a + p * lda + cg * 8);
+      *reinterpret_cast<u32x4*>(pd) = ar;
     }
+  };
+  const u32x4 z4 = {0u, 0u, 0u, 0u};
+  IDX i = (IDX)blockIdx.x * 256 + threadIdx.x;
+  for (; i + stride < n; i += 2 * stride) {
+    const bf16_t *pa0, *pc0, *pa1, *pc1;
+    bf16_t *pd0, *pd1;
+    one(i, pa0, pc0, pd0);
+    one(i + stride, pa1, pc1, pd1);
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(pa0), a1 = *reinterpret_cast<const u32x4*>(pa1);
+    const u32x4 c0 = mode != 0 ? *reinterpret_cast<const u32x4*>(pc0) : z4;
+    const u32x4 c1 = mode != 0 ? *reinterpret_cast<const u32x4*>(pc1) : z4;
+    fin(a0, c0, pd0);
+    fin(a1, c1, pd1);
   }
+  if (i < n) {
+    const bf16_t *pa0, *pc0;
+    bf16_t* pd0;
+    one(i, pa0, pc0, pd0);
+    const u32x4 a0 = *reinterpret_cast<const u32x4*>(pa0);
+    const u32x4 c0 = mode != 0 ? *reinterpret_cast<const u32x4*>(pc0) : z4;
+    fin(a0, c0, pd0);
+  }
+}
+
+static void bcopy_launch(const bf16_t* a, long lda, const bf16_t* c, long ldc, bf16_t* d, long ldd, long P, int C8,
+                         int mode, hipStream_t stream) {
+  const long n = P * C8;
+  long blocks = (n + 511) / 512;  // two pieces per thread and iteration
+  if (blocks > 16384) blocks = 16384;
+  if (blocks < 1) blocks = 1;
+  if (n + 2 * blocks * 256 < (1L << 31))
+    hipLaunchKernelGGL(cn_bcopy_kernel<int>, dim3((unsigned)blocks), dim3(256), 0, stream, a, lda, c, ldc, d, ldd, P, C8,
+                       mode);
+  else
+    hipLaunchKernelGGL(cn_bcopy_kernel<long>, dim3((unsigned)blocks), dim3(256), 0, stream, a, lda, c, ldc, d, ldd, P,
+                       C8, mode);
 }
 
 static inline unsigned bops_blocks(long n) {
@@ -106,8 +149,8 @@ extern "C" int cn_copy_bf16(const void* src, long lds_, void* dst, long ldd, lon
                             void* stream) {
   if (P <= 0 || C <= 0) return CN_OK;
   if (C & 7) return CN_ERR_ARG;
-  hipLaunchKernelGGL(cn_bcopy_kernel, dim3(bops_blocks(P * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)src, lds_, nullptr, 0L, (bf16_t*)dst, ldd, P, C >> 3, accumulate ? 1 : 0);
+  bcopy_launch((const bf16_t*)src, lds_, nullptr, 0L, (bf16_t*)dst, ldd, P, C >> 3, accumulate ? 1 : 0,
+               (hipStream_t)stream);
   return cn_check_launch();
 }
 
@@ -115,8 +158,7 @@ extern "C" int cn_add_bf16(const void* a, long lda, const void* c, long ldc, voi
                            void* stream) {
   if (P <= 0 || C <= 0) return CN_OK;
   if (C & 7) return CN_ERR_ARG;
-  hipLaunchKernelGGL(cn_bcopy_kernel, dim3(bops_blocks(P * (C >> 3))), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)a, lda, (const bf16_t*)c, ldc, (bf16_t*)dst, ldd, P, C >> 3, 2);
+  bcopy_launch((const bf16_t*)a, lda, (const bf16_t*)c, ldc, (bf16_t*)dst, ldd, P, C >> 3, 2, (hipStream_t)stream);
   return cn_check_launch();
 }
 
@@ -276,6 +318,147 @@ __global__ __launch_bounds__(256) void cn_bbilinear_bwd_kernel(const bf16_t* __r
   }
 }
 
+// Row-wise variants (the ones the launchers pick): one block per (image, row), 32-bit index math only, and for the
+// adjoint the candidate lists of the row (computed once) and of every column (LDS table built by the first Wi threads)
+// instead of two scalar search loops per 16-byte piece. Same candidate order and the same fp32 expressions as the
+// element-wise kernels above, so results are identical to them.
+#define BBL_MAXC 12   // candidates per axis held in the tables (up-scaling by up to ~5x); more => element-wise kernel
+#define BBL_MAXW 256  // widest input row the column table covers (25 KB of LDS)
+
+__global__ __launch_bounds__(256) void cn_bbilinear_fwd_rows_kernel(const bf16_t* __restrict__ x, long ldx,
+                                                                   bf16_t* __restrict__ y, long ldy, int C8, int Hi,
+                                                                   int Wi, int Ho, int Wo, float sh, float sw) {
+  const int oy = blockIdx.x, b = blockIdx.y;
+  int y0, y1;
+  float ly;
+  bbl_src(oy, sh, Hi, y0, y1, ly);
+  const float hy = 1.f - ly;
+  const bf16_t* r0 = x + ((long)b * Hi + y0) * Wi * ldx;
+  const bf16_t* r1 = x + ((long)b * Hi + y1) * Wi * ldx;
+  bf16_t* yo = y + ((long)b * Ho + oy) * Wo * ldy;
+  const int n = Wo * C8;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int ox = i / C8, cg = i - ox * C8;
+    int x0, x1;
+    float lx;
+    bbl_src(ox, sw, Wi, x0, x1, lx);
+    float v00[8], v01[8], v10[8], v11[8], o[8];
+    cn_unpack8(*reinterpret_cast<const u32x4*>(r0 + (long)x0 * ldx + cg * 8), v00);
+    cn_unpack8(*reinterpret_cast<const u32x4*>(r0 + (long)x1 * ldx + cg * 8), v01);
+    cn_unpack8(*reinterpret_cast<const u32x4*>(r1 + (long)x0 * ldx + cg * 8), v10);
+    cn_unpack8(*reinterpret_cast<const u32x4*>(r1 + (long)x1 * ldx + cg * 8), v11);
+    const float hx = 1.f - lx;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = hy * (hx * v00[j] + lx * v01[j]) + ly * (hx * v10[j] + lx * v11[j]);
+    *reinterpret_cast<u32x4*>(yo + (long)ox * ldy + cg * 8) = cn_pack8(o);
+  }
+}
+
+// all output indices reading input index i, in increasing order; returns the count (may exceed BBL_MAXC: caller checks)
+__device__ __forceinline__ int bbl_candidates_n(int i, int in_size, int out_size, float scale, float inv_scale,
+                                                int* idx, float* wgt) {
+  int lo = (int)floorf((i - 1) * inv_scale) - 1, hi = (int)ceilf((i + 1) * inv_scale) + 1;
+  if (scale == 0.f) { lo = 0; hi = out_size - 1; }
+  lo = max(lo, 0);
+  hi = min(hi, out_size - 1);
+  int n = 0;
+#pragma unroll 1
+  for (int o = lo; o <= hi; ++o) {
+    int i0, i1; float l1;
+    bbl_src(o, scale, in_size, i0, i1, l1);
+    float w = 0.f;
+    if (i0 == i) w += 1.f - l1;
+    if (i1 == i) w += l1;
+    if (w != 0.f) {
+      if (n < BBL_MAXC) { idx[n] = o; wgt[n] = w; }
+      ++n;
+    }
+  }
+  return n;
+}
+
+__global__ __launch_bounds__(256) void cn_bbilinear_bwd_rows_kernel(const bf16_t* __restrict__ dy, long lddy,
+                                                                   bf16_t* __restrict__ dx, long lddx, int C8, int Hi,
+                                                                   int Wi, int Ho, int Wo, float sh, float sw,
+                                                                   float inv_sh, float inv_sw, int accumulate) {
+  __shared__ int xn[BBL_MAXW];
+  __shared__ int xi[BBL_MAXW * BBL_MAXC];
+  __shared__ float xw[BBL_MAXW * BBL_MAXC];
+  __shared__ int yn, yi[BBL_MAXC];
+  __shared__ float yw[BBL_MAXC];
+  const int iy = blockIdx.x, b = blockIdx.y;
+  for (int ix = threadIdx.x; ix < Wi; ix += 256)
+    xn[ix] = bbl_candidates_n(ix, Wi, Wo, sw, inv_sw, xi + ix * BBL_MAXC, xw + ix * BBL_MAXC);
+  if (threadIdx.x == 255) yn = bbl_candidates_n(iy, Hi, Ho, sh, inv_sh, yi, yw);
+  __syncthreads();
+  const int ny = min(yn, BBL_MAXC);
+  const bf16_t* db = dy + (long)b * Ho * Wo * lddy;
+  bf16_t* dxr = dx + ((long)b * Hi + iy) * Wi * lddx;
+  const int n = Wi * C8;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const int ix = i / C8, cg = i - ix * C8;
+    const int nx = min(xn[ix], BBL_MAXC);
+    float acc[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+    if (nx > 0) {
+      // The first three column candidates of a row are loaded together (a serial load -> FMA chain per candidate left
+      // one L2 round trip exposed per 16 bytes); absent ones alias candidate 0 with weight 0, which leaves the sum
+      // unchanged. Resizes by less than 2x have at most three candidates per axis.
+      const int* xip = xi + ix * BBL_MAXC;
+      const float* xwp = xw + ix * BBL_MAXC;
+      const long o0 = (long)xip[0] * lddy;
+      const long o1 = nx > 1 ? (long)xip[1] * lddy : o0;
+      const long o2 = nx > 2 ? (long)xip[2] * lddy : o0;
+      const float wx0 = xwp[0], wx1 = nx > 1 ? xwp[1] : 0.f, wx2 = nx > 2 ? xwp[2] : 0.f;
+#pragma unroll 1
+      for (int k = 0; k < ny; ++k) {
+        const bf16_t* row = db + (long)yi[k] * Wo * lddy + cg * 8;
+        const float wy = yw[k];
+        const u32x4 r0 = *reinterpret_cast<const u32x4*>(row + o0);
+        const u32x4 r1 = *reinterpret_cast<const u32x4*>(row + o1);
+        const u32x4 r2 = *reinterpret_cast<const u32x4*>(row + o2);
+        float v[8];
+        const float w0 = wy * wx0, w1 = wy * wx1, w2 = wy * wx2;
+        cn_unpack8(r0, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += w0 * v[j];
+        cn_unpack8(r1, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += w1 * v[j];
+        cn_unpack8(r2, v);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) acc[j] += w2 * v[j];
+#pragma unroll 1
+        for (int l = 3; l < nx; ++l) {
+          const float w = wy * xwp[l];
+          cn_unpack8(*reinterpret_cast<const u32x4*>(row + (long)xip[l] * lddy), v);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) acc[j] += w * v[j];
+        }
+      }
+    }
+    bf16_t* o = dxr + (long)ix * lddx + cg * 8;
+    if (accumulate) {
+      float ov[8];
+      cn_unpack8(*reinterpret_cast<const u32x4*>(o), ov);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) acc[j] += ov[j];
+    }
+    *reinterpret_cast<u32x4*>(o) = cn_pack8(acc);
+  }
+}
+
+// largest number of output indices that read one input index (host restatement of the device search)
+static int bbl_max_candidates(int in_size, int out_size) {
+  if (out_size <= 1) return out_size;
+  if (in_size <= 1) return out_size;
+  // output o reads floor(o * scale) and its successor: an input index is read by the outputs of two consecutive
+  // unit intervals of o * scale
+  const double scale = (double)(in_size - 1) / (double)(out_size - 1);
+  return (int)(2.0 / scale) + 2;
+}
+
 static inline float bbl_scale(int in_size, int out_size) {
   return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
 }
@@ -284,9 +467,14 @@ extern "C" int cn_bilinear_fwd_bf16(const void* x, long ldx, void* y, long ldy, 
                                     int Wo, void* stream) {
   if (B <= 0 || C <= 0) return CN_OK;
   if (C & 7) return CN_ERR_ARG;
-  hipLaunchKernelGGL(cn_bbilinear_fwd_kernel, dim3(bops_blocks((long)B * Ho * Wo * (C >> 3))), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, B, C >> 3, Hi, Wi, Ho, Wo,
-                     bbl_scale(Hi, Ho), bbl_scale(Wi, Wo));
+  if (Ho <= 0 || Wo <= 0 || Hi <= 0 || Wi <= 0) return CN_OK;
+  if (B <= 65535 && (long)Wo * (C >> 3) < (1L << 30))
+    hipLaunchKernelGGL(cn_bbilinear_fwd_rows_kernel, dim3(Ho, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+                       ldx, (bf16_t*)y, ldy, C >> 3, Hi, Wi, Ho, Wo, bbl_scale(Hi, Ho), bbl_scale(Wi, Wo));
+  else
+    hipLaunchKernelGGL(cn_bbilinear_fwd_kernel, dim3(bops_blocks((long)B * Ho * Wo * (C >> 3))), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, B, C >> 3, Hi, Wi, Ho, Wo,
+                       bbl_scale(Hi, Ho), bbl_scale(Wi, Wo));
   return cn_check_launch();
 }
 
@@ -295,9 +483,16 @@ extern "C" int cn_bilinear_bwd_bf16(const void* dy, long lddy, void* dx, long ld
   if (B <= 0 || C <= 0) return CN_OK;
   if (C & 7) return CN_ERR_ARG;
   const float sh = bbl_scale(Hi, Ho), sw = bbl_scale(Wi, Wo);
-  hipLaunchKernelGGL(cn_bbilinear_bwd_kernel, dim3(bops_blocks((long)B * Hi * Wi * (C >> 3))), dim3(256), 0,
-                     (hipStream_t)stream, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, B, C >> 3, Hi, Wi, Ho, Wo, sh, sw,
-                     sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, accumulate);
+  if (Ho <= 0 || Wo <= 0 || Hi <= 0 || Wi <= 0) return CN_OK;
+  const float ish = sh > 0.f ? 1.f / sh : 0.f, isw = sw > 0.f ? 1.f / sw : 0.f;
+  if (B <= 65535 && Wi <= BBL_MAXW && (long)Wi * (C >> 3) < (1L << 30) && bbl_max_candidates(Hi, Ho) <= BBL_MAXC &&
+      bbl_max_candidates(Wi, Wo) <= BBL_MAXC)
+    hipLaunchKernelGGL(cn_bbilinear_bwd_rows_kernel, dim3(Hi, B), dim3(256), 0, (hipStream_t)stream,
+                       (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, C >> 3, Hi, Wi, Ho, Wo, sh, sw, ish, isw, accumulate);
+  else
+    hipLaunchKernelGGL(cn_bbilinear_bwd_kernel, dim3(bops_blocks((long)B * Hi * Wi * (C >> 3))), dim3(256), 0,
+                       (hipStream_t)stream, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, B, C >> 3, Hi, Wi, Ho, Wo, sh,
+                       sw, ish, isw, accumulate);
   return cn_check_launch();
 }
 

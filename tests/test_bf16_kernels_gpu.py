@@ -322,7 +322,9 @@ def test_na2d_bf16(shape, heads, dil):
 
 
 @pytest.mark.parametrize("case", [(2, 16, 13, 13, 14, 14), (1, 32, 49, 49, 50, 50), (2, 8, 97, 97, 100, 100),
-                                  (1, 8, 25, 25, 25, 25), (2, 16, 7, 9, 20, 23), (1, 8, 40, 40, 13, 17)])
+                                  (1, 8, 25, 25, 25, 25), (2, 16, 7, 9, 20, 23), (1, 8, 40, 40, 13, 17),
+                                  (2, 32, 25, 25, 100, 100), (1, 16, 13, 13, 100, 100), (1, 8, 100, 100, 25, 25),
+                                  (1, 8, 5, 300, 9, 310), (1, 8, 1, 6, 4, 1), (1, 8, 3, 3, 64, 64)])
 def test_bilinear_bf16(case):
     from cultionet_amd import _lib
 
@@ -340,6 +342,11 @@ def test_bilinear_bf16(case):
     dx = _empty_nhwc(B, C, Hi, Wi)
     _lib.call("cn_bilinear_bwd_bf16", dyg.data_ptr(), _ld(dyg), dx.data_ptr(), _ld(dx), B, C, Hi, Wi, Ho, Wo, 0, _s())
     _close(dx, xr.grad, 6e-3, "dx")
+    # accumulate mode: dx += adjoint
+    base = _r(_rand(B, C, Hi, Wi, seed=3))
+    dx2 = _nhwc(base)
+    _lib.call("cn_bilinear_bwd_bf16", dyg.data_ptr(), _ld(dyg), dx2.data_ptr(), _ld(dx2), B, C, Hi, Wi, Ho, Wo, 1, _s())
+    _close(dx2, xr.grad + base, 1.2e-2, "dx accumulate")
 
 
 def test_converters_and_slices_bf16():
