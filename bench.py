@@ -237,6 +237,21 @@ def predict_block(dev, hidden: int, cpu: bool, threads: int):
     return out
 
 
+def read_by_kernel(nk, steps, limit=8):
+    """Per-kernel-name aggregates of the profiling window just closed (cn_profile_top)."""
+    from cultionet_amd import _lib
+
+    out = {}
+    for r in range(min(nk, limit)):
+        nb = ctypes.create_string_buffer(96)
+        o3 = (ctypes.c_double * 3)()
+        _lib.query("cn_profile_top", r, nb, 96, o3)
+        out[nb.value.decode()] = {
+            "ms_per_step": o3[0] / steps, "tflops": (o3[1] / (o3[0] * 1e-3) / 1e12) if o3[0] else 0.0,
+            "launches_per_step": o3[2] / steps}
+    return out
+
+
 def main():
     args = parse()
     import torch
@@ -267,6 +282,7 @@ def main():
         rccl_ranks = dist.get_world_size()  # what the process group really initialised
 
     from cultionet_amd import _lib
+    from cultionet_amd import engine as E
     from cultionet_amd.data import Data
     from cultionet_amd.lightning import CultionetLitModel, HipTrainer
     from cultionet_amd import synthetic as O
@@ -335,14 +351,34 @@ def main():
         name_buf = ctypes.create_string_buffer(96)
         top3 = (ctypes.c_double * 3)()
         nk = _lib.query("cn_profile_top", 0, name_buf, 96, top3)
-        by_kernel = {}
-        for r in range(min(nk, 8)):
-            nb = ctypes.create_string_buffer(96)
-            o3 = (ctypes.c_double * 3)()
-            _lib.query("cn_profile_top", r, nb, 96, o3)
-            by_kernel[nb.value.decode()] = {
-                "ms_per_step": o3[0] / args.steps, "tflops": (o3[1] / (o3[0] * 1e-3) / 1e12) if o3[0] else 0.0,
-                "launches_per_step": o3[2] / args.steps}
+        by_kernel = read_by_kernel(nk, args.steps)
+        # The timed region runs the weight-gradient kernels on a second HIP stream beside the data-gradient chain, so
+        # the event-bracketed duration of a kernel there includes the time it shared the CUs with the other stream.
+        # `isolated`: the same step once more with that overlap switched off (one stream, nothing else resident), i.e.
+        # the kernel's own duration -- the figure to hold against the MFMA peak.
+        iso_kernel, iso_kinds = {}, None
+        if world == 1 and not args.no_extras:
+            iso_steps = min(args.steps, 3)
+            E.overlap_wgrad(False)
+            try:
+                trainer.training_step(batch)
+                torch.cuda.synchronize()
+                _lib.call("cn_profile_begin")
+                for _ in range(iso_steps):
+                    trainer.training_step(batch)
+                torch.cuda.synchronize()
+                iprof = (ctypes.c_double * 24)()
+                _lib.call("cn_profile_end", iprof)
+            finally:
+                E.overlap_wgrad(True)
+            iso_kinds = [(iprof[3 * k], iprof[3 * k + 1], iprof[3 * k + 2]) for k in range(8)]
+            nb0 = ctypes.create_string_buffer(96)
+            ink = _lib.query("cn_profile_top", 0, nb0, 96, (ctypes.c_double * 3)())
+            iso_kernel = read_by_kernel(ink, iso_steps, limit=16)
+            for name, rec in by_kernel.items():
+                if name in iso_kernel:
+                    rec["isolated_tflops"] = iso_kernel[name]["tflops"]
+                    rec["isolated_us"] = iso_kernel[name]["ms_per_step"] * 1e3 / max(iso_kernel[name]["launches_per_step"], 1e-9)
         top_name = name_buf.value.decode() if nk > 0 else ""
         ms, flops, nl = top3[0], top3[1], top3[2]
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
@@ -387,11 +423,18 @@ def main():
                 "avg_launch_us": ms * 1e3 / nl if nl else None,
                 "launches_per_step": nl / args.steps,
                 "share_of_step_time": ms * 1e-3 / dt,
+                "isolated": ({"achieved": iso_kernel[top_name]["tflops"], "frac": iso_kernel[top_name]["tflops"] / peak,
+                              "avg_launch_us": iso_kernel[top_name]["ms_per_step"] * 1e3
+                              / max(iso_kernel[top_name]["launches_per_step"], 1e-9),
+                              "note": "same step with the weight-gradient side stream off: the kernel alone on the GPU"}
+                             if top_name in iso_kernel else None),
                 "by_kernel": by_kernel,
                 "family": {FAMILY[k]: {"ms_per_step": kinds[k][0] / args.steps,
                                        "tflops": (kinds[k][1] / (kinds[k][0] * 1e-3) / 1e12) if kinds[k][0] else 0.0,
                                        "frac": ((kinds[k][1] / (kinds[k][0] * 1e-3) / 1e12) / peak) if kinds[k][0] else 0.0,
-                                       "launches_per_step": kinds[k][2] / args.steps}
+                                       "launches_per_step": kinds[k][2] / args.steps,
+                                       "isolated_frac": (((iso_kinds[k][1] / (iso_kinds[k][0] * 1e-3) / 1e12) / peak)
+                                                         if iso_kinds is not None and iso_kinds[k][0] else None)}
                            for k in range(6) if kinds[k][2] > 0},
                 "dominant_family": FAMILY.get(dom),
                 "end_to_end_tflops": value * train_gflop / 1e3,

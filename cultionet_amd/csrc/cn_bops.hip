@@ -221,12 +221,16 @@ __global__ __launch_bounds__(256) void cn_bbilinear_fwd_kernel(const bf16_t* __r
 
 // candidate output rows / columns reading input index i (<= 4 for resizes that shrink by less than 2x)
 __device__ __forceinline__ int bbl_candidates(int i, int in_size, int out_size, float scale, float inv_scale, int* idx,
-                                              float* wgt) {
+                                             float* wgt) {
   int lo = (int)floorf((i - 1) * inv_scale) - 1, hi = (int)ceilf((i + 1) * inv_scale) + 1;
   if (scale == 0.f) { lo = 0; hi = out_size - 1; }
   lo = max(lo, 0);
   hi = min(hi, out_size - 1);
-  int n = 0;
+  // The outputs reading input index i are CONSECUTIVE (the source coordinate is monotonic; a zero weight can only be
+  // the first output of the run, whose source falls exactly on i - 1): the search only counts them and notes the first,
+  // the <= 4 weights are then recomputed with static register indices. (Storing idx[n] / wgt[n] from inside the search
+  // loop through an if-chain on n lost candidate 1 whenever a fourth one was found -- resizes growing by 1.5x..2x.)
+  int n = 0, first = 0;
 #pragma unroll 1
   for (int o = lo; o <= hi; ++o) {
     int i0, i1; float l1;
@@ -235,12 +239,21 @@ __device__ __forceinline__ int bbl_candidates(int i, int in_size, int out_size, 
     if (i0 == i) w += 1.f - l1;
     if (i1 == i) w += l1;
     if (w != 0.f) {
-      if (n == 0) { idx[0] = o; wgt[0] = w; }
-      else if (n == 1) { idx[1] = o; wgt[1] = w; }
-      else if (n == 2) { idx[2] = o; wgt[2] = w; }
-      else if (n == 3) { idx[3] = o; wgt[3] = w; }
+      if (n == 0) first = o;
       ++n;
     }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool live = k < n;
+    const int o = live ? first + k : first;
+    int i0, i1; float l1;
+    bbl_src(o, scale, in_size, i0, i1, l1);
+    float w = 0.f;
+    if (i0 == i) w += 1.f - l1;
+    if (i1 == i) w += l1;
+    idx[k] = o;
+    wgt[k] = live ? w : 0.f;
   }
   return n;
 }

@@ -118,7 +118,11 @@ __device__ __forceinline__ int bl_candidates(int i, int in_size, int out_size, f
   if (scale == 0.f) { lo = 0; hi = out_size - 1; }
   lo = max(lo, 0);
   hi = min(hi, out_size - 1);
-  int n = 0;
+  // The outputs reading input index i are CONSECUTIVE (the source coordinate is monotonic; a zero weight can only be
+  // the first output of the run, whose source falls exactly on i - 1): the search only counts them and notes the first,
+  // the <= 4 weights are then recomputed with static register indices. (Storing idx[n] / wgt[n] from inside the search
+  // loop through an if-chain on n lost candidate 1 whenever a fourth one was found -- resizes growing by 1.5x..2x.)
+  int n = 0, first = 0;
 #pragma unroll 1
   for (int o = lo; o <= hi; ++o) {
     int i0, i1; float l1;
@@ -127,15 +131,21 @@ __device__ __forceinline__ int bl_candidates(int i, int in_size, int out_size, f
     if (i0 == i) w += 1.f - l1;
     if (i1 == i) w += l1;
     if (w != 0.f) {
-      if (n < 4) {
-        // static indexing keeps idx/wgt in registers
-        if (n == 0) { idx[0] = o; wgt[0] = w; }
-        else if (n == 1) { idx[1] = o; wgt[1] = w; }
-        else if (n == 2) { idx[2] = o; wgt[2] = w; }
-        else { idx[3] = o; wgt[3] = w; }
-      }
+      if (n == 0) first = o;
       ++n;
     }
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {
+    const bool live = k < n;
+    const int o = live ? first + k : first;
+    int i0, i1; float l1;
+    bl_src(o, scale, in_size, i0, i1, l1);
+    float w = 0.f;
+    if (i0 == i) w += 1.f - l1;
+    if (i1 == i) w += l1;
+    idx[k] = o;
+    wgt[k] = live ? w : 0.f;
   }
   return n;
 }
@@ -155,24 +165,47 @@ __global__ __launch_bounds__(256) void cn_bilinear_bwd_near_kernel(const float* 
   int c_end = c_begin + BL_CH;
   if (c_end > C) c_end = C;
   if (ny <= 4 && nx <= 4) {
-    // unused slots carry weight 0 and index 0: their loads hit the plane's first row / column and are multiplied out
+    // The 3 x 3 first candidate slots are loaded UNCONDITIONALLY (nine independent loads in flight per channel; a
+    // branch per slot serialised them: 150 us for a [8,128,99,99] -> 100x100 adjoint that moves 82 MB). Unused slots
+    // alias slot 0 -- a live candidate -- with weight 0, which leaves the sum unchanged; a fourth candidate per axis
+    // (resizes that shrink by almost 2x) goes through the predicated tail.
+    if (ny == 0 || nx == 0) {  // no output reads this pixel
+      for (int c = c_begin; c < c_end; ++c) {
+        float* o = dx + b * dxbs + (long)c * Hi * Wi + p;
+        if (!accumulate) *o = 0.f;
+      }
+      return;
+    }
     float w[4][4];
     int off[4][4];
 #pragma unroll
     for (int k = 0; k < 4; ++k)
 #pragma unroll
       for (int j = 0; j < 4; ++j) {
-        w[k][j] = wyv[k] * wxv[j];
-        off[k][j] = oyv[k] * Wo + oxv[j];
+        const bool live = k < ny && j < nx;
+        w[k][j] = live ? wyv[k] * wxv[j] : 0.f;
+        off[k][j] = live ? oyv[k] * Wo + oxv[j] : oyv[0] * Wo + oxv[0];
       }
+    const bool tail = ny == 4 || nx == 4;
     for (int c = c_begin; c < c_end; ++c) {
       const float* dp = dy + b * dybs + (long)c * Ho * Wo;
+      float v[3][3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[k][j] = dp[off[k][j]];
       float acc = 0.f;
 #pragma unroll
-      for (int k = 0; k < 4; ++k)
+      for (int k = 0; k < 3; ++k)
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
-          if (w[k][j] != 0.f) acc += w[k][j] * dp[off[k][j]];
+        for (int j = 0; j < 3; ++j) acc += w[k][j] * v[k][j];
+      if (tail) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+#pragma unroll
+          for (int j = 0; j < 4; ++j)
+            if ((k == 3 || j == 3) && w[k][j] != 0.f) acc += w[k][j] * dp[off[k][j]];
+      }
       float* o = dx + b * dxbs + (long)c * Hi * Wi + p;
       *o = accumulate ? *o + acc : acc;
     }

@@ -150,6 +150,16 @@ _OVERLAP_WGRAD = os.environ.get("CN_OVERLAP_WGRAD", "1") == "1"
 _side_streams: T.Dict[T.Any, T.Dict[str, T.Any]] = {}
 
 
+def overlap_wgrad(enabled: bool) -> bool:
+    """Switch the weight-gradient side stream on / off at run time (bench.py's isolated per-kernel pass); returns the
+    previous setting. Pending side-stream work is joined first."""
+    global _OVERLAP_WGRAD
+    prev = _OVERLAP_WGRAD
+    join_side_stream()
+    _OVERLAP_WGRAD = bool(enabled)
+    return prev
+
+
 def _side_state(dev) -> T.Dict[str, T.Any]:
     st = _side_streams.get(dev)
     if st is None:

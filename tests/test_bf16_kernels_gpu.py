@@ -324,7 +324,8 @@ def test_na2d_bf16(shape, heads, dil):
 @pytest.mark.parametrize("case", [(2, 16, 13, 13, 14, 14), (1, 32, 49, 49, 50, 50), (2, 8, 97, 97, 100, 100),
                                   (1, 8, 25, 25, 25, 25), (2, 16, 7, 9, 20, 23), (1, 8, 40, 40, 13, 17),
                                   (2, 32, 25, 25, 100, 100), (1, 16, 13, 13, 100, 100), (1, 8, 100, 100, 25, 25),
-                                  (1, 8, 5, 300, 9, 310), (1, 8, 1, 6, 4, 1), (1, 8, 3, 3, 64, 64)])
+                                  (1, 8, 5, 300, 9, 310), (1, 8, 1, 6, 4, 1), (1, 8, 3, 3, 64, 64),
+                                  (1, 8, 4, 260, 6, 500), (1, 16, 51, 51, 100, 100)])
 def test_bilinear_bf16(case):
     from cultionet_amd import _lib
 

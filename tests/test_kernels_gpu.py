@@ -259,7 +259,8 @@ def test_na2d(B, C, heads, H, W, dil):
 @pytest.mark.parametrize("B,C,Hi,Wi,Ho,Wo", [(2, 8, 13, 13, 14, 14), (1, 16, 49, 49, 50, 50), (2, 4, 99, 99, 100, 100),
                                              (2, 4, 97, 97, 100, 100), (1, 3, 27, 25, 28, 28),
                                              (1, 20, 99, 99, 100, 100), (1, 8, 100, 100, 60, 60),
-                                             (1, 8, 100, 100, 100, 100), (1, 40, 25, 25, 100, 100)])
+                                             (1, 8, 100, 100, 100, 100), (1, 40, 25, 25, 100, 100),
+                                             (1, 32, 51, 51, 100, 100), (1, 8, 100, 100, 51, 51)])
 def test_bilinear(B, C, Hi, Wi, Ho, Wo):
     from cultionet_amd import engine as E
 
