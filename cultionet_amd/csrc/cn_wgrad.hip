@@ -212,6 +212,17 @@ __global__ __launch_bounds__(256) void cn_wgrad_kernel(const float* __restrict__
 
 __device__ float cn_zero_line16[256];  // 1 KiB of zeros: per-lane 16-byte zero source
 
+// Diagnostic build (-DCNW_STAMP): s_memtime stamps of wave 0 of block 0 over its first chunks (tools/wgrad_stamps.py).
+#ifdef CNW_STAMP
+__device__ unsigned long long cnw_stamps[256];
+#define CNW_ST() do { if (do_stamp && stamp_i < 256) cnw_stamps[stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int cn_wgrad_read_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(cnw_stamps), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -2;
+}
+#else
+#define CNW_ST() do { } while (0)
+#endif
+
 __device__ __forceinline__ void cn_glds16(const float* src, float* lds_wave_base) {
   __builtin_amdgcn_global_load_lds((cn_gbl_ptr)src, (cn_lds_ptr)lds_wave_base, 16, 0, 0);
 }
@@ -273,18 +284,27 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
 
   // dense LDS images: S [arows][npix], Bg [WG_BC][plane_b]; piece p of an image = its p-th 16 bytes, so one
   // DMA wave-instruction (64 consecutive pieces = 1 KiB) may span several rows / channels.
-  int sp[WG_KS], bp[WG_KB];  // packed (row << 16 | piece-in-row) of this lane's piece in instruction k; -1 idle
+  // Per-lane BYTE offset of this lane's piece in DMA instruction k, relative to the chunk's base address (S: first
+  // pixel of the chunk in channel 0 of image n; Bg: the 16-byte aligned start of the halo in channel 0), or WG_IDLE
+  // for lanes past the image / past the channel count (their LDS rows only feed dW entries that are never stored).
+  // Interior chunks -- all but the first / last rows of an image -- then stage with ONE instruction per KiB: scalar
+  // base + per-lane offset, no per-chunk address arithmetic or bound checks (those took ~3000 cycles per chunk with
+  // the matrix pipe idle: one wave per SIMD). Boundary chunks re-derive the piece index and zero-fill per piece.
+  constexpr unsigned WG_IDLE = 0xFFFFFFFFu;
+  unsigned so[WG_KS], bo[WG_KB];
   {
     const int nsp = arows * n4s, nbp = WG_BC * n4b;
 #pragma unroll
     for (int k = 0; k < WG_KS; ++k) {
       const int p = (wid + 4 * k) * 64 + lane;
-      sp[k] = p < nsp ? ((p / n4s) << 16) | (p % n4s) : -1;
+      const int a = p / n4s, pc = p - a * n4s;
+      so[k] = (p < nsp && (a0 + a) < g.A) ? (unsigned)(((long)(a0 + a) * g.scs + 4 * pc) * 4) : WG_IDLE;
     }
 #pragma unroll
     for (int k = 0; k < WG_KB; ++k) {
       const int p = (wid + 4 * k) * 64 + lane;
-      bp[k] = p < nbp ? ((p / n4b) << 16) | (p % n4b) : -1;
+      const int bl = p / n4b, pi = p - bl * n4b;
+      bo[k] = (p < nbp && (b0 + bl) < g.Bc) ? (unsigned)(((long)(b0 + bl) * g.bcs + 4 * pi) * 4) : WG_IDLE;
     }
   }
   auto stage = [&](int ck, int buf) {
@@ -294,15 +314,21 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
     const int gy0 = (ck - n * g.chunks_per_img) * g.PR;
     const int nsp = arows * n4s, nbp = WG_BC * n4b;
     {
-      const float* Sn = S + (long)n * g.sbs + (long)gy0 * g.Ws;
       const int fs0 = gy0 * g.Ws;
+      const char* sbase = reinterpret_cast<const char*>(S + (long)n * g.sbs + fs0);
+      if (fs0 + npix <= (int)g.scs) {  // wave-uniform: the whole chunk lies inside the plane
 #pragma unroll
-      for (int k = 0; k < WG_KS; ++k) {
-        if ((wid + 4 * k) * 64 < nsp) {  // wave-uniform
-          if (sp[k] >= 0) {
-            const int a = sp[k] >> 16, pc = sp[k] & 0xFFFF;
-            const bool ok = (a0 + a) < g.A && (fs0 + 4 * pc + 3) < (int)g.scs;
-            const float* src = ok ? Sn + (long)(a0 + a) * g.scs + 4 * pc : zero;
+        for (int k = 0; k < WG_KS; ++k)
+          if ((wid + 4 * k) * 64 < nsp && so[k] != WG_IDLE)
+            cn_glds16(reinterpret_cast<const float*>(sbase + so[k]), s_lds + (wid + 4 * k) * 256);
+      } else {
+#pragma unroll
+        for (int k = 0; k < WG_KS; ++k) {
+          if ((wid + 4 * k) * 64 < nsp && so[k] != WG_IDLE) {
+            const int p = (wid + 4 * k) * 64 + lane;
+            const int pc = p % n4s;
+            const bool ok = (fs0 + 4 * pc + 3) < (int)g.scs;
+            const float* src = ok ? reinterpret_cast<const float*>(sbase + so[k]) : zero;
             cn_glds16(src, s_lds + (wid + 4 * k) * 256);
           }
         }
@@ -311,14 +337,20 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
     {
       const int start = (gy0 * g.s + g.min_oy) * g.Wb + g.min_ox;
       const int f0 = (start >> 2) << 2;
-      const float* Bn = Bg + (long)n * g.bbs;
+      const char* bbase = reinterpret_cast<const char*>(Bg + (long)n * g.bbs + f0);
+      if (f0 >= 0 && f0 + g.plane_b <= (int)g.bcs) {  // wave-uniform: the halo lies inside the plane
 #pragma unroll
-      for (int k = 0; k < WG_KB; ++k) {
-        if ((wid + 4 * k) * 64 < nbp) {  // wave-uniform
-          if (bp[k] >= 0) {
-            const int bl = bp[k] >> 16, fq = f0 + 4 * (bp[k] & 0xFFFF);
-            const bool ok = (b0 + bl) < g.Bc && fq >= 0 && (fq + 3) < (int)g.bcs;
-            const float* src = ok ? Bn + (long)(b0 + bl) * g.bcs + fq : zero;
+        for (int k = 0; k < WG_KB; ++k)
+          if ((wid + 4 * k) * 64 < nbp && bo[k] != WG_IDLE)
+            cn_glds16(reinterpret_cast<const float*>(bbase + bo[k]), b_lds + (wid + 4 * k) * 256);
+      } else {
+#pragma unroll
+        for (int k = 0; k < WG_KB; ++k) {
+          if ((wid + 4 * k) * 64 < nbp && bo[k] != WG_IDLE) {
+            const int p = (wid + 4 * k) * 64 + lane;
+            const int fq = f0 + 4 * (p % n4b);
+            const bool ok = fq >= 0 && (fq + 3) < (int)g.bcs;
+            const float* src = ok ? reinterpret_cast<const float*>(bbase + bo[k]) : zero;
             cn_glds16(src, b_lds + (wid + 4 * k) * 256);
           }
         }
@@ -327,14 +359,22 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
   };
 
   int cur = 0;
+#ifdef CNW_STAMP
+  const bool do_stamp = T == 9 && S_ == 1 && blockIdx.x == 8 && tid == 0;
+  int stamp_i = 0;
+#endif
+  CNW_ST();  // 0: prologue done
   if (chunk < chunk_end && g.nbuf == 2) stage(chunk, 0);
   for (; chunk < chunk_end; ++chunk) {
+    CNW_ST();  // chunk top
     if (g.nbuf == 1) {
       __syncthreads();
       stage(chunk, 0);
     }
     __syncthreads();
+    CNW_ST();  // after barrier
     if (g.nbuf == 2 && chunk + 1 < chunk_end) stage(chunk + 1, cur ^ 1);
+    CNW_ST();  // after DMA issue
     const float* s_lds = smem + cur * g.buf_stride;
     const float* b_lds = s_lds + g.b_lds_off;
     const int gy0c = (chunk % g.chunks_per_img) * g.PR;
@@ -355,20 +395,27 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
 #pragma unroll
         for (int j = 0; j < T; ++j) bp[j] = b_lds + boff[j] + sh + (r * S_) * g.Wb;
         int q = q_lo;
+        // masked and left-over single pairs: all T + 1 operands are read before the first MFMA (read / wait / MFMA per
+        // tap exposed one LDS round trip in front of every MFMA of the pair)
         for (; q < seg0; ++q) {  // leading masked pairs
           const float av = ap[2 * q];
           const int cs = 2 * q * S_;
+          float bv[T];
+#pragma unroll
+          for (int j = 0; j < T; ++j) bv[j] = bp[j][cs];
 #pragma unroll
           for (int j = 0; j < T; ++j) {
-            float bv = bp[j][cs];
-            bv = ((unsigned)(cs + ox[j]) < (unsigned)g.Wb) ? bv : 0.f;
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+            const float b_ = ((unsigned)(cs + ox[j]) < (unsigned)g.Wb) ? bv[j] : 0.f;
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_, acc[j], 0, 0, 0);
           }
         }
         // Interior pairs (no masks, immediate offsets), in groups of two k-steps with the operands double-buffered
         // in registers: the LDS reads of the NEXT group are issued before the 2*T MFMAs of the current one. One wave
         // per SIMD issues in order, so without this every group waited out the full LDS latency with the MFMA pipe
-        // idle (the compiler emitted read-all / s_waitcnt 0 / MFMA-all).
+        // idle (the compiler emitted read-all / s_waitcnt 0 / MFMA-all). (Folding the edge pairs into this pipeline
+        // as well was measured slower: 252 -> 273 us at 128->128, 100^2 -- the extra live operands cost more moves
+        // than the two exposed LDS round trips per row.)
+        CNW_ST();  // after leading masked pairs
         if constexpr (T == 1) {
           // one MFMA per k-step: the register pipeline below was measured slower (172 vs 161 us at 480->128, 100^2)
           for (; q + WG_U <= seg1; q += WG_U) {
@@ -411,26 +458,33 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
             q += GS * ng;
           }
         }
+        CNW_ST();  // after pipelined groups
         for (; q < seg1; ++q) {
           const float av = ap[2 * q];
+          float bv[T];
 #pragma unroll
-          for (int j = 0; j < T; ++j)
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bp[j][2 * q * S_], acc[j], 0, 0, 0);
+          for (int j = 0; j < T; ++j) bv[j] = bp[j][2 * q * S_];
+#pragma unroll
+          for (int j = 0; j < T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[j], 0, 0, 0);
         }
         for (; q < q_hi; ++q) {  // trailing masked pairs
           const float av = ap[2 * q];
           const int cs = 2 * q * S_;
+          float bv[T];
+#pragma unroll
+          for (int j = 0; j < T; ++j) bv[j] = bp[j][cs];
 #pragma unroll
           for (int j = 0; j < T; ++j) {
-            float bv = bp[j][cs];
-            bv = ((unsigned)(cs + ox[j]) < (unsigned)g.Wb) ? bv : 0.f;
-            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv, acc[j], 0, 0, 0);
+            const float b_ = ((unsigned)(cs + ox[j]) < (unsigned)g.Wb) ? bv[j] : 0.f;
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_, acc[j], 0, 0, 0);
           }
         }
       }
     }
+    CNW_ST();  // chunk end
     if (g.nbuf == 2) cur ^= 1;
   }
+  CNW_ST();
 
   // the k-part waves of a block hold partial sums of the SAME dW tile: add them up through LDS (free after the
   // main loop) so the block writes its tile once
