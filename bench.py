@@ -216,8 +216,18 @@ def predict_block(dev, hidden: int, cpu: bool, threads: int):
             model(xd)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
+        with torch.autocast("cuda", dtype=torch.bfloat16):  # the reference's default predict precision is 16-mixed
+            for _ in range(2):
+                model(xd)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(n):
+                model(xd)
+            torch.cuda.synchronize()
+            dt16 = (time.perf_counter() - t0) / n
     out = {"workload": f"eval forward [1,4,25,256,256], hidden {hidden}, fp32 (BASELINE configs[4])",
-           "ms_per_tile": dt * 1e3, "value": 256 * 256 / dt, "unit": "pixels/s"}
+           "ms_per_tile": dt * 1e3, "value": 256 * 256 / dt, "unit": "pixels/s",
+           "bf16_mixed": {"ms_per_tile": dt16 * 1e3, "value": 256 * 256 / dt16, "unit": "pixels/s"}}
     if cpu:
         from oracle import towerunet_oracle as O
 

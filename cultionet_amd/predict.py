@@ -34,9 +34,14 @@ class SlidingWindowPredictor:
 
     def __init__(self, lit, window_size: int = 100, padding: int = 5, batch_size: int = 8,
                  mean: T.Optional[torch.Tensor] = None, std: T.Optional[torch.Tensor] = None,
-                 scale: float = 1.0 / SCALE_FACTOR, lo: float = 1e-9, hi: float = 1.0):
+                 scale: float = 1.0 / SCALE_FACTOR, lo: float = 1e-9, hi: float = 1.0, precision: str = "32-true"):
         if window_size <= 0 or padding < 0 or batch_size <= 0:
             raise ValueError("window_size, batch_size must be positive and padding non-negative")
+        if precision not in ("32-true", "32", "bf16-mixed", "16-mixed"):
+            raise ValueError(f"unsupported precision {precision!r}")
+        # lightning.Trainer(precision=...) of the reference's predict entry (model.py:168-186): the mixed modes run the
+        # TowerUNet body in bf16 NHWC on the MFMA bf16 path (fp32 parameters / running statistics / heads)
+        self.bf16 = precision in ("bf16-mixed", "16-mixed")
         self.lit = lit
         self.ws, self.pad, self.bs = int(window_size), int(padding), int(batch_size)
         self.mean, self.std = mean, std
@@ -69,7 +74,8 @@ class SlidingWindowPredictor:
                           rc[i:i + n].data_ptr(), n, C, Tn, H, W, S, self.pad,
                           mean.data_ptr() if mean is not None else None, std.data_ptr() if std is not None else None,
                           self.scale, self.lo, self.hi, _stream())
-                pred = self.lit.cultionet_model.mask_model(x)
+                with torch.autocast("cuda", dtype=torch.bfloat16, enabled=self.bf16):
+                    pred = self.lit.cultionet_model.mask_model(x)
                 d, e, c = (pred[k].float().contiguous() for k in ("distance", "edge", "crop"))
                 _lib.call("cn_stitch_predictions_u16", d.data_ptr(), e.data_ptr(), c.data_ptr(), out.data_ptr(),
                           rc[i:i + n].data_ptr(), n, S, self.pad, self.ws, H, W, float(SCALE_FACTOR), _stream())

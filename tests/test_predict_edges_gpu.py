@@ -39,6 +39,29 @@ def test_sliding_window_predict_matches_restatement(H, W, ws, pad):
     assert got.shape == (3, H, W) and got.max() <= 10000
 
 
+def test_sliding_window_predict_bf16_mixed():
+    """precision="bf16-mixed" (the reference's default predict precision is 16-mixed): same mosaic within the bf16
+    tolerance of the probabilities (2e-2 absolute = 200 counts worst case, mean well below 1e-2)."""
+    from cultionet_amd.predict import SlidingWindowPredictor
+
+    lit, _ = _pair()
+    H, W, ws, pad = 70, 95, 40, 4
+    g = torch.Generator().manual_seed(5)
+    scene = torch.randint(0, 9000, (3, 12, H, W), generator=g, dtype=torch.int32).to(torch.int16).cuda()
+    mean = torch.tensor([0.31, 0.28, 0.35])
+    std = torch.tensor([0.21, 0.19, 0.24])
+    kw = dict(window_size=ws, padding=pad, batch_size=3, mean=mean, std=std)
+    f32 = SlidingWindowPredictor(lit, **kw).predict_scene(scene).cpu().numpy().astype(np.int64)
+    b16 = SlidingWindowPredictor(lit, precision="bf16-mixed", **kw).predict_scene(scene).cpu().numpy().astype(np.int64)
+    d = np.abs(f32 - b16)
+    assert b16.shape == (3, H, W) and b16.max() <= 10000
+    assert d.max() <= 400, d.max()
+    assert d.mean() <= 60, d.mean()
+    assert (b16 != f32).any()  # the bf16 path really ran
+    with pytest.raises(ValueError):
+        SlidingWindowPredictor(lit, precision="fp8")
+
+
 def test_collate_and_device_prologue():
     from cultionet_amd.data import Data, collate_fn
     from cultionet_amd.lightning import CultionetLitModel
