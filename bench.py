@@ -34,7 +34,7 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # MI355X_MICROARCH.md: f32-input M
 PEAK_HBM_GBS = 8000.0
 FAMILY = {0: "cn_conv_igemm*/cn_conv1x1 <NT=128>", 1: "cn_conv_igemm* <NT<=64>", 2: "cn_wgrad* <3x3>",
           3: "cn_wgrad* <1x1>", 4: "cn_bconv_kernel (bf16)", 5: "cn_bwgrad_kernel (bf16)"}
-PMC_FILE = "profiles/r01_pmc_traffic.json"
+PMC_FILES = {"f32": "profiles/r02_pmc_traffic_f32.json", "bf16": "profiles/r02_pmc_traffic_bf16.json"}
 
 
 def parse():
@@ -102,12 +102,12 @@ def cpu_baseline(batch: int, hidden: int, steps: int, threads: int = 0):
     }, first
 
 
-def pmc_traffic(prefixes):
+def pmc_traffic(prefixes, pmc_file):
     """HBM-side bytes per launch of a kernel family from the COMMITTED PMC passes of the default command
     (FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate rocprofv3 --pmc runs, tools/pmc_traffic.py). PMC counters cannot be
     collected inside the timed run: this is a constant read from that file, labelled as such in the JSON."""
     try:
-        with open(os.path.join(ROOT, PMC_FILE)) as f:
+        with open(os.path.join(ROOT, pmc_file)) as f:
             kernels = json.load(f)["kernels"]
     except (OSError, ValueError, KeyError):
         return None
@@ -394,9 +394,13 @@ def main():
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         dom = max(range(8), key=lambda k: kinds[k][0])
         train_gflop = 3.0 * FWD_GFLOP_PER_CHIP.get(hidden, 0.0)
+        # HBM-side bytes per launch of the dominant kernel: PMC passes of THIS command committed under profiles/
+        # (only valid for the configuration they were collected on: the default batch / hidden of each precision)
         traffic = None
-        if not bf16 and (hidden, B) == (32, 8) and top_name.startswith("cn_conv_igemm_vec_kernel<4, 1,"):
-            traffic = pmc_traffic(("cn_conv_igemm_vec_kernel<4, 1,",))
+        pmc_file = PMC_FILES["bf16" if bf16 else "f32"]
+        if hidden == 32 and B == (32 if bf16 else 8) and top_name:
+            traffic = pmc_traffic((top_name.split("<")[0] + "<" + top_name.split("<")[1] if "<" in top_name else top_name,),
+                                  pmc_file)
         out = {
             "metric": "train_chips_per_sec",
             "value": value,
@@ -428,7 +432,7 @@ def main():
                 "unit": "TFLOP/s",
                 "frac": achieved / peak,
                 "traffic": traffic,
-                "traffic_source": (f"{PMC_FILE} (committed rocprofv3 --pmc passes of this command; not measured in "
+                "traffic_source": (f"{pmc_file} (committed rocprofv3 --pmc passes of this command; not measured in "
                                    "this run)") if traffic is not None else None,
                 "avg_launch_us": ms * 1e3 / nl if nl else None,
                 "launches_per_step": nl / args.steps,

@@ -13,12 +13,19 @@ for P in f32 bf16; do
   A=""; [ $P = bf16 ] && A="--dtype bf16"
   rocprofv3 --kernel-trace --stats -d $O/stats_$P -o s -- python3 $R/bench.py $A --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
   python3 $R/tools/prof_db.py $O/stats_$P/s_results.db 400 --csv > $O/${TAG}_bench_${P}_kernel_stats.csv
+  python3 $R/tools/timeline.py $O/stats_$P/s_results.db 0.5 > $O/${TAG}_timeline_${P}.txt
+  # the same command with the weight-gradient side stream off: every kernel alone on the GPU (bench.py's `isolated`)
+  export CN_OVERLAP_WGRAD=0
+  rocprofv3 --kernel-trace --stats -d $O/stats_iso_$P -o s -- python3 $R/bench.py $A --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  python3 $R/tools/prof_db.py $O/stats_iso_$P/s_results.db 400 --csv > $O/${TAG}_bench_${P}_kernel_stats_isolated.csv
+  # PMC passes also run serialized, so that a kernel's counters are its own
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
      --kernel-trace --output-format csv -d $O/pmc_mfma_$P -o m -- python3 $R/bench.py $A --steps 3 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
   python3 $R/tools/pmc_mfma.py $O/pmc_mfma_$P/m_counter_collection.csv $O/${TAG}_pmc_mfma_$P.json > $O/${TAG}_pmc_mfma_${P}_summary.txt
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$P -o f -- python3 $R/bench.py $A --steps 3 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$P -o w -- python3 $R/bench.py $A --steps 3 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
   python3 $R/tools/pmc_traffic.py $O/pmc_fetch_$P/f_counter_collection.csv $O/pmc_write_$P/w_counter_collection.csv $O/${TAG}_pmc_traffic_$P.json > $O/${TAG}_pmc_traffic_${P}_summary.txt
-  rm -rf $O/stats_$P $O/pmc_mfma_$P $O/pmc_fetch_$P $O/pmc_write_$P
+  unset CN_OVERLAP_WGRAD
+  rm -rf $O/stats_$P $O/stats_iso_$P $O/pmc_mfma_$P $O/pmc_fetch_$P $O/pmc_write_$P
 done
 ls -la $O
