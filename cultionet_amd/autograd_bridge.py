@@ -4,7 +4,7 @@ The engine has its own reverse-mode tape (cultionet_amd.engine). For callers tha
 (lightning.Trainer.fit -> training_step -> loss.backward(), torch DDP hooks, torch optimizers) the whole
 TowerUNet is presented as ONE autograd.Function: forward runs the engine forward and keeps the tape,
 backward seeds the three output gradients, replays the tape and hands the parameter gradients back to
-autograd (views of one clone of the flat gradient buffer, so DDP hooks fire as usual).
+autograd (views of the flat gradient buffer, which is handed over whole, so DDP hooks fire as usual).
 """
 from __future__ import annotations
 
@@ -36,7 +36,10 @@ class _TowerUNetFn(torch.autograd.Function):
             ctx.outs[k].grad = g.contiguous() if g is not None else None
         with E.using_store(store):
             ctx.tape.backward()
-        flat = store.flat_grad.clone()
+        # hand the flat gradient buffer itself to autograd (AccumulateGrad keeps the views as p.grad) and give the store
+        # a fresh one: no 42 MB copy per backward; the next backward's zero_grad() fills the new buffer
+        flat = store.flat_grad
+        store.flat_grad = torch.empty_like(flat)
         pg = tuple(flat[o:o + p.numel()].view(p.shape) for p, o in zip(store.params, store.offsets))
         ctx.tape = ctx.outs = None
         return (None, None) + pg

@@ -20,6 +20,7 @@
 // w % WN and the pixel columns {w / WN + i * (4 / WN)}: its weight fragments come straight from global memory
 // (packed in fragment order: one 16-byte load per lane serves WN MFMAs, no cross-wave reuse exists to stage for),
 // the pixel image is staged once per 32-channel chunk and shared by the four waves and all taps.
+#include <cstdlib>
 #include "cn_bf16.h"
 #include "cn_profile.h"
 
@@ -39,6 +40,8 @@ struct CnBClass {
   int IH, IW;              // halo image size in pixels
   int grp;
   unsigned mgIW;           // ceil(2^32 / IW): x / IW == umulhi(x, mgIW) for x < 65536 (0 when IW == 1)
+  int rowpad;              // bytes added per halo row in LDS (see cnb_rowpad): keeps ds_read_b128 conflict-free
+                           // across the tile-row wraps of a 32-pixel column
 };
 
 struct CnBGeom {
@@ -110,6 +113,8 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
   const int wn = wid % WN, wm = wid / WN;
 
   // ---- logical block (XCD-aware order: consecutive logical blocks share an L2) ----
+  // (A persistent variant -- 768 resident blocks walking the tile list -- was measured: no gain from skipping the
+  // workgroup relaunch, and the loop-carried state pushed the kernel over its 168-VGPR budget into spills.)
   int L;
   {
     const int lin = blockIdx.x;
@@ -163,7 +168,7 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
   for (int i = 0; i < MPW; ++i) {
     const int m = (wm + i * WM) * 32 + r;
     const int ty = cnb_div(m, g.mgTW), tx = m - ty * g.TW;
-    pbase[i] = m < npix ? ((ty * g.is) * IW + tx * g.is) * PITCH + h * 16 : h * 16;
+    pbase[i] = m < npix ? ((ty * g.is) * IW + tx * g.is) * PITCH + (NP <= 6 ? (ty * g.is) * k.rowpad : 0) + h * 16 : h * 16;
   }
 
   f32x16 acc[MPW];
@@ -245,13 +250,16 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
     if ((I0) == 0) __syncthreads(); /* the previous chunk's reads are done */                           \
     _Pragma("unroll") for (int i = (I0); i < (I1); ++i) {                                               \
       const int q = tid + i * 256;                                                                      \
-      if (q < npieces) *reinterpret_cast<u32x4*>(lds + (q / PPP) * PITCH + (q % PPP) * 16) = sv[i - (I0)]; \
+      if (q < npieces) {                                                                                \
+        const int p_ = q / PPP;                                                                         \
+        *reinterpret_cast<u32x4*>(lds + p_ * PITCH + (NP <= 6 ? cnb_div(p_, k.mgIW) * k.rowpad : 0) + (q % PPP) * 16) = sv[i - (I0)]; \
+      }                                                                                                 \
     }                                                                                                   \
   }
 #define CNB_STAGE()                                                                                     \
   {                                                                                                     \
     const int cc = ch * (KSC * 16);                                                                     \
-    constexpr int H1 = NP > 5 ? 5 : NP;                                                                 \
+    constexpr int H1 = NP > 6 ? 5 : NP; /* NP <= 6: one phase (one exposed global latency per chunk instead of two) */                                                                 \
     CNB_ST(100 + ch * 4);                                                                               \
     CNB_PHASE(0, H1);                                                                                   \
     CNB_ST(101 + ch * 4);                                                                               \
@@ -298,6 +306,11 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
       CNB_HALF(X, X, ax0, ax1);
       if (s + 1 < nsteps) CNB_HALF(X, X, ay0, ay1);
     }
+    // The last two steps prefetched (clamped) fragments nobody consumes. The compiler does not know that an inline-asm
+    // load writes its destination LATER: it is free to reuse those registers at once -- e.g. for the epilogue's store
+    // addresses -- and a late-landing fragment then corrupts a pointer (seen as a GPU memory access fault, only when a
+    // concurrent stream delayed the loads). Drain them before any register is recycled.
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #undef CNB_PHASE
 #undef CNB_STAGE
 #undef CNB_READ
@@ -566,12 +579,31 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
   for (int c = 0; c < g.ncls; ++c) g.cls[c].mgIW = cnb_magic(g.cls[c].IW);
   const int np = (int)(((long)max_pix * KSC * 2 + 255) / 256);
   if (np > 10) return CN_ERR_LDS;
+  // A wave's ds_read_b128 covers 32 consecutive tile pixels m (lane groups of 16, one 256-byte bank row per group):
+  // with a pixel pitch of s = pitch/16 (odd) sixteen-byte slots the slot of pixel m is s*m mod 16, all distinct within
+  // a group -- as long as consecutive m are consecutive in LDS. A 32-pixel column wraps over tile rows (TW = 25), where
+  // the halo image jumps by IW - TW pixels and two lanes of a group land on one slot (PMC: 48 % of the LDS cycles of
+  // the 3x3 layers were conflict cycles). rowpad shifts every halo row by the slots that restore s*m mod 16:
+  // rowpad = (-s * (IW - TW)) mod 16 slots. Unit input stride only (a stride-2 image has an even slot step anyway).
+  // Measured: SQ_LDS_BANK_CONFLICT 11.8M -> 1.5M per 128->128 launch at 32x100^2, LDS busy 36 % -> 23 %; the kernel's
+  // duration did not move (the LDS was not the limiter), the headroom is there for the next restructuring.
+  int max_rowpad_bytes = 0;
+  for (int c = 0; c < g.ncls; ++c) {
+    CnBClass& k = g.cls[c];
+    k.rowpad = 0;
+    if (g.is == 1 && k.IH > 1 && np <= 6) {  // the big-halo (NP = 10) instantiations sit at the VGPR limit: no pad there
+      const int s16 = (pitch / 16) & 15;
+      const int slots = ((-(s16 * (k.IW - g.TW))) % 16 + 16) % 16;
+      k.rowpad = slots * 16;
+    }
+    if (k.IH * k.rowpad > max_rowpad_bytes) max_rowpad_bytes = k.IH * k.rowpad;
+  }
   long total = 0;
   for (int c = 0; c < g.ncls; ++c) {
     CnBClass& k = g.cls[c];
     for (int t = 0; t < k.ntaps; ++t) {
       const int dy = k.doff[t] >> 16, dx = (short)(k.doff[t] & 0xffff);
-      k.doff[t] = ((dy - k.iy_off) * k.IW + (dx - k.ix_off)) * pitch;
+      k.doff[t] = ((dy - k.iy_off) * k.IW + (dx - k.ix_off)) * pitch + (dy - k.iy_off) * k.rowpad;
     }
     k.tiles_x = (k.Wg + g.TW - 1) / g.TW;
     k.tiles_per_img = k.tiles_x * ((k.Hg + g.TH - 1) / g.TH);
@@ -581,7 +613,7 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
   if (total <= 0) return CN_OK;
   if (total > 0x7fffff00L) return CN_ERR_ARG;
   g.total = (int)total;
-  size_t shmem = (size_t)max_pix * pitch;
+  size_t shmem = (size_t)max_pix * pitch + max_rowpad_bytes;
   if (g.stats != nullptr && shmem < 4 * 64 * 33 * sizeof(float)) shmem = 4 * 64 * 33 * sizeof(float);
   const dim3 grid(cn_xcd_grid(total)), block(256);
   if (g.stats != nullptr) {
