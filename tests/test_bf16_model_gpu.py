@@ -93,6 +93,32 @@ def test_bf16_matches_own_fp32_path_and_trains():
     assert b[-1] < b[0] - 1e-3, b
 
 
+def test_bf16_bench_shape_under_stream_overlap_is_stable():
+    """The bench configuration in miniature (hidden 32, 100x100, weight gradients on the side stream): several steps
+    back to back without a sync in between, twice from the same state -- the losses must be finite and agree run to
+    run to the rounding noise of the few float-atomic reductions (LayerNorm / bias gradients): 1e-4. (An in-flight prefetch landing in a recycled register of the conv kernel showed up exactly here: as a GPU
+    memory fault, only when the second stream delayed the loads.)"""
+    from cultionet_amd.data import Data
+    from cultionet_amd.lightning import HipTrainer
+    from oracle import towerunet_oracle as O
+    from oracle.selfcheck import build_pair
+
+    x, y, bdist = O.seeded_batch(16, height=100, width=100, seed=9)
+    batch = Data(x=x.cuda(), y=y.cuda(), bdist=bdist.cuda())
+    runs = []
+    for _ in range(2):
+        lit, _ = build_pair(hidden=32, device="cuda:0")
+        lit.train()
+        tr = HipTrainer(lit, precision="bf16-mixed")
+        ls = [tr.training_step(batch).clone() for _ in range(4)]
+        torch.cuda.synchronize()
+        runs.append([float(l.item()) for l in ls])
+    assert all(np.isfinite(v) for v in runs[0]), runs
+    assert runs[0][0] == runs[1][0], runs  # the first forward has no atomics in it
+    assert np.abs(np.array(runs[0]) - np.array(runs[1])).max() <= 1e-4, runs
+    assert runs[0][-1] < runs[0][0], runs
+
+
 def test_bf16_eval_forward_and_dropin_autocast(golden_dir):
     """Eval-mode forward on the bf16 path (running statistics), and the drop-in surface under torch.autocast: the
     LightningModule forward picks the bf16 path up from the autocast state Lightning's precision plugin sets."""
