@@ -15,19 +15,34 @@
 // part[c][split][2] = {sum, sumsq} over this block's share.
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cn_bn_partial_kernel(const float* __restrict__ x, long xbs, int B, int C,
-                                                           int L, int splits, double* __restrict__ part) {
+                                                           int L, int splits, double* __restrict__ part, int vec4) {
   __shared__ double scratch[4];
   const int c = blockIdx.x, sp = blockIdx.y;
-  const int per = (L + splits - 1) / splits;
-  const int beg = sp * per;
-  const int end = (beg + per < L) ? beg + per : L;
   double s = 0.0, ss = 0.0;
-  for (int b = 0; b < B; ++b) {
-    const float* xp = x + b * xbs + (long)c * L;
-    for (int l = beg + threadIdx.x; l < end; l += 256) {
-      const float v = xp[l];
-      s += v;
-      ss += (double)v * v;
+  if (vec4) {  // L % 4 == 0, 16-byte aligned planes: one float4 per lane and iteration
+    const int L4 = L >> 2;
+    const int per = (L4 + splits - 1) / splits;
+    const int beg = sp * per;
+    const int end = (beg + per < L4) ? beg + per : L4;
+    for (int b = 0; b < B; ++b) {
+      const float4* xp = reinterpret_cast<const float4*>(x + b * xbs + (long)c * L);
+      for (int l = beg + threadIdx.x; l < end; l += 256) {
+        const float4 v = xp[l];
+        s += (double)((v.x + v.y) + (v.z + v.w));
+        ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+      }
+    }
+  } else {
+    const int per = (L + splits - 1) / splits;
+    const int beg = sp * per;
+    const int end = (beg + per < L) ? beg + per : L;
+    for (int b = 0; b < B; ++b) {
+      const float* xp = x + b * xbs + (long)c * L;
+      for (int l = beg + threadIdx.x; l < end; l += 256) {
+        const float v = xp[l];
+        s += v;
+        ss += (double)v * v;
+      }
     }
   }
   s = cn_block_sum<double, 256>(s, scratch);
@@ -106,23 +121,40 @@ __global__ __launch_bounds__(256) void cn_bn_bwd_partial_kernel(const float* __r
                                                                const float* __restrict__ rstd,
                                                                const float* __restrict__ gamma,
                                                                const float* __restrict__ beta, int B, int C, int L,
-                                                               int act, int splits, double* __restrict__ part) {
+                                                               int act, int splits, double* __restrict__ part,
+                                                               int vec4) {
   __shared__ double scratch[4];
   const int c = blockIdx.x, sp = blockIdx.y;
-  const int per = (L + splits - 1) / splits;
-  const int beg = sp * per;
-  const int end = (beg + per < L) ? beg + per : L;
   const float m = mean[c], rs = rstd[c], ga = gamma[c], be = beta[c];
   double s1 = 0.0, s2 = 0.0;
-  for (int b = 0; b < B; ++b) {
-    const float* xp = x + b * xbs + (long)c * L;
-    const float* dp = dy + b * dybs + (long)c * L;
-    for (int l = beg + threadIdx.x; l < end; l += 256) {
-      const float xh = (xp[l] - m) * rs;
-      float dz = dp[l];
-      if (act == 1) dz *= cn_silu_grad(ga * xh + be);
-      s1 += dz;
-      s2 += (double)dz * xh;
+  auto term = [&](float xv, float dv) {
+    const float xh = (xv - m) * rs;
+    float dz = dv;
+    if (act == 1) dz *= cn_silu_grad(ga * xh + be);
+    s1 += dz;
+    s2 += (double)dz * xh;
+  };
+  if (vec4) {
+    const int L4 = L >> 2;
+    const int per = (L4 + splits - 1) / splits;
+    const int beg = sp * per;
+    const int end = (beg + per < L4) ? beg + per : L4;
+    for (int b = 0; b < B; ++b) {
+      const float4* xp = reinterpret_cast<const float4*>(x + b * xbs + (long)c * L);
+      const float4* dp = reinterpret_cast<const float4*>(dy + b * dybs + (long)c * L);
+      for (int l = beg + threadIdx.x; l < end; l += 256) {
+        const float4 xv = xp[l], dv = dp[l];
+        term(xv.x, dv.x); term(xv.y, dv.y); term(xv.z, dv.z); term(xv.w, dv.w);
+      }
+    }
+  } else {
+    const int per = (L + splits - 1) / splits;
+    const int beg = sp * per;
+    const int end = (beg + per < L) ? beg + per : L;
+    for (int b = 0; b < B; ++b) {
+      const float* xp = x + b * xbs + (long)c * L;
+      const float* dp = dy + b * dybs + (long)c * L;
+      for (int l = beg + threadIdx.x; l < end; l += 256) term(xp[l], dp[l]);
     }
   }
   s1 = cn_block_sum<double, 256>(s1, scratch);
@@ -332,7 +364,8 @@ extern "C" int cn_bn_act_fwd_f32(const float* x, long xbs, const float* gamma, c
   }
   if (training) {
     const int splits = bn_splits(C, L);
-    hipLaunchKernelGGL(cn_bn_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, B, C, L, splits, ws);
+    hipLaunchKernelGGL(cn_bn_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, B, C, L, splits, ws,
+                       (int)(L % 4 == 0 && xbs % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0));
     hipLaunchKernelGGL(cn_bn_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, x, xbs, mean, rstd, gamma, beta,
                        res, rbs, y, ybs, B, C, L, act, (const double*)ws, splits, (double)B * L, eps, momentum,
                        running_mean, running_var);
@@ -364,7 +397,9 @@ extern "C" int cn_bn_act_bwd_f32(const float* x, long xbs, const float* dy, long
   }
   const int splits = bn_splits(C, L);
   hipLaunchKernelGGL(cn_bn_bwd_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, dy, dybs, mean, rstd,
-                     gamma, beta, B, C, L, act, splits, ws);
+                     gamma, beta, B, C, L, act, splits, ws,
+                     (int)(L % 4 == 0 && xbs % 4 == 0 && dybs % 4 == 0 &&
+                           ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0));
   (void)coef;
   hipLaunchKernelGGL(cn_bn_bwd_apply_kernel, dx != nullptr ? plane_grid(B, C, L) : dim3(1, C, 1), dim3(256), 0,
                      stream, x, xbs, dy, dybs, mean, rstd, gamma, beta, (const double*)ws, splits, (double)B * L,
