@@ -23,6 +23,17 @@
 #define CNW_PITCH 192  // bytes per pixel row in LDS (64 channels = 128 B + 64 B pad): conflict-free transposed reads
 #define CNW_MAX_TAPS 9
 
+// Diagnostic build (-DCNBW_STAMP): s_memtime stamps of wave 0 of one block (tools/bwgrad_stamps.py).
+#ifdef CNBW_STAMP
+__device__ unsigned long long cnbw_stamps[256];
+#define CNBW_ST() do { if (do_stamp && stamp_i < 256) cnbw_stamps[stamp_i++] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int cn_bwgrad_read_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(cnbw_stamps), sizeof(unsigned long long) * 256) == hipSuccess ? 0 : -2;
+}
+#else
+#define CNBW_ST() do { } while (0)
+#endif
+
 struct CnBWgGeom {
   const bf16_t* P;
   const bf16_t* Q;
@@ -108,7 +119,13 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
 
   // per-thread staging descriptors (tile independent): P piece i = pixel (tid + 256 i) / 8, Q piece likewise
   constexpr int NQR = NQ > 0 ? NQ : 1;
+  // One wave per SIMD pays ~4-5 cycles for EVERY instruction with the matrix pipe idle, and the tile-dependent address
+  // arithmetic of the 12 prefetch loads (two divisions, 64-bit multiplies, five compares per piece: ~450 instructions)
+  // took 2.5k of a tile's 6.7k cycles (tools/bwgrad_stamps.py). Everything that does not depend on the tile is folded
+  // into per-lane BYTE offsets once; per tile there is one scalar base per operand and two add + compare pairs per piece.
+  // Statically dead pieces (beyond the tile / the channel count / the halo image) get a row that fails every test.
   int pm[4], pty[4], ptx[4];
+  unsigned pob[4];
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     pm[i] = (tid + i * 256) >> 3;
@@ -116,40 +133,59 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
     ptx[i] = pm[i] - pty[i] * g.TW;
   }
   const int c8 = (tid & 7) * 8;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    pob[i] = (unsigned)((((long)pty[i] * g.Wg + ptx[i]) * g.ldp + c8) * 2);
+    if (!(pm[i] < npix && cp0 + c8 < g.CP)) pty[i] = 1 << 24;
+  }
   int qhy[NQR], qhx[NQR];
+  unsigned qob[NQR];
   if (NQ > 0) {
 #pragma unroll
     for (int i = 0; i < NQR; ++i) {
       const int p = (tid + i * 256) >> 3;
       qhy[i] = p / IW;
       qhx[i] = p - qhy[i] * IW;
+      qob[i] = (unsigned)((((long)qhy[i] * g.Wq + qhx[i]) * g.ldq + c8) * 2);
+      if (!(tid + i * 256 < nq_pieces && cq0 + c8 < g.CQ)) qhy[i] = 1 << 24;
     }
   }
+  // fetch cursor: the tile the next fetch() loads (tiles are fetched in order), kept as (image, tile row, tile column)
+  const int tiles_y = g.tiles_per_img / g.tiles_x;
+  int fb = t_begin / g.tiles_per_img;
+  int fty = (t_begin - fb * g.tiles_per_img) / g.tiles_x;
+  int ftx = t_begin - fb * g.tiles_per_img - fty * g.tiles_x;
   // Register prefetch sets A (and, for the 1x1 kernels, B: two tiles of distance).
   u32x4 pvA[4], qvA[NQR], pvB[4], qvB[NQR];
-  auto fetch = [&](int tile, u32x4 (&pv)[4], u32x4 (&qv)[NQR]) {
-    const int b = tile / g.tiles_per_img;
-    const int tl = tile - b * g.tiles_per_img;
-    const int tyi = tl / g.tiles_x, txi = tl - tyi * g.tiles_x;
-    const int gy0 = tyi * g.TH, gx0 = txi * g.TW;
+  // Buffer loads: a lane whose piece is out of range gets an offset beyond num_records and the hardware returns zeros --
+  // no EXEC masking, no zero initialisation of the destination registers (4 v_mov per piece).
+  constexpr unsigned CNW_OOB = 0x80000000u;
+  auto fetch = [&](int, u32x4 (&pv)[4], u32x4 (&qv)[NQR]) {
+    const int gy0 = fty * g.TH, gx0 = ftx * g.TW;
+    const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(g.P + (((long)fb * g.Hg + gy0) * g.Wg + gx0) * g.ldp + cp0), 0, 0x7fffffff, 0x00020000);
+    const int ylim = g.Hg - gy0, xlim = g.Wg - gx0;
 #pragma unroll
     for (int i = 0; i < 4; ++i) {
-      const int gy = gy0 + pty[i], gx = gx0 + ptx[i];
-      u32x4 v = {0u, 0u, 0u, 0u};
-      if (pm[i] < npix && gy < g.Hg && gx < g.Wg && cp0 + c8 < g.CP)
-        v = *reinterpret_cast<const u32x4*>(g.P + (((long)b * g.Hg + gy) * g.Wg + gx) * g.ldp + cp0 + c8);
-      pv[i] = v;
+      const unsigned off = (pty[i] < ylim && ptx[i] < xlim) ? pob[i] : CNW_OOB;
+      pv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(prs, off, 0, 0));
     }
     if (NQ > 0) {
       const int qy0 = gy0 * g.s + g.qy_off, qx0 = gx0 * g.s + g.qx_off;
+      // qy0 / qx0 may be negative (halo above / left of the image): the base then points before the plane and is only
+      // dereferenced by lanes whose pixel passes the range test
+      const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<bf16_t*>(g.Q + (((long)fb * g.Hq + qy0) * g.Wq + qx0) * g.ldq + cq0), 0, 0x7fffffff, 0x00020000);
 #pragma unroll
       for (int i = 0; i < NQR; ++i) {
-        const int iy = qy0 + qhy[i], ix = qx0 + qhx[i];
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (tid + i * 256 < nq_pieces && iy >= 0 && iy < g.Hq && ix >= 0 && ix < g.Wq && cq0 + c8 < g.CQ)
-          v = *reinterpret_cast<const u32x4*>(g.Q + (((long)b * g.Hq + iy) * g.Wq + ix) * g.ldq + cq0 + c8);
-        qv[i] = v;
+        const unsigned off =
+            ((unsigned)(qhy[i] + qy0) < (unsigned)g.Hq && (unsigned)(qhx[i] + qx0) < (unsigned)g.Wq) ? qob[i] : CNW_OOB;
+        qv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, off, 0, 0));
       }
+    }
+    if (++ftx == g.tiles_x) {
+      ftx = 0;
+      if (++fty == tiles_y) { fty = 0; ++fb; }
     }
   };
   auto store = [&](int tile, const u32x4 (&pv)[4], const u32x4 (&qv)[NQR]) {
@@ -157,9 +193,8 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
     for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(ldsP + pm[i] * CNW_PITCH + c8 * 2) = pv[i];
     if (NQ > 0) {
 #pragma unroll
-      for (int i = 0; i < NQR; ++i)
-        if (tid + i * 256 < nq_pieces)
-          *reinterpret_cast<u32x4*>(ldsQ + ((tid + i * 256) >> 3) * CNW_PITCH + c8 * 2) = qv[i];
+      for (int i = 0; i < NQR; ++i)  // unconditional: the LDS image is sized for all NQ * 256 pieces (dead ones hold zeros)
+        *reinterpret_cast<u32x4*>(ldsQ + ((tid + i * 256) >> 3) * CNW_PITCH + c8 * 2) = qv[i];
     } else {  // large halo: synchronous loop
       const int b = tile / g.tiles_per_img;
       const int tl = tile - b * g.tiles_per_img;
@@ -267,14 +302,25 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
       }
     }
   } else {
+#ifdef CNBW_STAMP
+    const bool do_stamp = T == 9 && NQ == 8 && FULL && blockIdx.x == 16 && tid == 0;
+    int stamp_i = 0;
+#endif
+    CNBW_ST();
     if (t_begin < t_end) fetch(t_begin, pvA, qvA);
 #pragma unroll 1
     for (int tile = t_begin; tile < t_end; ++tile) {
+      CNBW_ST();  // tile top
       __syncthreads();  // previous tile's reads are done
+      CNBW_ST();  // barrier 1
       store(tile, pvA, qvA);
+      CNBW_ST();  // LDS stores issued (includes the wait for the prefetched registers)
       __syncthreads();
+      CNBW_ST();  // barrier 2
       if (tile + 1 < t_end) fetch(tile + 1, pvA, qvA);  // next tile's global loads fly while this one is multiplied
+      CNBW_ST();  // fetch issued
       compute();
+      CNBW_ST();  // multiplied
     }
   }
 #undef CNW_READ
@@ -393,14 +439,16 @@ static int cnw_run(CnBWgGeom& g, float* dw, float* ws, long ws_floats, hipStream
   }
   if (ws == nullptr || cnw_ws_floats(g) > ws_floats) return CN_ERR_ARG;
   g.part = ws;
-  const size_t shmem = (size_t)(128 + g.IH * g.IW) * CNW_PITCH;
+  const int nq = (g.IH * g.IW * 8 + 255) / 256;  // Q pieces per thread: <= 8 are register-prefetched
+  // register-prefetched halo images are stored without a per-piece predicate: room for every thread's NQ pieces
+  const int q_pix = nq <= 8 ? (nq <= 4 && g.T == 1 ? 4 : 8) * 32 : g.IH * g.IW;
+  const size_t shmem = (size_t)(128 + (q_pix > g.IH * g.IW ? q_pix : g.IH * g.IW)) * CNW_PITCH;
   if (shmem > 160 * 1024) return CN_ERR_LDS;
   const dim3 grid(cn_xcd_grid(g.total)), block(256);
   const double flops = 2.0 * g.B * (double)g.Hg * g.Wg * g.CP * g.CQ * g.T;
   cn_prof_name("cn_bwgrad_kernel<%d, %d>", g.T, (g.IH * g.IW * 8 + 255) / 256 <= 8 ? (g.T == 1 && (g.IH * g.IW * 8 + 255) / 256 <= 4 ? 4 : 8) : 0);
   cn_prof_desc("bwgrad B%d %dx%d %dx%d T%d s%d split%d", g.B, g.Hg, g.Wg, g.CP, g.CQ, g.T, g.s, g.nsplit);
   cn_prof_before(stream);
-  const int nq = (g.IH * g.IW * 8 + 255) / 256;  // Q pieces per thread: <= 8 are register-prefetched
 #define CNW_GO1(T_, NQ_, F_)                                                                                   \
   do {                                                                                                         \
     if (shmem > 64 * 1024)                                                                                     \
