@@ -156,6 +156,9 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
   int fty = (t_begin - fb * g.tiles_per_img) / g.tiles_x;
   int ftx = t_begin - fb * g.tiles_per_img - fty * g.tiles_x;
   // Register prefetch sets A (and, for the 1x1 kernels, B: two tiles of distance).
+  // (Tried for the 3x3 kernels: two LDS images with the ds_write_b128 of tile t+1 and the buffer loads of tile t+2
+  // interleaved between the MFMAs of tile t, one barrier per tile -- 122 -> 132 us at 128->128, 100^2: the writes share
+  // the in-order LGKM counter with the transposed reads, so every read wait also drains the slow stores.)
   u32x4 pvA[4], qvA[NQR], pvB[4], qvB[NQR];
   // Buffer loads: a lane whose piece is out of range gets an offset beyond num_records and the hardware returns zeros --
   // no EXEC masking, no zero initialisation of the destination registers (4 v_mov per piece).
