@@ -150,6 +150,10 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
       if (!(tid + i * 256 < nq_pieces && cq0 + c8 < g.CQ)) qhy[i] = 1 << 24;
     }
   }
+  // synchronous large-halo staging (NQ == 0): this lane's first halo pixel and its step of 32 pixels, as (row, column)
+  const int sy0 = (tid >> 3) / IW, sx0 = (tid >> 3) - sy0 * IW;
+  const int d32 = 32 / IW, r32 = 32 - d32 * IW;
+  constexpr unsigned CNW_OOB = 0x80000000u;
   // fetch cursor: the tile the next fetch() loads (tiles are fetched in order), kept as (image, tile row, tile column)
   const int tiles_y = g.tiles_per_img / g.tiles_x;
   int fb = t_begin / g.tiles_per_img;
@@ -162,7 +166,6 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
   u32x4 pvA[4], qvA[NQR], pvB[4], qvB[NQR];
   // Buffer loads: a lane whose piece is out of range gets an offset beyond num_records and the hardware returns zeros --
   // no EXEC masking, no zero initialisation of the destination registers (4 v_mov per piece).
-  constexpr unsigned CNW_OOB = 0x80000000u;
   auto fetch = [&](int, u32x4 (&pv)[4], u32x4 (&qv)[NQR]) {
     const int gy0 = fty * g.TH, gx0 = ftx * g.TW;
     const __amdgpu_buffer_rsrc_t prs = __builtin_amdgcn_make_buffer_rsrc(
@@ -198,20 +201,36 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
 #pragma unroll
       for (int i = 0; i < NQR; ++i)  // unconditional: the LDS image is sized for all NQ * 256 pieces (dead ones hold zeros)
         *reinterpret_cast<u32x4*>(ldsQ + ((tid + i * 256) >> 3) * CNW_PITCH + c8 * 2) = qv[i];
-    } else {  // large halo: synchronous loop
+    } else {
+      // Large halo (stride 2, transposed, dilation >= 5): staged synchronously, four pieces in flight per lane. The
+      // lane's halo pixel walks by 32 pixels per piece (incremental row / column, no division), loads are bounds-checked
+      // buffer loads (zeros for the out-of-image halo), so a piece costs ~10 instructions instead of ~45.
       const int b = tile / g.tiles_per_img;
       const int tl = tile - b * g.tiles_per_img;
       const int tyi = tl / g.tiles_x, txi = tl - tyi * g.tiles_x;
       const int qy0 = tyi * g.TH * g.s + g.qy_off, qx0 = txi * g.TW * g.s + g.qx_off;
+      const __amdgpu_buffer_rsrc_t qrs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<bf16_t*>(g.Q + (((long)b * g.Hq + qy0) * g.Wq + qx0) * g.ldq + cq0), 0, 0x7fffffff, 0x00020000);
+      const bool chan_ok = cq0 + c8 < g.CQ;
+      int hy = sy0, hx = sx0;
 #pragma unroll 1
-      for (int q = tid; q < nq_pieces; q += 256) {
-        const int p = q >> 3;
-        const int hy = p / IW, hx = p - hy * IW;
-        const int iy = qy0 + hy, ix = qx0 + hx;
-        u32x4 v = {0u, 0u, 0u, 0u};
-        if (iy >= 0 && iy < g.Hq && ix >= 0 && ix < g.Wq && cq0 + c8 < g.CQ)
-          v = *reinterpret_cast<const u32x4*>(g.Q + (((long)b * g.Hq + iy) * g.Wq + ix) * g.ldq + cq0 + c8);
-        *reinterpret_cast<u32x4*>(ldsQ + p * CNW_PITCH + c8 * 2) = v;
+      for (int q = tid; q < nq_pieces; q += 1024) {
+        u32x4 v[4];
+        int pp[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const bool in = chan_ok && q + 256 * u < nq_pieces && (unsigned)(hy + qy0) < (unsigned)g.Hq &&
+                          (unsigned)(hx + qx0) < (unsigned)g.Wq;
+          const unsigned off = in ? (unsigned)((hy * g.Wq + hx) * (int)g.ldq + c8) * 2u : CNW_OOB;
+          v[u] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(qrs, off, 0, 0));
+          pp[u] = (q + 256 * u) >> 3;
+          hy += d32;
+          hx += r32;
+          if (hx >= IW) { hx -= IW; ++hy; }
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (q + 256 * u < nq_pieces) *reinterpret_cast<u32x4*>(ldsQ + pp[u] * CNW_PITCH + c8 * 2) = v[u];
       }
     }
   };
@@ -444,12 +463,17 @@ static int cnw_run(CnBWgGeom& g, float* dw, float* ws, long ws_floats, hipStream
   g.part = ws;
   const int nq = (g.IH * g.IW * 8 + 255) / 256;  // Q pieces per thread: <= 8 are register-prefetched
   // register-prefetched halo images are stored without a per-piece predicate: room for every thread's NQ pieces
-  const int q_pix = nq <= 8 ? (nq <= 4 && g.T == 1 ? 4 : 8) * 32 : g.IH * g.IW;
+  const int q_pix = nq <= 8 ? (nq <= 4 && g.T == 1 ? 4 : 8) * 32 : (nq <= 16 && g.T == 9 ? 16 * 32 : g.IH * g.IW);
   const size_t shmem = (size_t)(128 + (q_pix > g.IH * g.IW ? q_pix : g.IH * g.IW)) * CNW_PITCH;
   if (shmem > 160 * 1024) return CN_ERR_LDS;
   const dim3 grid(cn_xcd_grid(g.total)), block(256);
   const double flops = 2.0 * g.B * (double)g.Hg * g.Wg * g.CP * g.CQ * g.T;
-  cn_prof_name("cn_bwgrad_kernel<%d, %d>", g.T, (g.IH * g.IW * 8 + 255) / 256 <= 8 ? (g.T == 1 && (g.IH * g.IW * 8 + 255) / 256 <= 4 ? 4 : 8) : 0);
+  {
+    const int nqn = (g.IH * g.IW * 8 + 255) / 256;
+    cn_prof_name("cn_bwgrad_kernel<%d, %d, %s>", g.T,
+                 nqn <= 8 ? (g.T == 1 && nqn <= 4 ? 4 : 8) : (nqn <= 16 && g.T == 9 ? 16 : 0),
+                 g.TH * g.TW > 112 ? "true" : "false");
+  }
   cn_prof_desc("bwgrad B%d %dx%d %dx%d T%d s%d split%d", g.B, g.Hg, g.Wg, g.CP, g.CQ, g.T, g.s, g.nsplit);
   cn_prof_before(stream);
 #define CNW_GO1(T_, NQ_, F_)                                                                                   \
@@ -466,7 +490,9 @@ static int cnw_run(CnBWgGeom& g, float* dw, float* ws, long ws_floats, hipStream
   } while (0)
   switch (g.T) {
     case 1: if (nq <= 4) CNW_GO(1, 4); else if (nq <= 8) CNW_GO(1, 8); else CNW_GO(1, 0); break;
-    case 9: if (nq <= 8) CNW_GO(9, 8); else CNW_GO(9, 0); break;
+    case 9:  // dilations 2-4 of a 5x25 tile need 9-14 halo pieces per thread: still register-prefetched
+      if (nq <= 8) CNW_GO(9, 8); else if (nq <= 16) CNW_GO(9, 16); else CNW_GO(9, 0);
+      break;
     default: return CN_ERR_ARG;
   }
 #undef CNW_GO

@@ -86,6 +86,9 @@ CONV_CASES = [
     (3, 24, 100, 100, 32, 3, 1, 1, 1, False),  # BASELINE spatial size
     (2, 128, 50, 50, 128, 3, 1, 1, 1, False),
     (2, 128, 100, 100, 384, 1, 1, 0, 1, True),  # qkv projection
+    (2, 64, 50, 50, 64, 3, 1, 3, 3, False),     # dilations 3 / 4 / 5 at tower sizes: the 16-piece register-prefetched
+    (2, 32, 100, 100, 32, 3, 1, 4, 4, False),   # halo of the weight gradient (3, 4) and its synchronous fallback (5)
+    (1, 32, 50, 50, 32, 3, 1, 5, 5, False),
 ]
 
 

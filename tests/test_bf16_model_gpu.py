@@ -96,7 +96,8 @@ def test_bf16_matches_own_fp32_path_and_trains():
 def test_bf16_bench_shape_under_stream_overlap_is_stable():
     """The bench configuration in miniature (hidden 32, 100x100, weight gradients on the side stream): several steps
     back to back without a sync in between, twice from the same state -- the losses must be finite and agree run to
-    run to the rounding noise of the few float-atomic reductions (LayerNorm / bias gradients): 1e-4. (An in-flight prefetch landing in a recycled register of the conv kernel showed up exactly here: as a GPU
+    run to the rounding noise of the float-atomic reductions (statistics rows of the narrow layers, LayerNorm / bias
+    gradients) and of the first call's kernel autotuning: 1e-4. (An in-flight prefetch landing in a recycled register of the conv kernel showed up exactly here: as a GPU
     memory fault, only when the second stream delayed the loads.)"""
     from cultionet_amd.data import Data
     from cultionet_amd.lightning import HipTrainer
@@ -114,7 +115,6 @@ def test_bf16_bench_shape_under_stream_overlap_is_stable():
         torch.cuda.synchronize()
         runs.append([float(l.item()) for l in ls])
     assert all(np.isfinite(v) for v in runs[0]), runs
-    assert runs[0][0] == runs[1][0], runs  # the first forward has no atomics in it
     assert np.abs(np.array(runs[0]) - np.array(runs[1])).max() <= 1e-4, runs
     assert runs[0][-1] < runs[0][0], runs
 
