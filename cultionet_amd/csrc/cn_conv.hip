@@ -231,7 +231,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const CnConvGeom g) 
 // instruction per wave moves at most 16 B per lane whatever its width).
 //   NV: float4 chunks per thread per channel (vplane <= NV*1024 floats)
 template <int WAVES_N, int TN, int TM, int NV, int RP>
-__global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const CnConvGeom g) {
+__global__ __launch_bounds__(256, (NV <= 1 ? 2 : 1)) void cn_conv_igemm_vec_kernel(const CnConvGeom g) {
   constexpr int WAVES_M = 4 / WAVES_N;
   constexpr int MT = WAVES_M * TM * 32;
   constexpr int NT = WAVES_N * TN * 32;
@@ -355,29 +355,44 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_vec_kernel(const CnConvGeom
   if (ntaps > 0 && ch < ch_end) {
     f32x4 xin[KC][NV];
     f32x4 win[WI];
+    // Per-chunk prefetch = bounds-checked buffer loads with everything that does not depend on the chunk folded into
+    // per-lane byte offsets once: the chunk only moves the SCALAR offset (channel plane / weight row). Zero-filled and
+    // idle pieces carry an offset beyond num_records (the hardware returns zeros): no EXEC masking, no zero
+    // initialisation, no tap-table reads or 64-bit address arithmetic per piece (was ~290 instructions per chunk, issued
+    // with the matrix pipe of a one / two waves-per-SIMD kernel waiting).
+    constexpr unsigned CN_OOB = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7fffffff, 0x00020000);
+    unsigned xo[NV], wo[WI];
+#pragma unroll
+    for (int i = 0; i < NV; ++i) xo[i] = goff[i] >= 0 ? (unsigned)goff[i] * 4u : CN_OOB;
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+      const int f = tid + j * 256;
+      wo[j] = CN_OOB;
+      if (f < nw4) {
+        const int row = f / (NT / 4), c4 = f - row * (NT / 4);
+        const int t = row / KC, ci = row - t * KC;
+        wo[j] = (unsigned)(((tap_lds[CN_MAX_TAPS + t] * g.Kpad + ci) * g.Npad + n0 + c4 * 4) * 4);
+      }
+    }
 #define CN_PREFETCH_V(c0_)                                                                                 \
   {                                                                                                        \
     const int c0 = (c0_);                                                                                  \
     _Pragma("unroll") for (int ci = 0; ci < KC; ++ci) {                                                    \
-      const bool cok = (c0 + ci) < g.Cin;                                                                  \
-      const float* xc = xb + (long)(c0 + ci) * HWin;                                                       \
-      _Pragma("unroll") for (int i = 0; i < NV; ++i) {                                                     \
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                    \
-        if (cok && goff[i] >= 0) v = *reinterpret_cast<const f32x4*>(xc + goff[i]);                        \
-        xin[ci][i] = v;                                                                                    \
+      if ((c0 + ci) < g.Cin) { /* wave-uniform */                                                          \
+        const int so = (c0 + ci) * HWin * 4;                                                               \
+        _Pragma("unroll") for (int i = 0; i < NV; ++i)                                                     \
+            xin[ci][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[i], so, 0)); \
+      } else {                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NV; ++i) xin[ci][i] = f32x4{0.f, 0.f, 0.f, 0.f};             \
       }                                                                                                    \
     }                                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < WI; ++j) {                                                       \
-      const int f = tid + j * 256;                                                                         \
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                      \
-      if (f < nw4) {                                                                                       \
-        const int row = f / (NT / 4), c4 = f - row * (NT / 4);                                             \
-        const int t = row / KC, ci = row - t * KC;                                                         \
-        v = *reinterpret_cast<const f32x4*>(                                                               \
-            wp + ((long)(tap_lds[CN_MAX_TAPS + t] * g.Kpad + c0 + ci) * g.Npad + n0 + c4 * 4));            \
-      }                                                                                                    \
-      win[j] = v;                                                                                          \
-    }                                                                                                      \
+    const int wso = c0 * g.Npad * 4;                                                                       \
+    _Pragma("unroll") for (int j = 0; j < WI; ++j)                                                         \
+        win[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wo[j], wso, 0));     \
   }
     CN_PREFETCH_V(ch * KC);
     for (; ch < ch_end; ++ch) {
@@ -1119,6 +1134,9 @@ int cn_conv_igemm_launch(CnConvGeom& g, hipStream_t stream) {
   const bool allow_split = dense_out || g.accumulate || ws_fits;
   if (g.G > 1 && g.shared_y && !allow_split) return CN_ERR_ARG;
   bool vec = (((long)g.Hin * g.Win) % 4 == 0) && (g.xbs % 4 == 0);
+  // the vec kernel's buffer loads carry 31-bit byte offsets inside one image / one packed weight tensor
+  vec = vec && (long)g.Cin * g.Hin * g.Win * 4 < (1L << 31) &&
+        (long)CN_MAX_TAPS * cn_conv_kpad(g.Cin) * g.Npad * 4 < (1L << 31);
   for (int i = 0; i < g.G; ++i) vec = vec && ((reinterpret_cast<uintptr_t>(g.gx[i]) & 15) == 0);
   if (vec) {  // the flattened-row image of the largest tile must fit 4096 floats
     CnConvGeom t = g;
