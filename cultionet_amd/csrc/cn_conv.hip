@@ -118,29 +118,41 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const CnConvGeom g) 
   if (ntaps > 0 && ch < ch_end) {
     float xin[KC][NI_T];
     f32x4 win[WI];
+    // chunk-independent lane offsets + bounds-checked buffer loads (see the vec kernel below): the chunk only moves the
+    // scalar offset; zero-filled / idle elements read as zeros through an offset beyond num_records
+    constexpr unsigned CN_OOBD = 0x80000000u;
+    const __amdgpu_buffer_rsrc_t xrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(xb), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t wrs =
+        __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(wp), 0, 0x7fffffff, 0x00020000);
+    unsigned xo[NI_T], wo[WI];
+#pragma unroll
+    for (int i = 0; i < NI_T; ++i) xo[i] = goff[i] >= 0 ? (unsigned)goff[i] * 4u : CN_OOBD;
+#pragma unroll
+    for (int j = 0; j < WI; ++j) {
+      const int f = tid + j * 256;
+      wo[j] = CN_OOBD;
+      if (f < nw4) {
+        const int row = f / (NT / 4), c4 = f - row * (NT / 4);
+        const int t = row / KC, ci = row - t * KC;
+        wo[j] = (unsigned)(((tap_lds[CN_MAX_TAPS + t] * g.Kpad + ci) * g.Npad + n0 + c4 * 4) * 4);
+      }
+    }
 #define CN_PREFETCH(c0_)                                                                                   \
   {                                                                                                        \
     const int c0 = (c0_);                                                                                  \
     _Pragma("unroll") for (int ci = 0; ci < KC; ++ci) {                                                    \
-      const bool cok = (c0 + ci) < g.Cin;                                                                  \
-      const float* xc = xb + (long)(c0 + ci) * HWin;                                                       \
-      _Pragma("unroll") for (int i = 0; i < NI_T; ++i) {                                                   \
-        float v = 0.f;                                                                                     \
-        if (cok && goff[i] >= 0) v = xc[goff[i]];                                                          \
-        xin[ci][i] = v;                                                                                    \
+      if ((c0 + ci) < g.Cin) { /* wave-uniform */                                                          \
+        const int so = (c0 + ci) * HWin * 4;                                                               \
+        _Pragma("unroll") for (int i = 0; i < NI_T; ++i)                                                   \
+            xin[ci][i] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, xo[i], so, 0)); \
+      } else {                                                                                             \
+        _Pragma("unroll") for (int i = 0; i < NI_T; ++i) xin[ci][i] = 0.f;                                 \
       }                                                                                                    \
     }                                                                                                      \
-    _Pragma("unroll") for (int j = 0; j < WI; ++j) {                                                       \
-      const int f = tid + j * 256;                                                                         \
-      f32x4 v = {0.f, 0.f, 0.f, 0.f};                                                                      \
-      if (f < nw4) {                                                                                       \
-        const int row = f / (NT / 4), c4 = f - row * (NT / 4);                                             \
-        const int t = row / KC, ci = row - t * KC;                                                         \
-        v = *reinterpret_cast<const f32x4*>(                                                               \
-            wp + ((long)(tap_lds[CN_MAX_TAPS + t] * g.Kpad + c0 + ci) * g.Npad + n0 + c4 * 4));            \
-      }                                                                                                    \
-      win[j] = v;                                                                                          \
-    }                                                                                                      \
+    const int wso = c0 * g.Npad * 4;                                                                       \
+    _Pragma("unroll") for (int j = 0; j < WI; ++j)                                                         \
+        win[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, wo[j], wso, 0));     \
   }
     CN_PREFETCH(ch * KC);
     for (; ch < ch_end; ++ch) {
@@ -1134,9 +1146,9 @@ int cn_conv_igemm_launch(CnConvGeom& g, hipStream_t stream) {
   const bool allow_split = dense_out || g.accumulate || ws_fits;
   if (g.G > 1 && g.shared_y && !allow_split) return CN_ERR_ARG;
   bool vec = (((long)g.Hin * g.Win) % 4 == 0) && (g.xbs % 4 == 0);
-  // the vec kernel's buffer loads carry 31-bit byte offsets inside one image / one packed weight tensor
-  vec = vec && (long)g.Cin * g.Hin * g.Win * 4 < (1L << 31) &&
-        (long)CN_MAX_TAPS * cn_conv_kpad(g.Cin) * g.Npad * 4 < (1L << 31);
+  // the kernels' buffer loads carry 31-bit byte offsets inside one image / one packed weight tensor
+  if ((long)g.Cin * g.Hin * g.Win * 4 >= (1L << 31) || (long)CN_MAX_TAPS * cn_conv_kpad(g.Cin) * g.Npad * 4 >= (1L << 31))
+    return CN_ERR_ARG;
   for (int i = 0; i < g.G; ++i) vec = vec && ((reinterpret_cast<uintptr_t>(g.gx[i]) & 15) == 0);
   if (vec) {  // the flattened-row image of the largest tile must fit 4096 floats
     CnConvGeom t = g;
