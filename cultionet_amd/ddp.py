@@ -101,23 +101,26 @@ class GradientAllReduce:
             nodes[k]()
             nodes[k] = None
             ready = by_node.get(k, ())
-            if ready and on_gpu:
-                _engine.join_side_stream()  # weight gradients run on the engine's side stream
+            # weight gradients run on the engine's side stream: the bucket stream waits for them, the compute stream
+            # does not (joining it here five times per step would serialise the two streams at every bucket)
+            side_ev = _engine.side_stream_event() if (ready and on_gpu) else None
             for lo, hi in ready:
-                works.append(self._launch(flat[lo:hi], on_gpu))
+                works.append(self._launch(flat[lo:hi], on_gpu, side_ev))
         if on_gpu:
             _engine.join_side_stream()
         for lo, hi, r in plan:  # buckets whose ready index lies outside the tape (no nodes recorded)
             if r >= len(nodes) or r < 0:
-                works.append(self._launch(flat[lo:hi], on_gpu))
+                works.append(self._launch(flat[lo:hi], on_gpu, None))
         for w in works:
             w.wait()  # NCCL: makes the current (compute) stream wait for the collective; gloo: blocks
 
-    def _launch(self, chunk: torch.Tensor, on_gpu: bool):
+    def _launch(self, chunk: torch.Tensor, on_gpu: bool, side_ev=None):
         if not on_gpu:
             return dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
         ev = torch.cuda.Event()
         ev.record(torch.cuda.current_stream())
         with torch.cuda.stream(self.comm_stream):
             self.comm_stream.wait_event(ev)
+            if side_ev is not None:
+                self.comm_stream.wait_event(side_ev)
             return dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

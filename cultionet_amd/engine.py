@@ -214,6 +214,19 @@ def join_side_stream() -> None:
         st["dirty"] = False
 
 
+def side_stream_event() -> T.Optional["torch.cuda.Event"]:
+    """An event recorded on the weight-gradient side stream now (None when nothing is pending there): lets another
+    stream -- the RCCL bucket stream -- wait for the gradients issued so far without stalling the compute stream."""
+    if not torch.cuda.is_available():
+        return None
+    st = _side_streams.get(torch.cuda.current_stream().device)
+    if st is None or not st["dirty"]:
+        return None
+    ev = torch.cuda.Event()
+    ev.record(st["stream"])
+    return ev
+
+
 def current_tape() -> Tape:
     tp = getattr(_state, "tape", None)
     if tp is None:
