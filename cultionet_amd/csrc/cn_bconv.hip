@@ -301,10 +301,76 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
 #define CNB_STEP_STAMP() do { } while (0)
 #endif
     CNB_ST(2);
+    if constexpr (KPAIRS >= 2) {
+      // Nested (chunk, tap, k-pair) loops with the k-pairs unrolled: the register set of a step is its k-pair's parity
+      // (compile time), the tap's LDS offset is fetched once per tap, the prefetch target two steps ahead is "same tap,
+      // k-pair + 2" or "next tap, k-pair + 2 - KPAIRS" with the next (tap, chunk) worked out once per tap, and a weight
+      // fragment's scalar offset is one v_readlane of a per-tap base table + k-step * stride. The linear-sequence form
+      // below spent ~45 scalar instructions per step of 8 MFMAs on this bookkeeping (two (chunk, tap, k-pair) counters
+      // advanced with branches, five scalar multiply-adds per fragment): PMC 8 SALU per MFMA, the CU's one scalar unit
+      // as busy as the matrix pipes.
+      const int NTK = NT * 1024;  // bytes between consecutive k-steps of one tap
+      const int wtb_v = lane < CNB_MAX_TAPS ? (k.wt[lane < CNB_MAX_TAPS ? lane : 0] * KS * NT + nt_c) * 1024 : 0;
+      auto wl = [&](int chq, int tq, int kpq, int half) -> bf16x8 {
+        int ks = chq * KSC + kpq * 2 + half;
+        ks = ks < KS ? ks : KS - 1;
+        const int soff = __builtin_amdgcn_readlane(wtb_v, tq) + ks * NTK;
+        u32x4 v;
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(lane16), "s"(wrsrc), "s"(soff) : "memory");
+        return __builtin_bit_cast(bf16x8, v);
+      };
+      // (the prologue above loaded step 0 into ax and step 1 into ay: (0, 0, 0) and (0, 0, 1) for KPAIRS >= 2)
 #pragma unroll 1
-    for (int s = 0; s < nsteps; s += 2) {
-      CNB_HALF(X, X, ax0, ax1);
-      if (s + 1 < nsteps) CNB_HALF(X, X, ay0, ay1);
+      for (ch = 0; ch < nchunks; ++ch) {
+        CNB_STAGE();
+#pragma unroll 1
+        for (t = 0; t < ntaps; ++t) {
+          int tn = t + 1, chn = ch;
+          if (tn == ntaps) {
+            tn = 0;
+            chn = ch + 1 < nchunks ? ch + 1 : ch;  // past the end: a clamped, never consumed prefetch
+          }
+          const int toff_t = __builtin_amdgcn_readlane(doff_v, t);
+#pragma unroll
+          for (int kq = 0; kq < KPAIRS; ++kq) {
+#pragma unroll
+            for (int i = 0; i < MPW; ++i) {
+              X[i] = *reinterpret_cast<const bf16x8*>(lds + pbase[i] + toff_t + kq * 64);
+              X[MPW + i] = *reinterpret_cast<const bf16x8*>(lds + pbase[i] + toff_t + kq * 64 + 32);
+            }
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+            if ((kq & 1) == 0) {
+#pragma unroll
+              for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(ax0, X[i], acc[i]);
+#pragma unroll
+              for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(ax1, X[MPW + i], acc[i]);
+            } else {
+#pragma unroll
+              for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(ay0, X[i], acc[i]);
+#pragma unroll
+              for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(ay1, X[MPW + i], acc[i]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            const bool same = kq + 2 < KPAIRS;
+            const int cq = same ? ch : chn, tq = same ? t : tn, kpq = same ? kq + 2 : kq + 2 - KPAIRS;
+            if ((kq & 1) == 0) {
+              ax0 = wl(cq, tq, kpq, 0);
+              ax1 = wl(cq, tq, kpq, 1);
+            } else {
+              ay0 = wl(cq, tq, kpq, 0);
+              ay1 = wl(cq, tq, kpq, 1);
+            }
+            CNB_STEP_STAMP();
+          }
+        }
+      }
+    } else {
+#pragma unroll 1
+      for (int s = 0; s < nsteps; s += 2) {
+        CNB_HALF(X, X, ax0, ax1);
+        if (s + 1 < nsteps) CNB_HALF(X, X, ay0, ay1);
+      }
     }
     // The last two steps prefetched (clamped) fragments nobody consumes. The compiler does not know that an inline-asm
     // load writes its destination LATER: it is free to reuse those registers at once -- e.g. for the epilogue's store
