@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
       // fragments issued a few instructions earlier (a full L2 round trip per 8 MFMAs). These loads are waited for by
       // hand with a COUNTED s_waitcnt (CNB_WAIT_A) that leaves the other register set's two loads in flight.
       u32x4 v;
-      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(lane16), "s"(wrsrc), "s"(soff) : "memory");
+      asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(lane16), "s"(wrsrc), "s"(soff));
       return __builtin_bit_cast(bf16x8, v);
     };
     // The loop walks the linear step sequence (chunk, tap, k-pair), two steps per iteration with static register
@@ -265,6 +265,11 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
     CNB_ST(101 + ch * 4);                                                                               \
     if (NP > H1) CNB_PHASE(H1, NP);                                                                     \
     CNB_ST(102 + ch * 4);                                                                               \
+    /* A piece past the halo image is loaded (masked) but never stored, so the compiler's scoreboard leaves the  \
+       chunk with that load "pending" into a register the step loop re-uses for pixel fragments -- and answers \
+       with s_waitcnt vmcnt(0) in front of every tap's ds_reads, draining the hand-counted weight prefetch too. \
+       An explicit vmcnt(0) here (once per chunk) clears the scoreboard. */                                     \
+    __builtin_amdgcn_s_waitcnt(0x0F70);                                                                 \
     __syncthreads();                                                                                    \
     CNB_ST(103 + ch * 4);                                                                               \
   }
@@ -316,7 +321,7 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
         ks = ks < KS ? ks : KS - 1;
         const int soff = __builtin_amdgcn_readlane(wtb_v, tq) + ks * NTK;
         u32x4 v;
-        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(lane16), "s"(wrsrc), "s"(soff) : "memory");
+        asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(lane16), "s"(wrsrc), "s"(soff));
         return __builtin_bit_cast(bf16x8, v);
       };
       // (the prologue above loaded step 0 into ax and step 1 into ay: (0, 0, 0) and (0, 0, 1) for KPAIRS >= 2)
