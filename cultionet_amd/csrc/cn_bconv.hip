@@ -393,10 +393,15 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
   const float* __restrict__ bias = g.bias[grp];
   const int n0 = ntile * 32;
   float bsum[16];
+  if (bias != nullptr) {  // wave-uniform: ConvBlock2d is bias-free (BatchNorm follows), skip the 16 predicated loads
 #pragma unroll
-  for (int j = 0; j < 16; ++j) {
-    const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * h;
-    bsum[j] = (bias != nullptr && n_live && n < g.Cout) ? bias[n] : 0.f;
+    for (int j = 0; j < 16; ++j) {
+      const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * h;
+      bsum[j] = (n_live && n < g.Cout) ? bias[n] : 0.f;
+    }
+  } else {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) bsum[j] = 0.f;
   }
   float s1[16], s2[16];
   if (g.stats != nullptr) {
