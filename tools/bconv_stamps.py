@@ -38,6 +38,7 @@ for slot in range(2):
         a = st[100 + ch * 4:104 + ch * 4]
         if a[0]:
             print(f"    chunk {ch}: stage begin {a[0] - t0}  barrier1 +{a[1] - a[0]}  ds_write +{a[2] - a[1]}  barrier2 +{a[3] - a[2]}")
+    print("    epilogue groups start at:", [v - t0 for v in st[96:100] if v])
     steps = [v for v in st[8:96] if v]
     d = [steps[i + 1] - steps[i] for i in range(len(steps) - 1)]
     print("    half-steps (cycles):", d[:40])
