@@ -92,7 +92,29 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CONV_CASES)
+def _random_conv_cases(n, seed):
+    """Seeded random shapes around the tile / chunk boundaries of the kernels: channels across the 16 / 64 / 128 steps
+    (ragged k-steps and couts), sizes around the 5x25 and 128-pixel tiles, all kernel / stride / dilation modes."""
+    import random
+
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        k = rng.choice([1, 3, 3, 3])
+        d = rng.choice([1, 1, 2, 3]) if k == 3 else 1
+        s = rng.choice([1, 1, 1, 2]) if d == 1 else 1
+        p = d * (k // 2)
+        cin = rng.choice([8, 16, 24, 40, 64, 72, 128, 136, 200])
+        cout = rng.choice([8, 16, 24, 40, 64, 96, 128, 136, 264])
+        h = rng.choice([5, 9, 13, 24, 25, 26, 31, 50, 51])
+        w = rng.choice([6, 11, 13, 24, 25, 26, 33, 50, 52])
+        if k == 3 and (h <= 2 * d or w <= 2 * d):
+            h, w = h + 2 * d, w + 2 * d
+        out.append((rng.choice([1, 2, 3]), cin, h, w, cout, k, s, p, d, rng.random() < 0.3))
+    return out
+
+
+@pytest.mark.parametrize("case", CONV_CASES + _random_conv_cases(14, seed=20261002))
 def test_conv2d_bf16(case):
     from cultionet_amd import _lib
 

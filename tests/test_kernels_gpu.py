@@ -71,7 +71,29 @@ CONV_CASES = [
 ]
 
 
-@pytest.mark.parametrize("case", CONV_CASES)
+def _random_conv_cases(n, seed):
+    """Seeded random shapes across the kernels' paths: 16-byte (H*W % 4 == 0) and dword staging, ragged channel chunks
+    (Cin % 8 != 0), ragged couts, stride 2, dilation, 1x1, planes smaller than a tile."""
+    import random
+
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        k = rng.choice([1, 3, 3, 3])
+        d = rng.choice([1, 1, 2, 3]) if k == 3 else 1
+        s = rng.choice([1, 1, 1, 2]) if d == 1 else 1
+        p = d * (k // 2)
+        cin = rng.choice([3, 8, 12, 30, 36, 64, 70, 128, 132])
+        cout = rng.choice([1, 3, 8, 24, 32, 64, 100, 128, 136])
+        h = rng.choice([7, 9, 12, 13, 25, 26, 28, 50])
+        w = rng.choice([7, 10, 12, 13, 25, 26, 28, 50])
+        if k == 3 and (h <= 2 * d or w <= 2 * d):
+            h, w = h + 2 * d, w + 2 * d
+        out.append((rng.choice([1, 2, 3]), cin, h, w, cout, k, s, p, d, rng.random() < 0.3))
+    return out
+
+
+@pytest.mark.parametrize("case", CONV_CASES + _random_conv_cases(14, seed=20261003))
 def test_conv2d(case):
     from cultionet_amd import engine as E
 
