@@ -439,16 +439,31 @@ struct CnBnGroupArgs {
 __global__ __launch_bounds__(256) void cn_bn_group_partial_kernel(const CnBnGroupArgs a) {
   __shared__ double scratch[4];
   const int c = blockIdx.x, sp = blockIdx.y, g = blockIdx.z;
-  const int per = (a.L + a.splits - 1) / a.splits;
-  const int beg = sp * per;
-  const int end = (beg + per < a.L) ? beg + per : a.L;
   double s = 0.0, ss = 0.0;
-  for (int b = 0; b < a.B; ++b) {
-    const float* xp = a.x[g] + b * a.xbs + (long)c * a.L;
-    for (int l = beg + threadIdx.x; l < end; l += 256) {
-      const float v = xp[l];
-      s += v;
-      ss += (double)v * v;
+  if (a.vec4) {
+    const int L4 = a.L >> 2;
+    const int per = (L4 + a.splits - 1) / a.splits;
+    const int beg = sp * per;
+    const int end = (beg + per < L4) ? beg + per : L4;
+    for (int b = 0; b < a.B; ++b) {
+      const float4* xp = reinterpret_cast<const float4*>(a.x[g] + b * a.xbs + (long)c * a.L);
+      for (int l = beg + threadIdx.x; l < end; l += 256) {
+        const float4 v = xp[l];
+        s += (double)((v.x + v.y) + (v.z + v.w));
+        ss += (double)v.x * v.x + (double)v.y * v.y + (double)v.z * v.z + (double)v.w * v.w;
+      }
+    }
+  } else {
+    const int per = (a.L + a.splits - 1) / a.splits;
+    const int beg = sp * per;
+    const int end = (beg + per < a.L) ? beg + per : a.L;
+    for (int b = 0; b < a.B; ++b) {
+      const float* xp = a.x[g] + b * a.xbs + (long)c * a.L;
+      for (int l = beg + threadIdx.x; l < end; l += 256) {
+        const float v = xp[l];
+        s += v;
+        ss += (double)v * v;
+      }
     }
   }
   s = cn_block_sum<double, 256>(s, scratch);
@@ -505,6 +520,28 @@ __global__ __launch_bounds__(256) void cn_bn_group_apply_kernel(const CnBnGroupA
   }
   const long r0 = (long)c * a.L;
   const float* rp = a.res ? a.res + b * a.rbs + r0 : nullptr;
+  if (a.vec4) {  // 16-byte accesses: L % 4 == 0 and every plane 16-byte aligned
+    const float4 z4 = {0.f, 0.f, 0.f, 0.f};
+    for (int l = blockIdx.x * 256 + threadIdx.x; l < (a.L >> 2); l += gridDim.x * 256) {
+      float4 acc = rp ? reinterpret_cast<const float4*>(rp)[l] : z4;
+#pragma unroll
+      for (int g = 0; g < BN_MAX_GROUPS; ++g) {
+        if (g < a.G) {
+          const float4 xv = reinterpret_cast<const float4*>(a.x[g] + b * a.xbs + r0)[l];
+          float4 z;
+          z.x = (xv.x - m[g]) * sc[g] + be[g];
+          z.y = (xv.y - m[g]) * sc[g] + be[g];
+          z.z = (xv.z - m[g]) * sc[g] + be[g];
+          z.w = (xv.w - m[g]) * sc[g] + be[g];
+          if (a.act == 1) { z.x = cn_silu(z.x); z.y = cn_silu(z.y); z.z = cn_silu(z.z); z.w = cn_silu(z.w); }
+          if (a.sum_outputs) { acc.x += z.x; acc.y += z.y; acc.z += z.z; acc.w += z.w; }
+          else reinterpret_cast<float4*>(a.y[g] + b * a.ybs + r0)[l] = z;
+        }
+      }
+      if (a.sum_outputs) reinterpret_cast<float4*>(a.y[0] + b * a.ybs + r0)[l] = acc;
+    }
+    return;
+  }
   for (int l = blockIdx.x * 256 + threadIdx.x; l < a.L; l += gridDim.x * 256) {
     float acc = rp ? rp[l] : 0.f;
 #pragma unroll
@@ -643,6 +680,10 @@ extern "C" int cn_bn_act_group_fwd_f32(int G, const float* const* xs, long xbs, 
   a.G = G; a.B = B; a.C = C; a.L = L; a.act = act; a.training = training; a.sum_outputs = sum_outputs;
   a.eps = eps; a.momentum = momentum; a.part = ws;
   a.splits = bn_splits(C * G, L);
+  a.vec4 = (L % 4 == 0) && xbs % 4 == 0 && ybs % 4 == 0 && (res == nullptr || rbs % 4 == 0) &&
+           (reinterpret_cast<uintptr_t>(res) & 15) == 0;
+  for (int g = 0; g < G; ++g)
+    if ((reinterpret_cast<uintptr_t>(a.x[g]) | reinterpret_cast<uintptr_t>(a.y[g])) & 15) a.vec4 = 0;
   if (training)
     hipLaunchKernelGGL(cn_bn_group_partial_kernel, dim3(C, a.splits, G), dim3(256), 0, stream, a);
   hipLaunchKernelGGL(cn_bn_group_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, a);
