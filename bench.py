@@ -1,6 +1,11 @@
 """Benchmark of the TowerUNet training hot path on MI355X (BASELINE.json: train chips/sec).
 
-    python bench.py --gpus N --steps K --warmup W        (N > 1: launched by torch.distributed.run)
+    python bench.py --gpus N --steps K --warmup W
+
+With N > 1 and no WORLD_SIZE in the environment the command launches ITSELF: the parent -- before anything touches
+the GPU -- starts `python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 bench.py ...`
+as a child process, relays rank 0's single JSON line and exits with the child's code (a process that has initialised
+the GPU is never re-exec'ed). Started under torch.distributed.run directly (WORLD_SIZE set) it is a rank.
 
 A "step" is one pass of the hot path over one synthetic batch already resident in HBM:
 forward + Tanimoto loss + backward + global-norm clip + AdamW, all in the hand-written HIP kernels
@@ -14,7 +19,10 @@ launch stream inside the timed region (`kernel` = the real rocprof kernel name, 
 `cpu_baseline` is the CPU oracle (a port of the reference's PyTorch-CPU path) timed on this box's host cores on a
 bounded sample (rank 0, N=1 only); `loss_delta_vs_cpu` compares the step-1 loss of both legs (identical key-seeded
 weights and batch); `roofline.streaming` = GB/s of the HBM-bound BatchNorm / LayerNorm / bilinear entry points from a
-short separate pass after the timed region; `predict` = BASELINE configs[4] (large-tile eval pixels/s, GPU and CPU).
+short separate pass after the timed region; `bf16` = BASELINE configs[2] (batch 32, bf16 mixed precision: its own
+timed steps, roofline against the nominal 2.5 PFLOP/s and step-1 loss vs the CPU oracle) -- per-GPU batch 32 under
+N ranks is configs[3]; `predict` = BASELINE configs[4] (sliding-window scene prediction, pixels/s, GPU and CPU);
+`feed` = the same step fed a FRESH host batch per step through the pinned-host -> device double-buffered loader.
 """
 from __future__ import annotations
 
@@ -53,6 +61,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the streaming-kernel pass and the predict block")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = best of the documented sweep (16)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="launch + rendezvous check only (gloo, no GPU, no kernels): what tests/test_bench_launch.py runs")
     return ap.parse_args()
 
 
@@ -198,40 +208,63 @@ def streaming_pass(trainer, batch, steps: int = 2):
 
 
 def predict_block(dev, hidden: int, cpu: bool, threads: int):
-    """BASELINE configs[4]: eval forward of one [1,4,25,256,256] tile, pixels/s on the GPU and on the host CPU."""
+    """BASELINE configs[4]: sliding-window prediction of a raw [4,25,H,W] int16 scene resident in HBM through
+    cultionet_amd.predict.SlidingWindowPredictor -- the reference's tiling semantics (data/store.py:69-100,
+    callbacks.py:176-227): window 100 + 2 x padding 5 => batches of [n,4,25,110,110] windows, stitched to the uint16
+    mosaic. The scene is 600 x 600 (36 windows = 435 600 window pixels of forward work for 360 000 output pixels).
+    `value` counts OUTPUT pixels; the roofline counts the forward FLOP of the window pixels actually computed.
+    `tile` is the bare eval forward of one [1,4,25,256,256] tile (the shape BASELINE names), for continuity."""
     import torch
 
     from cultionet_amd import synthetic as S
     from cultionet_amd.lightning import CultionetLitModel
+    from cultionet_amd.predict import SlidingWindowPredictor
 
     lit = CultionetLitModel(in_channels=4, in_time=25, hidden_channels=hidden, dropout=0.0)
     model = lit.cultionet_model.mask_model
     model.load_state_dict(S.seeded_state_dict(model.state_dict()))
     lit = lit.to(dev).eval()
-    x, _, _ = S.seeded_batch(1, channels=4, time=25, height=256, width=256, seed=11)
-    xd = x.to(dev)
-    with torch.no_grad():
+    HS = 600
+    g = torch.Generator().manual_seed(11)
+    scene = (torch.rand(4, 25, HS, HS, generator=g) * 10000.0).to(torch.int16).to(dev)
+    gflop_px = FWD_GFLOP_PER_CHIP.get(hidden, 0.0) * (425.8 / 64.88) / (256 * 256)  # SURVEY 8(d): 425.8 GFLOP / 256^2 tile
+    out = {"workload": f"SlidingWindowPredictor: raw int16 scene [4,25,{HS},{HS}] -> uint16 mosaic, window 100 + 2 x "
+                       f"padding 5, batches of 12 windows [12,4,25,110,110], hidden {hidden} (BASELINE configs[4])",
+           "unit": "pixels/s"}
+    for tag, prec, peak in (("fp32", "32-true", PEAK_TFLOPS["f32"]), ("bf16_mixed", "bf16-mixed", PEAK_TFLOPS["bf16"])):
+        sp = SlidingWindowPredictor(lit, window_size=100, padding=5, batch_size=12, precision=prec)
         for _ in range(2):
-            model(xd)
+            sp.predict_scene(scene)
         torch.cuda.synchronize()
-        n = 10
+        n = 5
         t0 = time.perf_counter()
         for _ in range(n):
-            model(xd)
+            sp.predict_scene(scene)
         torch.cuda.synchronize()
         dt = (time.perf_counter() - t0) / n
-        with torch.autocast("cuda", dtype=torch.bfloat16):  # the reference's default predict precision is 16-mixed
-            for _ in range(2):
-                model(xd)
-            torch.cuda.synchronize()
-            t0 = time.perf_counter()
-            for _ in range(n):
-                model(xd)
-            torch.cuda.synchronize()
-            dt16 = (time.perf_counter() - t0) / n
-    out = {"workload": f"eval forward [1,4,25,256,256], hidden {hidden}, fp32 (BASELINE configs[4])",
-           "ms_per_tile": dt * 1e3, "value": 256 * 256 / dt, "unit": "pixels/s",
-           "bf16_mixed": {"ms_per_tile": dt16 * 1e3, "value": 256 * 256 / dt16, "unit": "pixels/s"}}
+        nwin = ((HS + 99) // 100) ** 2
+        tf = nwin * 110 * 110 * gflop_px / dt / 1e3
+        out[tag] = {"ms_per_scene": dt * 1e3, "value": HS * HS / dt, "windows": nwin,
+                    "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}}
+    out["value"] = out["bf16_mixed"]["value"]  # the reference's default predict precision is 16-mixed
+    # the bare tile forward (what rounds 1-2 reported)
+    x, _, _ = S.seeded_batch(1, channels=4, time=25, height=256, width=256, seed=11)
+    xd = x.to(dev)
+    tile = {}
+    with torch.no_grad():
+        for tag, on in (("fp32", False), ("bf16_mixed", True)):
+            with torch.autocast("cuda", dtype=torch.bfloat16, enabled=on):
+                for _ in range(2):
+                    model(xd)
+                torch.cuda.synchronize()
+                n = 10
+                t0 = time.perf_counter()
+                for _ in range(n):
+                    model(xd)
+                torch.cuda.synchronize()
+                dtt = (time.perf_counter() - t0) / n
+            tile[tag] = {"ms_per_tile": dtt * 1e3, "value": 256 * 256 / dtt}
+    out["tile"] = {"workload": "eval forward of one [1,4,25,256,256] tile", **tile}
     if cpu:
         from oracle import towerunet_oracle as O
 
@@ -247,7 +280,7 @@ def predict_block(dev, hidden: int, cpu: bool, threads: int):
             m(x)
             dtc = (time.perf_counter() - t0) / 2
         out["cpu_baseline"] = {"value": 256 * 256 / dtc, "unit": "pixels/s", "cores": cores, "kind": "port",
-                               "sample": "2 eval forwards of the same tile (1 warm-up discarded)"}
+                               "sample": "2 eval forwards of one [1,4,25,256,256] tile (1 warm-up discarded)"}
     return out
 
 
@@ -266,113 +299,152 @@ def read_by_kernel(nk, steps, limit=8):
     return out
 
 
-def main():
-    args = parse()
+def cpu_first_loss(batch: int, hidden: int, threads: int = 0) -> float:
+    """Step-1 loss of the CPU oracle (forward + Tanimoto only) on the key-seeded weights and seeded batch."""
     import torch
-    import torch.distributed as dist
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch N>1 with: python -m torch.distributed.run --nproc-per-node N bench.py --gpus N ...")
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    comm = None
-    rccl_ranks = 0
-    use_dist = world > 1 or os.environ.get("CN_FORCE_COMM") == "1"  # CN_FORCE_COMM: exercise RCCL with one rank
-    if use_dist:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        os.environ.setdefault("MASTER_PORT", "29533")
-        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
-            os.environ["NCCL_DEBUG"] = "WARN"  # RCCL's version banner goes to stdout; keep stdout to ONE JSON line
-        # RCCL logs (e.g. its rsmi warnings) default to stdout too: send them to stderr
-        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
-        from cultionet_amd.ddp import GradientAllReduce
+    from oracle import towerunet_oracle as O
 
-        comm = GradientAllReduce(world_size=world)
-        rccl_ranks = dist.get_world_size()  # what the process group really initialised
+    torch.set_num_threads(_cpu_threads(threads))
+    m = O.TowerUNet(3, 12, hidden_channels=hidden)
+    m.load_state_dict(O.seeded_state_dict(m.state_dict()))
+    m.train()
+    x, y, bdist = O.seeded_batch(batch, seed=7)
+    with torch.no_grad():
+        loss, _ = O.calc_loss(m(x), y, bdist)
+    return float(loss)
 
-    from cultionet_amd import _lib
-    from cultionet_amd import engine as E
-    from cultionet_amd.data import Data
-    from cultionet_amd.lightning import CultionetLitModel, HipTrainer
-    from cultionet_amd import synthetic as O
 
-    _lib.load()
-    bf16 = args.dtype == "bf16"
-    B = args.batch if args.batch is not None else (32 if bf16 else 8)
-    hidden = args.hidden
-    lit = CultionetLitModel(in_channels=3, in_time=12, hidden_channels=hidden, dropout=0.0)
-    model = lit.cultionet_model.mask_model
-    model.load_state_dict(O.seeded_state_dict(model.state_dict()))
-    lit = lit.to(dev).train()
-    x, y, bdist = O.seeded_batch(B, seed=7 + rank)
-    batch = Data(x=x.to(dev), y=y.to(dev), bdist=bdist.to(dev), lon=torch.zeros(B, device=dev),
-                 lat=torch.zeros(B, device=dev))
-    trainer = HipTrainer(lit, gradient_clip_val=1.0, comm=comm, precision="bf16-mixed" if bf16 else "32-true")
+def launch_ranks(args) -> int:
+    """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start the ranks as a CHILD process (this
+    parent has not touched the GPU and never does), relay rank 0's JSON line, return the child's exit code."""
+    import socket
+    import subprocess
 
-    def sync():
-        if use_dist:
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", "4")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    line = None
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{") and '"metric"' in ln:
+            line = ln
+        else:
+            print(ln, file=sys.stderr)
+    if line is not None:
+        print(line, flush=True)
+    return proc.returncode if (proc.returncode != 0 or line is not None) else 1
+
+
+class TrainLeg:
+    """One timed training configuration (precision, per-GPU batch) on this rank."""
+
+    def __init__(self, dev, rank: int, world: int, comm, use_dist: bool, dtype: str, B: int, hidden: int):
+        import torch
+
+        from cultionet_amd import synthetic as O
+        from cultionet_amd.data import Data
+        from cultionet_amd.lightning import CultionetLitModel, HipTrainer
+
+        self.dev, self.rank, self.world, self.comm, self.use_dist = dev, rank, world, comm, use_dist
+        self.dtype, self.B, self.hidden = dtype, B, hidden
+        lit = CultionetLitModel(in_channels=3, in_time=12, hidden_channels=hidden, dropout=0.0)
+        model = lit.cultionet_model.mask_model
+        model.load_state_dict(O.seeded_state_dict(model.state_dict()))
+        self.lit = lit.to(dev).train()
+        x, y, bdist = O.seeded_batch(B, seed=7 + rank)
+        self.host = (x, y, bdist)
+        self.batch = Data(x=x.to(dev), y=y.to(dev), bdist=bdist.to(dev), lon=torch.zeros(B, device=dev),
+                          lat=torch.zeros(B, device=dev))
+        self.trainer = HipTrainer(self.lit, gradient_clip_val=1.0, comm=comm,
+                                  precision="bf16-mixed" if dtype == "bf16" else "32-true")
+
+    def sync(self):
+        import torch
+        import torch.distributed as dist
+
+        if self.use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
-    first_loss = None
-    for i in range(args.warmup):
-        l = trainer.training_step(batch)
-        if i == 0:
-            first_loss = float(l.item())  # loss at the key-seeded initial weights (compared with the CPU leg)
-    sync()
-    launches = [0]
-    orig_call = _lib.call
+    def run(self, steps: int, warmup: int, extras: bool):
+        """W untimed + K timed steps (barrier + synchronize on both sides, max over ranks). Returns the record."""
+        import torch
+        import torch.distributed as dist
 
-    def counting(name, *a):
-        launches[0] += 1
-        return orig_call(name, *a)
+        from cultionet_amd import _lib
+        from cultionet_amd import engine as E
 
-    _lib.call("cn_profile_begin")
-    t0 = time.perf_counter()
-    for _ in range(args.steps):
-        loss = trainer.training_step(batch)
-    sync()
-    dt = time.perf_counter() - t0
-    prof = (ctypes.c_double * 24)()
-    _lib.call("cn_profile_end", prof)
-    loss_val = float(loss.item())
-    if first_loss is None:
-        first_loss = loss_val if args.steps == 1 else None
-    # C-ABI calls per step (each launches 1-3 kernels), counted on one extra untimed step
-    _lib.call = counting
-    try:
-        trainer.training_step(batch)
-    finally:
-        _lib.call = orig_call
-    torch.cuda.synchronize()
-
-    t = torch.tensor([dt], dtype=torch.float64, device=dev)
-    if use_dist:
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-    dt = float(t.item())
-
-    if rank == 0:
-        chips = world * B * args.steps
-        value = chips / dt
-        peak = PEAK_TFLOPS[args.dtype]
-        kinds = [(prof[3 * k], prof[3 * k + 1], prof[3 * k + 2]) for k in range(8)]
-        # dominant kernel = the top entry of the per-kernel-name aggregation (real rocprof names)
+        trainer, batch = self.trainer, self.batch
+        first_loss = None
+        for i in range(warmup):
+            l = trainer.training_step(batch)
+            if i == 0:
+                first_loss = float(l.item())  # loss at the key-seeded initial weights (compared with the CPU leg)
+        self.sync()
+        if self.comm is not None:
+            self.comm.measure = True
+            self.comm.exposed = []
+        _lib.call("cn_profile_begin")
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = trainer.training_step(batch)
+        self.sync()
+        dt = time.perf_counter() - t0
+        prof = (ctypes.c_double * 24)()
+        _lib.call("cn_profile_end", prof)
+        # per-kernel aggregates of the TIMED window (HIP events on the launch streams), read before any other window
         name_buf = ctypes.create_string_buffer(96)
         top3 = (ctypes.c_double * 3)()
         nk = _lib.query("cn_profile_top", 0, name_buf, 96, top3)
-        by_kernel = read_by_kernel(nk, args.steps)
-        # The timed region runs the weight-gradient kernels on a second HIP stream beside the data-gradient chain, so
-        # the event-bracketed duration of a kernel there includes the time it shared the CUs with the other stream.
-        # `isolated`: the same step once more with that overlap switched off (one stream, nothing else resident), i.e.
-        # the kernel's own duration -- the figure to hold against the MFMA peak.
+        by_kernel = read_by_kernel(nk, steps)
+        top_name = name_buf.value.decode() if nk > 0 else ""
+        ms, flops, nl = top3[0] / steps, top3[1] / steps, top3[2] / steps  # per step
+        loss_val = float(loss.item())
+        if first_loss is None:
+            first_loss = loss_val if steps == 1 else None
+        comm_ms = buckets = None
+        if self.comm is not None:
+            self.comm.measure = False
+            comm_ms = sum(a.elapsed_time(b) for a, b in self.comm.exposed) / max(steps, 1)
+            buckets = self.comm.buckets_last_step
+        # C-ABI calls and kernel launches per step, counted on one extra untimed step
+        calls = [0]
+        orig_call = _lib.call
+
+        def counting(name, *a):
+            calls[0] += 1
+            return orig_call(name, *a)
+
+        _lib.call = counting
+        _lib.query("cn_launch_count", 1)
+        try:
+            trainer.training_step(batch)
+        finally:
+            _lib.call = orig_call
+        launches = _lib.query("cn_launch_count", 1)
+        torch.cuda.synchronize()
+        t = torch.tensor([dt], dtype=torch.float64, device=self.dev)
+        if self.use_dist:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+        if self.rank != 0:
+            return None
+        world, B, hidden = self.world, self.B, self.hidden
+        bf16 = self.dtype == "bf16"
+        value = world * B * steps / dt
+        peak = PEAK_TFLOPS[self.dtype]
+        kinds = [(prof[3 * k], prof[3 * k + 1], prof[3 * k + 2]) for k in range(8)]
         iso_kernel, iso_kinds = {}, None
-        if world == 1 and not args.no_extras:
-            iso_steps = min(args.steps, 3)
+        if world == 1 and extras:
+            # `isolated`: the same step with the weight-gradient side stream off (one stream, nothing else resident),
+            # i.e. each kernel's own duration -- the figure to hold against the MFMA peak
+            iso_steps = min(steps, 3)
             E.overlap_wgrad(False)
             try:
                 trainer.training_step(batch)
@@ -393,40 +465,34 @@ def main():
                 if name in iso_kernel:
                     rec["isolated_tflops"] = iso_kernel[name]["tflops"]
                     rec["isolated_us"] = iso_kernel[name]["ms_per_step"] * 1e3 / max(iso_kernel[name]["launches_per_step"], 1e-9)
-        top_name = name_buf.value.decode() if nk > 0 else ""
-        ms, flops, nl = top3[0], top3[1], top3[2]
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         dom = max(range(8), key=lambda k: kinds[k][0])
         train_gflop = 3.0 * FWD_GFLOP_PER_CHIP.get(hidden, 0.0)
-        # HBM-side bytes per launch of the dominant kernel: PMC passes of THIS command committed under profiles/
-        # (only valid for the configuration they were collected on: the default batch / hidden of each precision)
         traffic = None
         pmc_file = PMC_FILES["bf16" if bf16 else "f32"]
         if hidden == 32 and B == (32 if bf16 else 8) and top_name:
             traffic = pmc_traffic((top_name.split("<")[0] + "<" + top_name.split("<")[1] if "<" in top_name else top_name,),
                                   pmc_file)
-        out = {
-            "metric": "train_chips_per_sec",
+        rec = {
             "value": value,
             "unit": "chips/s",
-            "n_gpus": world,
-            "steps": args.steps,
-            "warmup": args.warmup,
-            "ms_per_step": dt / args.steps * 1e3,
-            "higher_is_better": True,
-            "scaling": "weak",
-            "vs_baseline": None,
-            "dtype": args.dtype,
-            "data": "synthetic",
+            "ms_per_step": dt / steps * 1e3,
+            "steps": steps,
+            "warmup": warmup,
+            "dtype": self.dtype,
             "config": {
                 "workload": f"TowerUNet train step (fwd + Tanimoto + bwd + clip + AdamW), hidden {hidden}, "
                             f"per-GPU batch {B} x [3,12,100,100] "
-                            + ("bf16 mixed precision (BASELINE configs[2])" if bf16 else "fp32 (BASELINE configs[1])"),
+                            + ("bf16 mixed precision (BASELINE configs[2]" + ("; under N ranks: configs[3])" if world > 1 else ")")
+                               if bf16 else "fp32 (BASELINE configs[1])"),
                 "global_batch": world * B,
                 "parallelism": f"dp{world}" if world > 1 else "single",
-                "rccl_ranks": rccl_ranks,
+                "rccl_ranks": self.rccl_ranks,
+                "buckets_per_step": buckets,
+                "comm_ms_exposed": comm_ms,
                 "loss": loss_val,
-                "abi_calls_per_step": launches[0],
+                "abi_calls_per_step": calls[0],
+                "kernel_launches_per_step": launches,
             },
             "roofline": {
                 "bound": "mfma",
@@ -439,38 +505,150 @@ def main():
                 "traffic_source": (f"{pmc_file} (committed rocprofv3 --pmc passes of this command; not measured in "
                                    "this run)") if traffic is not None else None,
                 "avg_launch_us": ms * 1e3 / nl if nl else None,
-                "launches_per_step": nl / args.steps,
-                "share_of_step_time": ms * 1e-3 / dt,
+                "launches_per_step": nl,
+                "share_of_step_time": ms / (dt / steps * 1e3),
                 "isolated": ({"achieved": iso_kernel[top_name]["tflops"], "frac": iso_kernel[top_name]["tflops"] / peak,
                               "avg_launch_us": iso_kernel[top_name]["ms_per_step"] * 1e3
                               / max(iso_kernel[top_name]["launches_per_step"], 1e-9),
                               "note": "same step with the weight-gradient side stream off: the kernel alone on the GPU"}
                              if top_name in iso_kernel else None),
                 "by_kernel": by_kernel,
-                "family": {FAMILY[k]: {"ms_per_step": kinds[k][0] / args.steps,
+                "family": {FAMILY[k]: {"ms_per_step": kinds[k][0] / steps,
                                        "tflops": (kinds[k][1] / (kinds[k][0] * 1e-3) / 1e12) if kinds[k][0] else 0.0,
                                        "frac": ((kinds[k][1] / (kinds[k][0] * 1e-3) / 1e12) / peak) if kinds[k][0] else 0.0,
-                                       "launches_per_step": kinds[k][2] / args.steps,
+                                       "launches_per_step": kinds[k][2] / steps,
                                        "isolated_frac": (((iso_kinds[k][1] / (iso_kinds[k][0] * 1e-3) / 1e12) / peak)
                                                          if iso_kinds is not None and iso_kinds[k][0] else None)}
                            for k in range(6) if kinds[k][2] > 0},
                 "dominant_family": FAMILY.get(dom),
-                "end_to_end_tflops": value * train_gflop / 1e3,
-                "end_to_end_frac": value * train_gflop / 1e3 / peak,
+                "end_to_end_tflops": value / world * train_gflop / 1e3,
+                "end_to_end_frac": value / world * train_gflop / 1e3 / peak,
             },
         }
-        if world == 1 and not args.no_extras:
-            out["roofline"]["streaming"] = streaming_pass(trainer, batch)
+        rec["_first_loss"] = first_loss
+        return rec
+
+
+def feed_block(leg: "TrainLeg", steps: int, resident_ms: float):
+    """The timed step fed a FRESH batch per step: raw int16 chips in pinned host memory -> copy stream ->
+    cn_prepare_chips_f32 (scale, clip, z-score) -> the training step, double-buffered (cultionet_amd.feeder;
+    reference: data/modules.py:44-56 DataLoader(pin_memory) + data/utils.py:55-68 collate + datasets.py:443-446)."""
+    import torch
+
+    from cultionet_amd.data import Data
+    from cultionet_amd.feeder import DeviceFeeder
+
+    x, y, bdist = leg.host
+    hosts = []
+    for k in range(4):
+        xr = (x.roll(k, 0) * 10000.0).to(torch.int16).pin_memory()
+        hosts.append(Data(x=xr, y=y.roll(k, 0).pin_memory(), bdist=(bdist.roll(k, 0) * 10000.0).to(torch.int16).pin_memory()))
+
+    def stream(n):
+        for i in range(n):
+            yield hosts[i % len(hosts)]
+
+    feeder = DeviceFeeder(leg.dev)
+    for b in feeder.iterate(stream(3)):
+        leg.trainer.training_step(b)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for b in feeder.iterate(stream(steps)):
+        leg.trainer.training_step(b)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    nbytes = sum(t.numel() * t.element_size() for t in (hosts[0].x, hosts[0].y, hosts[0].bdist))
+    return {"workload": "same step, a fresh raw int16 batch per step from pinned host memory (H2D on a copy stream + "
+                        "cn_prepare_chips_f32, double-buffered)", "ms_per_step": dt * 1e3, "value": leg.B / dt,
+            "unit": "chips/s", "host_bytes_per_step": nbytes, "delta_ms_vs_resident": dt * 1e3 - resident_ms}
+
+
+def main():
+    args = parse()
+    world = int(os.environ.get("WORLD_SIZE", "0") or 0)
+    if args.gpus > 1 and world == 0:
+        raise SystemExit(launch_ranks(args))  # nothing has touched the GPU in this process
+    import torch
+    import torch.distributed as dist
+
+    world = max(world, 1)
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.dry_run:  # the launch path alone: ranks rendezvous over gloo, sum their ranks, rank 0 prints the line
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        t = torch.tensor([float(rank)])
+        dist.all_reduce(t)
+        n = dist.get_world_size()
+        dist.barrier()
+        dist.destroy_process_group()
+        if rank == 0:
+            print(json.dumps({"metric": "train_chips_per_sec", "value": None, "n_gpus": world, "dry_run": True,
+                              "config": {"ranks": n, "rank_sum": float(t.item())}}), flush=True)
+        return
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    comm = None
+    rccl_ranks = 0
+    use_dist = world > 1 or os.environ.get("CN_FORCE_COMM") == "1"  # CN_FORCE_COMM: exercise RCCL with one rank
+    if use_dist:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
+        if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
+            os.environ["NCCL_DEBUG"] = "WARN"  # RCCL's version banner goes to stdout; keep stdout to ONE JSON line
+        os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")  # RCCL logs default to stdout too
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        from cultionet_amd.ddp import GradientAllReduce
+
+        comm = GradientAllReduce(world_size=world)
+        rccl_ranks = dist.get_world_size()  # what the process group really initialised
+
+    from cultionet_amd import _lib
+
+    _lib.load()
+    TrainLeg.rccl_ranks = rccl_ranks
+    bf16 = args.dtype == "bf16"
+    B = args.batch if args.batch is not None else (32 if bf16 else 8)
+    extras = not args.no_extras
+    leg = TrainLeg(dev, rank, world, comm, use_dist, args.dtype, B, args.hidden)
+    rec = leg.run(args.steps, args.warmup, extras)
+    out = None
+    if rank == 0:
+        first_loss = rec.pop("_first_loss")
+        out = {"metric": "train_chips_per_sec", "value": rec["value"], "unit": "chips/s", "n_gpus": world,
+               "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
+               "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "config": rec["config"],
+               "roofline": rec["roofline"]}
+        if world == 1 and extras:
+            out["roofline"]["streaming"] = streaming_pass(leg.trainer, leg.batch)
+            out["feed"] = feed_block(leg, min(args.steps, 20), rec["ms_per_step"])
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"], cpu_first = cpu_baseline(B, hidden, args.cpu_steps, args.cpu_threads)
+            out["cpu_baseline"], cpu_first = cpu_baseline(B, args.hidden, args.cpu_steps, args.cpu_threads)
             if first_loss is not None:
                 out["loss_delta_vs_cpu"] = {"hip_step1_loss": first_loss, "cpu_step1_loss": cpu_first,
                                             "abs_delta": abs(first_loss - cpu_first),
                                             "tolerance": 5e-4 if bf16 else 1e-4}
-        if world == 1 and not args.no_extras and not bf16:
-            del trainer, batch
-            torch.cuda.empty_cache()
-            out["predict"] = predict_block(dev, hidden, not args.no_cpu_baseline, args.cpu_threads)
+    # BASELINE configs[2] (and, under N ranks, configs[3]): batch 32 per GPU in bf16 mixed precision, its own timed steps
+    if extras and not bf16 and args.batch is None:
+        del leg
+        torch.cuda.empty_cache()
+        leg16 = TrainLeg(dev, rank, world, comm, use_dist, "bf16", 32, args.hidden)
+        rec16 = leg16.run(args.steps, args.warmup, extras and world == 1)
+        if rank == 0:
+            fl16 = rec16.pop("_first_loss")
+            if world == 1 and not args.no_cpu_baseline and fl16 is not None:
+                c16 = cpu_first_loss(32, args.hidden, args.cpu_threads)  # forward + loss only: a few seconds
+                rec16["loss_delta_vs_cpu"] = {"hip_step1_loss": fl16, "cpu_step1_loss": c16,
+                                              "abs_delta": abs(fl16 - c16), "tolerance": 5e-4}
+                rec16["vs_cpu_baseline"] = rec16["value"] / out["cpu_baseline"]["value"]  # the batch-8 CPU leg's rate
+            out["bf16"] = rec16
+        del leg16
+        torch.cuda.empty_cache()
+    if rank == 0 and world == 1 and extras and not bf16:
+        out["predict"] = predict_block(dev, args.hidden, not args.no_cpu_baseline, args.cpu_threads)
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

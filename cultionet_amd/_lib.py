@@ -100,13 +100,18 @@ SIGNATURES = {
     "cn_zero_bf16": [P, L, L, I, P],
     "cn_bilinear_fwd_bf16": [P, L, P, L, I, I, I, I, I, I, P],
     "cn_bilinear_bwd_bf16": [P, L, P, L, I, I, I, I, I, I, I, P],
-    "cn_na2d_fwd_bf16": [P, L, P, L, P, I, I, I, I, I, I, I, P],
-    "cn_na2d_bwd_bf16": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, P],
+    "cn_na2d_fwd_bf16": [P, L, P, L, P, I, I, I, I, I, I, I, F, U64, P],
+    "cn_na2d_bwd_bf16": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, F, U64, P],
+    "cn_dropout_bf16": [P, L, P, L, I, I, I, F, U64, I, I, P],
     "cn_window_chips_f32": [P, I, P, P, I, I, I, I, I, I, I, P, P, F, F, F, P],
     "cn_stitch_predictions_u16": [P, P, P, P, P, I, I, I, I, I, I, F, P],
     "cn_profile_begin": [],
     "cn_profile_end": [P],
     "cn_profile_top": [I, P, I, P],
+    "cn_launch_count": [I],
+    "cn_stream_priority_range": [P],
+    "cn_stream_create": [I, P, I, P],
+    "cn_stream_destroy": [P],
 }
 
 ERRORS = {-1: "CN_ERR_ARG (invalid argument / unsupported shape)", -2: "CN_ERR_LAUNCH (HIP launch failed)",
@@ -154,7 +159,7 @@ def call(name: str, *args) -> int:
     return rc
 
 
-LONG_RESULT = {"cn_bconv_packed_elems", "cn_bwgrad_workspace_floats", "cn_bn_workspace_floats_bf16"}
+LONG_RESULT = {"cn_launch_count", "cn_bconv_packed_elems", "cn_bwgrad_workspace_floats", "cn_bn_workspace_floats_bf16"}
 
 
 def query(name: str, *args) -> int:

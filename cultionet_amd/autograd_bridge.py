@@ -22,7 +22,7 @@ class _TowerUNetFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, model, x, *params):
         store = model.param_store()
-        with E.using_store(store), E.recording(True) as tape, E.mixed_precision(_autocast_bf16()):
+        with E.using_store(store), E.recording(True) as tape, E.mixed_precision(_autocast_bf16(model)):
             outs = model.forward_vars(model.input_var(x))
         ctx.model, ctx.tape, ctx.outs, ctx.store = model, tape, outs, store
         ctx.n_params = len(params)
@@ -45,13 +45,60 @@ class _TowerUNetFn(torch.autograd.Function):
         return (None, None) + pg
 
 
-def _autocast_bf16() -> bool:
-    """lightning.Trainer(precision="16-mixed" / "bf16-mixed") runs the step under torch.autocast: that selects the
-    bf16 MFMA path here (MI355X has no reason to prefer fp16; the GradScaler of "16-mixed" is harmless on it)."""
-    try:
-        return bool(torch.is_autocast_enabled("cuda")) and torch.get_autocast_dtype("cuda") in (torch.bfloat16, torch.float16)
-    except Exception:  # pragma: no cover
+# torch >= 2.4 takes the device type; older releases only have the CUDA-specific spellings. Probed ONCE at import, no
+# blanket try/except around the query itself: a failure to read the autocast state must not silently mean "fp32".
+try:
+    torch.is_autocast_enabled("cuda")
+    _AUTOCAST_NEW_API = True
+except TypeError:  # pragma: no cover - older torch
+    _AUTOCAST_NEW_API = False
+_warned: T.Set[str] = set()
+
+
+def _warn_once(key: str, msg: str) -> None:
+    if key not in _warned:
+        _warned.add(key)
+        import warnings
+
+        warnings.warn(msg, stacklevel=3)
+
+
+def _ambient_autocast() -> T.Optional[torch.dtype]:
+    """dtype of the ambient CUDA autocast region, or None outside one."""
+    if _AUTOCAST_NEW_API:
+        return torch.get_autocast_dtype("cuda") if torch.is_autocast_enabled("cuda") else None
+    return torch.get_autocast_gpu_dtype() if torch.is_autocast_enabled() else None  # pragma: no cover
+
+
+def _autocast_bf16(model=None) -> bool:
+    """Does this forward run the mixed-precision (bf16 NHWC, MFMA) path?
+
+    1. An explicit ``model.precision`` ("32-true" / "bf16-mixed" / "16-mixed"; CultionetLitModel.precision forwards to
+       it) wins -- the choice is then independent of whatever autocast region the caller happens to be in.
+    2. Otherwise lightning.Trainer(precision="16-mixed" / "bf16-mixed") is recognised by its torch.autocast region
+       (model.py:168-186). fp16 autocast is served by the bf16 path (MI355X has no reason to prefer fp16, and the
+       GradScaler of "16-mixed" is harmless on it); that substitution and the implicit selection are announced once.
+    """
+    explicit = getattr(model, "precision", None) if model is not None else None
+    if explicit is not None:
+        if explicit in ("32-true", "32"):
+            return False
+        if explicit in ("bf16-mixed", "16-mixed"):
+            return True
+        raise ValueError(f"unsupported precision {explicit!r} (32-true | bf16-mixed | 16-mixed)")
+    dt = _ambient_autocast()
+    if dt is None:
         return False
+    if dt == torch.bfloat16:
+        _warn_once("bf16", "cultionet_amd: torch.autocast(bfloat16) is active -> TowerUNet runs its bf16 mixed-precision "
+                           "HIP path (set model.precision = '32-true' to force fp32)")
+        return True
+    if dt == torch.float16:
+        _warn_once("fp16", "cultionet_amd: fp16 autocast ('16-mixed') is served by the bf16 mixed-precision HIP path on "
+                           "MI355X (same exponent range as fp32: the GradScaler is a no-op in effect)")
+        return True
+    _warn_once("other", f"cultionet_amd: autocast dtype {dt} has no mixed-precision path; running fp32")
+    return False
 
 
 def run_towerunet(model, x: torch.Tensor) -> T.Dict[str, torch.Tensor]:
@@ -59,7 +106,7 @@ def run_towerunet(model, x: torch.Tensor) -> T.Dict[str, torch.Tensor]:
     if torch.is_grad_enabled() and any(p.requires_grad for p in store.params):
         d, e, c = _TowerUNetFn.apply(model, x, *store.params)
         return {_KEYS[0]: d, _KEYS[1]: e, _KEYS[2]: c}
-    with E.using_store(store), E.recording(False), E.mixed_precision(_autocast_bf16()):
+    with E.using_store(store), E.recording(False), E.mixed_precision(_autocast_bf16(model)):
         outs = model.forward_vars(model.input_var(x))
     return {k: outs[k].t for k in _KEYS}
 

@@ -67,8 +67,8 @@ __global__ __launch_bounds__(256) void cn_sca_c_pool_kernel(const float* __restr
 extern "C" int cn_sca_pool_fwd_f32(const float* x, long xbs, int B, int C, int L, float* avg, float* mx, int* idx,
                                    float* pooled, int* cidx, void* stream) {
   if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
-  hipLaunchKernelGGL(cn_sca_hw_pool_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, xbs, C, L, avg, mx, idx);
-  hipLaunchKernelGGL(cn_sca_c_pool_kernel, dim3((L + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, xbs, C, L,
+  CN_LAUNCH(cn_sca_hw_pool_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, xbs, C, L, avg, mx, idx);
+  CN_LAUNCH(cn_sca_c_pool_kernel, dim3((L + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, xbs, C, L,
                      pooled, cidx);
   return cn_check_launch();
 }
@@ -98,7 +98,7 @@ extern "C" int cn_sca_pool_bwd_f32(const float* davg, const float* dmx, const in
   if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
   int bx = (L + 1023) / 1024;
   if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(cn_sca_pool_bwd_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, davg, dmx, idx, dpooled,
+  CN_LAUNCH(cn_sca_pool_bwd_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, davg, dmx, idx, dpooled,
                      cidx, dx, dxbs, C, L, accumulate);
   return cn_check_launch();
 }
@@ -149,7 +149,7 @@ extern "C" int cn_sca_mlp_fwd_f32(const float* avg, const float* mx, const float
                                   int C, int Ch, void* stream) {
   if (C > SCA_MAXC || Ch > SCA_MAXC / 2 || Ch < 1) return CN_ERR_ARG;
   if (B <= 0) return CN_OK;
-  hipLaunchKernelGGL(cn_sca_mlp_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, avg, mx, w1a, w2a, w1m, w2m,
+  CN_LAUNCH(cn_sca_mlp_fwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, avg, mx, w1a, w2a, w1m, w2m,
                      hpre_a, hpre_m, ca, C, Ch);
   return cn_check_launch();
 }
@@ -214,7 +214,7 @@ extern "C" int cn_sca_mlp_bwd_f32(const float* avg, const float* mx, const float
                                   float* dw2m, float* davg, float* dmx, int B, int C, int Ch, void* stream) {
   if (C > SCA_MAXC || Ch > SCA_MAXC / 2 || Ch < 1) return CN_ERR_ARG;
   if (B <= 0) return CN_OK;
-  hipLaunchKernelGGL(cn_sca_mlp_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, avg, mx, w1a, w2a, w1m, w2m,
+  CN_LAUNCH(cn_sca_mlp_bwd_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, avg, mx, w1a, w2a, w1m, w2m,
                      hpre_a, hpre_m, ca, dca, dw1a, dw2a, dw1m, dw2m, davg, dmx, C, Ch);
   return cn_check_launch();
 }
@@ -241,7 +241,7 @@ extern "C" int cn_sca_apply_fwd_f32(const float* out, long obs, const float* ca,
   if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
   int bx = (L + 1023) / 1024;
   if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(cn_sca_apply_fwd_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, out, obs, ca, sconv,
+  CN_LAUNCH(cn_sca_apply_fwd_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, out, obs, ca, sconv,
                      gamma, y, ybs, C, L);
   return cn_check_launch();
 }
@@ -313,10 +313,10 @@ extern "C" int cn_sca_apply_bwd_f32(const float* dy, long dybs, const float* out
                                     int accumulate_dout, float* dca, float* dsconv, float* dgamma, float* scratch,
                                     int B, int C, int L, void* stream) {
   if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
-  hipLaunchKernelGGL(cn_sca_apply_bwd_a_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, dy, dybs, out, obs, ca,
+  CN_LAUNCH(cn_sca_apply_bwd_a_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, dy, dybs, out, obs, ca,
                      sconv, gamma, dout, dobs, accumulate_dout, dca, scratch, C, L);
-  hipLaunchKernelGGL(cn_sca_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, B * C, dgamma);
-  hipLaunchKernelGGL(cn_sca_apply_bwd_b_kernel, dim3((L + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, dy, dybs,
+  CN_LAUNCH(cn_sca_sum_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, scratch, B * C, dgamma);
+  CN_LAUNCH(cn_sca_apply_bwd_b_kernel, dim3((L + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, dy, dybs,
                      out, obs, sconv, gamma, dsconv, C, L);
   return cn_check_launch();
 }

@@ -559,7 +559,7 @@ extern "C" long cn_bconv_packed_elems(int T, int K, int N) {
 // descs: DEVICE array of n 64-byte records {const float* w; bf16* wp; int T, K, N, KS, NT, pad; long sk, sn, st}
 extern "C" int cn_pack_weights_batched_bf16(const void* descs, int n, void* stream) {
   if (n <= 0) return CN_OK;
-  hipLaunchKernelGGL(cn_bpack_kernel, dim3(32, n), dim3(256), 0, (hipStream_t)stream, (const CnBPackDesc*)descs);
+  CN_LAUNCH(cn_bpack_kernel, dim3(32, n), dim3(256), 0, (hipStream_t)stream, (const CnBPackDesc*)descs);
   return cn_check_launch();
 }
 
@@ -588,7 +588,7 @@ extern "C" int cn_pack_weights_bf16(const float* w, void* wp, int T, int K, int 
   CnBPackDesc d = {w, (bf16_t*)wp, T, K, N, (K + 15) / 16, (N + 31) / 32, 0, sk, sn, st};
   const long total = (long)d.T * d.KS * d.NT * 64;
   const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
-  hipLaunchKernelGGL(cn_bpack_one_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d);
+  CN_LAUNCH(cn_bpack_one_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d);
   return cn_check_launch();
 }
 
@@ -639,6 +639,12 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
   }
   g.KS = (g.Cin + 15) / 16;
   g.NT = (g.Cout + 31) / 32;
+  {  // weight fragments are fetched through a buffer resource with a 32-bit scalar byte offset: refuse packs >= 2 GiB
+    int wt_max = 0;
+    for (int c = 0; c < g.ncls; ++c)
+      for (int t = 0; t < g.cls[c].ntaps; ++t) wt_max = g.cls[c].wt[t] > wt_max ? g.cls[c].wt[t] : wt_max;
+    if ((long)(wt_max + 1) * g.KS * g.NT * 1024 >= (1L << 31)) return CN_ERR_ARG;
+  }
   const int WN = g.NT >= 4 ? 4 : (g.NT >= 2 ? 2 : 1);
   cnb_pick_tile(Hg, Wg, g.is, span, 128 * (4 / WN), g.TH, g.TW);
   g.nblk_n = (g.NT + WN - 1) / WN;
@@ -721,7 +727,7 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
     if (shmem > 64 * 1024)                                                                                       \
       (void)hipFuncSetAttribute((const void*)cn_bconv_kernel<WN_, NP_, KSC_>,                                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                         \
-    hipLaunchKernelGGL((cn_bconv_kernel<WN_, NP_, KSC_>), grid, block, shmem, stream, g);                        \
+    CN_LAUNCH((cn_bconv_kernel<WN_, NP_, KSC_>), grid, block, shmem, stream, g);                        \
   } while (0)
 #define CNB_GO(NP_, KSC_)                                                                                        \
   do {                                                                                                           \

@@ -293,16 +293,16 @@ extern "C" int cn_bn_act_fwd_bf16(const void* x, long ldx, const float* gamma, c
   long rows;
   bbn_grid(P, C, nblk, rows);
   if (training && !(conv_sums != nullptr && conv_rows > 0))
-    hipLaunchKernelGGL((cn_bbn_partial_kernel<0>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr,
+    CN_LAUNCH((cn_bbn_partial_kernel<0>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr,
                        0L, nullptr, nullptr, nullptr, nullptr, P, C, act, rows, ws);
   const bool fused = training && conv_sums != nullptr && conv_rows > 0;
-  hipLaunchKernelGGL(cn_bbn_finalize_fwd_kernel, dim3((C + BBN_FIN_CH - 1) / BBN_FIN_CH), dim3(256), 0, stream, fused ? conv_sums : ws,
+  CN_LAUNCH(cn_bbn_finalize_fwd_kernel, dim3((C + BBN_FIN_CH - 1) / BBN_FIN_CH), dim3(256), 0, stream, fused ? conv_sums : ws,
                      fused ? conv_rows : nblk, C, (double)P, eps, momentum, running_mean, running_var, mean, rstd,
                      training);
   int ablk;
   long arows;
   bbn_apply_grid(P, C, ablk, arows);
-  hipLaunchKernelGGL((cn_bbn_apply_kernel<0>), dim3(ablk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr, 0L,
+  CN_LAUNCH((cn_bbn_apply_kernel<0>), dim3(ablk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr, 0L,
                      mean, rstd, gamma, beta, nullptr, (const bf16_t*)res, ldr, (bf16_t*)y, ldy, P, C, act, 0, arows);
   return cn_check_launch();
 }
@@ -319,15 +319,15 @@ extern "C" int cn_bn_act_bwd_bf16(const void* x, long ldx, const void* dy, long 
   long rows;
   bbn_grid(P, C, nblk, rows);
   float* coef = ws + (long)BBN_MAX_BLOCKS * 2 * C;
-  hipLaunchKernelGGL((cn_bbn_partial_kernel<1>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx,
+  CN_LAUNCH((cn_bbn_partial_kernel<1>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx,
                      (const bf16_t*)dy, lddy, mean, rstd, gamma, beta, P, C, act, rows, ws);
-  hipLaunchKernelGGL(cn_bbn_finalize_bwd_kernel, dim3((C + BBN_FIN_CH - 1) / BBN_FIN_CH), dim3(256), 0, stream, ws, nblk, C, (double)P,
+  CN_LAUNCH(cn_bbn_finalize_bwd_kernel, dim3((C + BBN_FIN_CH - 1) / BBN_FIN_CH), dim3(256), 0, stream, ws, nblk, C, (double)P,
                      coef, dgamma, dbeta, training);
   if (dx != nullptr) {
     int ablk;
     long arows;
     bbn_apply_grid(P, C, ablk, arows);
-    hipLaunchKernelGGL((cn_bbn_apply_kernel<1>), dim3(ablk), dim3(256), 0, stream, (const bf16_t*)x, ldx,
+    CN_LAUNCH((cn_bbn_apply_kernel<1>), dim3(ablk), dim3(256), 0, stream, (const bf16_t*)x, ldx,
                        (const bf16_t*)dy, lddy, mean, rstd, gamma, beta, coef, nullptr, 0L, (bf16_t*)dx, lddx, P, C,
                        act, accumulate_dx, arows);
   }
@@ -440,13 +440,13 @@ __global__ __launch_bounds__(256) void cn_bln_bwd_kernel(const bf16_t* __restric
 
 #define BLN_DISPATCH(KERNEL, ...)                                                                       \
   switch (C >> 3) {                                                                                     \
-    case 1: hipLaunchKernelGGL((KERNEL<1>), grid, dim3(256), 0, stream, __VA_ARGS__); break;           \
-    case 2: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(256), 0, stream, __VA_ARGS__); break;           \
-    case 4: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(256), 0, stream, __VA_ARGS__); break;           \
-    case 8: hipLaunchKernelGGL((KERNEL<8>), grid, dim3(256), 0, stream, __VA_ARGS__); break;           \
-    case 16: hipLaunchKernelGGL((KERNEL<16>), grid, dim3(256), 0, stream, __VA_ARGS__); break;         \
-    case 32: hipLaunchKernelGGL((KERNEL<32>), grid, dim3(256), 0, stream, __VA_ARGS__); break;         \
-    case 64: hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, stream, __VA_ARGS__); break;         \
+    case 1: CN_LAUNCH((KERNEL<1>), grid, dim3(256), 0, stream, __VA_ARGS__); break;           \
+    case 2: CN_LAUNCH((KERNEL<2>), grid, dim3(256), 0, stream, __VA_ARGS__); break;           \
+    case 4: CN_LAUNCH((KERNEL<4>), grid, dim3(256), 0, stream, __VA_ARGS__); break;           \
+    case 8: CN_LAUNCH((KERNEL<8>), grid, dim3(256), 0, stream, __VA_ARGS__); break;           \
+    case 16: CN_LAUNCH((KERNEL<16>), grid, dim3(256), 0, stream, __VA_ARGS__); break;         \
+    case 32: CN_LAUNCH((KERNEL<32>), grid, dim3(256), 0, stream, __VA_ARGS__); break;         \
+    case 64: CN_LAUNCH((KERNEL<64>), grid, dim3(256), 0, stream, __VA_ARGS__); break;         \
     default: return CN_ERR_ARG;                                                                         \
   }
 
@@ -499,8 +499,8 @@ extern "C" int cn_channel_sum_bf16(const void* x, long ldx, long P, int C, float
   int nblk;
   long rows;
   bbn_grid(P, C, nblk, rows);
-  hipLaunchKernelGGL((cn_bbn_partial_kernel<0>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr, 0L,
+  CN_LAUNCH((cn_bbn_partial_kernel<0>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr, 0L,
                      nullptr, nullptr, nullptr, nullptr, P, C, 0, rows, ws);
-  hipLaunchKernelGGL(cn_bsum_finalize_kernel, dim3((C + BBN_FIN_CH - 1) / BBN_FIN_CH), dim3(256), 0, stream, ws, nblk, C, out, accumulate);
+  CN_LAUNCH(cn_bsum_finalize_kernel, dim3((C + BBN_FIN_CH - 1) / BBN_FIN_CH), dim3(256), 0, stream, ws, nblk, C, out, accumulate);
   return cn_check_launch();
 }

@@ -60,7 +60,7 @@ extern "C" int cn_convert_f32nchw_to_bf16nhwc(const float* src, long sbs, void* 
                                               int HW, void* stream) {
   if (B <= 0 || HW <= 0) return CN_OK;
   if (Cpad < C || (Cpad & 1) || ld < Cpad) return CN_ERR_ARG;
-  hipLaunchKernelGGL(cn_f32nchw_to_bf16nhwc_kernel, dim3((HW + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, src, sbs,
+  CN_LAUNCH(cn_f32nchw_to_bf16nhwc_kernel, dim3((HW + 63) / 64, B), dim3(256), 0, (hipStream_t)stream, src, sbs,
                      (bf16_t*)dst, ld, C, Cpad, HW);
   return cn_check_launch();
 }
@@ -68,7 +68,7 @@ extern "C" int cn_convert_f32nchw_to_bf16nhwc(const float* src, long sbs, void* 
 extern "C" int cn_convert_bf16nhwc_to_f32nchw(const void* src, long ld, float* dst, long dbs, int B, int C, int HW,
                                               int accumulate, void* stream) {
   if (B <= 0 || HW <= 0) return CN_OK;
-  hipLaunchKernelGGL(cn_bf16nhwc_to_f32nchw_kernel, dim3((HW + 63) / 64, B), dim3(256), 0, (hipStream_t)stream,
+  CN_LAUNCH(cn_bf16nhwc_to_f32nchw_kernel, dim3((HW + 63) / 64, B), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)src, ld, dst, dbs, C, HW, accumulate);
   return cn_check_launch();
 }
@@ -133,10 +133,10 @@ static void bcopy_launch(const bf16_t* a, long lda, const bf16_t* c, long ldc, b
   if (blocks > 16384) blocks = 16384;
   if (blocks < 1) blocks = 1;
   if (n + 2 * blocks * 256 < (1L << 31))
-    hipLaunchKernelGGL(cn_bcopy_kernel<int>, dim3((unsigned)blocks), dim3(256), 0, stream, a, lda, c, ldc, d, ldd, P, C8,
+    CN_LAUNCH(cn_bcopy_kernel<int>, dim3((unsigned)blocks), dim3(256), 0, stream, a, lda, c, ldc, d, ldd, P, C8,
                        mode);
   else
-    hipLaunchKernelGGL(cn_bcopy_kernel<long>, dim3((unsigned)blocks), dim3(256), 0, stream, a, lda, c, ldc, d, ldd, P,
+    CN_LAUNCH(cn_bcopy_kernel<long>, dim3((unsigned)blocks), dim3(256), 0, stream, a, lda, c, ldc, d, ldd, P,
                        C8, mode);
 }
 
@@ -174,7 +174,7 @@ __global__ __launch_bounds__(256) void cn_bfill_kernel(bf16_t* __restrict__ d, l
 extern "C" int cn_zero_bf16(void* dst, long ldd, long P, int C, void* stream) {
   if (P <= 0 || C <= 0) return CN_OK;
   if (C & 7) return CN_ERR_ARG;
-  hipLaunchKernelGGL(cn_bfill_kernel, dim3(bops_blocks(P * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dst,
+  CN_LAUNCH(cn_bfill_kernel, dim3(bops_blocks(P * (C >> 3))), dim3(256), 0, (hipStream_t)stream, (bf16_t*)dst,
                      ldd, P, C >> 3);
   return cn_check_launch();
 }
@@ -482,10 +482,10 @@ extern "C" int cn_bilinear_fwd_bf16(const void* x, long ldx, void* y, long ldy, 
   if (C & 7) return CN_ERR_ARG;
   if (Ho <= 0 || Wo <= 0 || Hi <= 0 || Wi <= 0) return CN_OK;
   if (B <= 65535 && (long)Wo * (C >> 3) < (1L << 30))
-    hipLaunchKernelGGL(cn_bbilinear_fwd_rows_kernel, dim3(Ho, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
+    CN_LAUNCH(cn_bbilinear_fwd_rows_kernel, dim3(Ho, B), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x,
                        ldx, (bf16_t*)y, ldy, C >> 3, Hi, Wi, Ho, Wo, bbl_scale(Hi, Ho), bbl_scale(Wi, Wo));
   else
-    hipLaunchKernelGGL(cn_bbilinear_fwd_kernel, dim3(bops_blocks((long)B * Ho * Wo * (C >> 3))), dim3(256), 0,
+    CN_LAUNCH(cn_bbilinear_fwd_kernel, dim3(bops_blocks((long)B * Ho * Wo * (C >> 3))), dim3(256), 0,
                        (hipStream_t)stream, (const bf16_t*)x, ldx, (bf16_t*)y, ldy, B, C >> 3, Hi, Wi, Ho, Wo,
                        bbl_scale(Hi, Ho), bbl_scale(Wi, Wo));
   return cn_check_launch();
@@ -500,10 +500,10 @@ extern "C" int cn_bilinear_bwd_bf16(const void* dy, long lddy, void* dx, long ld
   const float ish = sh > 0.f ? 1.f / sh : 0.f, isw = sw > 0.f ? 1.f / sw : 0.f;
   if (B <= 65535 && Wi <= BBL_MAXW && (long)Wi * (C >> 3) < (1L << 30) && bbl_max_candidates(Hi, Ho) <= BBL_MAXC &&
       bbl_max_candidates(Wi, Wo) <= BBL_MAXC)
-    hipLaunchKernelGGL(cn_bbilinear_bwd_rows_kernel, dim3(Hi, B), dim3(256), 0, (hipStream_t)stream,
+    CN_LAUNCH(cn_bbilinear_bwd_rows_kernel, dim3(Hi, B), dim3(256), 0, (hipStream_t)stream,
                        (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, C >> 3, Hi, Wi, Ho, Wo, sh, sw, ish, isw, accumulate);
   else
-    hipLaunchKernelGGL(cn_bbilinear_bwd_kernel, dim3(bops_blocks((long)B * Hi * Wi * (C >> 3))), dim3(256), 0,
+    CN_LAUNCH(cn_bbilinear_bwd_kernel, dim3(bops_blocks((long)B * Hi * Wi * (C >> 3))), dim3(256), 0,
                        (hipStream_t)stream, (const bf16_t*)dy, lddy, (bf16_t*)dx, lddx, B, C >> 3, Hi, Wi, Ho, Wo, sh,
                        sw, ish, isw, accumulate);
   return cn_check_launch();
@@ -530,6 +530,74 @@ __device__ __forceinline__ int nab_window_start(int i, int len, int dil) {
   return ni;
 }
 
+// attn_drop (nn.Dropout on the soft-maxed logits): keep/(1-p) factor of tap t from the same counter hash as the fp32
+// kernels (cn_na2d.hip na_keep), recomputed in forward and backward; 1.0 when dropout is off.
+__device__ __forceinline__ unsigned long long nab_splitmix64(unsigned long long z) {
+  z += 0x9E3779B97F4A7C15ull;
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+__device__ __forceinline__ float nab_keep(unsigned long long thresh, float scale, unsigned long long seed, long bh,
+                                          int t, int HW, int p) {
+  if (thresh == 0ull) return 1.0f;
+  const unsigned long long i = ((unsigned long long)bh * NAB_KK + t) * (unsigned long long)HW + p;
+  return nab_splitmix64(seed + i) >= thresh ? scale : 0.f;
+}
+static inline unsigned long long nab_thresh(float p) {
+  if (!(p > 0.f)) return 0ull;
+  const double t = (double)p * 18446744073709551616.0;  // p * 2^64
+  return t >= 18446744073709551615.0 ? ~0ull : (unsigned long long)t;
+}
+
+// ---- dropout on bf16 NHWC activations ---------------------------------------------------------------------------
+// nn.Dropout2d after the encoder blocks (convolution.py:495,511) and natten's proj_drop, on the mixed-precision path.
+// The SAME counter-based masks as cn_dropout_f32 (cn_pointwise.hip): channelwise: one decision per (b, c) from
+// splitmix64(seed + b*C + c); elementwise: splitmix64(seed + (b*C + c)*HW + pixel). y = x * keep / (1 - p); the same
+// entry point serves backward (x := dy, accumulate into dx).
+__global__ __launch_bounds__(256) void cn_bdropout_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y,
+                                                         long ldy, long P, int C, int HW, unsigned long long thresh,
+                                                         float scale, unsigned long long seed, int channelwise,
+                                                         int accumulate) {
+  const int groups = C >> 3;
+  const long n = P * groups;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
+    const long row = i / groups;
+    const int c0 = (int)(i - row * groups) << 3;
+    const long b = row / HW;
+    const int pix = (int)(row - b * HW);
+    float v[8];
+    cn_unpack8(*reinterpret_cast<const u32x4*>(x + row * ldx + c0), v);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const unsigned long long plane = (unsigned long long)b * C + c0 + j;
+      const unsigned long long ctr = channelwise ? plane : plane * (unsigned long long)HW + pix;
+      v[j] *= nab_splitmix64(seed + ctr) >= thresh ? scale : 0.f;
+    }
+    bf16_t* yp = y + row * ldy + c0;
+    if (accumulate) {
+      float o[8];
+      cn_unpack8(*reinterpret_cast<const u32x4*>(yp), o);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] += o[j];
+    }
+    *reinterpret_cast<u32x4*>(yp) = cn_pack8(v);
+  }
+}
+
+extern "C" int cn_dropout_bf16(const void* x, long ldx, void* y, long ldy, int B, int C, int HW, float p,
+                               unsigned long long seed, int channelwise, int accumulate, void* stream) {
+  if (B <= 0 || C <= 0 || HW <= 0) return CN_OK;
+  if (!(p >= 0.f && p < 1.f) || (C & 7)) return CN_ERR_ARG;
+  const long P = (long)B * HW;
+  const long n = P * (C >> 3);
+  long blocks = (n + 255) / 256;
+  if (blocks > 16384) blocks = 16384;
+  CN_LAUNCH(cn_bdropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+            (bf16_t*)y, ldy, P, C, HW, nab_thresh(p), 1.0f / (1.0f - p), seed, channelwise, accumulate);
+  return cn_check_launch();
+}
+
 template <int D>
 __device__ __forceinline__ void nab_load(const bf16_t* p, float* f) {
   if (D == 4) {
@@ -554,7 +622,9 @@ __device__ __forceinline__ void nab_store(bf16_t* p, const float* f) {
 template <int D>
 __global__ __launch_bounds__(256) void cn_bna_fwd_kernel(const bf16_t* __restrict__ qkv, long ldq,
                                                         bf16_t* __restrict__ out, long ldo, float* __restrict__ attn,
-                                                        int B, int C, int heads, int H, int W, int dil, float scale) {
+                                                        int B, int C, int heads, int H, int W, int dil, float scale,
+                                                        unsigned long long dthresh, float dscale,
+                                                        unsigned long long dseed) {
   const int HW = H * W;
   const long n = (long)B * HW * heads;
   const long i = blockIdx.x * 256L + threadIdx.x;
@@ -594,6 +664,7 @@ __global__ __launch_bounds__(256) void cn_bna_fwd_kernel(const bf16_t* __restric
   for (int t = 0; t < NAB_KK; ++t) {
     lg[t] *= inv;
     if (attn != nullptr) ap[(long)t * HW] = lg[t];
+    lg[t] *= nab_keep(dthresh, dscale, dseed, (long)b * heads + h, t, HW, p);
     const int kp = (sy + (t / 3) * dil) * W + sx + (t % 3) * dil;
     float vv[D];
     nab_load<D>(base + (long)kp * ldq + 2 * C, vv);
@@ -609,7 +680,9 @@ __global__ __launch_bounds__(256) void cn_bna_bwd_q_kernel(const bf16_t* __restr
                                                           const bf16_t* __restrict__ dout, long ldo,
                                                           const float* __restrict__ attn, float* __restrict__ dattn,
                                                           bf16_t* __restrict__ dqkv, long lddq, int B, int C,
-                                                          int heads, int H, int W, int dil, float scale) {
+                                                          int heads, int H, int W, int dil, float scale,
+                                                          unsigned long long dthresh, float dscale,
+                                                          unsigned long long dseed) {
   const int HW = H * W;
   const long n = (long)B * HW * heads;
   const long i = blockIdx.x * 256L + threadIdx.x;
@@ -634,6 +707,7 @@ __global__ __launch_bounds__(256) void cn_bna_bwd_q_kernel(const bf16_t* __restr
     float s = 0.f;
 #pragma unroll
     for (int d = 0; d < D; ++d) s += g[d] * vv[d];
+    s *= nab_keep(dthresh, dscale, dseed, (long)b * heads + h, t, HW, p);
     dp[t] = s;
     pr[t] = ap[(long)t * HW];
     dot += pr[t] * s;
@@ -664,7 +738,9 @@ __global__ __launch_bounds__(256) void cn_bna_bwd_kv_kernel(const bf16_t* __rest
                                                            const float* __restrict__ attn,
                                                            const float* __restrict__ dattn,
                                                            bf16_t* __restrict__ dqkv, long lddq, int B, int C,
-                                                           int heads, int H, int W, int dil, float scale) {
+                                                           int heads, int H, int W, int dil, float scale,
+                                                           unsigned long long dthresh, float dscale,
+                                                           unsigned long long dseed) {
   const int HW = H * W;
   const long n = (long)B * HW * heads;
   const long i = blockIdx.x * 256L + threadIdx.x;
@@ -695,7 +771,7 @@ __global__ __launch_bounds__(256) void cn_bna_bwd_kv_kernel(const bf16_t* __rest
       const int t = ti * NAB_K + offx / dil;
       const int qpix = qy * W + qx;
       const float ds = dap[(long)t * HW + qpix];
-      const float pr = ap[(long)t * HW + qpix];
+      const float pr = ap[(long)t * HW + qpix] * nab_keep(dthresh, dscale, dseed, (long)b * heads + h, t, HW, qpix);
       float qv[D], gv[D];
       nab_load<D>(qb + (long)qpix * ldq, qv);
       nab_load<D>(gb + (long)qpix * ldo, gv);
@@ -712,16 +788,17 @@ __global__ __launch_bounds__(256) void cn_bna_bwd_kv_kernel(const bf16_t* __rest
 
 #define NAB_DISPATCH(D_, KERNEL, ...)                                                          \
   switch (D_) {                                                                                \
-    case 4: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(256), 0, stream, __VA_ARGS__); break;  \
-    case 8: hipLaunchKernelGGL((KERNEL<8>), grid, dim3(256), 0, stream, __VA_ARGS__); break;  \
-    case 16: hipLaunchKernelGGL((KERNEL<16>), grid, dim3(256), 0, stream, __VA_ARGS__); break; \
-    case 32: hipLaunchKernelGGL((KERNEL<32>), grid, dim3(256), 0, stream, __VA_ARGS__); break; \
-    case 64: hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, stream, __VA_ARGS__); break; \
+    case 4: CN_LAUNCH((KERNEL<4>), grid, dim3(256), 0, stream, __VA_ARGS__); break;  \
+    case 8: CN_LAUNCH((KERNEL<8>), grid, dim3(256), 0, stream, __VA_ARGS__); break;  \
+    case 16: CN_LAUNCH((KERNEL<16>), grid, dim3(256), 0, stream, __VA_ARGS__); break; \
+    case 32: CN_LAUNCH((KERNEL<32>), grid, dim3(256), 0, stream, __VA_ARGS__); break; \
+    case 64: CN_LAUNCH((KERNEL<64>), grid, dim3(256), 0, stream, __VA_ARGS__); break; \
     default: return CN_ERR_ARG;                                                                \
   }
 
 extern "C" int cn_na2d_fwd_bf16(const void* qkv, long ldq, void* out, long ldo, float* attn, int B, int C, int heads,
-                                int H, int W, int kernel_size, int dilation, void* stream_) {
+                                int H, int W, int kernel_size, int dilation, float attn_drop, unsigned long long seed,
+                                void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (kernel_size != NAB_K || heads <= 0 || C % heads != 0) return CN_ERR_ARG;
   if (kernel_size * dilation > H || kernel_size * dilation > W) return CN_ERR_ARG;
@@ -729,24 +806,28 @@ extern "C" int cn_na2d_fwd_bf16(const void* qkv, long ldq, void* out, long ldo, 
   const float scale = 1.0f / sqrtf((float)D);
   const long n = (long)B * H * W * heads;
   const dim3 grid((unsigned)((n + 255) / 256));
+  if (!(attn_drop >= 0.f && attn_drop < 1.f)) return CN_ERR_ARG;
   NAB_DISPATCH(D, cn_bna_fwd_kernel, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, attn, B, C, heads, H, W, dilation,
-               scale);
+               scale, nab_thresh(attn_drop), 1.0f / (1.0f - attn_drop), seed);
   return cn_check_launch();
 }
 
 // dqkv bf16 [B][H][W][3C] fully overwritten; dattn: scratch of attn's size.
 extern "C" int cn_na2d_bwd_bf16(const void* qkv, long ldq, const void* dout, long ldo, const float* attn, float* dattn,
                                 void* dqkv, long lddq, int B, int C, int heads, int H, int W, int kernel_size,
-                                int dilation, void* stream_) {
+                                int dilation, float attn_drop, unsigned long long seed, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (kernel_size != NAB_K || heads <= 0 || C % heads != 0) return CN_ERR_ARG;
   const int D = C / heads;
   const float scale = 1.0f / sqrtf((float)D);
   const long n = (long)B * H * W * heads;
   const dim3 grid((unsigned)((n + 255) / 256));
+  if (!(attn_drop >= 0.f && attn_drop < 1.f)) return CN_ERR_ARG;
+  const unsigned long long th = nab_thresh(attn_drop);
+  const float ds = 1.0f / (1.0f - attn_drop);
   NAB_DISPATCH(D, cn_bna_bwd_q_kernel, (const bf16_t*)qkv, ldq, (const bf16_t*)dout, ldo, attn, dattn, (bf16_t*)dqkv,
-               lddq, B, C, heads, H, W, dilation, scale);
+               lddq, B, C, heads, H, W, dilation, scale, th, ds, seed);
   NAB_DISPATCH(D, cn_bna_bwd_kv_kernel, (const bf16_t*)qkv, ldq, (const bf16_t*)dout, ldo, attn, dattn, (bf16_t*)dqkv,
-               lddq, B, C, heads, H, W, dilation, scale);
+               lddq, B, C, heads, H, W, dilation, scale, th, ds, seed);
   return cn_check_launch();
 }

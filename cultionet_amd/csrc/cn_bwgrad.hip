@@ -453,6 +453,8 @@ static long cnw_ws_floats(const CnBWgGeom& g) { return (long)g.nsplit * g.T * g.
 
 static int cnw_run(CnBWgGeom& g, float* dw, float* ws, long ws_floats, hipStream_t stream) {
   if (g.ntiles <= 0 || g.CP <= 0 || g.CQ <= 0) return CN_OK;
+  // tile prefetches address an image through buffer resources with 32-bit byte offsets: refuse images beyond 2 GiB
+  if ((long)g.Hg * g.Wg * g.ldp * 2 >= (1L << 31) || (long)g.Hq * g.Wq * g.ldq * 2 >= (1L << 31)) return CN_ERR_ARG;
   // shrink the split until the partial slices fit the workspace
   while (cnw_ws_floats(g) > ws_floats && g.nsplit > 1) {
     g.tiles_per_split *= 2;
@@ -481,7 +483,7 @@ static int cnw_run(CnBWgGeom& g, float* dw, float* ws, long ws_floats, hipStream
     if (shmem > 64 * 1024)                                                                                     \
       (void)hipFuncSetAttribute((const void*)cn_bwgrad_kernel<T_, NQ_, F_>,                                    \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                       \
-    hipLaunchKernelGGL((cn_bwgrad_kernel<T_, NQ_, F_>), grid, block, shmem, stream, g);                        \
+    CN_LAUNCH((cn_bwgrad_kernel<T_, NQ_, F_>), grid, block, shmem, stream, g);                        \
   } while (0)
   const bool full = g.TH * g.TW > 112;  // all 8 k-steps of 16 pixels are live
 #define CNW_GO(T_, NQ_)                                                                                        \
@@ -500,7 +502,7 @@ static int cnw_run(CnBWgGeom& g, float* dw, float* ws, long ws_floats, hipStream
   cn_prof_after(stream, 5, flops);  // the contraction kernel alone
   const long n = (long)g.CP * g.CQ * g.T;
   const int rb = (int)((n + 63) / 64 < 8192 ? (n + 63) / 64 : 8192);
-  hipLaunchKernelGGL(cn_bwgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, g.part, dw, g.nsplit, g.T, g.CP, g.CQ,
+  CN_LAUNCH(cn_bwgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, g.part, dw, g.nsplit, g.T, g.CP, g.CQ,
                      (long)g.nbp * 64, (long)g.nbq * 64);
   return cn_check_launch();
 }

@@ -19,6 +19,11 @@ static inline int cn_check_launch() {
   return e == hipSuccess ? CN_OK : CN_ERR_LAUNCH;
 }
 
+// Every kernel launch of the library goes through CN_LAUNCH: a process-wide launch counter (cn_launch_count, read by
+// bench.py as kernel launches per step) in front of hipLaunchKernelGGL.
+extern long g_cn_launches;
+#define CN_LAUNCH(...) do { __atomic_fetch_add(&g_cn_launches, 1L, __ATOMIC_RELAXED); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
+
 static inline int cn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- XCD-aware block order -------------------------------------------------------------------------------

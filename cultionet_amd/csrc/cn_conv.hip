@@ -581,7 +581,7 @@ extern "C" int cn_pack_weights_f32(const float* w, float* wp, int T, int K, int 
   const int Kpad = cn_conv_kpad(K), Npad = cn_conv_npad(N);
   const long total = (long)T * Kpad * Npad;
   const int blocks = (int)((total + 255) / 256 < 2048 ? (total + 255) / 256 : 2048);
-  hipLaunchKernelGGL(cn_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, T, K, N,
+  CN_LAUNCH(cn_pack_weights_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, w, wp, T, K, N,
                      Kpad, Npad, sk, sn, st);
   return cn_check_launch();
 }
@@ -590,7 +590,7 @@ extern "C" int cn_pack_weights_f32(const float* w, float* wp, int T, int K, int 
 // pointers, five ints + 4 bytes padding, three longs = 64 bytes).
 extern "C" int cn_pack_weights_batched_f32(const void* descs, int n, void* stream) {
   if (n <= 0) return CN_OK;
-  hipLaunchKernelGGL(cn_pack_weights_batched_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream,
+  CN_LAUNCH(cn_pack_weights_batched_kernel, dim3(64, n), dim3(256), 0, (hipStream_t)stream,
                      (const CnPackDesc*)descs);
   return cn_check_launch();
 }
@@ -600,6 +600,10 @@ static int cn_launch_igemm_v(const float* x, const float* wp, const float* bias,
                              int total_tiles, int max_taps, int splits, double flops, hipStream_t stream) {
   constexpr int NT = WAVES_N * TN * 32;
   g.tap_lds_off = g.w_lds_off + (max_taps > 0 ? max_taps : 1) * KC * NT;
+  // the staging prefetch addresses an image through a buffer resource with 32-bit byte offsets (num_records 2 GiB):
+  // refuse images (or packed weight sets) beyond that instead of wrapping silently
+  if ((long)g.Cin * g.Hin * g.Win * 4 >= (1L << 31) || (long)(max_taps > 0 ? max_taps : 1) * g.Kpad * g.Npad * 4 >= (1L << 31))
+    return CN_ERR_ARG;
   const size_t lds = (size_t)(g.tap_lds_off + 3 * CN_MAX_TAPS + 1) * sizeof(float);
   if (lds > 160 * 1024) return CN_ERR_LDS;
   static bool attr_set = false;
@@ -617,7 +621,7 @@ static int cn_launch_igemm_v(const float* x, const float* wp, const float* bias,
                TM, NV, RP, g.G, g.B, g.Cin, g.Cout, g.Hin, g.Win, g.Hout, g.Wout, max_taps, g.ncls, g.is, g.os,
                total_tiles, (g.Cout + NT - 1) / NT, splits);
   cn_prof_before(stream);
-  hipLaunchKernelGGL((cn_conv_igemm_vec_kernel<WAVES_N, TN, TM, NV, RP>), grid, dim3(256), lds, stream, g);
+  CN_LAUNCH((cn_conv_igemm_vec_kernel<WAVES_N, TN, TM, NV, RP>), grid, dim3(256), lds, stream, g);
   cn_prof_after(stream, NT == 128 ? 0 : 1, flops);  // the contraction kernel alone (matches rocprof's per-kernel rows)
   const int rrc = cn_reduce_slices(g, stream);
   return rrc != CN_OK ? rrc : cn_check_launch();
@@ -628,6 +632,10 @@ static int cn_launch_igemm_t(const float* x, const float* wp, const float* bias,
                              int total_tiles, int max_taps, int splits, double flops, hipStream_t stream) {
   constexpr int NT = WAVES_N * TN * 32;
   g.tap_lds_off = g.w_lds_off + (max_taps > 0 ? max_taps : 1) * KC * NT;
+  // the staging prefetch addresses an image through a buffer resource with 32-bit byte offsets (num_records 2 GiB):
+  // refuse images (or packed weight sets) beyond that instead of wrapping silently
+  if ((long)g.Cin * g.Hin * g.Win * 4 >= (1L << 31) || (long)(max_taps > 0 ? max_taps : 1) * g.Kpad * g.Npad * 4 >= (1L << 31))
+    return CN_ERR_ARG;
   const size_t lds = (size_t)(g.tap_lds_off + 3 * CN_MAX_TAPS + 1) * sizeof(float);
   if (lds > 160 * 1024) return CN_ERR_LDS;
   static bool attr_set = false;
@@ -645,7 +653,7 @@ static int cn_launch_igemm_t(const float* x, const float* wp, const float* bias,
                g.G, g.B, g.Cin, g.Cout, g.Hin, g.Win, g.Hout, g.Wout, max_taps, g.ncls, g.is, g.os, total_tiles,
                (g.Cout + NT - 1) / NT, splits);
   cn_prof_before(stream);
-  hipLaunchKernelGGL((cn_conv_igemm_kernel<WAVES_N, TN, NI_T>), grid, dim3(256), lds, stream, g);
+  CN_LAUNCH((cn_conv_igemm_kernel<WAVES_N, TN, NI_T>), grid, dim3(256), lds, stream, g);
   cn_prof_after(stream, NT == 128 ? 0 : 1, flops);  // the contraction kernel alone (matches rocprof's per-kernel rows)
   const int rrc = cn_reduce_slices(g, stream);
   return rrc != CN_OK ? rrc : cn_check_launch();
@@ -883,7 +891,7 @@ static int cn_reduce_slices(const CnConvGeom& g, hipStream_t stream) {
   const long n = (long)g.Cout * a.HW;
   long bx = (n + 1023) / 1024;
   if (bx > 1024) bx = 1024;
-  hipLaunchKernelGGL(cn_conv_reduce_kernel, dim3((unsigned)bx, g.B, a.ngrp), dim3(256), 0, stream, a);
+  CN_LAUNCH(cn_conv_reduce_kernel, dim3((unsigned)bx, g.B, a.ngrp), dim3(256), 0, stream, a);
   return cn_check_launch();
 }
 
@@ -1052,9 +1060,9 @@ static int cn_conv1x1_launch(const float* x, long xbs, const float* wp, const fl
   cn_prof_desc("gemm1x1<%d> B%d %d->%d HW%d grid%dx%d", use160 ? 5 : 4, B, Cin, Cout, HW, g.grid_x, g.grid_y);
   cn_prof_before(stream);
   if (use160)
-    hipLaunchKernelGGL((cn_conv1x1_kernel<5>), dim3(cn_xcd_grid(blocks)), dim3(256), 0, stream, x, wp, bias, y, g);
+    CN_LAUNCH((cn_conv1x1_kernel<5>), dim3(cn_xcd_grid(blocks)), dim3(256), 0, stream, x, wp, bias, y, g);
   else
-    hipLaunchKernelGGL((cn_conv1x1_kernel<4>), dim3(cn_xcd_grid(blocks)), dim3(256), 0, stream, x, wp, bias, y, g);
+    CN_LAUNCH((cn_conv1x1_kernel<4>), dim3(cn_xcd_grid(blocks)), dim3(256), 0, stream, x, wp, bias, y, g);
   cn_prof_after(stream, 0, flops);
   return cn_check_launch();
 }
@@ -1441,7 +1449,7 @@ extern "C" int cn_pack_timeconv_f32(const float* w, float* wp, int Cout, int Cin
   const int Kd = transposed ? Cout * Tout : Cin * Tin, Nd = transposed ? Cin * Tin : Cout * Tout;
   const int Kpad = cn_conv_kpad(Kd), Npad = cn_conv_npad(Nd);
   const long total = (long)Kpad * Npad;
-  hipLaunchKernelGGL(cn_pack_timeconv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+  CN_LAUNCH(cn_pack_timeconv_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, w, wp, Cout, Cin, Tin, k, transposed, Kpad, Npad);
   return cn_check_launch();
 }
@@ -1461,7 +1469,7 @@ __global__ void cn_fold_timeconv_kernel(const float* __restrict__ dwexp, float* 
 extern "C" int cn_fold_timeconv_grad_f32(const float* dwexp, float* dw, int Cout, int Cin, int Tin, int k,
                                          void* stream) {
   const int n = Cout * Cin * k;
-  hipLaunchKernelGGL(cn_fold_timeconv_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, dwexp, dw, Cout,
+  CN_LAUNCH(cn_fold_timeconv_kernel, dim3((n + 63) / 64), dim3(64), 0, (hipStream_t)stream, dwexp, dw, Cout,
                      Cin, Tin, k);
   return cn_check_launch();
 }

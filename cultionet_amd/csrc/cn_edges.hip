@@ -30,10 +30,10 @@ extern "C" int cn_prepare_chips_f32(const void* x, int dtype, float* y, const fl
   if (bx > 1024) bx = 1024;
   dim3 grid((unsigned)bx, C, B);
   switch (dtype) {
-    case 0: hipLaunchKernelGGL(cn_prepare_chips_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, y, mean, stdv, C, L, scale, lo, hi); break;
-    case 1: hipLaunchKernelGGL(cn_prepare_chips_kernel<int>, grid, dim3(256), 0, stream, (const int*)x, y, mean, stdv, C, L, scale, lo, hi); break;
-    case 2: hipLaunchKernelGGL(cn_prepare_chips_kernel<short>, grid, dim3(256), 0, stream, (const short*)x, y, mean, stdv, C, L, scale, lo, hi); break;
-    case 3: hipLaunchKernelGGL(cn_prepare_chips_kernel<unsigned short>, grid, dim3(256), 0, stream, (const unsigned short*)x, y, mean, stdv, C, L, scale, lo, hi); break;
+    case 0: CN_LAUNCH(cn_prepare_chips_kernel<float>, grid, dim3(256), 0, stream, (const float*)x, y, mean, stdv, C, L, scale, lo, hi); break;
+    case 1: CN_LAUNCH(cn_prepare_chips_kernel<int>, grid, dim3(256), 0, stream, (const int*)x, y, mean, stdv, C, L, scale, lo, hi); break;
+    case 2: CN_LAUNCH(cn_prepare_chips_kernel<short>, grid, dim3(256), 0, stream, (const short*)x, y, mean, stdv, C, L, scale, lo, hi); break;
+    case 3: CN_LAUNCH(cn_prepare_chips_kernel<unsigned short>, grid, dim3(256), 0, stream, (const unsigned short*)x, y, mean, stdv, C, L, scale, lo, hi); break;
     default: return CN_ERR_ARG;
   }
   return cn_check_launch();
@@ -61,7 +61,7 @@ extern "C" int cn_predictions_to_u16(const float* dist, const float* edge, const
                                      void* stream) {
   if (B <= 0 || h <= 0 || w <= 0) return CN_OK;
   if (pad_top < 0 || pad_left < 0 || pad_top + h > H || pad_left + w > W) return CN_ERR_ARG;
-  hipLaunchKernelGGL(cn_predictions_u16_kernel, dim3((h * w + 255) / 256, 3, B), dim3(256), 0, (hipStream_t)stream, dist,
+  CN_LAUNCH(cn_predictions_u16_kernel, dim3((h * w + 255) / 256, 3, B), dim3(256), 0, (hipStream_t)stream, dist,
                      edge, crop, out, H, W, pad_top, pad_left, h, w, scale);
   return cn_check_launch();
 }
@@ -103,7 +103,7 @@ extern "C" int cn_window_chips_f32(const void* scene, int dtype, float* out, con
   if (pad < 0 || 2 * pad >= S) return CN_ERR_ARG;
   int bx = (S * S + 1023) / 1024;
   dim3 grid((unsigned)bx, C * T, nwin);
-#define CN_WC(TY) hipLaunchKernelGGL(cn_window_chips_kernel<TY>, grid, dim3(256), 0, stream, (const TY*)scene, out, \
+#define CN_WC(TY) CN_LAUNCH(cn_window_chips_kernel<TY>, grid, dim3(256), 0, stream, (const TY*)scene, out, \
                                      win_rc, mean, stdv, T, H, W, S, pad, scale, lo, hi)
   switch (dtype) {
     case 0: CN_WC(float); break;
@@ -141,7 +141,7 @@ extern "C" int cn_stitch_predictions_u16(const float* dist, const float* edge, c
                                          void* stream) {
   if (nwin <= 0) return CN_OK;
   if (ws <= 0 || pad < 0 || ws + 2 * pad > S) return CN_ERR_ARG;
-  hipLaunchKernelGGL(cn_stitch_u16_kernel, dim3((ws * ws + 1023) / 1024, 3, nwin), dim3(256), 0, (hipStream_t)stream,
+  CN_LAUNCH(cn_stitch_u16_kernel, dim3((ws * ws + 1023) / 1024, 3, nwin), dim3(256), 0, (hipStream_t)stream,
                      dist, edge, crop, out, win_rc, S, pad, ws, H, W, scale);
   return cn_check_launch();
 }

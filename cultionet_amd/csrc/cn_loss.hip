@@ -173,9 +173,9 @@ extern "C" int cn_tanimoto_fwd_f32(const float* pred, long pbs, const float* tar
   hipStream_t stream = (hipStream_t)stream_;
   if (B <= 0 || B > 65535) return CN_ERR_ARG;
   if (hipMemsetAsync(sums, 0, sizeof(double) * 5 * B, stream) != hipSuccess) return CN_ERR_LAUNCH;
-  hipLaunchKernelGGL(cn_tanimoto_sums_kernel, loss_grid(B, (long)C * HW), dim3(256), 0, stream, pred, pbs, target_f,
+  CN_LAUNCH(cn_tanimoto_sums_kernel, loss_grid(B, (long)C * HW), dim3(256), 0, stream, pred, pbs, target_f,
                      labels, mask, target_mode, mask_mode, klass, C, HW, sums);
-  hipLaunchKernelGGL(cn_tanimoto_finalize_kernel, dim3(1), dim3(256), 0, stream, sums, B, (double)C * HW, loss_kind,
+  CN_LAUNCH(cn_tanimoto_finalize_kernel, dim3(1), dim3(256), 0, stream, sums, B, (double)C * HW, loss_kind,
                      smooth, depth, loss_out, coef, weight, total_out);
   return cn_check_launch();
 }
@@ -185,7 +185,7 @@ extern "C" int cn_tanimoto_bwd_f32(const float* pred, long pbs, const float* tar
                                    const float* coef, float upstream, float* dpred, long dbs, int accumulate,
                                    void* stream_) {
   if (B <= 0 || B > 65535) return CN_ERR_ARG;
-  hipLaunchKernelGGL(cn_tanimoto_bwd_kernel, loss_grid(B, (long)C * HW), dim3(256), 0, (hipStream_t)stream_, pred, pbs,
+  CN_LAUNCH(cn_tanimoto_bwd_kernel, loss_grid(B, (long)C * HW), dim3(256), 0, (hipStream_t)stream_, pred, pbs,
                      target_f, labels, mask, target_mode, mask_mode, klass, C, HW, coef, upstream, dpred, dbs,
                      accumulate);
   return cn_check_launch();
@@ -229,9 +229,21 @@ __global__ __launch_bounds__(256) void cn_eval_counts_kernel(const float* __rest
   }
 }
 
+// MatthewsCorrCoef(task="multiclass", num_classes=2): torchmetrics >= 1.0 `_matthews_corrcoef_reduce` on the 2x2
+// confusion matrix (setup.cfg pins torchmetrics>=1.3; restated, the package is in neither image): all predictions
+// right -> 1, all wrong -> -1, and when a marginal is empty (denominator 0) the eps-regularised ratio
+// sqrt(eps) * ((tp + tn) - (fp + fn)) / sqrt(prod(marginal + eps)) with eps = float32 machine epsilon -- batches with
+// no predicted or no true edge pixels are common early in training and on background chips, and val_score (what the
+// reference checkpoints on, callbacks.py:246) contains both MCC terms.
 __device__ __forceinline__ double ev_mcc(double tp, double fp, double fn, double tn) {
+  if (tp + tn != 0.0 && fp + fn == 0.0) return 1.0;
+  if (tp + tn == 0.0 && fp + fn != 0.0) return -1.0;
   const double den = (tp + fp) * (tp + fn) * (tn + fp) * (tn + fn);
-  return den > 0.0 ? (tp * tn - fp * fn) / sqrt(den) : 0.0;  // torchmetrics: 0 when a marginal is empty
+  if (den > 0.0) return (tp * tn - fp * fn) / sqrt(den);
+  const double eps = 1.1920928955078125e-07;
+  const double num = sqrt(eps) * ((tp + tn) - (fp + fn));
+  const double d = (tp + fp + eps) * (tp + fn + eps) * (tn + fp + eps) * (tn + fn + eps);
+  return num / sqrt(d);
 }
 
 // out[7] = {dist_mae, dist_mse, edge_f, crop_f, edge_mcc, crop_mcc, score}
@@ -257,9 +269,9 @@ extern "C" int cn_eval_metrics_f32(const float* dist, const float* edge, const f
   if (n > 0) {
     long nb = (n + 255) / 256;
     if (nb > 1024) nb = 1024;
-    hipLaunchKernelGGL(cn_eval_counts_kernel, dim3((unsigned)nb), dim3(256), 0, stream, dist, edge, crop, bdist, labels,
+    CN_LAUNCH(cn_eval_counts_kernel, dim3((unsigned)nb), dim3(256), 0, stream, dist, edge, crop, bdist, labels,
                        klass, thresh, n, counts);
   }
-  hipLaunchKernelGGL(cn_eval_finalize_kernel, dim3(1), dim3(1), 0, stream, counts, loss, out);
+  CN_LAUNCH(cn_eval_finalize_kernel, dim3(1), dim3(1), 0, stream, counts, loss, out);
   return cn_check_launch();
 }

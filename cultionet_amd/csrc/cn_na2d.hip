@@ -224,12 +224,12 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_kv_kernel(const float* __rest
 
 #define NA_DISPATCH(D_, KERNEL, ...)                                                                          \
   switch (D_) {                                                                                               \
-    case 2: hipLaunchKernelGGL((KERNEL<2>), grid, dim3(256), 0, stream, __VA_ARGS__); break;                 \
-    case 4: hipLaunchKernelGGL((KERNEL<4>), grid, dim3(256), 0, stream, __VA_ARGS__); break;                 \
-    case 8: hipLaunchKernelGGL((KERNEL<8>), grid, dim3(256), 0, stream, __VA_ARGS__); break;                 \
-    case 16: hipLaunchKernelGGL((KERNEL<16>), grid, dim3(256), 0, stream, __VA_ARGS__); break;               \
-    case 32: hipLaunchKernelGGL((KERNEL<32>), grid, dim3(256), 0, stream, __VA_ARGS__); break;               \
-    case 64: hipLaunchKernelGGL((KERNEL<64>), grid, dim3(256), 0, stream, __VA_ARGS__); break;               \
+    case 2: CN_LAUNCH((KERNEL<2>), grid, dim3(256), 0, stream, __VA_ARGS__); break;                 \
+    case 4: CN_LAUNCH((KERNEL<4>), grid, dim3(256), 0, stream, __VA_ARGS__); break;                 \
+    case 8: CN_LAUNCH((KERNEL<8>), grid, dim3(256), 0, stream, __VA_ARGS__); break;                 \
+    case 16: CN_LAUNCH((KERNEL<16>), grid, dim3(256), 0, stream, __VA_ARGS__); break;               \
+    case 32: CN_LAUNCH((KERNEL<32>), grid, dim3(256), 0, stream, __VA_ARGS__); break;               \
+    case 64: CN_LAUNCH((KERNEL<64>), grid, dim3(256), 0, stream, __VA_ARGS__); break;               \
     default: return CN_ERR_ARG;                                                                               \
   }
 

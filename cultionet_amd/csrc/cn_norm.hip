@@ -356,7 +356,7 @@ extern "C" int cn_bn_act_fwd_f32(const float* x, long xbs, const float* gamma, c
   if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
   if (training && (long)B * L <= BN_FUSED_MAX && C >= 32) {
 #define CN_BN_FWD(NV_)                                                                                               \
-  hipLaunchKernelGGL((cn_bn_fused_fwd_kernel<NV_>), dim3(C), dim3(256), 0, stream, x, xbs, mean, rstd, gamma, beta, res, \
+  CN_LAUNCH((cn_bn_fused_fwd_kernel<NV_>), dim3(C), dim3(256), 0, stream, x, xbs, mean, rstd, gamma, beta, res, \
                      rbs, y, ybs, B, C, L, act, eps, momentum, running_mean, running_var)
     CN_BN_FWD(8);
 #undef CN_BN_FWD
@@ -364,15 +364,15 @@ extern "C" int cn_bn_act_fwd_f32(const float* x, long xbs, const float* gamma, c
   }
   if (training) {
     const int splits = bn_splits(C, L);
-    hipLaunchKernelGGL(cn_bn_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, B, C, L, splits, ws,
+    CN_LAUNCH(cn_bn_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, B, C, L, splits, ws,
                        (int)(L % 4 == 0 && xbs % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0));
-    hipLaunchKernelGGL(cn_bn_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, x, xbs, mean, rstd, gamma, beta,
+    CN_LAUNCH(cn_bn_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, x, xbs, mean, rstd, gamma, beta,
                        res, rbs, y, ybs, B, C, L, act, (const double*)ws, splits, (double)B * L, eps, momentum,
                        running_mean, running_var);
   } else {
-    hipLaunchKernelGGL(cn_bn_eval_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, running_mean,
+    CN_LAUNCH(cn_bn_eval_stats_kernel, dim3((C + 63) / 64), dim3(64), 0, stream, running_mean,
                        running_var, C, eps, mean, rstd);
-    hipLaunchKernelGGL(cn_bn_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, x, xbs, mean, rstd, gamma, beta,
+    CN_LAUNCH(cn_bn_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, x, xbs, mean, rstd, gamma, beta,
                        res, rbs, y, ybs, B, C, L, act, (const double*)nullptr, 0, 1.0, eps, momentum,
                        (float*)nullptr, (float*)nullptr);
   }
@@ -389,19 +389,19 @@ extern "C" int cn_bn_act_bwd_f32(const float* x, long xbs, const float* dy, long
   if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
   if ((long)B * L <= BN_FUSED_MAX && C >= 32) {
 #define CN_BN_BWD(NV_)                                                                                              \
-  hipLaunchKernelGGL((cn_bn_fused_bwd_kernel<NV_>), dim3(C), dim3(256), 0, stream, x, xbs, dy, dybs, mean, rstd, gamma, \
+  CN_LAUNCH((cn_bn_fused_bwd_kernel<NV_>), dim3(C), dim3(256), 0, stream, x, xbs, dy, dybs, mean, rstd, gamma, \
                      beta, training, dgamma, dbeta, accumulate_params, dx, dxbs, B, C, L, act, accumulate_dx)
     CN_BN_BWD(8);
 #undef CN_BN_BWD
     return cn_check_launch();
   }
   const int splits = bn_splits(C, L);
-  hipLaunchKernelGGL(cn_bn_bwd_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, dy, dybs, mean, rstd,
+  CN_LAUNCH(cn_bn_bwd_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, dy, dybs, mean, rstd,
                      gamma, beta, B, C, L, act, splits, ws,
                      (int)(L % 4 == 0 && xbs % 4 == 0 && dybs % 4 == 0 &&
                            ((reinterpret_cast<uintptr_t>(x) | reinterpret_cast<uintptr_t>(dy)) & 15) == 0));
   (void)coef;
-  hipLaunchKernelGGL(cn_bn_bwd_apply_kernel, dx != nullptr ? plane_grid(B, C, L) : dim3(1, C, 1), dim3(256), 0,
+  CN_LAUNCH(cn_bn_bwd_apply_kernel, dx != nullptr ? plane_grid(B, C, L) : dim3(1, C, 1), dim3(256), 0,
                      stream, x, xbs, dy, dybs, mean, rstd, gamma, beta, (const double*)ws, splits, (double)B * L,
                      training, dgamma, dbeta, accumulate_params, dx, dxbs, B, C, L, act, accumulate_dx);
   return cn_check_launch();
@@ -685,8 +685,8 @@ extern "C" int cn_bn_act_group_fwd_f32(int G, const float* const* xs, long xbs, 
   for (int g = 0; g < G; ++g)
     if ((reinterpret_cast<uintptr_t>(a.x[g]) | reinterpret_cast<uintptr_t>(a.y[g])) & 15) a.vec4 = 0;
   if (training)
-    hipLaunchKernelGGL(cn_bn_group_partial_kernel, dim3(C, a.splits, G), dim3(256), 0, stream, a);
-  hipLaunchKernelGGL(cn_bn_group_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, a);
+    CN_LAUNCH(cn_bn_group_partial_kernel, dim3(C, a.splits, G), dim3(256), 0, stream, a);
+  CN_LAUNCH(cn_bn_group_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, a);
   return cn_check_launch();
 }
 
@@ -716,9 +716,9 @@ extern "C" int cn_bn_act_group_bwd_f32(int G, const float* const* xs, long xbs, 
     if ((reinterpret_cast<uintptr_t>(a.x[g]) | reinterpret_cast<uintptr_t>(a.dy[g]) |
          reinterpret_cast<uintptr_t>(a.dx[g])) & 15)
       a.vec4 = 0;
-  hipLaunchKernelGGL(cn_bn_group_bwd_partial_kernel, dim3(C, a.splits, G), dim3(256), 0, stream, a);
+  CN_LAUNCH(cn_bn_group_bwd_partial_kernel, dim3(C, a.splits, G), dim3(256), 0, stream, a);
   const dim3 pg = plane_grid(B, C, L);
-  hipLaunchKernelGGL(cn_bn_group_bwd_apply_kernel, dim3(pg.x * G, pg.y, pg.z), dim3(256), 0, stream, a, (int)pg.x);
+  CN_LAUNCH(cn_bn_group_bwd_apply_kernel, dim3(pg.x * G, pg.y, pg.z), dim3(256), 0, stream, a, (int)pg.x);
   return cn_check_launch();
 }
 
@@ -747,7 +747,7 @@ extern "C" int cn_channel_sum_f32(const float* x, long xbs, int B, int C, int L,
   if (C <= 0) return CN_OK;
   if (!accumulate && hipMemsetAsync(out, 0, sizeof(float) * C, stream) != hipSuccess) return CN_ERR_LAUNCH;
   const int splits = bn_splits(C, L);
-  hipLaunchKernelGGL(cn_channel_sum_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, B, C, L, splits, out);
+  CN_LAUNCH(cn_channel_sum_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, B, C, L, splits, out);
   return cn_check_launch();
 }
 
@@ -988,7 +988,7 @@ extern "C" int cn_layernorm_c_fwd_f32(const float* x, long xbs, const float* w, 
   if (C <= 128) {
     const dim3 grid((unsigned)((P + 63) / 64));
 #define CN_LN_FWD(CPW_)                                                                                             \
-  hipLaunchKernelGGL((cn_ln_fwd_reg_kernel<CPW_>), grid, dim3(256), 0, (hipStream_t)stream, x, xbs, w, b, res, rbs, y, \
+  CN_LAUNCH((cn_ln_fwd_reg_kernel<CPW_>), grid, dim3(256), 0, (hipStream_t)stream, x, xbs, w, b, res, rbs, y, \
                      ybs, mu, rstd, B, C, L, eps)
     if (C <= 32) CN_LN_FWD(8);
     else if (C <= 64) CN_LN_FWD(16);
@@ -996,7 +996,7 @@ extern "C" int cn_layernorm_c_fwd_f32(const float* x, long xbs, const float* w, 
 #undef CN_LN_FWD
     return cn_check_launch();
   }
-  hipLaunchKernelGGL(cn_ln_fwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, xbs,
+  CN_LAUNCH(cn_ln_fwd_kernel, dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream, x, xbs,
                      w, b, res, rbs, y, ybs, mu, rstd, B, C, L, eps);
   return cn_check_launch();
 }
@@ -1023,17 +1023,17 @@ extern "C" int cn_layernorm_c_bwd_f32(const float* x, long xbs, const float* dy,
     if (ws == nullptr || ws_floats < (long)nblk * 2 * C) return CN_ERR_ARG;
     const dim3 grid((unsigned)nblk);
 #define CN_LN_BWD(CPW_)                                                                                           \
-  hipLaunchKernelGGL((cn_ln_bwd_reg_kernel<CPW_>), grid, dim3(256), 0, (hipStream_t)stream, x, xbs, dy, dybs, w, mu, \
+  CN_LAUNCH((cn_ln_bwd_reg_kernel<CPW_>), grid, dim3(256), 0, (hipStream_t)stream, x, xbs, dy, dybs, w, mu, \
                      rstd, dx, dxbs, ws, B, C, L, accumulate_dx, (int)ntiles)
     if (C <= 32) CN_LN_BWD(8);
     else if (C <= 64) CN_LN_BWD(16);
     else CN_LN_BWD(32);
 #undef CN_LN_BWD
-    hipLaunchKernelGGL(cn_ln_param_finalize_kernel, dim3((2 * C + 31) / 32, 16), dim3(256), 0, (hipStream_t)stream, ws,
+    CN_LAUNCH(cn_ln_param_finalize_kernel, dim3((2 * C + 31) / 32, 16), dim3(256), 0, (hipStream_t)stream, ws,
                        nblk, C, dw, db);
     return cn_check_launch();
   }
-  hipLaunchKernelGGL((cn_ln_bwd_kernel<512>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
+  CN_LAUNCH((cn_ln_bwd_kernel<512>), dim3((unsigned)((P + 255) / 256)), dim3(256), 0, (hipStream_t)stream,
                      x, xbs, dy, dybs, w, mu, rstd, dx, dxbs, dw, db, B, C, L, accumulate_dx);
   return cn_check_launch();
 }

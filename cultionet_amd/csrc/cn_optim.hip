@@ -26,7 +26,7 @@ extern "C" int cn_grad_sumsq_f32(const float* g, long n, double* out, void* stre
   if (n <= 0) return CN_OK;
   long bx = (n + 2047) / 2048;
   if (bx > 1024) bx = 1024;
-  hipLaunchKernelGGL(cn_sumsq_kernel, dim3((unsigned)bx), dim3(256), 0, stream, g, n, out);
+  CN_LAUNCH(cn_sumsq_kernel, dim3((unsigned)bx), dim3(256), 0, stream, g, n, out);
   return cn_check_launch();
 }
 
@@ -67,7 +67,7 @@ extern "C" int cn_adamw_step_f32(float* p, const float* g, float* m, float* v, l
   const float bc2_sqrt = (float)sqrt(1.0 - pow((double)beta2, (double)step));
   long bx = (n + 1023) / 1024;
   if (bx > 2048) bx = 2048;
-  hipLaunchKernelGGL(cn_adamw_kernel, dim3((unsigned)bx), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
+  CN_LAUNCH(cn_adamw_kernel, dim3((unsigned)bx), dim3(256), 0, (hipStream_t)stream, p, g, m, v, n, lr, beta1,
                      beta2, eps, weight_decay, bc1, bc2_sqrt, grad_scale, sumsq, max_norm);
   return cn_check_launch();
 }

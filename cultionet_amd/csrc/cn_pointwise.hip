@@ -250,7 +250,7 @@ extern "C" int cn_bilinear_fwd_f32(const float* x, long xbs, float* y, long ybs,
                                    int Wo, void* stream) {
   if (B <= 0 || C <= 0) return CN_OK;
   dim3 grid((Ho * Wo + 255) / 256, C, B);
-  hipLaunchKernelGGL(cn_bilinear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, xbs, y, ybs, C, Hi, Wi, Ho,
+  CN_LAUNCH(cn_bilinear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, xbs, y, ybs, C, Hi, Wi, Ho,
                      Wo, bl_scale(Hi, Ho), bl_scale(Wi, Wo));
   return cn_check_launch();
 }
@@ -261,12 +261,12 @@ extern "C" int cn_bilinear_bwd_f32(const float* dy, long dybs, float* dx, long d
   const float sh = bl_scale(Hi, Ho), sw = bl_scale(Wi, Wo);
   if (2 * Hi > Ho && 2 * Wi > Wo && (long)B * C * Hi * Wi >= 1 << 16) {  // near-1:1 resize of a large tensor
     dim3 gridn((Hi * Wi + 255) / 256, (C + BL_CH - 1) / BL_CH, B);
-    hipLaunchKernelGGL(cn_bilinear_bwd_near_kernel, gridn, dim3(256), 0, (hipStream_t)stream, dy, dybs, dx, dxbs, C,
+    CN_LAUNCH(cn_bilinear_bwd_near_kernel, gridn, dim3(256), 0, (hipStream_t)stream, dy, dybs, dx, dxbs, C,
                        Hi, Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, accumulate);
     return cn_check_launch();
   }
   dim3 grid((Hi * Wi + 255) / 256, C, B);
-  hipLaunchKernelGGL(cn_bilinear_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dybs, dx, dxbs, C, Hi, Wi,
+  CN_LAUNCH(cn_bilinear_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dybs, dx, dxbs, C, Hi, Wi,
                      Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, accumulate);
   return cn_check_launch();
 }
@@ -289,7 +289,7 @@ extern "C" int cn_copy_f32(const float* src, long sbs, float* dst, long dbs, int
   if (B <= 0 || n <= 0) return CN_OK;
   long bx = (n + 1023) / 1024;
   if (bx > 2048) bx = 2048;
-  hipLaunchKernelGGL(cn_copy_kernel, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, src, sbs, dst, dbs, n,
+  CN_LAUNCH(cn_copy_kernel, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, src, sbs, dst, dbs, n,
                      accumulate);
   return cn_check_launch();
 }
@@ -307,7 +307,7 @@ extern "C" int cn_add_f32(const float* a, long abs_, const float* c, long cbs, f
   if (B <= 0 || n <= 0) return CN_OK;
   long bx = (n + 1023) / 1024;
   if (bx > 2048) bx = 2048;
-  hipLaunchKernelGGL(cn_add_kernel, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, a, abs_, c, cbs, dst,
+  CN_LAUNCH(cn_add_kernel, dim3((unsigned)bx, B), dim3(256), 0, (hipStream_t)stream, a, abs_, c, cbs, dst,
                      dbs, n);
   return cn_check_launch();
 }
@@ -320,7 +320,7 @@ extern "C" int cn_fill_f32(float* p, long n, float v, void* stream) {
   if (n <= 0) return CN_OK;
   long bx = (n + 1023) / 1024;
   if (bx > 2048) bx = 2048;
-  hipLaunchKernelGGL(cn_fill_kernel, dim3((unsigned)bx), dim3(256), 0, (hipStream_t)stream, p, n, v);
+  CN_LAUNCH(cn_fill_kernel, dim3((unsigned)bx), dim3(256), 0, (hipStream_t)stream, p, n, v);
   return cn_check_launch();
 }
 
@@ -430,7 +430,7 @@ extern "C" int cn_final_combine_fwd_f32(const float* ha, const float* hb, const 
   if (n <= 0) return CN_OK;
   CnPtr16 pp;
   for (int k = 0; k < 16; ++k) pp.p[k] = params[k];
-  hipLaunchKernelGGL(cn_final_combine_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+  CN_LAUNCH(cn_final_combine_fwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, ha, hb, hc, pp, dist, edge, crop, B, HW, smooth);
   return cn_check_launch();
 }
@@ -445,7 +445,7 @@ extern "C" int cn_final_combine_bwd_f32(const float* ha, const float* hb, const 
   CnPtr16 pp;
   CnMutPtr16 dpp;
   for (int k = 0; k < 16; ++k) { pp.p[k] = params[k]; dpp.p[k] = dparams[k]; }
-  hipLaunchKernelGGL(cn_final_combine_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
+  CN_LAUNCH(cn_final_combine_bwd_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, ha, hb, hc, pp, dist, edge, crop, ddist, dedge, dcrop, dha, dhb, dhc,
                      dpp, B, HW, smooth);
   return cn_check_launch();
@@ -489,7 +489,7 @@ extern "C" int cn_dropout_f32(const float* x, long xbs, float* y, long ybs, int 
   const unsigned long long thresh = t >= 18446744073709551615.0 ? ~0ull : (unsigned long long)t;
   int bx = (L + 1023) / 1024;
   if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(cn_dropout_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, x, xbs, y, ybs, C, L,
+  CN_LAUNCH(cn_dropout_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, x, xbs, y, ybs, C, L,
                      thresh, 1.0f / (1.0f - p), seed, channelwise, accumulate);
   return cn_check_launch();
 }
@@ -550,7 +550,7 @@ __global__ __launch_bounds__(256) void cn_adaptive_maxpool_bwd_kernel(const floa
 extern "C" int cn_adaptive_maxpool_fwd_f32(const float* x, long xbs, float* y, long ybs, int* idx, int B, int C,
                                            int Hi, int Wi, int Ho, int Wo, void* stream) {
   if (B <= 0 || C <= 0 || Ho <= 0 || Wo <= 0) return CN_OK;
-  hipLaunchKernelGGL(cn_adaptive_maxpool_fwd_kernel, dim3((Ho * Wo + 255) / 256, C, B), dim3(256), 0,
+  CN_LAUNCH(cn_adaptive_maxpool_fwd_kernel, dim3((Ho * Wo + 255) / 256, C, B), dim3(256), 0,
                      (hipStream_t)stream, x, xbs, y, ybs, idx, C, Hi, Wi, Ho, Wo);
   return cn_check_launch();
 }
@@ -558,7 +558,7 @@ extern "C" int cn_adaptive_maxpool_fwd_f32(const float* x, long xbs, float* y, l
 extern "C" int cn_adaptive_maxpool_bwd_f32(const float* dy, long dybs, const int* idx, float* dx, long dxbs, int B,
                                            int C, int Hi, int Wi, int Ho, int Wo, int accumulate, void* stream) {
   if (B <= 0 || C <= 0) return CN_OK;
-  hipLaunchKernelGGL(cn_adaptive_maxpool_bwd_kernel, dim3((Hi * Wi + 255) / 256, C, B), dim3(256), 0,
+  CN_LAUNCH(cn_adaptive_maxpool_bwd_kernel, dim3((Hi * Wi + 255) / 256, C, B), dim3(256), 0,
                      (hipStream_t)stream, dy, dybs, idx, dx, dxbs, C, Hi, Wi, Ho, Wo, accumulate);
   return cn_check_launch();
 }

@@ -28,6 +28,13 @@ hipEvent_t get_event() {
 }
 }  // namespace
 
+long g_cn_launches = 0;
+
+// Kernel launches issued by the library since the last reset (reset != 0: return the count and zero it).
+extern "C" long cn_launch_count(int reset) {
+  return reset ? __atomic_exchange_n(&g_cn_launches, 0L, __ATOMIC_RELAXED) : __atomic_load_n(&g_cn_launches, __ATOMIC_RELAXED);
+}
+
 bool cn_prof_on() { return g_on; }
 
 // Shape tag of the next recorded launch (only formatted while profiling; dumped when CN_PROF_DUMP names a file).

@@ -444,9 +444,9 @@ extern "C" int cn_thin_conv3x3_fwd_f32(const float* x, long xbs, const float* co
     const size_t lds = sizeof(float) * (size_t)((wpack ? 0 : 4 * Cq * 84) + 4 * 9 * 64);
     if (lds <= 64 * 1024) {
       if (wpack)
-        hipLaunchKernelGGL((cn_thin_pack_kernel<3, 3>), dim3(cn_cdiv((long)Cin * 84, 256)), dim3(256), 0,
+        CN_LAUNCH((cn_thin_pack_kernel<3, 3>), dim3(cn_cdiv((long)Cin * 84, 256)), dim3(256), 0,
                            (hipStream_t)stream, w[0], w[1], w[2], wpack, Cin);
-      hipLaunchKernelGGL((cn_thin_fwd_ks_kernel<3, 3>), dim3(cn_xcd_grid((long)cn_cdiv((long)H * W, 64) * B)), dim3(256), lds,
+      CN_LAUNCH((cn_thin_fwd_ks_kernel<3, 3>), dim3(cn_xcd_grid((long)cn_cdiv((long)H * W, 64) * B)), dim3(256), lds,
                          (hipStream_t)stream, x, xbs, w[0], w[1], w[2], b[0], b[1], b[2], y, ybs, Cin, H, W, dil, Cq, B,
                          (const float*)wpack);
       return cn_check_launch();
@@ -454,7 +454,7 @@ extern "C" int cn_thin_conv3x3_fwd_f32(const float* x, long xbs, const float* co
   }
   const dim3 grid(cn_cdiv((long)H * W, 256), B);
 #define CN_CALL(NG_, CP_, GR_)                                                                                      \
-  hipLaunchKernelGGL((cn_thin_fwd_kernel<NG_, CP_, GR_>), grid, dim3(256), 0, (hipStream_t)stream, x, xbs, w[0], w[1], \
+  CN_LAUNCH((cn_thin_fwd_kernel<NG_, CP_, GR_>), grid, dim3(256), 0, (hipStream_t)stream, x, xbs, w[0], w[1], \
                      w[2], b[0], b[1], b[2], y, ybs, Cin, H, W, dil)
   CN_THIN_DISPATCH(cfg, CN_CALL)
 #undef CN_CALL
@@ -473,9 +473,9 @@ extern "C" int cn_thin_conv3x3_bwd_data_f32(const float* dy, long dybs, const fl
     const size_t lds = sizeof(float) * (size_t)(wpack ? 0 : 4 * Cq * 84);
     if (lds <= 64 * 1024) {
       if (wpack)
-        hipLaunchKernelGGL((cn_thin_pack_kernel<3, 3>), dim3(cn_cdiv((long)Cin * 84, 256)), dim3(256), 0,
+        CN_LAUNCH((cn_thin_pack_kernel<3, 3>), dim3(cn_cdiv((long)Cin * 84, 256)), dim3(256), 0,
                            (hipStream_t)stream, w[0], w[1], w[2], wpack, Cin);
-      hipLaunchKernelGGL((cn_thin_bwd_data_ks_kernel<3, 3>), dim3(cn_xcd_grid((long)cn_cdiv((long)H * W, 64) * B)), dim3(256), lds,
+      CN_LAUNCH((cn_thin_bwd_data_ks_kernel<3, 3>), dim3(cn_xcd_grid((long)cn_cdiv((long)H * W, 64) * B)), dim3(256), lds,
                          (hipStream_t)stream, dy, dybs, w[0], w[1], w[2], dx, dxbs, Cin, H, W, dil, accumulate, Cq, B,
                          (const float*)wpack);
       return cn_check_launch();
@@ -483,7 +483,7 @@ extern "C" int cn_thin_conv3x3_bwd_data_f32(const float* dy, long dybs, const fl
   }
   const dim3 grid(cn_cdiv((long)H * W, 256), B);
 #define CN_CALL(NG_, CP_, GR_)                                                                                   \
-  hipLaunchKernelGGL((cn_thin_bwd_data_kernel<NG_, CP_, GR_>), grid, dim3(256), 0, (hipStream_t)stream, dy, dybs, \
+  CN_LAUNCH((cn_thin_bwd_data_kernel<NG_, CP_, GR_>), grid, dim3(256), 0, (hipStream_t)stream, dy, dybs, \
                      w[0], w[1], w[2], dx, dxbs, Cin, H, W, dil, accumulate)
   CN_THIN_DISPATCH(cfg, CN_CALL)
 #undef CN_CALL
@@ -510,7 +510,7 @@ extern "C" int cn_thin_conv3x3_bwd_weight_f32(const float* x, long xbs, const fl
   chunks = (R + per - 1) / per;
   const dim3 grid((unsigned)(chunks * col_tiles), cin_total);
 #define CN_CALL(NG_, CP_, GR_)                                                                                      \
-  hipLaunchKernelGGL((cn_thin_bwd_weight_kernel<NG_, CP_, GR_>), grid, dim3(256), 0, (hipStream_t)stream, x, xbs, dy, \
+  CN_LAUNCH((cn_thin_bwd_weight_kernel<NG_, CP_, GR_>), grid, dim3(256), 0, (hipStream_t)stream, x, xbs, dy, \
                      dybs, dw[0], dw[1], dw[2], B, Cin, H, W, dil, per, col_tiles)
   CN_THIN_DISPATCH(cfg, CN_CALL)
 #undef CN_CALL

@@ -646,13 +646,13 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
   }
   cn_prof_before(stream);
   if (g.s == 1)
-    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 1>), grid, dim3(256), lds, stream, g.gS[0], g.gB[0], out, g);
+    CN_LAUNCH((cn_wgrad_vec_kernel<T, 1>), grid, dim3(256), lds, stream, g.gS[0], g.gB[0], out, g);
   else
-    hipLaunchKernelGGL((cn_wgrad_vec_kernel<T, 2>), grid, dim3(256), lds, stream, g.gS[0], g.gB[0], out, g);
+    CN_LAUNCH((cn_wgrad_vec_kernel<T, 2>), grid, dim3(256), lds, stream, g.gS[0], g.gB[0], out, g);
   cn_prof_after(stream, T == 9 ? 2 : 3, g.flops * g.G);  // the contraction kernel alone
   if (g.slice_stride != 0) {
     CnWgradReduceArgs ra = {ws, g.slice_stride, (int)nslices, dw_floats, {g.gdW[0], g.gdW[1], g.gdW[2], g.gdW[3]}};
-    hipLaunchKernelGGL(cn_wgrad_reduce_kernel,
+    CN_LAUNCH(cn_wgrad_reduce_kernel,
                        dim3((unsigned)((dw_floats + 255) / 256), nslices > 128 ? 16 : 1, g.G), dim3(256), 0, stream,
                        ra);
   }
@@ -715,7 +715,7 @@ static int cn_wgrad_launch_t(const float* S, const float* Bg, float* dW, CnWgrad
                gx, gy, splits);
   g.grid_x = gx; g.grid_y = gy; g.grid_z = splits;
   cn_prof_before(stream);
-  hipLaunchKernelGGL((cn_wgrad_kernel<T>), dim3(cn_xcd_grid((long)gx * gy * splits)), dim3(256), lds, stream, S, Bg,
+  CN_LAUNCH((cn_wgrad_kernel<T>), dim3(cn_xcd_grid((long)gx * gy * splits)), dim3(256), lds, stream, S, Bg,
                      dW, g);
   cn_prof_after(stream, T == 9 ? 2 : 3, g.flops);
   return cn_check_launch();
@@ -761,7 +761,7 @@ static int cn_pad_planes(CnPadArgs& a, int B, hipStream_t stream) {
   a.cbegin[a.nsets] = ctot;
   int bx = (cs + 1023) / 1024;
   if (bx < 1) bx = 1;
-  hipLaunchKernelGGL(cn_pad_planes_kernel, dim3(bx, ctot, B), dim3(256), 0, stream, a);
+  CN_LAUNCH(cn_pad_planes_kernel, dim3(bx, ctot, B), dim3(256), 0, stream, a);
   return cn_check_launch();
 }
 

@@ -70,6 +70,11 @@ class GradientAllReduce:
         self.comm_stream = None
         self._plan = None
         self._plan_key = None
+        # diagnostics (bench.py): with ``measure`` on, every backward appends an event pair bracketing the compute
+        # stream's wait for the collectives to ``exposed`` (elapsed = communication time NOT hidden behind backward)
+        self.measure = False
+        self.exposed: T.List[T.Tuple[T.Any, T.Any]] = []
+        self.buckets_last_step = 0
 
     def sync_initial_state(self, store, module=None) -> None:
         """Replicas must start identical (init_conv_weights is random per process): broadcast rank 0's state."""
@@ -111,8 +116,17 @@ class GradientAllReduce:
         for lo, hi, r in plan:  # buckets whose ready index lies outside the tape (no nodes recorded)
             if r >= len(nodes) or r < 0:
                 works.append(self._launch(flat[lo:hi], on_gpu, None))
+        self.buckets_last_step = len(works)
+        ev0 = None
+        if on_gpu and self.measure:
+            ev0 = torch.cuda.Event(enable_timing=True)
+            ev0.record(torch.cuda.current_stream())
         for w in works:
             w.wait()  # NCCL: makes the current (compute) stream wait for the collective; gloo: blocks
+        if ev0 is not None:
+            ev1 = torch.cuda.Event(enable_timing=True)
+            ev1.record(torch.cuda.current_stream())
+            self.exposed.append((ev0, ev1))
 
     def _launch(self, chunk: torch.Tensor, on_gpu: bool, side_ev=None):
         if not on_gpu:

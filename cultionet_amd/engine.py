@@ -171,10 +171,38 @@ def overlap_wgrad(enabled: bool) -> bool:
     return prev
 
 
+def _make_side_stream(dev) -> "torch.cuda.Stream":
+    """The weight-gradient stream. Its kernels (one wave per SIMD, hundreds of microseconds each) must not take CUs
+    from the data-gradient chain on the compute stream, which is the critical path: it is created with the LOWEST
+    priority the device offers through the C ABI (torch.cuda.Stream can only ask for normal or higher) and wrapped as
+    a torch ExternalStream for events / record_stream. CN_SIDE_STREAM = "low" (default) | "normal" |
+    "mask:<n>" (hipExtStreamCreateWithCUMask over the first n CUs of every XCD-interleaved group)."""
+    import ctypes
+
+    mode = os.environ.get("CN_SIDE_STREAM", "low")
+    if mode == "normal":
+        return torch.cuda.Stream(device=dev)
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(dev):
+        if mode.startswith("mask:"):
+            n = int(mode.split(":")[1])
+            ncu = torch.cuda.get_device_properties(dev).multi_processor_count
+            words = (ncu + 31) // 32
+            mask = (ctypes.c_uint * words)()
+            for i in range(min(n, ncu)):
+                mask[i // 32] |= 1 << (i % 32)
+            _lib.call("cn_stream_create", 0, mask, words, ctypes.byref(handle))
+        else:
+            rng = (ctypes.c_int * 2)()
+            _lib.call("cn_stream_priority_range", rng)
+            _lib.call("cn_stream_create", int(rng[0]), None, 0, ctypes.byref(handle))
+    return torch.cuda.ExternalStream(handle.value, device=dev)
+
+
 def _side_state(dev) -> T.Dict[str, T.Any]:
     st = _side_streams.get(dev)
     if st is None:
-        st = {"stream": torch.cuda.Stream(device=dev), "event": torch.cuda.Event(), "dirty": False}
+        st = {"stream": _make_side_stream(dev), "event": torch.cuda.Event(), "dirty": False}
         _side_streams[dev] = st
     return st
 
@@ -356,7 +384,9 @@ class ParamStore:
         return self.flat_grad[o:o + p.numel()].view(p.shape)
 
     def attach_grads(self) -> None:
-        """Point every ``param.grad`` at its slice of the flat gradient (for torch optimizers)."""
+        """Point every ``param.grad`` at its slice of the flat gradient (for torch optimizers driving the NATIVE step).
+        Not for drop-in mode: autograd_bridge hands the flat buffer itself to autograd at every backward (p.grad then
+        IS a view of that step's buffer) and gives the store a fresh one, so views attached here would go stale."""
         for p, o in zip(self.params, self.offsets):
             p.grad = self.flat_grad[o:o + p.numel()].view(p.shape)
 
@@ -1053,9 +1083,7 @@ def na2d(qkv: Var, heads: int, kernel_size: int, dilation: int, attn_drop: float
     tape = current_tape()
     qt = _check(qkv.t)
     if is16(qt):
-        if attn_drop > 0.0:
-            raise NotImplementedError("attention dropout on the bf16 path")
-        return _na2d_bf16(qkv, heads, kernel_size, dilation)
+        return _na2d_bf16(qkv, heads, kernel_size, dilation, attn_drop)
     B, C3, H, W = qt.shape
     C = C3 // 3
     out = _new((B, C, H, W), qt)
@@ -1499,14 +1527,16 @@ def dropout(x: Var, p: float, channelwise: bool, training: bool) -> Var:
         return x
     tape = current_tape()
     xt = _check(x.t)
-    if is16(xt):
-        raise NotImplementedError("dropout > 0 has no bf16 kernel yet (train mixed precision with dropout=0.0)")
     B, C = xt.shape[0], xt.shape[1]
-    L = int(xt[0, 0].numel())
+    L = int(xt.shape[2] * xt.shape[3]) if is16(xt) else int(xt[0, 0].numel())
     seed = _next_seed()
     y = _new(xt.shape, xt)
-    _lib.call("cn_dropout_f32", xt.data_ptr(), bstride(xt), y.data_ptr(), bstride(y), B, C, L, float(p), seed,
-              1 if channelwise else 0, 0, _stream())
+    cw = 1 if channelwise else 0
+    if is16(xt):  # mixed precision: the same counter-based masks on the NHWC buffer
+        _lib.call("cn_dropout_bf16", xt.data_ptr(), ld(xt), y.data_ptr(), ld(y), B, C, L, float(p), seed, cw, 0, _stream())
+    else:
+        _lib.call("cn_dropout_f32", xt.data_ptr(), bstride(xt), y.data_ptr(), bstride(y), B, C, L, float(p), seed, cw,
+                  0, _stream())
     yv = Var(y, tape.enabled and x.req)
     if tape.enabled and x.req:
 
@@ -1515,8 +1545,12 @@ def dropout(x: Var, p: float, channelwise: bool, training: bool) -> Var:
             if dy is None:
                 return
             dx, acc = grad_buffer(x)
-            _lib.call("cn_dropout_f32", dy.data_ptr(), bstride(dy), dx.data_ptr(), bstride(dx), B, C, L, float(p), seed,
-                      1 if channelwise else 0, acc, _stream())
+            if is16(dy):
+                _lib.call("cn_dropout_bf16", dy.data_ptr(), ld(dy), dx.data_ptr(), ld(dx), B, C, L, float(p), seed, cw,
+                          acc, _stream())
+            else:
+                _lib.call("cn_dropout_f32", dy.data_ptr(), bstride(dy), dx.data_ptr(), bstride(dx), B, C, L, float(p),
+                          seed, cw, acc, _stream())
             yv.grad = None
 
         tape.add(bwd)
@@ -1770,15 +1804,16 @@ def _layer_norm_c_bf16(x: Var, ln, residual: T.Optional[Var]) -> Var:
     return yv
 
 
-def _na2d_bf16(qkv: Var, heads: int, kernel_size: int, dilation: int) -> Var:
+def _na2d_bf16(qkv: Var, heads: int, kernel_size: int, dilation: int, attn_drop: float = 0.0) -> Var:
     tape = current_tape()
+    seed = _next_seed() if attn_drop > 0.0 else 0
     qt = qkv.t
     B, C3, H, W = qt.shape
     C = C3 // 3
     out = _new((B, C, H, W), qt)
     attn = torch.empty((B, heads, kernel_size * kernel_size, H, W), dtype=torch.float32, device=qt.device)
     _lib.call("cn_na2d_fwd_bf16", qt.data_ptr(), ld(qt), out.data_ptr(), ld(out), attn.data_ptr(), B, C, heads, H, W,
-              kernel_size, dilation, _stream())
+              kernel_size, dilation, float(attn_drop), seed, _stream())
     ov = Var(out, tape.enabled)
     if tape.enabled:
 
@@ -1789,7 +1824,8 @@ def _na2d_bf16(qkv: Var, heads: int, kernel_size: int, dilation: int) -> Var:
             dattn = torch.empty_like(attn)
             dq = _new(qt.shape, qt)
             _lib.call("cn_na2d_bwd_bf16", qt.data_ptr(), ld(qt), do.data_ptr(), ld(do), attn.data_ptr(),
-                      dattn.data_ptr(), dq.data_ptr(), ld(dq), B, C, heads, H, W, kernel_size, dilation, _stream())
+                      dattn.data_ptr(), dq.data_ptr(), ld(dq), B, C, heads, H, W, kernel_size, dilation,
+                      float(attn_drop), seed, _stream())
             if qkv.grad is None and qkv.parent is None:
                 qkv.grad = dq
             else:  # pragma: no cover - qkv has a single consumer in TowerUNet

@@ -91,6 +91,18 @@ class LightningModuleMixin(_Base):
     def cultionet_model(self) -> CultioNet:
         return getattr(self, self.model_attr)
 
+    @property
+    def hip_precision(self) -> T.Optional[str]:
+        """Explicit precision of the drop-in forward ("32-true" | "bf16-mixed" | "16-mixed"), or None (default): follow
+        the torch.autocast region lightning.Trainer(precision=...) opens (model.py:168-186)."""
+        return self.cultionet_model.mask_model.precision
+
+    @hip_precision.setter
+    def hip_precision(self, value: T.Optional[str]) -> None:
+        if value not in (None, "32-true", "32", "bf16-mixed", "16-mixed"):
+            raise ValueError(f"unsupported precision {value!r}")
+        self.cultionet_model.mask_model.precision = value
+
     # ---- device-side input prologue (SURVEY 8f rank 2) ----------------------------------------------------------
     def set_norm_values(self, mean: T.Optional[torch.Tensor], std: T.Optional[torch.Tensor]) -> None:
         """Per-channel z-score statistics (NormValues, utils/normalize.py:63-82) applied by the device prologue."""
@@ -418,6 +430,11 @@ class CultionetLitTransferModel(LightningModuleMixin):
                 mm.__dict__["_cn_store"] = None  # modules were replaced: re-flatten the parameters on next use
         self.model_attr = f"{model_name}_{model_type}"
         setattr(self, self.model_attr, cultionet_model)
+        # Upstream ALSO assigns ``self.cultionet_model = ...`` (lightning.py:742-744), which nn.Module.__setattr__ files
+        # under _modules: its transfer checkpoints carry every tensor twice, as ``cultionet_model.*`` and as
+        # ``cultionet_transfer_TowerUNet.*``. Registered under both names here too, so those checkpoints load strictly
+        # and checkpoints written here hold the keys upstream expects (parameters() de-duplicates the shared module).
+        self._modules["cultionet_model"] = cultionet_model
         self.configure_loss()
         self.configure_scorer()
 
@@ -553,6 +570,7 @@ class HipTrainer:
         _lib.call("cn_fill_f32", self.total.data_ptr(), 1, 0.0, s)
         with E.using_store(store), E.recording(True) as tape, E.mixed_precision(self.bf16):
             outs = self.model.forward_vars(self.model.input_var(batch.x))
+            self.last_outputs = {k: v.t for k, v in outs.items()}  # distance / edge / crop of this step (no copies)
             for key, kw in lit._loss_terms(batch):
                 E.tanimoto_loss(outs[key], loss_kind=kind, weight=1.0 / 3.0, total=self.total, **kw)
             store.zero_grad()

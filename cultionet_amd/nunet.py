@@ -133,6 +133,10 @@ class TowerUNet(nn.Module):
                 state_dict[k.replace("pre_unet._orig_mod.", "pre_unet.")] = state_dict.pop(k)
         super()._load_from_state_dict(state_dict, prefix, *args, **kwargs)
 
+    #: explicit precision of the drop-in forward: None = follow the ambient torch.autocast region (what
+    #: lightning.Trainer(precision=...) opens); "32-true" / "bf16-mixed" pin it (see autograd_bridge._autocast_bf16)
+    precision: T.Optional[str] = None
+
     #: write checkpoints with the reference's key spelling ``pre_unet._orig_mod.*`` (upstream wraps pre_unet in
     #: torch.compile, nunet.py:141, so ITS strict load expects that prefix). Off by default: plain keys.
     upstream_checkpoint_keys = False

@@ -391,9 +391,15 @@ int cn_bilinear_bwd_bf16(const void* dy, long lddy, void* dx, long lddx, int B, 
 
 /* NeighborhoodAttention2D core: qkv [B][H][W][3C], out [B][H][W][C]; attn / dattn fp32 [B][heads][9][H][W]. */
 int cn_na2d_fwd_bf16(const void* qkv, long ldq, void* out, long ldo, float* attn, int B, int C, int heads, int H, int W,
-                     int kernel_size, int dilation, void* stream);
+                     int kernel_size, int dilation, float attn_drop, unsigned long long seed, void* stream);
 int cn_na2d_bwd_bf16(const void* qkv, long ldq, const void* dout, long ldo, const float* attn, float* dattn, void* dqkv,
-                     long lddq, int B, int C, int heads, int H, int W, int kernel_size, int dilation, void* stream);
+                     long lddq, int B, int C, int heads, int H, int W, int kernel_size, int dilation, float attn_drop,
+                     unsigned long long seed, void* stream);
+
+/* nn.Dropout2d (channelwise) / nn.Dropout on bf16 NHWC activations [B*HW rows][C], the same counter-based masks as
+ * cn_dropout_f32 (convolution.py:495,511; natten proj_drop); backward = the same call on dy with accumulate. */
+int cn_dropout_bf16(const void* x, long ldx, void* y, long ldy, int B, int C, int HW, float p, unsigned long long seed,
+                    int channelwise, int accumulate, void* stream);
 
 /* ---- diagnostics: per-launch HIP-event timing of the contraction kernels (bench.py roofline) ---
  * begin() starts recording event pairs around every implicit-GEMM / weight-gradient launch on the
@@ -406,6 +412,18 @@ int cn_profile_end(double* out);
  * "cn_conv_igemm_vec_kernel<4, 1, 5, 1, 1>") with out[3] = {milliseconds, algorithmic flops, launches};
  * returns the number of distinct kernels recorded. */
 int cn_profile_top(int rank, char* name_out, int cap, double* out);
+/* kernel launches issued by the library so far (every launch goes through one counting macro);
+ * reset != 0 returns the count and zeroes it. bench.py reports it as kernel launches per step. */
+long cn_launch_count(int reset);
+
+/* ---- runtime plumbing: streams torch cannot create ---------------------------------------------------
+ * The training step issues weight gradients on a second stream (engine.py side_stream; the reference has no
+ * counterpart: torch.autograd runs one stream). That stream must not starve the data-gradient chain:
+ * cn_stream_create(priority) = hipStreamCreateWithPriority (out[0] = least, out[1] = greatest of
+ * cn_stream_priority_range), or with cu_mask != NULL hipExtStreamCreateWithCUMask (bit i = CU i). */
+int cn_stream_priority_range(int* out);
+int cn_stream_create(int priority, const unsigned* cu_mask, int cu_mask_words, void** stream_out);
+int cn_stream_destroy(void* stream);
 
 #ifdef __cplusplus
 }

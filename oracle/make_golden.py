@@ -2,7 +2,8 @@
 
 TEST INFRASTRUCTURE ONLY. Run from the repo root:
 
-    TORCHDYNAMO_DISABLE=1 python -m oracle.make_golden
+    TORCHDYNAMO_DISABLE=1 python -m oracle.make_golden          (--keys-only: TORCHDYNAMO_DISABLE=0, so that
+                                                                 torch.compile renames pre_unet as upstream does)
 
 Every vector is produced by /root/reference's own code (CultionetLitModel.forward,
 calc_loss, autograd) on PyTorch-CPU fp32 with key-seeded weights
@@ -145,6 +146,15 @@ def main():
         np.savez_compressed(path, **d)
         print(name, os.path.getsize(path) // 1024, "KiB", "loss" in d and d["loss"])
 
+    if "--keys-only" in sys.argv:
+        # checkpoint compatibility: the state-dict key set (with shapes) of the REAL reference's CultionetLitModel at
+        # the default configuration, once as written by upstream (torch.compile wraps pre_unet, nunet.py:141 => keys
+        # spelt pre_unet._orig_mod.*) -- tests/test_checkpoint_keys.py loads / writes both spellings against it
+        m = ns.CultionetLitModel(in_channels=3, in_time=12, hidden_channels=32, dropout=0.0)
+        sd = m.state_dict()
+        save("state_dict_keys_h32.npz", {"keys": np.array(list(sd.keys())),
+                                         "shapes": np.array([",".join(map(str, v.shape)) for v in sd.values()])})
+        return
     if "--h64-only" in sys.argv:
         # the CLI default width (scripts/args.yml:220-226: hidden_channels 64)
         save("train_h64_b1_100.npz", _train_case(ns, 64, 1, 100, 100, True))

@@ -11,7 +11,11 @@ reference is imported to generate fixtures and (b) as the checker of the HIP met
       F_beta = (1+b^2) tp / ((1+b^2) tp + b^2 fn + fp) = tp / N, i.e. plain accuracy whatever beta is;
   MatthewsCorrCoef(task="multiclass", num_classes=2)
       from the confusion matrix C: (c*s - sum_k p_k t_k) / sqrt((s^2 - sum p_k^2) (s^2 - sum t_k^2)) with
-      c = trace, s = total, p_k / t_k = predicted / true counts; 0 when the denominator is 0.
+      c = trace, s = total, p_k / t_k = predicted / true counts. Degenerate 2x2 cases as torchmetrics >= 1.0
+      (`_matthews_corrcoef_reduce`; setup.cfg pins torchmetrics>=1.3): every prediction right -> 1, every prediction
+      wrong -> -1, and with an empty marginal (denominator 0) the eps-regularised ratio
+      sqrt(eps) * ((tp + tn) - (fp + fn)) / sqrt((tp+fp+eps)(tp+fn+eps)(tn+fp+eps)(tn+fn+eps)), eps = float32 epsilon.
+      (Rounds 1-2 returned 0 there, which is torchmetrics < 1.0.) tests/test_metrics_ref.py holds hand-computed answers.
 
 ``forward`` returns the value of the current batch (what ``scorer(preds, target)`` returns in the reference).
 Parity status: restatement-checked (a real torchmetrics is used instead whenever it is importable).
@@ -65,8 +69,20 @@ class MatthewsCorrCoef(nn.Module):
 
     def forward(self, preds, target):
         c = _confmat(preds, target, self.num_classes)
+        if self.num_classes == 2:
+            tn, fp, fn, tp = (float(v) for v in c.reshape(-1))
+            if tp + tn != 0 and fp + fn == 0:
+                return torch.ones((), dtype=torch.float32)
+            if tp + tn == 0 and fp + fn != 0:
+                return -torch.ones((), dtype=torch.float32)
         tk, pk = c.sum(1), c.sum(0)
         cc, s = c.diag().sum(), c.sum()
         num = cc * s - (tk * pk).sum()
-        den = torch.sqrt(s ** 2 - (pk ** 2).sum()) * torch.sqrt(s ** 2 - (tk ** 2).sum())
-        return (num / den).float() if float(den) > 0 else torch.zeros((), dtype=torch.float32)
+        den = (s ** 2 - (pk ** 2).sum()) * (s ** 2 - (tk ** 2).sum())
+        if float(den) == 0:
+            if self.num_classes != 2:
+                return torch.zeros((), dtype=torch.float32)
+            eps = float(torch.finfo(torch.float32).eps)
+            num = torch.tensor(eps ** 0.5 * ((tp + tn) - (fp + fn)), dtype=torch.float64)
+            den = torch.tensor((tp + fp + eps) * (tp + fn + eps) * (tn + fp + eps) * (tn + fn + eps), dtype=torch.float64)
+        return (num / torch.sqrt(den)).float()

@@ -89,6 +89,11 @@ CONV_CASES = [
     (2, 64, 50, 50, 64, 3, 1, 3, 3, False),     # dilations 3 / 4 / 5 at tower sizes: the 16-piece register-prefetched
     (2, 32, 100, 100, 32, 3, 1, 4, 4, False),   # halo of the weight gradient (3, 4) and its synchronous fallback (5)
     (1, 32, 50, 50, 32, 3, 1, 5, 5, False),
+    # the shapes that carry the step time at batch 8 (the batch-32 launches only add pixel tiles)
+    (8, 128, 100, 100, 128, 3, 1, 1, 1, False),
+    (8, 480, 100, 100, 128, 3, 1, 1, 1, False),
+    (8, 576, 50, 50, 128, 3, 1, 1, 1, False),
+    (8, 640, 25, 25, 128, 3, 1, 1, 1, False),
 ]
 
 
@@ -336,14 +341,86 @@ def test_na2d_bf16(shape, heads, dil):
     out = _empty_nhwc(B, C, H, W)
     at = torch.empty((B, heads, 9, H, W), device=dev)
     _lib.call("cn_na2d_fwd_bf16", qg.data_ptr(), _ld(qg), out.data_ptr(), _ld(out), at.data_ptr(), B, C, heads, H, W, 3,
-              dil, _s())
+              dil, 0.0, 0, _s())
     _close(out, outr, 6e-3, "out")
     dyg = _nhwc(dy)
     dq = _empty_nhwc(B, 3 * C, H, W)
     dat = torch.empty_like(at)
     _lib.call("cn_na2d_bwd_bf16", qg.data_ptr(), _ld(qg), dyg.data_ptr(), _ld(dyg), at.data_ptr(), dat.data_ptr(),
-              dq.data_ptr(), _ld(dq), B, C, heads, H, W, 3, dil, _s())
+              dq.data_ptr(), _ld(dq), B, C, heads, H, W, 3, dil, 0.0, 0, _s())
     _close(dq, qr.grad, 8e-3, "dqkv")
+
+
+@pytest.mark.parametrize("shape,heads,dil", [((2, 32, 12, 12), 4, 1), ((1, 128, 20, 21), 4, 2)])
+def test_na2d_bf16_attention_dropout(shape, heads, dil):
+    """attn_drop > 0 on the mixed-precision path (the reference's default dropout=0.1 reaches natten's attn_drop in the
+    decoder, unet_parts.py:452-525): the bf16 kernels draw the SAME counter-based masks as the fp32 kernels, so on the
+    same bf16-rounded operands and seed both paths must agree to bf16 rounding, forward and backward."""
+    from cultionet_amd import _lib
+
+    B, C, H, W = shape
+    dev = _dev()
+    p, seed = 0.25, 0xABCDEF12345
+    qkv = _r(_rand(B, 3 * C, H, W, seed=1))
+    dy = _r(_rand(B, C, H, W, seed=2))
+    # fp32 NCHW kernels
+    q32 = qkv.to(dev)
+    o32 = torch.empty((B, C, H, W), device=dev)
+    a32 = torch.empty((B, heads, 9, H, W), device=dev)
+    _lib.call("cn_na2d_fwd_f32", q32.data_ptr(), 3 * C * H * W, o32.data_ptr(), C * H * W, a32.data_ptr(), B, C, heads,
+              H, W, 3, dil, p, seed, _s())
+    dy32 = dy.to(dev)
+    da32 = torch.empty_like(a32)
+    dq32 = torch.empty_like(q32)
+    _lib.call("cn_na2d_bwd_f32", q32.data_ptr(), 3 * C * H * W, dy32.data_ptr(), C * H * W, a32.data_ptr(),
+              da32.data_ptr(), dq32.data_ptr(), 3 * C * H * W, B, C, heads, H, W, 3, dil, p, seed, _s())
+    # bf16 NHWC kernels
+    qg = _nhwc(qkv)
+    out = _empty_nhwc(B, C, H, W)
+    at = torch.empty((B, heads, 9, H, W), device=dev)
+    _lib.call("cn_na2d_fwd_bf16", qg.data_ptr(), _ld(qg), out.data_ptr(), _ld(out), at.data_ptr(), B, C, heads, H, W, 3,
+              dil, p, seed, _s())
+    _close(at, a32, 1e-5, "saved probabilities (undropped)")
+    _close(out, o32, 6e-3, "out")
+    # the dropout is real: without it the output differs
+    out0 = _empty_nhwc(B, C, H, W)
+    _lib.call("cn_na2d_fwd_bf16", qg.data_ptr(), _ld(qg), out0.data_ptr(), _ld(out0), at.data_ptr(), B, C, heads, H, W, 3,
+              dil, 0.0, 0, _s())
+    assert (out0.float() - out.float()).abs().max() > 0.05
+    dyg = _nhwc(dy)
+    dq = _empty_nhwc(B, 3 * C, H, W)
+    dat = torch.empty_like(at)
+    _lib.call("cn_na2d_bwd_bf16", qg.data_ptr(), _ld(qg), dyg.data_ptr(), _ld(dyg), at.data_ptr(), dat.data_ptr(),
+              dq.data_ptr(), _ld(dq), B, C, heads, H, W, 3, dil, p, seed, _s())
+    _close(dq, dq32, 8e-3, "dqkv")
+
+
+@pytest.mark.parametrize("channelwise", [True, False])
+def test_dropout_bf16_draws_the_fp32_masks(channelwise):
+    """cn_dropout_bf16 (NHWC) against cn_dropout_f32 (NCHW) on the same seed: identical keep pattern, kept values
+    x / (1 - p) to bf16 rounding, backward (accumulate) with the same mask."""
+    from cultionet_amd import _lib
+
+    dev = _dev()
+    B, C, H, W = 3, 24, 9, 11
+    p, seed = 0.3, 0x1234567
+    x = _r(_rand(B, C, H, W, seed=5).abs() + 0.5)
+    x32 = x.to(dev)
+    y32 = torch.empty_like(x32)
+    cw = 1 if channelwise else 0
+    _lib.call("cn_dropout_f32", x32.data_ptr(), C * H * W, y32.data_ptr(), C * H * W, B, C, H * W, p, seed, cw, 0, _s())
+    xg = _nhwc(x, ld=C + 8)
+    y = _empty_nhwc(B, C, H, W, ld=C + 16)
+    _lib.call("cn_dropout_bf16", xg.data_ptr(), _ld(xg), y.data_ptr(), _ld(y), B, C, H * W, p, seed, cw, 0, _s())
+    torch.cuda.synchronize()
+    assert torch.equal(y.float().cpu() != 0, y32.cpu() != 0)
+    _close(y, y32, 4e-3, "y")
+    frac = (y32 != 0).float().mean().item()
+    assert abs(frac - (1 - p)) < (0.15 if channelwise else 0.03), frac
+    base = _r(_rand(B, C, H, W, seed=6))
+    acc = _nhwc(base)
+    _lib.call("cn_dropout_bf16", xg.data_ptr(), _ld(xg), acc.data_ptr(), _ld(acc), B, C, H * W, p, seed, cw, 1, _s())
+    _close(acc, y32.cpu() + base, 8e-3, "accumulate")
 
 
 @pytest.mark.parametrize("case", [(2, 16, 13, 13, 14, 14), (1, 32, 49, 49, 50, 50), (2, 8, 97, 97, 100, 100),

@@ -144,3 +144,108 @@ def test_bf16_eval_forward_and_dropin_autocast(golden_dir):
     assert abs(float(loss) - float(g["fp32_loss"])) <= 5e-4
     gsum = sum(float(p.grad.abs().sum()) for p in model.parameters())
     assert np.isfinite(gsum) and gsum > 0
+
+
+def test_bf16_dropin_with_default_dropout_trains():
+    """The reference's default operating point (model.py:59,86,168-186): precision "16-mixed" + dropout 0.1, driven the
+    drop-in way -- forward(Data) under torch.autocast, calc_loss, loss.backward(), torch AdamW. Dropout2d after the
+    encoder blocks and natten's attn / proj dropout run on the bf16 NHWC kernels with counter-based masks: the step is
+    reproducible from the seed, finite, and the loss goes down over a few optimizer steps."""
+    from cultionet_amd import engine as E
+    from cultionet_amd import synthetic as S
+    from cultionet_amd.data import Data
+    from cultionet_amd.lightning import CultionetLitModel
+
+    dev = torch.device("cuda:0")
+    lit = CultionetLitModel(in_channels=3, in_time=12, hidden_channels=8, dropout=0.1)
+    m = lit.cultionet_model.mask_model
+    m.load_state_dict(S.seeded_state_dict(m.state_dict()))
+    lit = lit.to(dev).train()
+    x, y, bdist = S.seeded_batch(2, height=28, width=28, with_mask=True)
+    batch = Data(x=x.to(dev), y=y.to(dev), bdist=bdist.to(dev))
+    opt = torch.optim.AdamW(m.parameters(), lr=0.005, weight_decay=1e-3, eps=1e-4, betas=(0.9, 0.98))
+
+    def step(seed):
+        E.manual_seed(seed)
+        opt.zero_grad(set_to_none=True)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            pred = lit(batch)
+            loss, _ = lit.calc_loss(batch, pred)
+        loss.backward()
+        return float(loss), torch.cat([p.grad.flatten() for p in m.parameters()]).clone()
+
+    l1, g1 = step(11)
+    l2, g2 = step(11)
+    assert l1 == l2 and torch.equal(g1, g2) and torch.isfinite(g1).all()
+    l3, _ = step(12)
+    assert l3 != l1  # another seed draws other masks
+    losses = []
+    for i in range(8):
+        l, _ = step(100 + i)
+        opt.step()
+        losses.append(l)
+    assert all(np.isfinite(losses)) and min(losses[-3:]) < losses[0], losses
+
+
+def test_native_bf16_step_with_dropout_runs():
+    from cultionet_amd import engine as E
+    from cultionet_amd import synthetic as S
+    from cultionet_amd.data import Data
+    from cultionet_amd.lightning import CultionetLitModel, HipTrainer
+
+    dev = torch.device("cuda:0")
+    lit = CultionetLitModel(in_channels=3, in_time=12, hidden_channels=8, dropout=0.2)
+    m = lit.cultionet_model.mask_model
+    m.load_state_dict(S.seeded_state_dict(m.state_dict()))
+    lit = lit.to(dev).train()
+    x, y, bdist = S.seeded_batch(2, height=28, width=28, with_mask=True)
+    batch = Data(x=x.to(dev), y=y.to(dev), bdist=bdist.to(dev))
+    tr = HipTrainer(lit, precision="bf16-mixed")
+    E.manual_seed(7)
+    l1 = float(tr.forward_backward(batch).item())
+    E.manual_seed(7)
+    l2 = float(tr.forward_backward(batch).item())
+    assert l1 == l2 and torch.isfinite(tr.store.flat_grad).all() and 0.3 < l1 < 1.0
+
+
+def test_precision_selection_of_the_dropin_forward():
+    """autograd_bridge._autocast_bf16: ambient bf16 autocast selects the mixed path (announced once), fp16 autocast is
+    served by it too (announced), and an explicit ``hip_precision`` wins over whatever autocast region is open."""
+    import warnings
+
+    from cultionet_amd import autograd_bridge as AB
+    from cultionet_amd import synthetic as S
+    from cultionet_amd.lightning import CultionetLitModel
+
+    dev = torch.device("cuda:0")
+    lit = CultionetLitModel(in_channels=3, in_time=12, hidden_channels=8, dropout=0.0)
+    m = lit.cultionet_model.mask_model
+    m.load_state_dict(S.seeded_state_dict(m.state_dict()))
+    lit = lit.to(dev).eval()
+    x, _, _ = S.seeded_batch(2, height=28, width=28)
+    xd = x.to(dev)
+    with torch.no_grad():
+        ref32 = m(xd)["crop"].clone()
+        AB._warned.clear()
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            with torch.autocast("cuda", dtype=torch.bfloat16):
+                mixed = m(xd)["crop"].clone()
+                m(xd)
+            assert sum("bf16 mixed-precision" in str(i.message) for i in w) == 1  # once, not per call
+        assert not torch.equal(mixed, ref32) and (mixed - ref32).abs().max() < 0.1
+        with warnings.catch_warnings(record=True) as w:
+            warnings.simplefilter("always")
+            with torch.autocast("cuda", dtype=torch.float16):
+                half = m(xd)["crop"].clone()
+            assert any("fp16 autocast" in str(i.message) for i in w)
+        assert torch.equal(half, mixed)  # the same bf16 path
+        lit.hip_precision = "32-true"
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            assert torch.equal(m(xd)["crop"], ref32)
+        lit.hip_precision = "bf16-mixed"
+        assert torch.equal(m(xd)["crop"], mixed)  # no autocast region needed
+        lit.hip_precision = None
+        assert torch.equal(m(xd)["crop"], ref32)
+    with pytest.raises(ValueError):
+        lit.hip_precision = "64-true"

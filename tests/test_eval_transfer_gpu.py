@@ -44,20 +44,27 @@ def test_validation_step_matches_reference(golden_dir, name):
 
 def test_eval_metrics_kernel_against_restatement():
     """The fused metrics kernel against oracle/metrics_ref.py on random maps, incl. masked pixels and the degenerate
-    all-negative case (MCC denominator 0 => 0, as torchmetrics)."""
+    confusion matrices torchmetrics >= 1.0 special-cases: no positive prediction (eps-regularised ratio), every
+    prediction right (1) and every prediction wrong (-1)."""
     from cultionet_amd import _lib
     from oracle import metrics_ref as M
 
     dev = torch.device("cuda:0")
     gen = torch.Generator().manual_seed(5)
     B, H, W = 3, 37, 41
-    for case in range(3):
+    for case in range(5):
         dist, edge, crop = (torch.rand(B, 1, H, W, generator=gen) for _ in range(3))
         bdist = torch.rand(B, H, W, generator=gen)
         y = torch.randint(-1 if case != 1 else 0, 3, (B, H, W), generator=gen)
         if case == 2:
             edge = edge * 0.4  # no positive edge prediction at all
             y = torch.where(y == 2, torch.zeros_like(y), y)
+        if case == 3:  # edge predictions all right, crop predictions all wrong
+            edge = (y == 2).float().unsqueeze(1) * 0.8 + 0.1
+            crop = 1.0 - ((y > 0) & (y < 2)).float().unsqueeze(1) * 0.8 - 0.1
+        if case == 4:  # no true edge pixel and no predicted one: both marginals empty, all right -> 1
+            y = torch.where(y == 2, torch.ones_like(y), y)
+            edge = edge * 0.4
         loss = torch.tensor([0.625])
         valid = y != -1
         te, tc = (y == 2).long()[valid], ((y > 0) & (y < 2)).long()[valid]
@@ -92,6 +99,15 @@ def test_transfer_model(tmp_path, finetune):
     torch.save({"state_dict": base.state_dict(), "hyper_parameters": dict(base.hparams)}, ckpt)
     lit = CultionetLitTransferModel(pretrained_ckpt_file=ckpt, finetune=finetune, **kw)
     assert lit.is_transfer_model and lit.model_attr == "cultionet_transfer_TowerUNet"
+    # upstream registers the network under BOTH names (lightning.py:742-744 + :797-801): its transfer checkpoints carry
+    # cultionet_model.* and cultionet_transfer_TowerUNet.* -- same key set here, and a strict round trip
+    sd = lit.state_dict()
+    a = {k[len("cultionet_model."):] for k in sd if k.startswith("cultionet_model.")}
+    b = {k[len("cultionet_transfer_TowerUNet."):] for k in sd if k.startswith("cultionet_transfer_TowerUNet.")}
+    assert a == b and len(a) == len(base.state_dict()) and len(sd) == 2 * len(a)
+    assert len(list(lit.parameters())) == len(list(base.parameters()))  # the shared module is not counted twice
+    res = lit.load_state_dict(sd, strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
     model = lit.cultionet_model.mask_model
     named = dict(lit.cultionet_model.named_parameters())
     heads = {n for n in named if n.startswith("mask_model.final_")}

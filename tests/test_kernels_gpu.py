@@ -68,6 +68,12 @@ CONV_CASES = [
     (3, 24, 100, 100, 32, 3, 1, 1, 1, False), # BASELINE spatial size
     (4, 48, 100, 100, 256, 1, 1, 0, 1, True),   # large 1x1: the dedicated GEMM kernel (fwd and bwd-data)
     (8, 130, 50, 50, 200, 1, 1, 0, 1, False),   # same, ragged channels
+    # the shapes that carry the step time at BASELINE configs[1] (batch 8, hidden 32)
+    (8, 128, 100, 100, 128, 3, 1, 1, 1, False),  # up_au / tower_a block 1
+    (8, 480, 100, 100, 128, 3, 1, 1, 1, False),  # tower_a block 0
+    (8, 576, 50, 50, 128, 3, 1, 1, 1, False),    # tower_b block 0
+    (8, 640, 25, 25, 128, 3, 1, 1, 1, False),    # tower_c block 0
+    (8, 480, 100, 100, 128, 1, 1, 0, 1, True),   # tower_a skip
 ]
 
 

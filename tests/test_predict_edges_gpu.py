@@ -87,3 +87,40 @@ def test_collate_and_device_prologue():
     assert (out.bdist.cpu() - wb).abs().max() <= 1e-7
     pred = lit.eval()(out)  # the prepared batch feeds the forward
     assert pred["distance"].shape == (3, 1, 20, 20)
+
+
+def test_device_feeder_double_buffers_raw_batches():
+    """cultionet_amd.feeder.DeviceFeeder: raw int16 batches in pinned host memory -> copy stream -> cn_prepare_chips_f32
+    -> the consumer's stream. Every yielded batch equals the reference arithmetic (datasets.py:443-446 +
+    normalize.py:63-82: x / 10000 -> clip(1e-9, 1) -> z-score) of ITS host batch, also when the consumer is slow or
+    fast relative to the copies (ordering is by stream events, not by luck)."""
+    from cultionet_amd.data import Data
+    from cultionet_amd.feeder import DeviceFeeder, pin_batch
+
+    dev = torch.device("cuda:0")
+    g = torch.Generator().manual_seed(5)
+    mean = torch.rand(3, generator=g) * 0.3
+    std = torch.rand(3, generator=g) * 0.2 + 0.05
+    hosts = []
+    for k in range(5):
+        xr = torch.randint(-20, 11000, (4, 3, 6, 20, 24), generator=g).to(torch.int16)
+        y = torch.randint(-1, 3, (4, 20, 24), generator=g)
+        bd = torch.randint(0, 10001, (4, 20, 24), generator=g).to(torch.int16)
+        hosts.append(pin_batch(Data(x=xr, y=y, bdist=bd)))
+    feeder = DeviceFeeder(dev, mean=mean, std=std)
+    burn = torch.empty(4096, 4096, device=dev)
+    seen = 0
+    for i, b in enumerate(feeder.iterate(hosts)):
+        if i % 2 == 0:
+            for _ in range(20):  # a slow consumer: the next batch's copy + prologue overlap this
+                burn.normal_()
+        h = hosts[i]
+        ref = (h.x.float() / 10_000.0).clip(1e-9, 1)
+        ref = (ref - mean.view(1, 3, 1, 1, 1)) / std.view(1, 3, 1, 1, 1)
+        assert b.x.dtype == torch.float32 and b.x.is_cuda
+        assert (b.x.cpu() - ref).abs().max() <= 1e-5
+        assert torch.equal(b.y.cpu(), h.y)
+        assert (b.bdist.cpu() - (h.bdist.float() / 10_000.0).clip(1e-9, 1)).abs().max() <= 1e-6
+        seen += 1
+    assert seen == len(hosts)
+    assert list(feeder.iterate([])) == []
