@@ -108,6 +108,7 @@ SIGNATURES = {
     "cn_profile_begin": [],
     "cn_profile_end": [P],
     "cn_profile_top": [I, P, I, P],
+    "cn_profile_set_filter": [P],
     "cn_launch_count": [I],
     "cn_stream_priority_range": [P],
     "cn_stream_create": [I, P, I, P],

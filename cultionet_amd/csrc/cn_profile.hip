@@ -14,6 +14,7 @@ struct Rec { hipEvent_t a, b; int kind; double flops; char desc[96]; char name[6
 struct Agg { char name[64]; double ms, flops, launches; };
 char g_desc[96] = {0};
 char g_name[64] = {0};
+char g_filter[64] = {0};  // non-empty: record only launches whose cn_prof_name equals it
 std::vector<Agg> g_aggs;  // per kernel name, filled by cn_profile_end, sorted by time
 bool g_on = false;
 std::vector<Rec> g_recs;
@@ -56,6 +57,9 @@ void cn_prof_name(const char* fmt, ...) {
 
 void cn_prof_before(hipStream_t stream) {
   if (!g_on) return;
+  // filtered window: bracket only launches of the named kernel (a few per step) so that the events themselves --
+  // two markers on the launch stream per recorded kernel -- do not perturb the region being timed
+  if (g_filter[0] != 0 && strncmp(g_filter, g_name, sizeof(g_name)) != 0) { g_desc[0] = 0; g_name[0] = 0; return; }
   g_pending = get_event();
   (void)hipEventRecord(g_pending, stream);
 }
@@ -76,6 +80,12 @@ void cn_prof_after(hipStream_t stream, int kind, double flops) {
 // Start recording (not thread-safe; one profiling client per process).
 extern "C" int cn_profile_begin(void) {
   g_on = true;
+  return CN_OK;
+}
+
+// Restrict the NEXT windows to one kernel (exact rocprof-style name as reported by cn_profile_top); "" or NULL: all.
+extern "C" int cn_profile_set_filter(const char* name) {
+  snprintf(g_filter, sizeof(g_filter), "%s", name ? name : "");
   return CN_OK;
 }
 

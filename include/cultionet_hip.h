@@ -412,6 +412,10 @@ int cn_profile_end(double* out);
  * "cn_conv_igemm_vec_kernel<4, 1, 5, 1, 1>") with out[3] = {milliseconds, algorithmic flops, launches};
  * returns the number of distinct kernels recorded. */
 int cn_profile_top(int rank, char* name_out, int cap, double* out);
+/* record only launches of the kernel with exactly this name in the windows that follow ("" / NULL: every
+ * contraction launch): bench.py brackets just the dominant kernel inside the timed region, so that the event
+ * markers of the other ~250 launches per step do not perturb the time being measured. */
+int cn_profile_set_filter(const char* name);
 /* kernel launches issued by the library so far (every launch goes through one counting macro);
  * reset != 0 returns the count and zeroes it. bench.py reports it as kernel launches per step. */
 long cn_launch_count(int reset);

@@ -176,9 +176,12 @@ def test_bf16_dropin_with_default_dropout_trains():
 
     l1, g1 = step(11)
     l2, g2 = step(11)
-    assert l1 == l2 and torch.equal(g1, g2) and torch.isfinite(g1).all()
-    l3, _ = step(12)
-    assert l3 != l1  # another seed draws other masks
+    # same seed -> same masks: equal up to the rounding noise of the float-atomic statistics rows of the narrow layers
+    # (hidden 8: every conv is "narrow"); another seed draws other masks and moves the loss by far more
+    assert abs(l1 - l2) <= 1e-5 and torch.isfinite(g1).all()
+    assert (g1 - g2).norm() <= 2e-2 * g1.norm()
+    l3, g3 = step(12)
+    assert abs(l3 - l1) > 2e-5 and (g3 - g1).norm() > 0.1 * g1.norm()
     losses = []
     for i in range(8):
         l, _ = step(100 + i)
@@ -205,7 +208,7 @@ def test_native_bf16_step_with_dropout_runs():
     l1 = float(tr.forward_backward(batch).item())
     E.manual_seed(7)
     l2 = float(tr.forward_backward(batch).item())
-    assert l1 == l2 and torch.isfinite(tr.store.flat_grad).all() and 0.3 < l1 < 1.0
+    assert abs(l1 - l2) <= 1e-5 and torch.isfinite(tr.store.flat_grad).all() and 0.3 < l1 < 1.0
 
 
 def test_precision_selection_of_the_dropin_forward():

@@ -46,3 +46,47 @@ def test_interior_equals_unfold_attention():
     logits = torch.einsum("bhxyd,bhdkxy->bhxyk", qi, ku)
     ref = torch.einsum("bhxyk,bhdkxy->bhxyd", logits.softmax(-1), vu)
     assert (out[:, :, 1:-1, 1:-1] - ref).abs().max() < 1e-5
+
+
+def _na_subgrid_unfold(q, k, v, K, d):
+    """A THIRD formulation that shares no code (and no window rule) with oracle/na2d_ref.py: dilated neighborhood
+    attention as published (DiNAT): split the plane into its d x d residue-class sub-grids (pixel-unshuffle), run plain
+    (dilation 1) neighborhood attention inside every sub-grid, where the window of query j on an axis of length n is the
+    K-wide window CENTRED at clamp(j, K//2, n-1-K//2). All centred windows of a sub-grid come from torch's own
+    F.unfold; edge queries pick the unfold column of their clamped centre. q is already scaled."""
+    import torch.nn.functional as F
+
+    B, h, H, W, D = q.shape
+    out = torch.empty_like(q)
+    n = K // 2
+    for ry in range(d):
+        for rx in range(d):
+            qs, ks, vs = (t[:, :, ry::d, rx::d] for t in (q, k, v))
+            Hs, Ws = qs.shape[2], qs.shape[3]
+            unf = lambda t: F.unfold(t.permute(0, 1, 4, 2, 3).reshape(B, h * D, Hs, Ws), K).reshape(
+                B, h, D, K * K, Hs - 2 * n, Ws - 2 * n)
+            ku, vu = unf(ks), unf(vs)
+            cy = torch.arange(Hs).clamp(n, Hs - 1 - n) - n   # unfold row of each query's clamped centre
+            cx = torch.arange(Ws).clamp(n, Ws - 1 - n) - n
+            kq = ku[:, :, :, :, cy][:, :, :, :, :, cx]        # [B,h,D,KK,Hs,Ws]
+            vq = vu[:, :, :, :, cy][:, :, :, :, :, cx]
+            logits = torch.einsum("bhxyd,bhdkxy->bhxyk", qs, kq)
+            out[:, :, ry::d, rx::d] = torch.einsum("bhxyk,bhdkxy->bhxyd", logits.softmax(-1), vq)
+    return out
+
+
+@pytest.mark.parametrize("heads,H,W,d", [(4, 100, 100, 2), (4, 50, 50, 1), (8, 25, 25, 1),   # unet_parts.py:19-40 at
+                                         (4, 28, 28, 2), (4, 14, 14, 1), (8, 7, 7, 1),        # 100^2 and at 28^2
+                                         (2, 11, 13, 3), (2, 9, 101, 2)])                     # ragged residue classes
+def test_subgrid_unfold_formulation_matches_everywhere(heads, H, W, d):
+    """oracle/na2d_ref.py (what every default-configuration fixture flows through, natten being absent) against the
+    sub-grid / F.unfold formulation on ALL pixels -- edges included -- at the reference's three call-site shapes
+    (C = 128: head dims 32 / 32 / 16). This does not pin natten; it removes the shared-author risk of the edge rule:
+    the two formulations have no line in common (window_start is not used by the third one)."""
+    g = torch.Generator().manual_seed(17)
+    D = 128 // heads
+    q, k, v = (torch.randn(1, heads, H, W, D, generator=g) for _ in range(3))
+    q = q * D ** -0.5
+    a = N.na2d_av(N.na2d_qk(q, k, 3, d).softmax(-1), v, 3, d)
+    b = _na_subgrid_unfold(q, k, v, 3, d)
+    assert (a - b).abs().max() < 2e-5
