@@ -78,6 +78,9 @@ SIGNATURES = {
     "cn_pack_weights_bf16": [P, P, I, I, I, L, L, L, P],
     "cn_pack_weights_batched_bf16": [P, I, P],
     "cn_conv2d_fwd_bf16": [P, L, P, P, P, L, L, I, I, I, I, I, I, I, I, I, I, I, I, P, P],
+    "cn_conv2d_fwd_fused_bf16": [P, L, P, P, P, L, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
+    "cn_pack_weights_scaled_bf16": [P, P, P, I, I, I, L, L, L, P],
+    "cn_bn_fold_f32": [P, P, P, P, P, F, I, P, P, P],
     "cn_conv2d_fwd_grouped_bf16": [I, P, L, P, P, P, L, I, I, I, I, I, I, I, I, P, P, I, P],
     "cn_conv2d_bwd_data_bf16": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
     "cn_conv2d_bwd_data_grouped_bf16": [I, P, L, P, P, L, I, I, I, I, I, I, I, I, P, P, I, P],

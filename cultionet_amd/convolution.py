@@ -78,6 +78,10 @@ class ConvBlock2d(nn.Module):
         self.seq = nn.Sequential(*layers)
 
     def forward(self, x: E.Var, residual: T.Optional[E.Var] = None) -> E.Var:
+        if not self.batchnorm_first and E.can_fuse_eval(x, self.seq[1], self.training):
+            # inference on the mixed-precision path: conv + BatchNorm(running statistics) + SiLU (+ residual), one launch
+            return E.conv_bn_act_eval(x, self.seq[0], self.seq[1], self.act, self.stride, self.padding, self.dilation,
+                                      residual)
         if self.batchnorm_first:
             h = E.bn_act(x, self.seq[0], E.ACT_SILU, training=self.training)
             y = E.conv2d(h, self.seq[2], self.stride, self.padding, self.dilation)
@@ -249,7 +253,10 @@ class ResidualAConv(nn.Module):
     def forward(self, x: E.Var) -> E.Var:
         G = len(self.res_modules)
         blocks0 = [m.block[0] for m in self.res_modules]
-        if 2 <= G <= 4 and all(len(m.block) == 2 for m in self.res_modules) and not blocks0[0].batchnorm_first:
+        fused_eval = (not blocks0[0].batchnorm_first
+                      and all(E.can_fuse_eval(x, b.seq[1], self.training) for m in self.res_modules for b in m.block))
+        if 2 <= G <= 4 and all(len(m.block) == 2 for m in self.res_modules) and not blocks0[0].batchnorm_first \
+                and not fused_eval:
             # the G dilation branches run level by level: one grouped launch for their first convs (shared input),
             # one for their second convs; out + SiLU(BN(.)) is fused into the last BN of each branch
             blocks1 = [m.block[1] for m in self.res_modules]

@@ -60,6 +60,9 @@ struct CnBGeom {
   int nblk_n;     // cout blocks (of 32*WN) per pixel tile
   int out_kind;   // 0: bf16 NHWC   1: f32 NCHW (thin head convolutions)
   int accumulate;
+  int act;        // fused eval epilogue: 1 = SiLU applied to conv + bias BEFORE the residual / accumulate add
+  const bf16_t* res[CNB_MAX_GROUPS];  // fused eval epilogue: y = res + act(conv + bias) (bf16 NHWC, pixel stride ldres,
+  long ldres;                         // same spatial size as y); nullptr: none. res == y is the in-place accumulate.
   int total;      // logical blocks
   int ncls;
   float* stats;   // nullable: per pixel tile {sum, sum of squares}[Cout] of the fp32 results, rows [tile][2][Cout]
@@ -97,12 +100,15 @@ struct CnbPitch { static constexpr int value = KSC * 32 + 16; };  // bytes per h
 // Three blocks per CU (<= 168 VGPRs): measured against the two-blocks variant that double-buffered the pixel
 // fragments and register-prefetched the staging (209-237 VGPRs), thread-level parallelism wins on every 3x3 shape
 // (128->128 @100^2: 767 -> 842 TFLOP/s, @50^2: 531 -> 647): while one block stages or stores, two others multiply.
-template <int WN, int NP, int KSC>
+template <int WN, int NP, int KSC, int MPW_ = 4>
 __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int WM = 4 / WN;   // waves along the pixel columns
-  constexpr int MPW = 4;       // 32-pixel columns per wave: every weight fragment (one 16-byte global load per
-                               // lane) feeds 4 MFMAs; the block tile is 32 * 4 * WM pixels x 32 * WN couts
+  constexpr int MPW = MPW_;    // 32-pixel columns per wave: every weight fragment (one 16-byte global load per
+                               // lane) feeds MPW MFMAs; the block tile is 32 * MPW * WM pixels x 32 * WN couts.
+                               // MPW = 4 everywhere but on small planes: (WN, MPW) = (2, 2) keeps the 128-pixel tile
+                               // (5 x 25 covers 25 / 50 / 100 exactly) and halves the couts per block, i.e. doubles
+                               // the blocks of a launch that would leave half of the 256 CUs idle
   constexpr int PITCH = CnbPitch<KSC>::value;
   constexpr int PPP = KSC * 2;  // 16-byte pieces per pixel
   constexpr int KPAIRS = KSC / 2;
@@ -430,10 +436,23 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
     // 8q+4..8q+7). v_permlane32_swap trades group q of the upper half for group q+1 of the lower half, so every
     // lane ends up with 8 CONSECUTIVE couts: two 16-byte stores per pixel column instead of four 8-byte ones.
     const bool accum = g.accumulate != 0;
+    const bf16_t* __restrict__ resb = g.res[grp];
+    if (g.act != 0) {  // fused eval epilogue (BatchNorm folded into weights / bias): SiLU before the residual add
+#pragma unroll
+      for (int i = 0; i < MPW; ++i)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const float v = acc[i][j] + bsum[j];
+          acc[i][j] = v / (1.0f + __expf(-v));
+        }
+#pragma unroll
+      for (int j = 0; j < 16; ++j) bsum[j] = 0.f;  // the bias is inside the activation now
+    }
 #pragma unroll
     for (int i = 0; i < MPW; ++i) {
       CNB_GROUP_HEAD(i)
-      bf16_t* yp = reinterpret_cast<bf16_t*>(g.y[grp]) + (((long)b * g.Hout + oy) * g.Wout + ox) * g.ldy + n0;
+      const long opix = ((long)b * g.Hout + oy) * g.Wout + ox;
+      bf16_t* yp = reinterpret_cast<bf16_t*>(g.y[grp]) + opix * g.ldy + n0;
 #pragma unroll
       for (int q = 0; q < 4; q += 2) {
         unsigned a0 = cn_pack_bf16(acc[i][4 * q] + bsum[4 * q], acc[i][4 * q + 1] + bsum[4 * q + 1]);
@@ -446,9 +465,10 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
         if (!ok || n >= g.Cout) continue;
         u32x4* dst = reinterpret_cast<u32x4*>(yp + 8 * (q + h));
         u32x4 pk = {sw0[0], sw1[0], sw0[1], sw1[1]};
-        if (accum) {
+        if (accum || resb != nullptr) {
           float ov[8], nv[8];
-          cn_unpack8(*dst, ov);
+          if (resb != nullptr) cn_unpack8(*reinterpret_cast<const u32x4*>(resb + opix * g.ldres + n0 + 8 * (q + h)), ov);
+          else cn_unpack8(*dst, ov);
           cn_unpack8(pk, nv);
 #pragma unroll
           for (int e = 0; e < 8; ++e) nv[e] += ov[e];
@@ -529,6 +549,7 @@ struct CnBPackDesc {
   int T, K, N, KS, NT;
   int pad;
   long sk, sn, st;
+  const float* nscale;  // nullable: per-n (cout) factor folded into the packed copy (eval-mode BatchNorm)
 };
 
 __global__ __launch_bounds__(256) void cn_bpack_kernel(const CnBPackDesc* __restrict__ descs) {
@@ -547,6 +568,11 @@ __global__ __launch_bounds__(256) void cn_bpack_kernel(const CnBPackDesc* __rest
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       v[j] = (n < d.N && k0 + j < d.K) ? d.w[(k0 + j) * d.sk + n * d.sn + t * d.st] : 0.f;
+    if (d.nscale != nullptr && n < d.N) {
+      const float sc = d.nscale[n];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= sc;
+    }
     u32x4 o = {cn_pack_bf16(v[0], v[1]), cn_pack_bf16(v[2], v[3]), cn_pack_bf16(v[4], v[5]), cn_pack_bf16(v[6], v[7])};
     reinterpret_cast<u32x4*>(d.wp)[i] = o;
   }
@@ -556,7 +582,8 @@ extern "C" long cn_bconv_packed_elems(int T, int K, int N) {
   return (long)T * ((K + 15) / 16) * ((N + 31) / 32) * 512;
 }
 
-// descs: DEVICE array of n 64-byte records {const float* w; bf16* wp; int T, K, N, KS, NT, pad; long sk, sn, st}
+// descs: DEVICE array of n 72-byte records {const float* w; bf16* wp; int T, K, N, KS, NT, pad; long sk, sn, st;
+// const float* nscale (nullable)}
 extern "C" int cn_pack_weights_batched_bf16(const void* descs, int n, void* stream) {
   if (n <= 0) return CN_OK;
   CN_LAUNCH(cn_bpack_kernel, dim3(32, n), dim3(256), 0, (hipStream_t)stream, (const CnBPackDesc*)descs);
@@ -578,6 +605,11 @@ __global__ __launch_bounds__(256) void cn_bpack_one_kernel(const CnBPackDesc d) 
 #pragma unroll
     for (int j = 0; j < 8; ++j)
       v[j] = (n < d.N && k0 + j < d.K) ? d.w[(k0 + j) * d.sk + n * d.sn + t * d.st] : 0.f;
+    if (d.nscale != nullptr && n < d.N) {
+      const float sc = d.nscale[n];
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v[j] *= sc;
+    }
     u32x4 o = {cn_pack_bf16(v[0], v[1]), cn_pack_bf16(v[2], v[3]), cn_pack_bf16(v[4], v[5]), cn_pack_bf16(v[6], v[7])};
     reinterpret_cast<u32x4*>(d.wp)[i] = o;
   }
@@ -586,6 +618,17 @@ __global__ __launch_bounds__(256) void cn_bpack_one_kernel(const CnBPackDesc d) 
 extern "C" int cn_pack_weights_bf16(const float* w, void* wp, int T, int K, int N, long sk, long sn, long st,
                                     void* stream) {
   CnBPackDesc d = {w, (bf16_t*)wp, T, K, N, (K + 15) / 16, (N + 31) / 32, 0, sk, sn, st};
+  const long total = (long)d.T * d.KS * d.NT * 64;
+  const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
+  CN_LAUNCH(cn_bpack_one_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d);
+  return cn_check_launch();
+}
+
+// The same pack with a per-n (cout) factor folded in: W'[n] = W[n] * nscale[n] -- eval-mode BatchNorm folded into the
+// convolution that feeds it (nscale = gamma / sqrt(running_var + eps), from cn_bn_fold_f32).
+extern "C" int cn_pack_weights_scaled_bf16(const float* w, const float* nscale, void* wp, int T, int K, int N, long sk,
+                                           long sn, long st, void* stream) {
+  CnBPackDesc d = {w, (bf16_t*)wp, T, K, N, (K + 15) / 16, (N + 31) / 32, 0, sk, sn, st, nscale};
   const long total = (long)d.T * d.KS * d.NT * 64;
   const int blocks = (int)((total + 255) / 256 < 1024 ? (total + 255) / 256 : 1024);
   CN_LAUNCH(cn_bpack_one_kernel, dim3(blocks), dim3(256), 0, (hipStream_t)stream, d);
@@ -645,8 +688,16 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
       for (int t = 0; t < g.cls[c].ntaps; ++t) wt_max = g.cls[c].wt[t] > wt_max ? g.cls[c].wt[t] : wt_max;
     if ((long)(wt_max + 1) * g.KS * g.NT * 1024 >= (1L << 31)) return CN_ERR_ARG;
   }
-  const int WN = g.NT >= 4 ? 4 : (g.NT >= 2 ? 2 : 1);
+  int WN = g.NT >= 4 ? 4 : (g.NT >= 2 ? 2 : 1);
+  int MPWv = 4;
   cnb_pick_tile(Hg, Wg, g.is, span, 128 * (4 / WN), g.TH, g.TW);
+  if (WN == 4 && getenv("CN_BCONV_NO_HALF") == nullptr) {
+    // small planes (25x25 at batch 32: 160 tiles x 1 cout block on 256 CUs): two 64-cout blocks per pixel tile instead
+    long blocks = 0;
+    for (int c = 0; c < g.ncls; ++c)
+      blocks += (long)((g.cls[c].Wg + g.TW - 1) / g.TW) * ((g.cls[c].Hg + g.TH - 1) / g.TH) * g.B * ((g.NT + 3) / 4);
+    if (blocks <= 224) { WN = 2; MPWv = 2; }
+  }
   g.nblk_n = (g.NT + WN - 1) / WN;
   // halo sizes, then the chunk depth: as many 16-channel k-steps per staged image as the staging budget allows
   // (10 pieces of 16 bytes per thread), 1x1 launches preferring the deepest (one tap per chunk to amortise the
@@ -718,7 +769,10 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
       return CN_ERR_LAUNCH;
   }
   const int NPv = np <= 4 ? 4 : (np <= 6 ? 6 : 10);
-  cn_prof_name("cn_bconv_kernel<%d, %d, %d>", WN, (KSC == 2 ? NPv : (KSC == 4 ? (NPv <= 6 ? 6 : 10) : 10)), KSC);
+  if (MPWv == 2)
+    cn_prof_name("cn_bconv_kernel<%d, %d, %d, 2>", WN, (KSC == 2 ? NPv : (KSC == 4 ? (NPv <= 6 ? 6 : 10) : 10)), KSC);
+  else
+    cn_prof_name("cn_bconv_kernel<%d, %d, %d>", WN, (KSC == 2 ? NPv : (KSC == 4 ? (NPv <= 6 ? 6 : 10) : 10)), KSC);
   cn_prof_desc("bconv B%d %dx%d %d->%d cls%d taps%d s%d/%d", g.B, g.Hin, g.Win, g.Cin, g.Cout, g.ncls, g.cls[0].ntaps,
                g.is, g.os);
   cn_prof_before(stream);
@@ -729,9 +783,17 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                         \
     CN_LAUNCH((cn_bconv_kernel<WN_, NP_, KSC_>), grid, block, shmem, stream, g);                        \
   } while (0)
+#define CNB_GO3H(NP_, KSC_)                                                                                      \
+  do {                                                                                                           \
+    if (shmem > 64 * 1024)                                                                                       \
+      (void)hipFuncSetAttribute((const void*)cn_bconv_kernel<2, NP_, KSC_, 2>,                                   \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                         \
+    CN_LAUNCH((cn_bconv_kernel<2, NP_, KSC_, 2>), grid, block, shmem, stream, g);                                \
+  } while (0)
 #define CNB_GO(NP_, KSC_)                                                                                        \
   do {                                                                                                           \
-    if (WN == 4) CNB_GO3(4, NP_, KSC_); else if (WN == 2) CNB_GO3(2, NP_, KSC_); else CNB_GO3(1, NP_, KSC_);     \
+    if (MPWv == 2) CNB_GO3H(NP_, KSC_);                                                                          \
+    else if (WN == 4) CNB_GO3(4, NP_, KSC_); else if (WN == 2) CNB_GO3(2, NP_, KSC_); else CNB_GO3(1, NP_, KSC_); \
   } while (0)
   if (KSC == 2) {
     if (NPv == 4) CNB_GO(4, 2); else if (NPv == 6) CNB_GO(6, 2); else CNB_GO(10, 2);
@@ -742,6 +804,7 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
   }
 #undef CNB_GO
 #undef CNB_GO3
+#undef CNB_GO3H
   cn_prof_after(stream, 4, flops);
   return cn_check_launch();
 }
@@ -752,13 +815,16 @@ static inline int cnb_pack_d(int dy, int dx) { return (dy << 16) | (dx & 0xffff)
 static int cnb_gather(int G, const bf16_t* const* xs, long ldx, const bf16_t* const* wps, const float* const* biases,
                       void* const* ys, long ldy, long y_bs, int B, int Cin, int Hin, int Win, int Cout, int Hout,
                       int Wout, int KH, int KW, int stride, const int* pads, const int* dils, int accumulate,
-                      int out_kind, float* stats, hipStream_t stream) {
+                      int out_kind, float* stats, hipStream_t stream, int act = 0, const bf16_t* const* ress = nullptr,
+                      long ldres = 0) {
   if (G < 1 || G > CNB_MAX_GROUPS || KH * KW > CNB_MAX_TAPS || stride < 1) return CN_ERR_ARG;
   if (Hout <= 0 || Wout <= 0 || B <= 0) return CN_OK;
   CnBGeom g = {};
   for (int i = 0; i < G; ++i) {
     g.x[i] = xs[i]; g.wp[i] = wps[i]; g.bias[i] = biases ? biases[i] : nullptr; g.y[i] = ys[i];
+    g.res[i] = ress ? ress[i] : nullptr;
   }
+  g.act = act; g.ldres = ldres;
   g.ldx = ldx; g.ldy = ldy; g.y_bs = y_bs;
   g.B = B; g.Cin = Cin; g.Hin = Hin; g.Win = Win; g.Cout = Cout; g.Hout = Hout; g.Wout = Wout;
   g.is = stride; g.os = 1; g.out_kind = out_kind; g.accumulate = accumulate; g.stats = stats;
@@ -863,6 +929,24 @@ extern "C" int cn_conv2d_fwd_bf16(const void* x, long ldx, const void* wp, const
 }
 
 // G (<= 4) convolutions of one shape in one launch (the dilation branches of ResidualAConv, convolution.py:376-395).
+// Eval-mode ConvBlock2d in ONE launch (convolution.py:71-120 with BatchNorm in inference mode): the caller folds the
+// running statistics into the packed weights (cn_pack_weights_scaled_bf16: W' = W * gamma / sqrt(var + eps) per cout)
+// and into `bias` (beta - mean * gamma / sqrt(var + eps)); y = res + act(conv(x, W') + bias), act 0 = identity,
+// 1 = SiLU; res (nullable) bf16 NHWC with pixel stride ldres -- the ResUNet-a running sum (convolution.py:376-395).
+// Cout must be a multiple of 8 (bf16 NHWC fast path). No BatchNorm launch, no second pass over the activation.
+extern "C" int cn_conv2d_fwd_fused_bf16(const void* x, long ldx, const void* wp, const float* bias, const void* res,
+                                        long ldres, void* y, long ldy, int B, int Cin, int Hin, int Win, int Cout, int KH,
+                                        int KW, int stride, int pad, int dil, int act, void* stream) {
+  if (stride < 1 || (Cout & 7) || act < 0 || act > 1) return CN_ERR_ARG;
+  const int Hout = (Hin + 2 * pad - dil * (KH - 1) - 1) / stride + 1;
+  const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
+  const bf16_t* xs = (const bf16_t*)x;
+  const bf16_t* ws = (const bf16_t*)wp;
+  const bf16_t* rs = (const bf16_t*)res;
+  return cnb_gather(1, &xs, ldx, &ws, &bias, &y, ldy, 0, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride, &pad,
+                    &dil, 0, 0, nullptr, (hipStream_t)stream, act, &rs, ldres);
+}
+
 extern "C" int cn_conv2d_fwd_grouped_bf16(int G, const void* const* xs, long ldx, const void* const* wps,
                                           const float* const* biases, void* const* ys, long ldy, int B, int Cin,
                                           int Hin, int Win, int Cout, int KH, int KW, int stride, const int* pads,

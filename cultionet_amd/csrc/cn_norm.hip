@@ -1037,3 +1037,30 @@ extern "C" int cn_layernorm_c_bwd_f32(const float* x, long xbs, const float* dy,
                      x, xbs, dy, dybs, w, mu, rstd, dx, dxbs, dw, db, B, C, L, accumulate_dx);
   return cn_check_launch();
 }
+
+
+// ---------------------------------------------------------------------------------------------------------------
+// Eval-mode BatchNorm folded into the convolution in front of it (ConvBlock2d, convolution.py:71-120, in inference
+// mode): scale[c] = gamma[c] / sqrt(running_var[c] + eps), shift[c] = beta[c] - running_mean[c] * scale[c]
+// (+ conv_bias[c] * scale[c] when the convolution has a bias). The packed weights are multiplied by `scale`
+// (cn_pack_weights_scaled_bf16) and `shift` becomes the fused launch's bias.
+// ---------------------------------------------------------------------------------------------------------------
+__global__ void cn_bn_fold_kernel(const float* __restrict__ gamma, const float* __restrict__ beta,
+                                  const float* __restrict__ mean, const float* __restrict__ var,
+                                  const float* __restrict__ conv_bias, float eps, int C, float* __restrict__ scale,
+                                  float* __restrict__ shift) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  const float s = gamma[c] / sqrtf(var[c] + eps);
+  scale[c] = s;
+  shift[c] = beta[c] - mean[c] * s + (conv_bias != nullptr ? conv_bias[c] * s : 0.f);
+}
+
+extern "C" int cn_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                              const float* conv_bias, float eps, int C, float* scale, float* shift, void* stream) {
+  if (C <= 0) return CN_OK;
+  if (!gamma || !beta || !running_mean || !running_var || !scale || !shift) return CN_ERR_ARG;
+  CN_LAUNCH(cn_bn_fold_kernel, dim3((C + 255) / 256), dim3(256), 0, (hipStream_t)stream, gamma, beta, running_mean,
+            running_var, conv_bias, eps, C, scale, shift);
+  return cn_check_launch();
+}

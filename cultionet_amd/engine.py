@@ -428,8 +428,8 @@ class ParamStore:
 
                 buf = bytearray()
                 for (_pw, _attr, dst, wptr, T_, K, N, sk, sn, st) in self._packs16:
-                    buf += struct.pack("<QQiiiiiiqqq", wptr, dst.data_ptr(), T_, K, N, (K + 15) // 16, (N + 31) // 32, 0,
-                                       sk, sn, st)
+                    buf += struct.pack("<QQiiiiiiqqqQ", wptr, dst.data_ptr(), T_, K, N, (K + 15) // 16, (N + 31) // 32, 0,
+                                       sk, sn, st, 0)  # 72-byte CnBPackDesc records (nscale = NULL)
                 self._pack_table16 = torch.frombuffer(buf, dtype=torch.uint8).clone().to(self.flat.device)
             _lib.call("cn_pack_weights_batched_bf16", self._pack_table16.data_ptr(), len(self._packs16), _stream())
             for (pw, _attr, _dst, *_rest) in self._packs16:
@@ -888,6 +888,16 @@ def time_conv(x: Var, mod, tin: int) -> Var:
 
 ACT_NONE, ACT_SILU = 0, 1
 
+# bumped by every train-mode BatchNorm forward (the kernels update running_mean / running_var in place, which torch's
+# version counters do not see): invalidates the eval-mode folded weights below
+_bn_stats_epoch = 0
+
+
+def _note_bn_update(training: bool) -> None:
+    global _bn_stats_epoch
+    if training:
+        _bn_stats_epoch += 1
+
 
 def _bn_momentum(bn) -> float:
     """torch's momentum=None means a cumulative moving average (factor 1/num_batches_tracked, a device counter);
@@ -918,6 +928,7 @@ def bn_act(x: Var, bn, act: int, residual: T.Optional[Var] = None, channels: T.O
     rt = residual.t if residual is not None else None
     mom = _bn_momentum(bn)
     use_batch = training or (bn.running_mean is None)
+    _note_bn_update(training)
     _lib.call("cn_bn_act_fwd_f32", xt.data_ptr(), bstride(xt), bn.weight.data_ptr(), bn.bias.data_ptr(),
               bn.running_mean.data_ptr() if bn.running_mean is not None else None,
               bn.running_var.data_ptr() if bn.running_var is not None else None,
@@ -981,6 +992,7 @@ def bn_act_group(xs: T.Sequence[Var], bns: T.Sequence, act: int, residual: T.Opt
             raise ValueError("bn_act_group: inputs must have the same shape and strides")
     dev = xts[0].device
     use_batch = training or any(bn.running_mean is None for bn in bns)
+    _note_bn_update(training)
     tab = lambda ptrs: (ctypes.c_void_p * G)(*ptrs)
     if outs is not None:  # caller-provided outputs (e.g. channel slices of one buffer, all with the same strides)
         ys = list(outs)
@@ -1688,6 +1700,76 @@ def _conv2d_bf16(x: Var, mod, stride: int, padding: int, dilation: int, out: T.O
     return yv
 
 
+class _Fold16:
+    """Eval-mode BatchNorm folded into the bf16 packed weights of the convolution in front of it."""
+
+    __slots__ = ("wp", "scale", "shift", "key")
+
+    def __init__(self):
+        self.wp = self.scale = self.shift = None
+        self.key = None
+
+
+_EVAL_FUSION = os.environ.get("CN_EVAL_FUSION", "1") == "1"
+
+
+def eval_fusion(enabled: bool) -> bool:
+    """Switch the fused inference ConvBlock2d on / off (tests compare both forms); returns the previous setting."""
+    global _EVAL_FUSION
+    prev, _EVAL_FUSION = _EVAL_FUSION, bool(enabled)
+    return prev
+
+
+def can_fuse_eval(x: Var, bn, training: bool) -> bool:
+    """ConvBlock2d as ONE launch: inference mode, mixed-precision (bf16 NHWC) input, nothing recorded for backward,
+    running statistics present and a channel count the 16-byte NHWC stores cover."""
+    return (_EVAL_FUSION and not training and not current_tape().enabled and is16(x.t)
+            and bn.running_mean is not None and bn.weight.shape[0] % 8 == 0)
+
+
+def conv_bn_act_eval(x: Var, conv, bn, act: int, stride: int, padding: int, dilation: int,
+                     residual: T.Optional[Var] = None) -> Var:
+    """y = residual + act(BatchNorm_eval(conv(x))) in ONE launch (cn_conv2d_fwd_fused_bf16): the running statistics
+    are folded into a scaled copy of the packed weights (W' = W * gamma / sigma per cout) and a bias
+    (beta - mu * gamma / sigma); the activation and the ResUNet-a running sum ride in the conv epilogue. The folded
+    copy is refreshed when the parameters change (ParamStore version), when a train-mode forward has updated running
+    statistics anywhere (engine epoch), or when the buffers were written through torch (their version counters)."""
+    xt = x.t
+    B, Cin, H, W = xt.shape
+    w = conv.weight
+    Cout = w.shape[0]
+    KH, KW = (w.shape[2], w.shape[3]) if w.dim() == 4 else (1, 1)
+    taps = KH * KW
+    Ho = (H + 2 * padding - dilation * (KH - 1) - 1) // stride + 1
+    Wo = (W + 2 * padding - dilation * (KW - 1) - 1) // stride + 1
+    store = current_store()
+    fd = conv.__dict__.get("_cn_fold16")
+    if fd is None:
+        fd = conv.__dict__["_cn_fold16"] = _Fold16()
+    key = (id(store), store.version, _bn_stats_epoch, bn.running_mean._version, bn.running_var._version)
+    s = _stream()
+    if fd.key != key:
+        if fd.wp is None or fd.key is None or fd.key[0] != key[0]:
+            fd.wp = torch.empty(_lib.query("cn_bconv_packed_elems", taps, Cin, Cout), dtype=torch.bfloat16, device=xt.device)
+            fd.scale = torch.empty(Cout, dtype=torch.float32, device=xt.device)
+            fd.shift = torch.empty(Cout, dtype=torch.float32, device=xt.device)
+        cb = conv.bias
+        _lib.call("cn_bn_fold_f32", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
+                  bn.running_var.data_ptr(), cb.data_ptr() if cb is not None else None, float(bn.eps), Cout,
+                  fd.scale.data_ptr(), fd.shift.data_ptr(), s)
+        _lib.call("cn_pack_weights_scaled_bf16", w.data_ptr(), fd.scale.data_ptr(), fd.wp.data_ptr(), taps, Cin, Cout,
+                  taps, Cin * taps, 1, s)
+        fd.key = key
+    y = _new((B, Cout, Ho, Wo), xt)
+    rt = _check(residual.t) if residual is not None else None
+    if rt is not None and tuple(rt.shape) != (B, Cout, Ho, Wo):
+        raise ValueError("conv_bn_act_eval: the residual must have the output's shape")
+    _lib.call("cn_conv2d_fwd_fused_bf16", xt.data_ptr(), ld(xt), fd.wp.data_ptr(), fd.shift.data_ptr(),
+              rt.data_ptr() if rt is not None else None, ld(rt) if rt is not None else 0, y.data_ptr(), ld(y), B, Cin, H, W,
+              Cout, KH, KW, stride, padding, dilation, 1 if act == ACT_SILU else 0, s)
+    return Var(y, False)
+
+
 def _conv_transpose2d_bf16(x: Var, mod, stride: int, padding: int) -> Var:
     tape = current_tape()
     xt = x.t
@@ -1741,6 +1823,7 @@ def _bn_act_bf16(x: Var, bn, act: int, residual: T.Optional[Var], training: bool
     rstd = torch.empty(C, dtype=torch.float32, device=dev)
     rt = _check(residual.t) if residual is not None else None
     use_batch = training or (bn.running_mean is None)
+    _note_bn_update(training)
     sums = x.stats if use_batch else None
     _lib.call("cn_bn_act_fwd_bf16", xt.data_ptr(), ld(xt), bn.weight.data_ptr(), bn.bias.data_ptr(),
               bn.running_mean.data_ptr() if bn.running_mean is not None else None,

@@ -44,7 +44,7 @@ int cn_version(void);
 int cn_conv_kpad(int k_in);
 int cn_conv_npad(int n_out);
 int cn_pack_weights_f32(const float* w, float* wp, int T, int K, int N, long sk, long sn, long st, void* stream);
-/* Same for n tensors in one launch. descs: DEVICE array of 64-byte records
+/* Same for n tensors in one launch. descs: DEVICE array of 72-byte records
  * {const float* w; float* wp; int T, K, N, Kpad, Npad; int pad; long sk, sn, st;}. */
 int cn_pack_weights_batched_f32(const void* descs, int n, void* stream);
 
@@ -310,8 +310,22 @@ int cn_stitch_predictions_u16(const float* dist, const float* edge, const float*
  * w[k = kstep*16 + 8*(l>>5) + j][n = ntile*32 + (l&31)] of tap t, zero beyond K / N. Strides as cn_pack_weights_f32. */
 long cn_bconv_packed_elems(int T, int K, int N);
 int cn_pack_weights_bf16(const float* w, void* wp, int T, int K, int N, long sk, long sn, long st, void* stream);
-/* descs: DEVICE array of 64-byte records {const float* w; void* wp; int T, K, N, KS, NT, pad; long sk, sn, st;} */
+/* descs: DEVICE array of 72-byte records {const float* w; void* wp; int T, K, N, KS, NT, pad; long sk, sn, st;
+ * const float* nscale (nullable per-cout factor, see cn_pack_weights_scaled_bf16);} */
 int cn_pack_weights_batched_bf16(const void* descs, int n, void* stream);
+
+/* Eval-mode ConvBlock2d (convolution.py:71-120, BatchNorm in inference mode) in ONE launch:
+ * y = res + act(conv(x, W') + bias) with the running statistics folded in by the caller
+ * (cn_bn_fold_f32 -> scale / shift; cn_pack_weights_scaled_bf16 -> W' = W * scale per cout; bias = shift).
+ * act: 0 identity, 1 SiLU. res (nullable): bf16 NHWC [B,Hout,Wout,>=Cout] with pixel stride ldres (the ResUNet-a
+ * running sum, convolution.py:376-395; may alias y). Cout % 8 == 0. */
+int cn_conv2d_fwd_fused_bf16(const void* x, long ldx, const void* wp, const float* bias, const void* res, long ldres,
+                             void* y, long ldy, int B, int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride,
+                             int pad, int dil, int act, void* stream);
+int cn_pack_weights_scaled_bf16(const float* w, const float* nscale, void* wp, int T, int K, int N, long sk, long sn,
+                                long st, void* stream);
+int cn_bn_fold_f32(const float* gamma, const float* beta, const float* running_mean, const float* running_var,
+                   const float* conv_bias, float eps, int C, float* scale, float* shift, void* stream);
 
 /* nn.Conv2d forward (convolution.py:71-120). out_kind 0: y bf16 NHWC (ldy); 1: y f32 NCHW with batch stride y_bs
  * (the thin head convolutions hand over to the fp32 head kernels). stats (nullable): cn_conv2d_stats_rows_bf16(...)

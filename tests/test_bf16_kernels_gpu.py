@@ -480,3 +480,60 @@ def test_converters_and_slices_bf16():
     assert torch.equal(d.float().cpu(), _r(a + c))
     _lib.call("cn_zero_bf16", d.data_ptr(), _ld(d), B * H * W, 16, _s())
     assert float(d.float().abs().max()) == 0.0
+
+
+@pytest.mark.parametrize("case", [(2, 32, 25, 25, 64, 3, 1, 1, 1, 1, True), (1, 72, 13, 13, 128, 3, 1, 1, 1, 0, False),
+                                  (2, 16, 28, 28, 16, 3, 2, 1, 1, 0, False), (2, 40, 14, 14, 128, 1, 1, 0, 1, 1, True),
+                                  (2, 128, 50, 50, 128, 3, 1, 1, 1, 1, True), (1, 64, 20, 20, 64, 3, 1, 2, 2, 1, False),
+                                  (3, 128, 110, 110, 128, 3, 1, 1, 1, 1, True)])
+def test_conv_bn_act_fused_eval_bf16(case):
+    """cn_conv2d_fwd_fused_bf16 + cn_bn_fold_f32 + cn_pack_weights_scaled_bf16: y = res + SiLU(BN_eval(conv(x))) in one
+    launch against torch (conv2d -> batch_norm(training=False) -> silu -> + res) in fp32 on the bf16-rounded operands.
+    The folded weights W * gamma / sigma are rounded to bf16 AFTER the scaling: one more half-ulp than the unfused form,
+    hence the slightly wider tolerance (8e-3 of the output range)."""
+    from cultionet_amd import _lib
+
+    B, Cin, H, W, Cout, k, s, p, d, act, with_res = case
+    T = k * k
+    dev = _dev()
+    w = _rand(Cout, Cin, k, k, seed=2, scale=(Cin * T) ** -0.5)
+    gamma, beta = 1 + 0.2 * _rand(Cout, seed=3), 0.3 * _rand(Cout, seed=4)
+    mean = 0.2 * _rand(Cout, seed=5)
+    var = torch.rand(Cout, generator=torch.Generator().manual_seed(6)) + 0.4
+    eps = 1e-5
+    x = _r(_rand(B, Cin, H, W, seed=1))
+    scale = gamma / torch.sqrt(var + eps)
+    # reference: the folded weights as the kernel rounds them
+    wf = _r(w * scale.view(-1, 1, 1, 1))
+    yr = F.conv2d(x, wf, None, stride=s, padding=p, dilation=d) + (beta - mean * scale).view(1, -1, 1, 1)
+    if act:
+        yr = F.silu(yr)
+    Ho, Wo = yr.shape[-2:]
+    res = _r(_rand(B, Cout, Ho, Wo, seed=7)) if with_res else None
+    if with_res:
+        yr = yr + res
+    # and it is the module semantics: conv -> BatchNorm(eval) -> SiLU (+ res), up to that extra rounding
+    ym = F.batch_norm(F.conv2d(x, _r(w), None, stride=s, padding=p, dilation=d), mean, var, gamma, beta, False, 0.0, eps)
+    ym = (F.silu(ym) if act else ym) + (res if with_res else 0)
+    assert (ym - yr).abs().max() <= 2e-2 * max(1.0, float(ym.abs().max()))
+    sc = torch.empty(Cout, device=dev)
+    sh = torch.empty(Cout, device=dev)
+    gd, bd, md, vd = (t.to(dev) for t in (gamma, beta, mean, var))
+    _lib.call("cn_bn_fold_f32", gd.data_ptr(), bd.data_ptr(), md.data_ptr(), vd.data_ptr(), None, eps, Cout,
+              sc.data_ptr(), sh.data_ptr(), _s())
+    _close(sc, scale, 1e-6, "scale")
+    wd = w.to(dev)
+    wp = torch.empty(_lib.query("cn_bconv_packed_elems", T, Cin, Cout), dtype=BF, device=dev)
+    _lib.call("cn_pack_weights_scaled_bf16", wd.data_ptr(), sc.data_ptr(), wp.data_ptr(), T, Cin, Cout, T, Cin * T, 1, _s())
+    xg = _nhwc(x, ld=Cin + 8)
+    y = _empty_nhwc(B, Cout, Ho, Wo, ld=Cout + 16)
+    rg = _nhwc(res, ld=Cout + 8) if with_res else None
+    _lib.call("cn_conv2d_fwd_fused_bf16", xg.data_ptr(), _ld(xg), wp.data_ptr(), sh.data_ptr(),
+              rg.data_ptr() if with_res else None, _ld(rg) if with_res else 0, y.data_ptr(), _ld(y), B, Cin, H, W, Cout,
+              k, k, s, p, d, act, _s())
+    _close(y, yr, 8e-3, "y")
+    if with_res:  # in place: res aliases y (the ResUNet-a running sum accumulated where it lives)
+        y2 = _nhwc(res, ld=Cout + 8)
+        _lib.call("cn_conv2d_fwd_fused_bf16", xg.data_ptr(), _ld(xg), wp.data_ptr(), sh.data_ptr(), y2.data_ptr(),
+                  _ld(y2), y2.data_ptr(), _ld(y2), B, Cin, H, W, Cout, k, k, s, p, d, act, _s())
+        _close(y2, yr, 8e-3, "y in place")

@@ -97,7 +97,8 @@ def test_bf16_bench_shape_under_stream_overlap_is_stable():
     """The bench configuration in miniature (hidden 32, 100x100, weight gradients on the side stream): several steps
     back to back without a sync in between, twice from the same state -- the losses must be finite and agree run to
     run to the rounding noise of the float-atomic reductions (statistics rows of the narrow layers, LayerNorm / bias
-    gradients) and of the first call's kernel autotuning: 1e-4. (An in-flight prefetch landing in a recycled register of the conv kernel showed up exactly here: as a GPU
+    gradients), amplified over the optimizer steps in between (AdamW normalises near-zero gradients, so
+    1e-7 of summation noise moves such a parameter by a full learning-rate step): 5e-4 after four steps. (An in-flight prefetch landing in a recycled register of the conv kernel showed up exactly here: as a GPU
     memory fault, only when the second stream delayed the loads.)"""
     from cultionet_amd.data import Data
     from cultionet_amd.lightning import HipTrainer
@@ -115,7 +116,7 @@ def test_bf16_bench_shape_under_stream_overlap_is_stable():
         torch.cuda.synchronize()
         runs.append([float(l.item()) for l in ls])
     assert all(np.isfinite(v) for v in runs[0]), runs
-    assert np.abs(np.array(runs[0]) - np.array(runs[1])).max() <= 1e-4, runs
+    assert np.abs(np.array(runs[0]) - np.array(runs[1])).max() <= 5e-4, runs
     assert runs[0][-1] < runs[0][0], runs
 
 
@@ -135,6 +136,40 @@ def test_bf16_eval_forward_and_dropin_autocast(golden_dir):
     for k in KEYS:
         d = (p32[k] - p16[k].float()).abs()
         assert float(d.max()) > 0.0  # the bf16 path really ran
+        assert float(d.mean()) <= 6e-3 and float(d.max()) <= 8e-2, (k, float(d.mean()), float(d.max()))
+    # inference fuses every ConvBlock2d into ONE launch (BatchNorm folded into the packed weights, SiLU and the
+    # ResUNet-a sum in the conv epilogue): against the unfused bf16 form (conv, BatchNorm apply, ...) the maps agree to
+    # bf16 rounding, and the fused form launches far fewer kernels
+    from cultionet_amd import _lib
+    from cultionet_amd import engine as E
+
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        _lib.query("cn_launch_count", 1)
+        lit(batch)
+        n_fused = _lib.query("cn_launch_count", 1)
+        prev = E.eval_fusion(False)
+        try:
+            lit(batch)
+            n_plain = _lib.query("cn_launch_count", 1)
+            p16u = lit(batch)
+        finally:
+            E.eval_fusion(prev)
+    assert n_fused <= n_plain - 60, (n_fused, n_plain)
+    for k in KEYS:  # two different bf16 roundings of the same fp32 function: each within 6e-3 / 8e-2 of fp32 (above)
+        d = (p16u[k].float() - p16[k].float()).abs()
+        assert float(d.mean()) <= 9e-3 and float(d.max()) <= 0.12, (k, float(d.mean()), float(d.max()))
+    # a train-mode forward updates running statistics in-kernel: the folded copies must follow
+    lit.train()
+    with torch.no_grad():
+        model(batch.x * 1.5 + 0.1)
+    lit.eval()
+    with torch.no_grad():
+        q32 = lit(batch)
+        with torch.autocast("cuda", dtype=torch.bfloat16):
+            q16 = lit(batch)
+    assert float((q32["crop"] - p32["crop"]).abs().max()) > 1e-4  # the statistics did move
+    for k in KEYS:
+        d = (q32[k] - q16[k].float()).abs()
         assert float(d.mean()) <= 6e-3 and float(d.max()) <= 8e-2, (k, float(d.mean()), float(d.max()))
     lit.train()
     with torch.autocast("cuda", dtype=torch.bfloat16):
