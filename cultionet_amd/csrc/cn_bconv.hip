@@ -528,12 +528,23 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
     float tot = 0.f;
 #pragma unroll
     for (int rr = 0; rr < 32; ++rr) tot += red[(hh * 32 + rr) * 33 + jj];
+    if (WM > 1) {
+      // WM waves share a cout tile (each saw a part of the tile's pixels): combine them in LDS in a FIXED order -- no
+      // float atomics (run-to-run identical sums), no zero-fill of the rows by the launcher (a hipMemsetAsync in front
+      // of every such launch sat on the critical path with ~10-30 us of dispatch latency)
+      __syncthreads();  // every wave has read its transposed partials
+      float* comb = reinterpret_cast<float*>(lds);
+      comb[wid * 64 + lane] = tot;
+      __syncthreads();
+      tot = 0.f;
+#pragma unroll
+      for (int m = 0; m < WM; ++m) tot += comb[(m * WN + wn) * 64 + lane];
+    }
     const int j = jj & 15;
     const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-    if (n_live && n < g.Cout) {
+    if (n_live && n < g.Cout && wm == 0) {  // wid = wm * WN + wn: the wm == 0 wave of each cout tile stores the row
       float* row = g.stats + (long)tile * 2 * g.Cout + (jj >= 16 ? g.Cout : 0) + n;
-      if (WM == 1) *row = tot;   // this wave saw every pixel of the tile
-      else atomicAdd(row, tot);  // WM waves share a cout tile: few adders per address, rows zeroed by the launcher
+      *row = tot;
     }
   }
   CNB_ST(5);
@@ -762,12 +773,7 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
   size_t shmem = (size_t)max_pix * pitch + max_rowpad_bytes;
   if (g.stats != nullptr && shmem < 4 * 64 * 33 * sizeof(float)) shmem = 4 * 64 * 33 * sizeof(float);
   const dim3 grid(cn_xcd_grid(total)), block(256);
-  if (g.stats != nullptr) {
-    if (g.ncls != 1) return CN_ERR_ARG;
-    if (WN != 4 &&
-        hipMemsetAsync(g.stats, 0, sizeof(float) * 2 * g.Cout * (size_t)g.cls[0].tiles_per_img * g.B, stream) != hipSuccess)
-      return CN_ERR_LAUNCH;
-  }
+  if (g.stats != nullptr && g.ncls != 1) return CN_ERR_ARG;  // (rows are plain-stored by every tile: no zero-fill)
   const int NPv = np <= 4 ? 4 : (np <= 6 ? 6 : 10);
   if (MPWv == 2)
     cn_prof_name("cn_bconv_kernel<%d, %d, %d, 2>", WN, (KSC == 2 ? NPv : (KSC == 4 ? (NPv <= 6 ? 6 : 10) : 10)), KSC);

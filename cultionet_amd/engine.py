@@ -158,6 +158,8 @@ class Tape:
 # 13x13: a fraction of the 256 CUs each) run beside the dx chain instead of in front of it. The main stream joins
 # the side stream once, before the gradient exchange / optimizer. CN_OVERLAP_WGRAD=0 keeps everything on one stream.
 _OVERLAP_WGRAD = os.environ.get("CN_OVERLAP_WGRAD", "1") == "1"
+# diagnostic: weight gradients of more than this many multiply-accumulates stay on the compute stream (0 = no limit)
+_SIDE_MAX_WORK = float(os.environ.get("CN_SIDE_MAX_WORK", "0"))
 _side_streams: T.Dict[T.Any, T.Dict[str, T.Any]] = {}
 
 
@@ -212,12 +214,13 @@ class side_stream:
     the current stream. ``tensors`` are the buffers those launches read (kept from being recycled by the caching
     allocator until the side stream has passed them)."""
 
-    def __init__(self, *tensors: torch.Tensor):
+    def __init__(self, *tensors: torch.Tensor, work: float = 0.0):
         self.tensors = tensors
         self.ctx = None
+        self.work = work  # multiply-accumulates of the enclosed launches (0: unknown / small)
 
     def __enter__(self):
-        if not _OVERLAP_WGRAD:
+        if not _OVERLAP_WGRAD or (_SIDE_MAX_WORK > 0 and self.work > _SIDE_MAX_WORK):
             return self
         main = _main_stream()
         st = _side_state(main.device)
@@ -667,7 +670,7 @@ def conv2d(x: Var, mod, stride: int = 1, padding: int = 0, dilation: int = 1, ou
             dy = yv.grad
             if dy is None:
                 return
-            with side_stream(xt, dy):
+            with side_stream(xt, dy, work=float(B) * Ho * Wo * Cin * Cout * KH * KW):
                 s = _stream()
                 wsp, wsn = _pad_ws(xt, dy)
                 _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
@@ -727,7 +730,8 @@ def conv2d_group(xs: T.Sequence[Var], mods: T.Sequence, paddings: T.Sequence[int
             live = [i for i in range(G) if yvs[i].grad is not None]
             grouped_w = (len(live) == G and len(set(paddings)) == 1 and len(set(dilations)) == 1
                          and len({bstride(yvs[i].grad) for i in live}) == 1)
-            with side_stream(*(list(xts) + [yvs[i].grad for i in live])):
+            with side_stream(*(list(xts) + [yvs[i].grad for i in live]),
+                             work=float(G) * B * Ho * Wo * Cin * Cout * KH * KW):
                 s = _stream()
                 if grouped_w:  # one launch for the G weight gradients
                     wsp, wsn = _pad_ws(*([xts[i] for i in range(G)] + [yvs[i].grad for i in range(G)]))
@@ -1680,7 +1684,7 @@ def _conv2d_bf16(x: Var, mod, stride: int, padding: int, dilation: int, out: T.O
             dy = yv.grad
             if dy is None:
                 return
-            with side_stream(xt, dy):
+            with side_stream(xt, dy, work=float(B) * Ho * Wo * Cin * Cout * KH * KW):
                 s = _stream()
                 need = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, Cout, KH, KW, stride, padding, dilation, 0)
                 wsp, wsn = _ws16(need, xt.device)

@@ -1,13 +1,15 @@
 #!/bin/bash
-# Round evidence on the GPU box: bench JSON lines, rocprofv3 kernel stats and PMC passes for both precisions.
-# usage (through gpurun): bash tools/evidence.sh r02   -> files under gpurun_out/evidence/
+# Round evidence on the GPU box: bench JSON lines, rocprofv3 kernel stats (as shipped + isolated), queue timelines and
+# PMC passes (MFMA busy incl. GRBM_GUI_ACTIVE for the shader clock; FETCH / WRITE traffic) for both precisions.
+# usage (through gpurun): bash tools/evidence.sh r03_v1 [nopmc]   -> files under gpurun_out/evidence/
 set -u
-TAG=${1:-r02}
+TAG=${1:-r03}
+NOPMC=${2:-}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out/evidence
 mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
-python3 $R/bench.py > $O/${TAG}_bench_f32_b8.json 2> $O/bench_f32.err
+python3 $R/bench.py > $O/${TAG}_bench_default.json 2> $O/bench_default.err
 python3 $R/bench.py --dtype bf16 > $O/${TAG}_bench_bf16_b32.json 2> $O/bench_bf16.err
 for P in f32 bf16; do
   A=""; [ $P = bf16 ] && A="--dtype bf16"
@@ -18,6 +20,7 @@ for P in f32 bf16; do
   export CN_OVERLAP_WGRAD=0
   rocprofv3 --kernel-trace --stats -d $O/stats_iso_$P -o s -- python3 $R/bench.py $A --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
   python3 $R/tools/prof_db.py $O/stats_iso_$P/s_results.db 400 --csv > $O/${TAG}_bench_${P}_kernel_stats_isolated.csv
+  if [ -z "$NOPMC" ]; then
   # PMC passes also run serialized, so that a kernel's counters are its own
   rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_MFMA SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY GRBM_GUI_ACTIVE \
      --kernel-trace --output-format csv -d $O/pmc_mfma_$P -o m -- python3 $R/bench.py $A --steps 3 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
@@ -25,6 +28,7 @@ for P in f32 bf16; do
   rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $O/pmc_fetch_$P -o f -- python3 $R/bench.py $A --steps 3 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
   rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $O/pmc_write_$P -o w -- python3 $R/bench.py $A --steps 3 --warmup 2 --no-cpu-baseline --no-extras > /dev/null 2>&1
   python3 $R/tools/pmc_traffic.py $O/pmc_fetch_$P/f_counter_collection.csv $O/pmc_write_$P/w_counter_collection.csv $O/${TAG}_pmc_traffic_$P.json > $O/${TAG}_pmc_traffic_${P}_summary.txt
+  fi
   unset CN_OVERLAP_WGRAD
   rm -rf $O/stats_$P $O/stats_iso_$P $O/pmc_mfma_$P $O/pmc_fetch_$P $O/pmc_write_$P
 done
