@@ -106,9 +106,18 @@ def run_towerunet(model, x: torch.Tensor) -> T.Dict[str, torch.Tensor]:
     if torch.is_grad_enabled() and any(p.requires_grad for p in store.params):
         d, e, c = _TowerUNetFn.apply(model, x, *store.params)
         return {_KEYS[0]: d, _KEYS[1]: e, _KEYS[2]: c}
-    with E.using_store(store), E.recording(False), E.mixed_precision(_autocast_bf16(model)):
-        outs = model.forward_vars(model.input_var(x))
-    return {k: outs[k].t for k in _KEYS}
+    bf16 = _autocast_bf16(model)
+
+    def eager(xx: torch.Tensor) -> T.Dict[str, torch.Tensor]:
+        with E.using_store(store), E.recording(False), E.mixed_precision(bf16):
+            outs = model.forward_vars(model.input_var(xx))
+        return {k: outs[k].t for k in _KEYS}
+
+    if getattr(model, "replay", False) and not model.training and not torch.is_grad_enabled():
+        from . import replay  # inference through a recorded launch plan (cultionet_amd/replay.py)
+
+        return replay.forward(model, x, bf16, eager)
+    return eager(x)
 
 
 class _TanimotoFn(torch.autograd.Function):

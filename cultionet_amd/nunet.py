@@ -137,6 +137,10 @@ class TowerUNet(nn.Module):
     #: lightning.Trainer(precision=...) opens); "32-true" / "bf16-mixed" pin it (see autograd_bridge._autocast_bf16)
     precision: T.Optional[str] = None
 
+    #: inference through a recorded launch plan (cultionet_amd/replay.py): set by the sliding-window predictor; the
+    #: outputs of a replayed forward are the plan's own buffers (consume them before the next forward)
+    replay = False
+
     #: write checkpoints with the reference's key spelling ``pre_unet._orig_mod.*`` (upstream wraps pre_unet in
     #: torch.compile, nunet.py:141, so ITS strict load expects that prefix). Off by default: plain keys.
     upstream_checkpoint_keys = False

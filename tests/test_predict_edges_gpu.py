@@ -124,3 +124,44 @@ def test_device_feeder_double_buffers_raw_batches():
         seen += 1
     assert seen == len(hosts)
     assert list(feeder.iterate([])) == []
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16-mixed"])
+def test_launch_plan_replay_is_bitwise_the_eager_forward(precision):
+    """cultionet_amd/replay.py: the recorded launch plan of the eval forward replays the SAME kernels on the same
+    buffers -- mosaics are bit-identical to the eager path, for new scene data, for the ragged last batch (its own
+    plan), and plans are dropped when the parameters or the BatchNorm running statistics change."""
+    from cultionet_amd.predict import SlidingWindowPredictor
+
+    lit, _ = _pair()
+    model = lit.cultionet_model.mask_model
+    H, W, ws, pad = 70, 95, 32, 4   # 3 x 3 = 9 windows, batches of 4 -> 4, 4, 1
+    g = torch.Generator().manual_seed(9)
+    mean = torch.tensor([0.31, 0.28, 0.35])
+    std = torch.tensor([0.21, 0.19, 0.24])
+    kw = dict(window_size=ws, padding=pad, batch_size=4, mean=mean, std=std, precision=precision)
+    eager = SlidingWindowPredictor(lit, replay=False, **kw)
+    plan = SlidingWindowPredictor(lit, replay=True, **kw)
+    for rep in range(3):
+        scene = torch.randint(0, 9000, (3, 12, H, W), generator=g, dtype=torch.int32).to(torch.int16).cuda()
+        a = eager.predict_scene(scene)
+        b = plan.predict_scene(scene)
+        assert torch.equal(a, b), rep
+    plans = model.__dict__["_cn_plans"]
+    assert len(plans) == 2 and all(len(p.calls) > 50 for p in plans.values())  # full batches and the ragged last one
+    assert model.replay is False  # the predictor restores the switch
+    # parameters change -> the old plan must not be replayed
+    with torch.no_grad():
+        for p in model.final_a.parameters():
+            p.mul_(1.5)
+    a = eager.predict_scene(scene)
+    b = plan.predict_scene(scene)
+    assert torch.equal(a, b)
+    # running statistics change (train-mode forward through the HIP kernels) -> same
+    lit.train()
+    with torch.no_grad():
+        model(torch.rand(2, 3, 12, 28, 28, device="cuda"))
+    lit.eval()
+    a2 = eager.predict_scene(scene)
+    b2 = plan.predict_scene(scene)
+    assert torch.equal(a2, b2) and not torch.equal(a2, a)

@@ -9,6 +9,8 @@ from cultionet_amd.predict import SlidingWindowPredictor
 
 prec = "bf16-mixed" if (len(sys.argv) < 2 or sys.argv[1] == "bf16") else "32-true"
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 5
+bs = int(sys.argv[3]) if len(sys.argv) > 3 else 12
+rp = (sys.argv[4] != "0") if len(sys.argv) > 4 else True
 dev = torch.device("cuda:0")
 lit = CultionetLitModel(in_channels=4, in_time=25, hidden_channels=32, dropout=0.0)
 m = lit.cultionet_model.mask_model
@@ -16,7 +18,7 @@ m.load_state_dict(S.seeded_state_dict(m.state_dict()))
 lit = lit.to(dev).eval()
 HS = 600
 scene = (torch.rand(4, 25, HS, HS, generator=torch.Generator().manual_seed(11)) * 10000.0).to(torch.int16).to(dev)
-sp = SlidingWindowPredictor(lit, window_size=100, padding=5, batch_size=12, precision=prec)
+sp = SlidingWindowPredictor(lit, window_size=100, padding=5, batch_size=bs, precision=prec, replay=rp)
 for _ in range(2):
     sp.predict_scene(scene)
 torch.cuda.synchronize()
@@ -26,5 +28,5 @@ for _ in range(reps):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
-print(f"{prec}: {(t2 - t0) / reps * 1e3:.2f} ms per scene ({HS * HS / ((t2 - t0) / reps) / 1e6:.1f} Mpx/s), "
+print(f"{prec} batch {bs} replay {rp}: {(t2 - t0) / reps * 1e3:.2f} ms per scene ({HS * HS / ((t2 - t0) / reps) / 1e6:.1f} Mpx/s), "
       f"host enqueue {(t1 - t0) / reps * 1e3:.2f} ms per scene")
