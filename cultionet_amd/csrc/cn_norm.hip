@@ -8,7 +8,8 @@
 // lanes walk consecutive pixels so every access is coalesced.
 #include "cn_common.h"
 
-#define BN_SPLIT_MAX 64
+#define BN_SPLIT_MAX 256  // workspace rows per channel
+#define BN_SPLIT_GROUP 64 // cap of the grouped kernels and the channel sums (every thread walks the partials serially there)
 
 // ---------------------------------------------------------------------------
 // BatchNorm statistics: x viewed as [B][C][L] (batch stride xbs). Partial sums in fp64.
@@ -53,6 +54,20 @@ __global__ __launch_bounds__(256) void cn_bn_partial_kernel(const float* __restr
   }
 }
 
+// Sum of a channel's `splits` partial pairs by the whole block (thread t takes partials t, t + 256, ...): every thread
+// returns the totals.
+__device__ __forceinline__ void cn_bn_sum_parts(const double* __restrict__ part, int c, int splits, double& s,
+                                                double& ss) {
+  __shared__ double scratch[4];
+  double a = 0.0, b = 0.0;
+  for (int i = threadIdx.x; i < splits; i += 256) {
+    a += part[((long)c * splits + i) * 2 + 0];
+    b += part[((long)c * splits + i) * 2 + 1];
+  }
+  s = cn_block_sum<double, 256>(a, scratch);
+  ss = cn_block_sum<double, 256>(b, scratch);
+}
+
 // Eval mode: mean/rstd from running statistics.
 __global__ void cn_bn_eval_stats_kernel(const float* __restrict__ running_mean, const float* __restrict__ running_var,
                                         int C, float eps, float* __restrict__ mean, float* __restrict__ rstd) {
@@ -78,11 +93,8 @@ __global__ __launch_bounds__(256) void cn_bn_apply_kernel(const float* __restric
   const int c = blockIdx.y, b = blockIdx.z;
   float m, rs;
   if (part != nullptr) {
-    double s = 0.0, ss = 0.0;
-    for (int i = 0; i < splits; ++i) {
-      s += part[((long)c * splits + i) * 2 + 0];
-      ss += part[((long)c * splits + i) * 2 + 1];
-    }
+    double s, ss;
+    cn_bn_sum_parts(part, c, splits, s, ss);
     const double md = s / count;
     double var = ss / count - md * md;
     if (var < 0.0) var = 0.0;
@@ -180,11 +192,8 @@ __global__ __launch_bounds__(256) void cn_bn_bwd_apply_kernel(const float* __res
                                                              int accumulate_params, float* __restrict__ dx, long dxbs,
                                                              int B, int C, int L, int act, int accumulate) {
   const int c = blockIdx.y, b = blockIdx.z;
-  double s1 = 0.0, s2 = 0.0;
-  for (int i = 0; i < splits; ++i) {
-    s1 += part[((long)c * splits + i) * 2 + 0];
-    s2 += part[((long)c * splits + i) * 2 + 1];
-  }
+  double s1, s2;
+  cn_bn_sum_parts(part, c, splits, s1, s2);
   if (blockIdx.x == 0 && b == 0 && threadIdx.x == 0) {
     if (accumulate_params) {
       dgamma[c] += (float)s2;
@@ -328,11 +337,22 @@ __global__ __launch_bounds__(256) void cn_bn_fused_bwd_kernel(const float* __res
 
 #define BN_FUSED_MAX (8 * 256)  // larger channels are faster as two wide launches than as one block per channel
 
+// Single BatchNorm with few channels (BatchNorm3d of the time reduction: C = 3 channels of 3.2M elements at batch 32
+// were 192 blocks on 256 CUs, ~2 TB/s): up to 256 splits per channel, reduced block-parallel by the apply kernels.
+static int bn_splits_wide(int C, long L) {
+  int s = (2048 + C - 1) / C;
+  const long maxs = (L + 511) / 512;
+  if (s > maxs) s = (int)maxs;
+  if (s > BN_SPLIT_MAX) s = BN_SPLIT_MAX;
+  if (s < 1) s = 1;
+  return s;
+}
+
 static int bn_splits(int C, long L) {
   int s = (1024 + C - 1) / C;
   const long maxs = (L + 511) / 512;
   if (s > maxs) s = (int)maxs;
-  if (s > BN_SPLIT_MAX) s = BN_SPLIT_MAX;
+  if (s > BN_SPLIT_GROUP) s = BN_SPLIT_GROUP;
   if (s < 1) s = 1;
   return s;
 }
@@ -363,7 +383,7 @@ extern "C" int cn_bn_act_fwd_f32(const float* x, long xbs, const float* gamma, c
     return cn_check_launch();
   }
   if (training) {
-    const int splits = bn_splits(C, L);
+    const int splits = bn_splits_wide(C, L);
     CN_LAUNCH(cn_bn_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, B, C, L, splits, ws,
                        (int)(L % 4 == 0 && xbs % 4 == 0 && (reinterpret_cast<uintptr_t>(x) & 15) == 0));
     CN_LAUNCH(cn_bn_apply_kernel, plane_grid(B, C, L), dim3(256), 0, stream, x, xbs, mean, rstd, gamma, beta,
@@ -395,7 +415,7 @@ extern "C" int cn_bn_act_bwd_f32(const float* x, long xbs, const float* dy, long
 #undef CN_BN_BWD
     return cn_check_launch();
   }
-  const int splits = bn_splits(C, L);
+  const int splits = bn_splits_wide(C, L);
   CN_LAUNCH(cn_bn_bwd_partial_kernel, dim3(C, splits), dim3(256), 0, stream, x, xbs, dy, dybs, mean, rstd,
                      gamma, beta, B, C, L, act, splits, ws,
                      (int)(L % 4 == 0 && xbs % 4 == 0 && dybs % 4 == 0 &&
