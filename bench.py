@@ -35,7 +35,7 @@ import time
 
 # compute, weight-gradient and RCCL bucket streams must not share a hardware queue (see cultionet_amd/__init__.py);
 # set before anything initialises the HIP runtime
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
@@ -663,6 +663,8 @@ def main():
     if extras and not bf16 and args.batch is None:
         del leg
         torch.cuda.empty_cache()
+        # (the SAME GradientAllReduce object: a second one -- a second bucket stream in the process -- was measured at
+        # 1046 instead of 1754 chips/s for this block with a one-rank RCCL group; a fresh process gets 1866)
         leg16 = TrainLeg(dev, rank, world, comm, use_dist, "bf16", 32, args.hidden)
         rec16 = leg16.run(args.steps, args.warmup, extras and world == 1)
         if rank == 0:
