@@ -35,7 +35,7 @@ import time
 
 # compute, weight-gradient and RCCL bucket streams must not share a hardware queue (see cultionet_amd/__init__.py);
 # set before anything initialises the HIP runtime
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
