@@ -28,6 +28,7 @@ from __future__ import annotations
 
 import argparse
 import ctypes
+import typing
 import json
 import os
 import sys
@@ -61,6 +62,8 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the streaming-kernel pass and the predict block")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = best of the documented sweep (16)")
+    ap.add_argument("--child", choices=("train", "predict"), default=None,
+                    help="internal: one block of the default line in a process of its own (see run_child)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch + rendezvous check only (gloo, no GPU, no kernels): what tests/test_bench_launch.py runs")
     return ap.parse_args()
@@ -348,6 +351,26 @@ def launch_ranks(args) -> int:
     if line is not None:
         print(line, flush=True)
     return proc.returncode if (proc.returncode != 0 or line is not None) else 1
+
+
+def run_child(kind: str, args, extra: typing.Sequence[str] = ()) -> dict:
+    """One block of the default line -- the bf16 configuration, the predict scene -- in a FRESH child process of rank 0
+    (N = 1 only). Which HIP streams end up sharing a hardware queue depends on the creation history of a process
+    (DESIGN.md section 7): the second configuration of a process measured 1611-1937 chips/s where a process of its own
+    gets 1900-1955. A child is started (never exec'ed), after this process has released its GPU memory."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--child", kind, "--gpus", "1", "--steps", str(args.steps),
+           "--warmup", str(args.warmup), "--hidden", str(args.hidden), "--cpu-threads", str(args.cpu_threads)]
+    cmd += list(extra)
+    if args.no_cpu_baseline:
+        cmd.append("--no-cpu-baseline")
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    for ln in proc.stdout.splitlines():
+        if ln.startswith("{"):
+            return json.loads(ln)
+    raise RuntimeError(f"bench child {kind!r} failed (rc {proc.returncode})")
 
 
 class TrainLeg:
@@ -638,9 +661,13 @@ def main():
 
     _lib.load()
     TrainLeg.rccl_ranks = rccl_ranks
+    if args.child == "predict":  # the predict block alone (child of a default run)
+        print(json.dumps(predict_block(dev, args.hidden, not args.no_cpu_baseline, args.cpu_threads)), flush=True)
+        return
     bf16 = args.dtype == "bf16"
     B = args.batch if args.batch is not None else (32 if bf16 else 8)
     extras = not args.no_extras
+    child = args.child == "train"
     leg = TrainLeg(dev, rank, world, comm, use_dist, args.dtype, B, args.hidden)
     rec = leg.run(args.steps, args.warmup, extras)
     out = None
@@ -650,35 +677,51 @@ def main():
                "steps": args.steps, "warmup": args.warmup, "ms_per_step": rec["ms_per_step"], "higher_is_better": True,
                "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic", "config": rec["config"],
                "roofline": rec["roofline"]}
+        if child:
+            out["first_loss"] = first_loss
         if world == 1 and extras:
             out["roofline"]["streaming"] = streaming_pass(leg.trainer, leg.batch)
-            out["feed"] = feed_block(leg, min(args.steps, 20), rec["ms_per_step"])
-        if world == 1 and not args.no_cpu_baseline:
+            if not child:
+                out["feed"] = feed_block(leg, min(args.steps, 20), rec["ms_per_step"])
+        if world == 1 and not args.no_cpu_baseline and not child:
             out["cpu_baseline"], cpu_first = cpu_baseline(B, args.hidden, args.cpu_steps, args.cpu_threads)
             if first_loss is not None:
                 out["loss_delta_vs_cpu"] = {"hip_step1_loss": first_loss, "cpu_step1_loss": cpu_first,
                                             "abs_delta": abs(first_loss - cpu_first),
                                             "tolerance": 5e-4 if bf16 else 1e-4}
     # BASELINE configs[2] (and, under N ranks, configs[3]): batch 32 per GPU in bf16 mixed precision, its own timed steps
-    if extras and not bf16 and args.batch is None:
+    if extras and not bf16 and args.batch is None and not child:
         del leg
         torch.cuda.empty_cache()
-        # (the SAME GradientAllReduce object: a second one -- a second bucket stream in the process -- was measured at
-        # 1046 instead of 1754 chips/s for this block with a one-rank RCCL group; a fresh process gets 1866)
-        leg16 = TrainLeg(dev, rank, world, comm, use_dist, "bf16", 32, args.hidden)
-        rec16 = leg16.run(args.steps, args.warmup, extras and world == 1)
+        if not use_dist:
+            # N = 1: a process of its own (run_child), so the block is exactly `python bench.py --dtype bf16`
+            c = run_child("train", args, ["--dtype", "bf16"])
+            rec16 = {k: c[k] for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "config", "roofline")}
+            rec16["process"] = "child of rank 0 (fresh HIP context)"
+            fl16 = c.get("first_loss")
+        else:
+            # N ranks: the ranks cannot relaunch themselves, so the second configuration runs in this process, with the
+            # SAME GradientAllReduce object (a second bucket stream measured 1046 instead of 1754 chips/s with a one-rank
+            # RCCL group; a fresh process gets 1866)
+            leg16 = TrainLeg(dev, rank, world, comm, use_dist, "bf16", 32, args.hidden)
+            rec16 = leg16.run(args.steps, args.warmup, False)
+            fl16 = rec16.pop("_first_loss") if rank == 0 else None
+            if rank == 0:
+                rec16["process"] = "second configuration of the rank processes"
+            del leg16
+            torch.cuda.empty_cache()
         if rank == 0:
-            fl16 = rec16.pop("_first_loss")
             if world == 1 and not args.no_cpu_baseline and fl16 is not None:
                 c16 = cpu_first_loss(32, args.hidden, args.cpu_threads)  # forward + loss only: a few seconds
                 rec16["loss_delta_vs_cpu"] = {"hip_step1_loss": fl16, "cpu_step1_loss": c16,
                                               "abs_delta": abs(fl16 - c16), "tolerance": 5e-4}
                 rec16["vs_cpu_baseline"] = rec16["value"] / out["cpu_baseline"]["value"]  # the batch-8 CPU leg's rate
             out["bf16"] = rec16
-        del leg16
-        torch.cuda.empty_cache()
-    if rank == 0 and world == 1 and extras and not bf16:
-        out["predict"] = predict_block(dev, args.hidden, not args.no_cpu_baseline, args.cpu_threads)
+    if rank == 0 and world == 1 and extras and not bf16 and not child and args.batch is None:
+        if not use_dist:
+            out["predict"] = run_child("predict", args)
+        else:
+            out["predict"] = predict_block(dev, args.hidden, not args.no_cpu_baseline, args.cpu_threads)
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

@@ -2,7 +2,7 @@
 # A/B runs of the bench on ONE box: each "NAME ENV..." line = one configuration, both precisions, 2 repeats
 set -u
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r03_ab}
+O=$R/gpurun_out/${1:-ab}
 mkdir -p $O
 cd $R
 run() {

@@ -2,7 +2,7 @@
 # per-launch dumps (CN_PROF_DUMP) of the contraction kernels for both precisions, isolated (side stream off)
 set -u
 R=$GRAFT_REPO_ROOT
-O=$R/gpurun_out/${1:-r03_layers}
+O=$R/gpurun_out/${1:-layers}
 mkdir -p $O
 cd $R
 for P in f32 bf16; do
