@@ -11,6 +11,9 @@ mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 python3 $R/bench.py > $O/${TAG}_bench_default.json 2> $O/bench_default.err
 python3 $R/bench.py --dtype bf16 > $O/${TAG}_bench_bf16_b32.json 2> $O/bench_bf16.err
+# hidden 64 = the reference CLI's default width (scripts/args.yml:220-226), both precisions, short runs
+python3 $R/bench.py --hidden 64 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/${TAG}_bench_f32_b8_h64.json 2> $O/bench_h64.err
+python3 $R/bench.py --hidden 64 --dtype bf16 --batch 16 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/${TAG}_bench_bf16_b16_h64.json 2>> $O/bench_h64.err
 for P in f32 bf16; do
   A=""; [ $P = bf16 ] && A="--dtype bf16"
   rocprofv3 --kernel-trace --stats -d $O/stats_$P -o s -- python3 $R/bench.py $A --steps 10 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
