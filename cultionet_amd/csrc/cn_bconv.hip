@@ -778,7 +778,7 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
   if (MPWv == 2)
     cn_prof_name("cn_bconv_kernel<%d, %d, %d, 2>", WN, (KSC == 2 ? NPv : (KSC == 4 ? (NPv <= 6 ? 6 : 10) : 10)), KSC);
   else
-    cn_prof_name("cn_bconv_kernel<%d, %d, %d>", WN, (KSC == 2 ? NPv : (KSC == 4 ? (NPv <= 6 ? 6 : 10) : 10)), KSC);
+    cn_prof_name("cn_bconv_kernel<%d, %d, %d, 4>", WN, (KSC == 2 ? NPv : (KSC == 4 ? (NPv <= 6 ? 6 : 10) : 10)), KSC);
   cn_prof_desc("bconv B%d %dx%d %d->%d cls%d taps%d s%d/%d", g.B, g.Hin, g.Win, g.Cin, g.Cout, g.ncls, g.cls[0].ntaps,
                g.is, g.os);
   cn_prof_before(stream);
