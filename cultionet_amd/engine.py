@@ -27,6 +27,19 @@ from . import _lib
 _state = threading.local()
 
 
+# ---- launch-plan recording (cultionet_amd/replay.py) ----------------------------------------------------------------
+# While a plan is being recorded, every stream / event operation and every host-side torch call that launches work is
+# routed through _py_op so that the plan can repeat it; C-ABI calls are captured by a recording _lib.call.
+_recorder: T.Optional[T.List] = None
+
+
+def _py_op(fn: T.Callable, *args) -> None:
+    """Run ``fn(*args)`` now and, while a launch plan is being recorded, append it to the plan."""
+    fn(*args)
+    if _recorder is not None:
+        _recorder.append((1, fn, args))
+
+
 def _main_stream() -> "torch.cuda.Stream":
     """torch's current stream, looked up once per ``using_store`` scope (a forward, a backward or a whole native step:
     the stream cannot change inside one) -- ``torch.cuda.current_stream()`` costs ~11 us, and at ~420 launches per step
@@ -224,8 +237,8 @@ class side_stream:
             return self
         main = _main_stream()
         st = _side_state(main.device)
-        st["event"].record(main)
-        st["stream"].wait_event(st["event"])
+        _py_op(st["event"].record, main)
+        _py_op(st["stream"].wait_event, st["event"])
         st["dirty"] = True
         self.st = st
         # launches go through the C ABI with an explicit stream handle: redirect _stream() instead of switching torch's
@@ -252,7 +265,7 @@ def join_side_stream() -> None:
     main = _main_stream()
     st = _side_streams.get(main.device)
     if st is not None and st["dirty"]:
-        main.wait_stream(st["stream"])
+        _py_op(main.wait_stream, st["stream"])
         st["dirty"] = False
 
 
@@ -1178,7 +1191,8 @@ def spatial_channel_attention(skip: Var, out: Var, mod) -> Var:
             if skip.req:
                 dpool = pv.grad
                 if dpool is None:
-                    dpool = torch.zeros_like(pooled)
+                    dpool = torch.empty_like(pooled)
+                    _lib.call("cn_fill_f32", dpool.data_ptr(), dpool.numel(), 0.0, s2)
                 dx, acc = grad_buffer(skip)
                 _lib.call("cn_sca_pool_bwd_f32", davg.data_ptr(), dmx.data_ptr(), idx.data_ptr(), dpool.data_ptr(),
                           cidx.data_ptr(), dx.data_ptr(), bstride(dx), B, C, L, acc, s2)

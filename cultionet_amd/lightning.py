@@ -522,8 +522,14 @@ class HipTrainer:
 
     def __init__(self, lit: CultionetLitModel, gradient_clip_val: T.Optional[float] = 1.0,
                  lr_fn: T.Optional[T.Callable[[int], T.Union[float, T.Tuple[float, float]]]] = None, comm=None,
-                 total_steps: T.Optional[int] = None, precision: str = "32-true"):
+                 total_steps: T.Optional[int] = None, precision: str = "32-true", replay: bool = False):
         self.lit = lit
+        # replay=True: forward + loss + backward run from a recorded launch plan after the first steps
+        # (cultionet_amd/replay.py): the Python of a step drops from ~8-10 ms to ~1.5 ms, which is what bounds the step at
+        # the reference's default batch of 4 in mixed precision. Needs dropout == 0 and no communicator (else eager).
+        self.replay = bool(replay)
+        self._plan = None
+        self._eager_steps = 0
         self.model = lit.cultionet_model.mask_model
         self.store = self.model.param_store()
         dev = self.store.flat.device
@@ -562,6 +568,24 @@ class HipTrainer:
 
     def forward_backward(self, batch: Data) -> torch.Tensor:
         """Forward + loss + backward; leaves d(loss)/d(params) in store.flat_grad. Returns the loss (1-elem tensor)."""
+        if self.replay and self.comm is None and self.model.training and not self._has_dropout():
+            from . import replay as R
+
+            if self._plan is not None and self._plan.key == R.step_key(self, batch):
+                R.replay_step(self._plan, batch)
+                self.last_outputs = self._plan.outputs
+                return self.total
+            if self._eager_steps >= 2:  # everything lazily created exists by now: record this step
+                self._plan = R.record_step(self, batch, self._forward_backward_eager)
+                return self.total
+        self._eager_steps += 1
+        return self._forward_backward_eager(batch)
+
+    def _has_dropout(self) -> bool:
+        return any(isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)) and m.p > 0 for m in self.model.modules()) or \
+            any(getattr(m, "attn_drop", 0.0) > 0 or getattr(m, "proj_drop", 0.0) > 0 for m in self.model.modules())
+
+    def _forward_backward_eager(self, batch: Data) -> torch.Tensor:
         from . import _lib
 
         lit, store = self.lit, self.store

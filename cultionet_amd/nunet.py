@@ -184,7 +184,7 @@ class TowerUNet(nn.Module):
         out_b = self.final_b(tow["x_tower_b"], size=size, suffix="_b")
         out_c = self.final_c(tow["x_tower_c"], size=size, suffix="_c")
         if self.training:
-            torch._foreach_add_(self.__dict__["_cn_nbt"], 1)  # BatchNorm bookkeeping (not arithmetic on the path)
+            E._py_op(torch._foreach_add_, self.__dict__["_cn_nbt"], 1)  # BatchNorm bookkeeping (not arithmetic on the path)
         return self.final_combine(out_a, out_b, out_c, suffixes=["_a", "_b", "_c"])
 
     def input_var(self, x: torch.Tensor) -> E.Var:

@@ -105,3 +105,108 @@ def forward(model, x: torch.Tensor, bf16: bool, run: T.Callable[[torch.Tensor], 
     plan.key = _key(model, store, x, bf16)  # (recording may have refreshed packed weights: the key after it)
     plans[slot] = plan
     return plan.outputs
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# The native TRAINING step (forward + loss + backward of HipTrainer) as a launch plan.
+#
+# At the reference's defaults -- batch 4, precision "16-mixed" (scripts/args.yml:248-254, model.py:168-186) -- the step
+# is ~2.5-4 ms of GPU work behind ~9.8 ms of Python (the tape, ~470 C-ABI calls, ~2400 small torch calls): host-bound.
+# The same recording trick as above, with what a training step adds:
+#   * two streams: the weight-gradient side stream's event record / wait calls and the final join are part of the plan
+#     (engine._py_op), in program order;
+#   * NO buffer is reused inside a recorded step. The caching allocator makes cross-stream reuse safe EAGERLY by looking
+#     at events when a block is freed; a replay has no such check, so a block that held a weight gradient's operand and
+#     was later handed to the compute stream would be a race. While recording, every tensor torch hands out is kept alive
+#     (torch.empty / empty_like / zeros_like are wrapped), so each kernel of the step has buffers of its own; the price
+#     is memory (the sum of a step's allocations instead of its peak), which is what 288 GB are for;
+#   * the optimizer (clip + AdamW: two launches with per-step scalars) stays outside the plan.
+# Valid for one (batch shapes, precision, stream, store, loss kind); dropout > 0 (per-step seeds) and a communicator
+# (per-bucket collectives) fall back to the eager step. Bit-exact w.r.t. the eager step except where the eager step itself
+# is not (float-atomic parameter-gradient sums): tests/test_replay_train_gpu.py.
+# ---------------------------------------------------------------------------------------------------------------------
+class StepPlan:
+    __slots__ = ("ops", "pool", "keep", "inputs", "outputs", "key", "n_calls")
+
+    def __init__(self):
+        self.ops: T.List[T.Tuple[int, T.Any, tuple]] = []
+        self.pool = None
+        self.keep: T.List[torch.Tensor] = []
+        self.inputs: T.Optional[T.Tuple[torch.Tensor, torch.Tensor, torch.Tensor]] = None
+        self.outputs: T.Optional[T.Dict[str, torch.Tensor]] = None
+        self.key = None
+        self.n_calls = 0
+
+
+def step_key(trainer, batch) -> tuple:
+    x, y, bd = batch.x, batch.y, batch.bdist
+    return (tuple(x.shape), x.dtype, tuple(y.shape), y.dtype, tuple(bd.shape), bd.dtype, trainer.bf16, id(trainer.store),
+            str(trainer.lit.loss_name), torch.cuda.current_stream(x.device).cuda_stream, E._OVERLAP_WGRAD)
+
+
+def record_step(trainer, batch, eager: T.Callable) -> StepPlan:
+    """Record ``eager(plan_batch)`` (HipTrainer's forward + loss + backward) into a StepPlan. The caller has run at least
+    two eager steps before (every lazily created workspace, packed weight and stream exists)."""
+    from .data import Data
+
+    plan = StepPlan()
+    plan.pool = torch.cuda.MemPool()
+    lib = _lib.load()
+    orig_call = _lib.call
+    ops = plan.ops
+
+    def recording(name: str, *args):
+        fn = getattr(lib, name)
+        rc = fn(*args)
+        if rc != 0:
+            raise _lib.HipKernelError(f"{name} failed: {_lib.ERRORS.get(rc, rc)}")
+        ops.append((0, fn, args))
+        return rc
+
+    wrapped = {}
+
+    def keepalive(fname):
+        real = getattr(torch, fname)
+
+        def f(*a, **k):
+            t = real(*a, **k)
+            plan.keep.append(t)
+            return t
+
+        wrapped[fname] = real
+        setattr(torch, fname, f)
+
+    with torch.cuda.use_mem_pool(plan.pool):
+        plan.inputs = (torch.empty_like(batch.x), torch.empty_like(batch.y), torch.empty_like(batch.bdist))
+        for dst, src in zip(plan.inputs, (batch.x, batch.y, batch.bdist)):
+            dst.copy_(src)
+        pb = Data(x=plan.inputs[0], y=plan.inputs[1], bdist=plan.inputs[2])
+        for fname in ("empty", "empty_like", "zeros_like"):
+            keepalive(fname)
+        _lib.call = recording
+        E._recorder = ops
+        try:
+            eager(pb)
+        finally:
+            E._recorder = None
+            _lib.call = orig_call
+            for fname, real in wrapped.items():
+                setattr(torch, fname, real)
+    plan.outputs = dict(trainer.last_outputs)
+    plan.key = step_key(trainer, batch)
+    plan.n_calls = sum(1 for o in ops if o[0] == 0)
+    return plan
+
+
+def replay_step(plan: StepPlan, batch) -> None:
+    for dst, src in zip(plan.inputs, (batch.x, batch.y, batch.bdist)):
+        if dst.data_ptr() != src.data_ptr():
+            dst.copy_(src)
+    for kind, fn, args in plan.ops:
+        if kind == 0:
+            rc = fn(*args)
+            if rc != 0:
+                raise _lib.HipKernelError(f"replayed launch failed: {_lib.ERRORS.get(rc, rc)}")
+        else:
+            fn(*args)
+    E._note_bn_update(True)  # the recorded BatchNorm launches updated running statistics: invalidate eval-mode folds
