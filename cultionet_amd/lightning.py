@@ -529,6 +529,7 @@ class HipTrainer:
         # the reference's default batch of 4 in mixed precision. Needs dropout == 0 and no communicator (else eager).
         self.replay = bool(replay)
         self._plan = None
+        self._plan_key = None
         self._eager_steps = 0
         self.model = lit.cultionet_model.mask_model
         self.store = self.model.param_store()
@@ -571,10 +572,13 @@ class HipTrainer:
         if self.replay and self.comm is None and self.model.training and not self._has_dropout():
             from . import replay as R
 
-            if self._plan is not None and self._plan.key == R.step_key(self, batch):
+            key = R.step_key(self, batch)
+            if self._plan is not None and self._plan.key == key:
                 R.replay_step(self._plan, batch)
                 self.last_outputs = self._plan.outputs
                 return self.total
+            if self._plan_key != key:  # new shapes / stream: two eager steps first (workspaces grow, packs are built)
+                self._plan_key, self._eager_steps, self._plan = key, 0, None
             if self._eager_steps >= 2:  # everything lazily created exists by now: record this step
                 self._plan = R.record_step(self, batch, self._forward_backward_eager)
                 return self.total

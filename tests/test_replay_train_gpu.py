@@ -67,7 +67,10 @@ def test_replay_falls_back_for_new_shapes_and_dropout():
     x, y, bd = S.seeded_batch(3, height=28, width=28, seed=9)  # another batch size: a new plan, not a wrong replay
     other = Data(x=x.cuda(), y=y.cuda(), bdist=bd.cuda())
     l_plan = float(plan.training_step(other).item())
-    assert plan._plan is not first and np.isfinite(l_plan)
+    assert plan._plan is None and np.isfinite(l_plan)  # eager again for the new shape ...
+    for _ in range(3):
+        plan.training_step(other)
+    assert plan._plan is not None and plan._plan is not first  # ... until its own plan is recorded
     # dropout > 0 needs a fresh seed per step: the trainer stays eager
     lit = CultionetLitModel(in_channels=3, in_time=12, hidden_channels=8, dropout=0.1).to("cuda:0").train()
     tr = HipTrainer(lit, replay=True)
