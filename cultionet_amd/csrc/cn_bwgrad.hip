@@ -14,9 +14,14 @@
 // channels per 16-lane group, column-major), and because every row of a transposed block is addressed by its own
 // lane, a tap is again just a row offset into the halo image -- no alignment constraints, no shifted copies.
 //
-// Block = 4 waves = 64 cP x 64 cQ x all T taps (wave = 32 x 32 x T, T*16 accumulator registers); it walks a
-// contiguous range of pixel tiles (split-K over tiles) and stores its partial [T][64][64] fp32 slice into the
-// workspace; cn_bwgrad_reduce_kernel sums the slices into dW (+=).
+// Block = 4 waves = 64 cP x 64 cQ x all T taps, T*16 accumulator registers per wave; it walks a contiguous range of
+// pixel tiles (split-K over tiles) and stores its partial [T][64][64] fp32 slice into the workspace;
+// cn_bwgrad_reduce_kernel sums the slices into dW (+=).
+//   1x1: wave = one 32 x 32 quadrant.
+//   3x3: wave = ALL FOUR quadrants of two taps + one quadrant of the centre tap (9 MFMAs per k-step either way). With a
+//   quadrant x 9 taps per wave every k-step read 2 + 18 transposed fragments for 9 MFMAs: 4 waves x 20 x 4 cycles = 320
+//   cycles of LDS for 288 cycles of matrix pipe -- the multiplication phase was LDS-bound (2888 of a tile's 5090 cycles,
+//   tools/bwgrad_stamps.py). Two P fragments x (2 taps x 2 Q fragments) + the centre's = 14 reads per k-step: 224.
 #include "cn_bf16.h"
 #include "cn_profile.h"
 
@@ -101,9 +106,18 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
       qrow[ks * 2 + e] = (m < npix ? ((ty * g.s) * IW + tx * g.s) * CNW_PITCH : 0) + wq * 64 + colb + 128 * CNW_PITCH;
     }
   const int prow0 = (kh8 + rq) * CNW_PITCH + wp * 64 + colb;
-  int doff[T];
+  // 3x3: fragment 0 of either operand is the wave's OWN quadrant (wp / wq: the centre tap's), fragment 1 the other one
+  const int pflip = 64 - 128 * wp, qflip = 64 - 128 * wq;
+  const int ta = wid < 2 ? 2 * wid : 2 * wid + 1;  // taps ta, ta + 1 (0 1 | 2 3 | 5 6 | 7 8) and a quarter of tap 4
+  constexpr int TB = T == 9 ? 5 : T;               // Q fragments per k-step and set
+  int doff[TB];
+  if constexpr (T == 9) {
+    doff[0] = g.doff[ta]; doff[1] = g.doff[ta] + qflip; doff[2] = g.doff[ta + 1]; doff[3] = g.doff[ta + 1] + qflip;
+    doff[4] = g.doff[4];
+  } else {
 #pragma unroll
-  for (int t = 0; t < T; ++t) doff[t] = g.doff[t];
+    for (int t = 0; t < T; ++t) doff[t] = g.doff[t];
+  }
 
   f32x16 acc[T];
 #pragma unroll
@@ -194,6 +208,36 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
       if (++fty == tiles_y) { fty = 0; ++fb; }
     }
   };
+  // The same fetch in pieces, for the kernels that issue it BETWEEN the MFMAs of the running tile (TRICKLE below): the
+  // scalar part (cursor, two buffer resources, limits) and twelve independent (offset select + load) pieces. `live` =
+  // there is a next tile; otherwise every lane's offset is out of range (zeros, no memory access, no branch).
+  __amdgpu_buffer_rsrc_t tprs, tqrs;
+  int tylim = 0, txlim = 0, tqy0 = 0, tqx0 = 0, thq = 0;
+  auto fetch_setup = [&](bool live) __attribute__((always_inline)) {
+    const int gy0 = fty * g.TH, gx0 = ftx * g.TW;
+    tprs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(g.P + (((long)fb * g.Hg + gy0) * g.Wg + gx0) * g.ldp + cp0), 0, 0x7fffffff, 0x00020000);
+    tylim = live ? g.Hg - gy0 : 0;
+    txlim = g.Wg - gx0;
+    tqy0 = gy0 * g.s + g.qy_off;
+    tqx0 = gx0 * g.s + g.qx_off;
+    thq = live ? g.Hq : 0;
+    tqrs = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<bf16_t*>(g.Q + (((long)fb * g.Hq + tqy0) * g.Wq + tqx0) * g.ldq + cq0), 0, 0x7fffffff, 0x00020000);
+    if (++ftx == g.tiles_x) {
+      ftx = 0;
+      if (++fty == tiles_y) { fty = 0; ++fb; }
+    }
+  };
+  auto fetch_p = [&](int i, u32x4 (&pv)[4]) __attribute__((always_inline)) {
+    const unsigned off = (pty[i] < tylim && ptx[i] < txlim) ? pob[i] : CNW_OOB;
+    pv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(tprs, off, 0, 0));
+  };
+  auto fetch_q = [&](int i, u32x4 (&qv)[NQR]) __attribute__((always_inline)) {
+    const unsigned off =
+        ((unsigned)(qhy[i] + tqy0) < (unsigned)thq && (unsigned)(qhx[i] + tqx0) < (unsigned)g.Wq) ? qob[i] : CNW_OOB;
+    qv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(tqrs, off, 0, 0));
+  };
   auto store = [&](int tile, const u32x4 (&pv)[4], const u32x4 (&qv)[NQR]) {
 #pragma unroll
     for (int i = 0; i < 4; ++i) *reinterpret_cast<u32x4*>(ldsP + pm[i] * CNW_PITCH + c8 * 2) = pv[i];
@@ -240,24 +284,86 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
   // the LDS latency in front of every MFMA: one wave per SIMD has nothing else to run)
 #define CNW_READ(A_, B_, KS_)                                                                   \
   {                                                                                             \
-    const bf16x4 pa_ = cnw_tr(lds + prow0 + (KS_) * 16 * CNW_PITCH);                            \
-    const bf16x4 pb_ = cnw_tr(lds + prow0 + ((KS_) * 16 + 4) * CNW_PITCH);                      \
-    A_ = bf16x8{pa_[0], pa_[1], pa_[2], pa_[3], pb_[0], pb_[1], pb_[2], pb_[3]};                \
-    _Pragma("unroll") for (int t = 0; t < T; ++t) {                                             \
+    _Pragma("unroll") for (int a = 0; a < NA; ++a) {                                            \
+      const bf16x4 pa_ = cnw_tr(lds + prow0 + a * pflip + (KS_) * 16 * CNW_PITCH);              \
+      const bf16x4 pb_ = cnw_tr(lds + prow0 + a * pflip + ((KS_) * 16 + 4) * CNW_PITCH);        \
+      A_[a] = bf16x8{pa_[0], pa_[1], pa_[2], pa_[3], pb_[0], pb_[1], pb_[2], pb_[3]};           \
+    }                                                                                           \
+    _Pragma("unroll") for (int t = 0; t < TB; ++t) {                                            \
       const bf16x4 qa_ = cnw_tr(lds + qrow[(KS_) * 2] + doff[t]);                               \
       const bf16x4 qb_ = cnw_tr(lds + qrow[(KS_) * 2 + 1] + doff[t]);                           \
       B_[t] = bf16x8{qa_[0], qa_[1], qa_[2], qa_[3], qb_[0], qb_[1], qb_[2], qb_[3]};           \
     }                                                                                           \
   }
+  // 3x3 accumulators: [0..3] tap ta, [4..7] tap ta + 1, each (P frag, Q frag) = (0,0) (0,1) (1,0) (1,1); [8] centre
 #define CNW_MMA(A_, B_)                                                                         \
   {                                                                                             \
-    _Pragma("unroll") for (int t = 0; t < T; ++t)                                               \
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_, B_[t], acc[t], 0, 0, 0);           \
+    if constexpr (T == 9) {                                                                     \
+      _Pragma("unroll") for (int u = 0; u < 8; ++u)                                             \
+          acc[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[(u >> 1) & 1], B_[(u >> 2) * 2 + (u & 1)], acc[u], 0, 0, 0); \
+      acc[8] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_[4], acc[8], 0, 0, 0);          \
+    } else {                                                                                    \
+      _Pragma("unroll") for (int t = 0; t < T; ++t)                                             \
+          acc[t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(A_[0], B_[t], acc[t], 0, 0, 0);      \
+    }                                                                                           \
   }
-  bf16x8 AX, AY, BX[T], BY[T];
-  auto compute = [&]() __attribute__((always_inline)) {
+  constexpr int NA = T == 9 ? 2 : 1;
+  bf16x8 AX[NA], AY[NA], BX[TB], BY[TB];
+  // TRICKLE (3x3, register-prefetched halo, full tiles): the next tile's fetch -- ~135 instructions that cost 1060 of a
+  // tile's 5090 cycles with the matrix pipe idle (tools/bwgrad_stamps.py) -- is issued in six parts of two pieces inside
+  // the MFMA shadows of k-steps 0-5 instead of in front of the multiplication.
+  constexpr bool TRICKLE = FULL && T == 9 && NQ == 8;
+  auto compute = [&](bool live) __attribute__((always_inline)) {
     CNW_READ(AX, BX, 0);
-    if (FULL) {
+    if constexpr (TRICKLE) {
+#define CNW_INTERLEAVE_F()                                               \
+  {                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < T; ++i_) {                   \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* MFMA */      \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0); /* DS read */   \
+      __builtin_amdgcn_sched_group_barrier(0x002, 3, 0); /* VALU */      \
+      if (i_ == 3 || i_ == 7)                                            \
+        __builtin_amdgcn_sched_group_barrier(0x020, 1, 0); /* VMEM */    \
+    }                                                                    \
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                   \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                   \
+  }
+#define CNW_INTERLEAVE()                                                 \
+  {                                                                      \
+    _Pragma("unroll") for (int i_ = 0; i_ < T; ++i_) {                   \
+      __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);                 \
+      __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);                 \
+      __builtin_amdgcn_sched_group_barrier(0x002, 2, 0);                 \
+    }                                                                    \
+    __builtin_amdgcn_sched_group_barrier(0x100, 4, 0);                   \
+    __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);                   \
+  }
+      fetch_setup(live);
+#pragma unroll
+      for (int ks = 0; ks < 8; ks += 2) {
+        __builtin_amdgcn_sched_barrier(0);
+        CNW_READ(AY, BY, ks + 1);
+        CNW_MMA(AX, BX);
+        if (ks < 6) {
+          if (ks == 0) { fetch_p(0, pvA); fetch_p(1, pvA); }
+          else { fetch_q(2 * ks - 4, qvA); fetch_q(2 * ks - 3, qvA); }   // ks 2: q0 q1, ks 4: q4 q5
+          CNW_INTERLEAVE_F();
+        } else {
+          CNW_INTERLEAVE();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (ks + 2 < 8) CNW_READ(AX, BX, ks + 2);
+        CNW_MMA(AY, BY);
+        if (ks < 6) {
+          if (ks == 0) { fetch_p(2, pvA); fetch_p(3, pvA); }
+          else { fetch_q(2 * ks - 2, qvA); fetch_q(2 * ks - 1, qvA); }   // ks 2: q2 q3, ks 4: q6 q7
+          CNW_INTERLEAVE_F();
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+#undef CNW_INTERLEAVE
+#undef CNW_INTERLEAVE_F
+    } else if (FULL) {
       // Full tiles (8 k-steps, no conditionals => one basic block per k-step): the transposed reads and address adds
       // of k-step ks+1 are INTERLEAVED with the MFMAs of k-step ks, two reads + two VALU in each MFMA's 32-cycle
       // shadow.  One wave per SIMD has nobody to hide behind: a phase-separated order leaves the matrix pipe idle for
@@ -314,13 +420,13 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
       store(tile, pvA, qvA);
       __syncthreads();
       if (tile + 2 < t_end) fetch(tile + 2, pvA, qvA);  // global loads fly over two tiles of multiplication
-      compute();
+      compute(false);
       if (tile + 1 < t_end) {
         __syncthreads();
         store(tile + 1, pvB, qvB);
         __syncthreads();
         if (tile + 3 < t_end) fetch(tile + 3, pvB, qvB);
-        compute();
+        compute(false);
       }
     }
   } else {
@@ -339,9 +445,11 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
       CNBW_ST();  // LDS stores issued (includes the wait for the prefetched registers)
       __syncthreads();
       CNBW_ST();  // barrier 2
-      if (tile + 1 < t_end) fetch(tile + 1, pvA, qvA);  // next tile's global loads fly while this one is multiplied
+      if constexpr (!TRICKLE) {
+        if (tile + 1 < t_end) fetch(tile + 1, pvA, qvA);  // next tile's global loads fly while this one is multiplied
+      }
       CNBW_ST();  // fetch issued
-      compute();
+      compute(tile + 1 < t_end);
       CNBW_ST();  // multiplied
     }
   }
@@ -352,12 +460,23 @@ __global__ __launch_bounds__(256, (T > 4 ? 1 : 2)) void cn_bwgrad_kernel(const C
   const long CPp = (long)g.nbp * 64, CQp = (long)g.nbq * 64;
   float* out = g.part + (long)split * T * CPp * CQp;
 #pragma unroll
-  for (int t = 0; t < T; ++t)
+  for (int u = 0; u < T; ++u) {
+    int t = u, tp = wp, tq = wq;  // tap and quadrant of accumulator u
+    if constexpr (T == 9) {
+      if (u < 8) {
+        t = ta + (u >> 2);
+        tp = wp ^ ((u >> 1) & 1);
+        tq = wq ^ (u & 1);
+      } else {
+        t = 4;
+      }
+    }
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
-      const int cp = cp0 + wp * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
-      out[((long)t * CPp + cp) * CQp + cq0 + wq * 32 + r] = acc[t][j];
+      const int cp = cp0 + tp * 32 + (j & 3) + 8 * (j >> 2) + 4 * h;
+      out[((long)t * CPp + cp) * CQp + cq0 + tq * 32 + r] = acc[u][j];
     }
+  }
 }
 
 // dw[(cP*CQ + cQ)*T + t] += sum_split part[split][t][cP][cQ]
