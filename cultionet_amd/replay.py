@@ -183,6 +183,7 @@ def record_step(trainer, batch, eager: T.Callable) -> StepPlan:
         pb = Data(x=plan.inputs[0], y=plan.inputs[1], bdist=plan.inputs[2])
         for fname in ("empty", "empty_like", "zeros_like"):
             keepalive(fname)
+        trainer.store.bump()  # the batched weight re-pack must be PART of the plan even if nothing changed since the last pack
         _lib.call = recording
         E._recorder = ops
         try:

@@ -77,3 +77,19 @@ def test_replay_falls_back_for_new_shapes_and_dropout():
     for _ in range(4):
         tr.training_step(batches[0])
     assert tr._plan is None
+
+
+def test_plan_recorded_without_a_weight_update_still_repacks():
+    """A plan recorded from forward_backward() calls with NO optimizer step in between (gradient-accumulation style) must
+    still contain the batched weight re-pack: later replays follow optimizer updates like the eager step does."""
+    (eager, plan), batches = _pair("32-true")
+    for _ in range(3):  # two eager passes + the recorded one, the parameters untouched in between
+        eager.forward_backward(batches[0])
+        plan.forward_backward(batches[0])
+    assert plan._plan is not None
+    le, lp = [], []
+    for i in range(5):
+        le.append(float(eager.training_step(batches[i % 3]).item()))
+        lp.append(float(plan.training_step(batches[i % 3]).item()))
+    assert np.abs(np.array(le) - np.array(lp)).max() <= 2e-6, (le, lp)
+    assert le[-1] < le[0]
