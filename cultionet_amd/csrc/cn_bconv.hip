@@ -82,6 +82,27 @@ extern "C" int cn_bconv_read_stamps(unsigned long long* out) {
 #else
 #define CNB_ST(i) do { } while (0)
 #endif
+// Diagnostic build (-DCNB_TRACE): start / end (s_memrealtime, 100 MHz) and HW_ID of EVERY block of the last launch
+// (tools/bconv_trace.py: how many blocks a CU really holds over a launch). Never compiled into the shipped library.
+#ifdef CNB_TRACE
+#define CNB_TRACE_MAX 16384
+__device__ unsigned long long cnb_trace[3 * CNB_TRACE_MAX];
+extern "C" int cn_bconv_read_trace(unsigned long long* out, int n) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(cnb_trace), sizeof(unsigned long long) * 3 * n) == hipSuccess ? 0 : -2;
+}
+#define CNB_TRACE_BEGIN() const unsigned long long trace_t0 = __builtin_amdgcn_s_memrealtime()
+#define CNB_TRACE_END()                                                                         \
+  do {                                                                                          \
+    if (threadIdx.x == 0 && L < CNB_TRACE_MAX) {                                                \
+      cnb_trace[3 * L] = trace_t0;                                                              \
+      cnb_trace[3 * L + 1] = __builtin_amdgcn_s_memrealtime();                                  \
+      cnb_trace[3 * L + 2] = __builtin_amdgcn_s_getreg((4 << 0) | (0 << 6) | (31 << 11));       \
+    }                                                                                           \
+  } while (0)
+#else
+#define CNB_TRACE_BEGIN() do { } while (0)
+#define CNB_TRACE_END() do { } while (0)
+#endif
 
 // x / d for 0 <= x < 65536 with mg = ceil(2^32 / d) precomputed on the host (two instructions instead of ~40)
 __device__ __forceinline__ int cnb_div(int x, unsigned mg) { return mg ? (int)__umulhi((unsigned)x, mg) : x; }
@@ -134,6 +155,7 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
   int stamp_i = 8;
 #endif
   CNB_ST(0);
+  CNB_TRACE_BEGIN();
   int ci = 0;
 #pragma unroll 1
   for (int c = 1; c < g.ncls; ++c)
@@ -548,6 +570,7 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
     }
   }
   CNB_ST(5);
+  CNB_TRACE_END();
 }
 
 // ------------------------------------------------------------------------------------------------------------
