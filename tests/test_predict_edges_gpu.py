@@ -139,7 +139,8 @@ def test_launch_plan_replay_is_bitwise_the_eager_forward(precision):
     g = torch.Generator().manual_seed(9)
     mean = torch.tensor([0.31, 0.28, 0.35])
     std = torch.tensor([0.21, 0.19, 0.24])
-    kw = dict(window_size=ws, padding=pad, batch_size=4, mean=mean, std=std, precision=precision)
+    kw = dict(window_size=ws, padding=pad, batch_size=4, mean=mean, std=std, precision=precision,
+              pixels_per_launch=0)  # batches as given: this test wants the ragged last batch
     eager = SlidingWindowPredictor(lit, replay=False, **kw)
     plan = SlidingWindowPredictor(lit, replay=True, **kw)
     for rep in range(3):
@@ -165,3 +166,27 @@ def test_launch_plan_replay_is_bitwise_the_eager_forward(precision):
     a2 = eager.predict_scene(scene)
     b2 = plan.predict_scene(scene)
     assert torch.equal(a2, b2) and not torch.equal(a2, a)
+
+
+@pytest.mark.parametrize("precision", ["32-true", "bf16-mixed"])
+def test_packed_window_batches_give_the_same_mosaic(precision):
+    """pixels_per_launch (default 400k): consecutive batches of ``batch_size`` windows are packed into one forward. The
+    eval forward is independent per window, so the mosaic is the one the reference's loop granularity gives (fp32: the
+    launch-cost model may pick another K split for another batch size -> last-bit differences, at most one count)."""
+    from cultionet_amd.predict import SlidingWindowPredictor
+
+    lit, _ = _pair()
+    H, W, ws, pad = 70, 95, 32, 4   # 9 windows: 4 + 4 + 1 as given, one launch of 9 when packed
+    g = torch.Generator().manual_seed(21)
+    scene = torch.randint(0, 9000, (3, 12, H, W), generator=g, dtype=torch.int32).to(torch.int16).cuda()
+    kw = dict(window_size=ws, padding=pad, batch_size=4, precision=precision)
+    given = SlidingWindowPredictor(lit, pixels_per_launch=0, **kw)
+    packed = SlidingWindowPredictor(lit, **kw)
+    assert given.launch_bs == 4 and packed.launch_bs == 250  # 400k / 40^2
+    a = given.predict_scene(scene).cpu().numpy().astype(np.int64)
+    b = packed.predict_scene(scene).cpu().numpy().astype(np.int64)
+    d = np.abs(a - b)
+    assert d.max() <= 1 and (d > 0).mean() <= 1e-3, (d.max(), (d > 0).mean())
+    # a large window keeps the caller's batch size: 266^2 padded pixels -> 6 windows per launch, never fewer than asked
+    assert SlidingWindowPredictor(lit, window_size=256, padding=5, batch_size=8).launch_bs == 8
+    assert SlidingWindowPredictor(lit, window_size=256, padding=5, batch_size=2).launch_bs == 6
