@@ -711,12 +711,15 @@ def main():
             # N ranks: the ranks cannot relaunch themselves, so the second configuration runs in this process, with the
             # SAME GradientAllReduce object (a second bucket stream measured 1046 instead of 1754 chips/s with a one-rank
             # RCCL group; a fresh process gets 1866)
-            leg16 = TrainLeg(dev, rank, world, comm, use_dist, "bf16", 32, args.hidden)
-            rec16 = leg16.run(args.steps, args.warmup, False)
-            fl16 = rec16.pop("_first_loss") if rank == 0 else None
-            if rank == 0:
-                rec16["process"] = "second configuration of the rank processes"
-            del leg16
+            try:  # (a failure that every rank hits the same way must not take the headline line down)
+                leg16 = TrainLeg(dev, rank, world, comm, use_dist, "bf16", 32, args.hidden)
+                rec16 = leg16.run(args.steps, args.warmup, False)
+                fl16 = rec16.pop("_first_loss") if rank == 0 else None
+                if rank == 0:
+                    rec16["process"] = "second configuration of the rank processes"
+                del leg16
+            except Exception as e:
+                rec16, fl16 = {"error": repr(e)}, None
             torch.cuda.empty_cache()
         if rank == 0:
             if world == 1 and not args.no_cpu_baseline and fl16 is not None and "value" in rec16:
