@@ -335,17 +335,15 @@ def cpu_first_loss(batch: int, hidden: int, threads: int = 0) -> float:
 def launch_ranks(args) -> int:
     """`python bench.py --gpus N` with N > 1 outside torch.distributed.run: start the ranks as a CHILD process (this
     parent has not touched the GPU and never does), relay rank 0's JSON line, return the child's exit code."""
-    import socket
     import subprocess
 
-    with socket.socket() as sk:
-        sk.bind(("127.0.0.1", 0))
-        port = sk.getsockname()[1]
     env = dict(os.environ)
     env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     env.setdefault("OMP_NUM_THREADS", "4")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}",
-           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    # --standalone: torchrun's own c10d rendezvous on a port IT binds (no bind-then-close race between benches
+    # sharing a box); workers get MASTER_ADDR / MASTER_PORT from it
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--standalone", "--local-addr", "127.0.0.1", "--nnodes=1",
+           f"--nproc-per-node={args.gpus}", os.path.abspath(__file__)] + sys.argv[1:]
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     line = None
     for ln in proc.stdout.splitlines():
@@ -450,8 +448,13 @@ class TrainLeg:
         t0 = time.perf_counter()
         for _ in range(steps):
             loss = trainer.training_step(batch)
+        # closing fence: this rank's GPU first, THEN the barrier (so its cost / the wait for slower ranks is visible as
+        # `config.end_barrier_ms` instead of hiding inside the timed region), then the clock
+        torch.cuda.synchronize()
+        t_local = time.perf_counter()
         self.sync()
         dt = time.perf_counter() - t0
+        end_barrier_ms = (time.perf_counter() - t_local) * 1e3
         _lib.call("cn_profile_end", (ctypes.c_double * 24)())
         _lib.call("cn_profile_set_filter", None)
         nk2 = _lib.query("cn_profile_top", 0, name_buf, 96, top3)  # the dominant kernel inside the timed region
@@ -544,6 +547,7 @@ class TrainLeg:
                 "rccl_ranks": self.rccl_ranks,
                 "buckets_per_step": buckets,
                 "comm_ms_exposed": comm_ms,
+                "end_barrier_ms": end_barrier_ms if self.use_dist else 0.0,
                 "loss": loss_val,
                 "abi_calls_per_step": calls[0],
                 "kernel_launches_per_step": launches,
@@ -656,7 +660,11 @@ def main():
         if os.environ.get("NCCL_DEBUG", "VERSION").upper() == "VERSION":
             os.environ["NCCL_DEBUG"] = "WARN"  # RCCL's version banner goes to stdout; keep stdout to ONE JSON line
         os.environ.setdefault("NCCL_DEBUG_FILE", "/dev/stderr")  # RCCL logs default to stdout too
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        import datetime
+
+        # a rank that dies inside a step leaves the others in an all-reduce: bound that wait (the watchdog aborts)
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev,
+                                timeout=datetime.timedelta(seconds=int(os.environ.get("CN_PG_TIMEOUT_S", "600"))))
         from cultionet_amd.ddp import GradientAllReduce
 
         comm = GradientAllReduce(world_size=world)
@@ -710,16 +718,35 @@ def main():
         else:
             # N ranks: the ranks cannot relaunch themselves, so the second configuration runs in this process, with the
             # SAME GradientAllReduce object (a second bucket stream measured 1046 instead of 1754 chips/s with a one-rank
-            # RCCL group; a fresh process gets 1866)
-            try:  # (a failure that every rank hits the same way must not take the headline line down)
+            # RCCL group; a fresh process gets 1866). Success is decided COLLECTIVELY: a rank that fails alone would
+            # leave the others inside an all-reduce, so every stage ends with a MAX-reduce of a failure flag and all
+            # ranks skip (or abort) together; a rank that dies INSIDE a step is caught by the process-group timeout set
+            # at init (CN_PG_TIMEOUT_S), which turns the others' hang into a non-zero exit.
+            def agree(ok: bool) -> bool:
+                t = torch.tensor([0.0 if ok else 1.0], device=dev)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                return float(t.item()) == 0.0
+
+            err, leg16, rec16, fl16 = None, None, None, None
+            try:
                 leg16 = TrainLeg(dev, rank, world, comm, use_dist, "bf16", 32, args.hidden)
-                rec16 = leg16.run(args.steps, args.warmup, False)
+            except Exception as e:
+                err = repr(e)
+            if not agree(err is None):
+                rec16 = {"error": err or "another rank failed to set the bf16 configuration up"}
+            else:
+                try:
+                    rec16 = leg16.run(args.steps, args.warmup, False)
+                except Exception as e:
+                    err = repr(e)
+                if not agree(err is None):  # the step loop holds collectives: a one-rank failure is fatal for the job
+                    print(f"[bench rank {rank}] bf16 configuration failed on a rank: {err}", file=sys.stderr, flush=True)
+                    dist.destroy_process_group()
+                    raise SystemExit(3)
                 fl16 = rec16.pop("_first_loss") if rank == 0 else None
                 if rank == 0:
                     rec16["process"] = "second configuration of the rank processes"
-                del leg16
-            except Exception as e:
-                rec16, fl16 = {"error": repr(e)}, None
+            del leg16
             torch.cuda.empty_cache()
         if rank == 0:
             if world == 1 and not args.no_cpu_baseline and fl16 is not None and "value" in rec16:
@@ -736,6 +763,26 @@ def main():
                 out["predict"] = {"error": repr(e)}
         else:
             out["predict"] = predict_block(dev, args.hidden, not args.no_cpu_baseline, args.cpu_threads)
+    if rank == 0:
+        # scalars of the extra blocks inside `config` (the driver's record keeps `config` whole, the blocks by name only)
+        cfg = out["config"]
+        b16 = out.get("bf16") or {}
+        if "value" in b16:
+            cfg["bf16_chips_per_s"] = b16["value"]
+            cfg["bf16_ms_per_step"] = b16["ms_per_step"]
+            cfg["bf16_kernel_launches_per_step"] = b16.get("config", {}).get("kernel_launches_per_step")
+            cfg["bf16_end_to_end_frac"] = b16.get("roofline", {}).get("end_to_end_frac")
+        pr = out.get("predict") or {}
+        if "value" in pr:
+            cfg["predict_mpx_per_s"] = pr["value"] / 1e6
+            cfg["predict_tile_ms_bf16"] = pr.get("tile", {}).get("bf16_mixed", {}).get("ms_per_tile")
+        if "feed" in out:
+            cfg["feed_delta_ms"] = out["feed"]["delta_ms_vs_resident"]
+        dp = out.get("default_point") or {}
+        if "value" in dp:
+            cfg["default_point_chips_per_s"] = dp["value"]
+            cfg["default_point_ms_per_step"] = dp["ms_per_step"]
+            cfg["default_point_eager_chips_per_s"] = dp.get("eager", {}).get("value")
     if use_dist:
         dist.destroy_process_group()
     if rank == 0:

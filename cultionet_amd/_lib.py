@@ -52,14 +52,15 @@ SIGNATURES = {
     "cn_sca_mlp_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, I, P],
     "cn_sca_apply_fwd_f32": [P, L, P, P, P, P, L, I, I, I, P],
     "cn_sca_apply_bwd_f32": [P, L, P, L, P, P, P, P, L, I, P, P, P, P, I, I, I, P],
-    "cn_na2d_fwd_f32": [P, L, P, L, P, I, I, I, I, I, I, I, F, U64, P],
-    "cn_na2d_bwd_f32": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, F, U64, P],
+    "cn_na2d_fwd_f32": [P, L, P, L, P, I, I, I, I, I, I, I, F, U64, P, P],
+    "cn_na2d_bwd_f32": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, F, U64, P, P],
     "cn_bilinear_fwd_f32": [P, L, P, L, I, I, I, I, I, I, P],
     "cn_bilinear_bwd_f32": [P, L, P, L, I, I, I, I, I, I, I, P],
     "cn_copy_f32": [P, L, P, L, I, L, I, P],
     "cn_add_f32": [P, L, P, L, P, L, I, L, P],
     "cn_fill_f32": [P, L, F, P],
-    "cn_dropout_f32": [P, L, P, L, I, I, I, F, U64, I, I, P],
+    "cn_dropout_f32": [P, L, P, L, I, I, I, F, U64, P, I, I, P],
+    "cn_rng_advance_u64": [P, U64, I, P],
     "cn_adaptive_maxpool_fwd_f32": [P, L, P, L, P, I, I, I, I, I, I, P],
     "cn_adaptive_maxpool_bwd_f32": [P, L, P, P, L, I, I, I, I, I, I, I, P],
     "cn_final_combine_fwd_f32": [P, P, P, P, P, P, P, I, I, F, P],
@@ -81,7 +82,7 @@ SIGNATURES = {
     "cn_conv2d_fwd_fused_bf16": [P, L, P, P, P, L, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
     "cn_pack_weights_scaled_bf16": [P, P, P, I, I, I, L, L, L, P],
     "cn_bn_fold_f32": [P, P, P, P, P, F, I, P, P, P],
-    "cn_conv2d_fwd_grouped_bf16": [I, P, L, P, P, P, L, I, I, I, I, I, I, I, I, P, P, I, P],
+    "cn_conv2d_fwd_grouped_bf16": [I, P, L, P, P, P, L, I, I, I, I, I, I, I, I, P, P, I, P, P],
     "cn_conv2d_bwd_data_bf16": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
     "cn_conv2d_bwd_data_grouped_bf16": [I, P, L, P, P, L, I, I, I, I, I, I, I, I, P, P, I, P],
     "cn_conv_transpose2d_fwd_bf16": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, P],
@@ -93,6 +94,9 @@ SIGNATURES = {
     "cn_conv2d_stats_rows_bf16": [I, I, I, I, I, I, I, I, I],
     "cn_bn_act_fwd_bf16": [P, L, P, P, P, P, P, L, P, L, P, P, P, L, I, I, F, F, I, P, I, P],
     "cn_bn_act_bwd_bf16": [P, L, P, L, P, P, P, P, P, L, P, P, P, L, I, I, I, I, P],
+    "cn_bn_group_workspace_floats_bf16": [I, I],
+    "cn_bn_act_group_fwd_bf16": [I, P, L, P, P, P, P, P, L, P, L, P, P, P, L, I, I, F, F, I, I, P, I, P],
+    "cn_bn_act_group_bwd_bf16": [I, P, L, P, L, P, P, P, P, P, L, P, P, P, P, L, I, I, I, P],
     "cn_channel_sum_bf16": [P, L, L, I, P, I, P, P],
     "cn_layernorm_c_fwd_bf16": [P, L, P, P, P, L, P, L, L, I, F, P],
     "cn_layernorm_c_bwd_bf16": [P, L, P, L, P, P, L, P, P, L, I, F, I, P],
@@ -103,9 +107,9 @@ SIGNATURES = {
     "cn_zero_bf16": [P, L, L, I, P],
     "cn_bilinear_fwd_bf16": [P, L, P, L, I, I, I, I, I, I, P],
     "cn_bilinear_bwd_bf16": [P, L, P, L, I, I, I, I, I, I, I, P],
-    "cn_na2d_fwd_bf16": [P, L, P, L, P, I, I, I, I, I, I, I, F, U64, P],
-    "cn_na2d_bwd_bf16": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, F, U64, P],
-    "cn_dropout_bf16": [P, L, P, L, I, I, I, F, U64, I, I, P],
+    "cn_na2d_fwd_bf16": [P, L, P, L, P, I, I, I, I, I, I, I, F, U64, P, P],
+    "cn_na2d_bwd_bf16": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, F, U64, P, P],
+    "cn_dropout_bf16": [P, L, P, L, I, I, I, F, U64, P, I, I, P],
     "cn_window_chips_f32": [P, I, P, P, I, I, I, I, I, I, I, P, P, F, F, F, P],
     "cn_stitch_predictions_u16": [P, P, P, P, P, I, I, I, I, I, I, F, P],
     "cn_profile_begin": [],
@@ -163,7 +167,8 @@ def call(name: str, *args) -> int:
     return rc
 
 
-LONG_RESULT = {"cn_launch_count", "cn_bconv_packed_elems", "cn_bwgrad_workspace_floats", "cn_bn_workspace_floats_bf16"}
+LONG_RESULT = {"cn_launch_count", "cn_bconv_packed_elems", "cn_bwgrad_workspace_floats", "cn_bn_workspace_floats_bf16",
+               "cn_bn_group_workspace_floats_bf16"}
 
 
 def query(name: str, *args) -> int:

@@ -65,7 +65,8 @@ struct CnBGeom {
   long ldres;                         // same spatial size as y); nullptr: none. res == y is the in-place accumulate.
   int total;      // logical blocks
   int ncls;
-  float* stats;   // nullable: per pixel tile {sum, sum of squares}[Cout] of the fp32 results, rows [tile][2][Cout]
+  float* stats[CNB_MAX_GROUPS];  // nullable (all or none): per group and pixel tile {sum, sum of squares}[Cout] of the
+                  // fp32 results, rows [tile][2][Cout]
                   // (plain stores, one row per tile: same-address float atomics serialise at ~200 ns each and
                   // 2560 tiles x 4 waves of them made a 128->128 conv at 100x100 nine times slower)
   CnBClass cls[CNB_MAX_CLASSES];
@@ -432,7 +433,8 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
     for (int j = 0; j < 16; ++j) bsum[j] = 0.f;
   }
   float s1[16], s2[16];
-  if (g.stats != nullptr) {
+  float* const stats_g = g.stats[grp];
+  if (stats_g != nullptr) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) s1[j] = s2[j] = 0.f;
   }
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
   const int gy = gy0 + ty, gx = gx0 + tx;                                                      \
   const bool ok = n_live && m < npix && gy < k.Hg && gx < k.Wg;                                \
   const int oy = gy * g.os + k.oy0, ox = gx * g.os + k.ox0;                                    \
-  if (g.stats != nullptr) {                                                                    \
+  if (stats_g != nullptr) {                                                                    \
     _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                           \
       const float v = ok ? acc[i][j] + bsum[j] : 0.f;                                          \
       s1[j] += v;                                                                              \
@@ -535,7 +537,7 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
   }
 #undef CNB_GROUP_HEAD
   CNB_ST(4);
-  if (g.stats != nullptr) {
+  if (stats_g != nullptr) {
     // Per-cout sums over this wave's pixels = sums over the LANES of 32 values per lane: transposed through LDS
     // (each lane writes its 32 partials as one padded row, then sums ONE column over its half-wave's 32 rows): ~100
     // instructions per wave instead of 160 cross-lane shuffles + 160 adds.
@@ -565,7 +567,7 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
     const int j = jj & 15;
     const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * hh;
     if (n_live && n < g.Cout && wm == 0) {  // wid = wm * WN + wn: the wm == 0 wave of each cout tile stores the row
-      float* row = g.stats + (long)tile * 2 * g.Cout + (jj >= 16 ? g.Cout : 0) + n;
+      float* row = stats_g + (long)tile * 2 * g.Cout + (jj >= 16 ? g.Cout : 0) + n;
       *row = tot;
     }
   }
@@ -794,9 +796,9 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
   if (total > 0x7fffff00L) return CN_ERR_ARG;
   g.total = (int)total;
   size_t shmem = (size_t)max_pix * pitch + max_rowpad_bytes;
-  if (g.stats != nullptr && shmem < 4 * 64 * 33 * sizeof(float)) shmem = 4 * 64 * 33 * sizeof(float);
+  if (g.stats[0] != nullptr && shmem < 4 * 64 * 33 * sizeof(float)) shmem = 4 * 64 * 33 * sizeof(float);
   const dim3 grid(cn_xcd_grid(total)), block(256);
-  if (g.stats != nullptr && g.ncls != 1) return CN_ERR_ARG;  // (rows are plain-stored by every tile: no zero-fill)
+  if (g.stats[0] != nullptr && g.ncls != G) return CN_ERR_ARG;  // one class per group: a tile's row has ONE writer
   const int NPv = np <= 4 ? 4 : (np <= 6 ? 6 : 10);
   if (MPWv == 2)
     cn_prof_name("cn_bconv_kernel<%d, %d, %d, 2>", WN, (KSC == 2 ? NPv : (KSC == 4 ? (NPv <= 6 ? 6 : 10) : 10)), KSC);
@@ -844,19 +846,20 @@ static inline int cnb_pack_d(int dy, int dx) { return (dy << 16) | (dx & 0xffff)
 static int cnb_gather(int G, const bf16_t* const* xs, long ldx, const bf16_t* const* wps, const float* const* biases,
                       void* const* ys, long ldy, long y_bs, int B, int Cin, int Hin, int Win, int Cout, int Hout,
                       int Wout, int KH, int KW, int stride, const int* pads, const int* dils, int accumulate,
-                      int out_kind, float* stats, hipStream_t stream, int act = 0, const bf16_t* const* ress = nullptr,
-                      long ldres = 0) {
+                      int out_kind, float* const* stats, hipStream_t stream, int act = 0,
+                      const bf16_t* const* ress = nullptr, long ldres = 0) {
   if (G < 1 || G > CNB_MAX_GROUPS || KH * KW > CNB_MAX_TAPS || stride < 1) return CN_ERR_ARG;
   if (Hout <= 0 || Wout <= 0 || B <= 0) return CN_OK;
   CnBGeom g = {};
   for (int i = 0; i < G; ++i) {
     g.x[i] = xs[i]; g.wp[i] = wps[i]; g.bias[i] = biases ? biases[i] : nullptr; g.y[i] = ys[i];
     g.res[i] = ress ? ress[i] : nullptr;
+    g.stats[i] = stats ? stats[i] : nullptr;
   }
   g.act = act; g.ldres = ldres;
   g.ldx = ldx; g.ldy = ldy; g.y_bs = y_bs;
   g.B = B; g.Cin = Cin; g.Hin = Hin; g.Win = Win; g.Cout = Cout; g.Hout = Hout; g.Wout = Wout;
-  g.is = stride; g.os = 1; g.out_kind = out_kind; g.accumulate = accumulate; g.stats = stats;
+  g.is = stride; g.os = 1; g.out_kind = out_kind; g.accumulate = accumulate;
   g.ncls = G;
   for (int i = 0; i < G; ++i) {
     if (dils[i] < 1) return CN_ERR_ARG;
@@ -888,7 +891,8 @@ static int cnb_scatter(int G, const bf16_t* const* srcs, long lds_, const bf16_t
   }
   g.ldx = lds_; g.ldy = ldo;
   g.B = B; g.Cin = Csrc; g.Hin = Hs; g.Win = Ws; g.Cout = Cdst; g.Hout = Ho; g.Wout = Wo;
-  g.is = 1; g.os = stride; g.out_kind = 0; g.accumulate = accumulate; g.stats = stats;
+  g.is = 1; g.os = stride; g.out_kind = 0; g.accumulate = accumulate;
+  (void)stats;  // (strided scatters have s*s classes per group: no per-tile statistics rows)
   int nc = 0;
   double macs = 0.0;
   for (int gi = 0; gi < G; ++gi) {
@@ -954,7 +958,7 @@ extern "C" int cn_conv2d_fwd_bf16(const void* x, long ldx, const void* wp, const
   const bf16_t* xs = (const bf16_t*)x;
   const bf16_t* ws = (const bf16_t*)wp;
   return cnb_gather(1, &xs, ldx, &ws, &bias, &y, ldy, y_bs, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride, &pad,
-                    &dil, accumulate, out_kind, stats, (hipStream_t)stream);
+                    &dil, accumulate, out_kind, stats != nullptr ? &stats : nullptr, (hipStream_t)stream);
 }
 
 // G (<= 4) convolutions of one shape in one launch (the dilation branches of ResidualAConv, convolution.py:376-395).
@@ -979,7 +983,7 @@ extern "C" int cn_conv2d_fwd_fused_bf16(const void* x, long ldx, const void* wp,
 extern "C" int cn_conv2d_fwd_grouped_bf16(int G, const void* const* xs, long ldx, const void* const* wps,
                                           const float* const* biases, void* const* ys, long ldy, int B, int Cin,
                                           int Hin, int Win, int Cout, int KH, int KW, int stride, const int* pads,
-                                          const int* dils, int accumulate, void* stream) {
+                                          const int* dils, int accumulate, float* const* stats, void* stream) {
   if (stride < 1 || G < 1 || G > CNB_MAX_GROUPS) return CN_ERR_ARG;
   const int Hout = (Hin + 2 * pads[0] - dils[0] * (KH - 1) - 1) / stride + 1;
   const int Wout = (Win + 2 * pads[0] - dils[0] * (KW - 1) - 1) / stride + 1;
@@ -988,7 +992,7 @@ extern "C" int cn_conv2d_fwd_grouped_bf16(int G, const void* const* xs, long ldx
         (Win + 2 * pads[i] - dils[i] * (KW - 1) - 1) / stride + 1 != Wout)
       return CN_ERR_ARG;
   return cnb_gather(G, (const bf16_t* const*)xs, ldx, (const bf16_t* const*)wps, biases, ys, ldy, 0, B, Cin, Hin, Win,
-                    Cout, Hout, Wout, KH, KW, stride, pads, dils, accumulate, 0, nullptr, (hipStream_t)stream);
+                    Cout, Hout, Wout, KH, KW, stride, pads, dils, accumulate, 0, stats, (hipStream_t)stream);
 }
 
 // Conv2d backward-data: dx [B,Hin,Win,Cin] (+)= scatter(dy [B,Hout,Wout,Cout]); wp_t packed with K = Cout, N = Cin.

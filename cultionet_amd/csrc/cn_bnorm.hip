@@ -334,6 +334,466 @@ extern "C" int cn_bn_act_bwd_bf16(const void* x, long ldx, const void* dy, long 
   return cn_check_launch();
 }
 
+// =====================================================================================================================
+// Grouped BatchNorm(+SiLU): the G (<= 4) BatchNorm layers of one ResidualAConv level (convolution.py:376-395) in one
+// launch per pass, and a ONE-LAUNCH finalize. Round 3's profile of the mixed-precision step: 84 finalize launches of
+// 6-9 us (one wave per channel reading 4-byte columns of the partial rows: every 128-byte line fetched by 32 waves),
+// the running sum `res + SiLU(BN_0) + SiLU(BN_1)` read and re-written once per branch, dy of the summed level read
+// once per branch and pass. Here:
+//   * finalize = coalesced column sums (thread = column of the [rows][2C] partial matrix, a block = a slice of rows,
+//     fp64) whose per-block slices are combined by the LAST ARRIVING block of each group (device ticket: slices
+//     stored write-through, one relaxed agent-scope fetch-add per block, the last arriver reads the slices with
+//     agent-scope loads -- MI355X_MICROARCH.md 'inter-workgroup visibility'; cdna_hip_programming.md 5 'in-launch split-K
+//     reduction'); the order of the sums is fixed by the indices, not by the arrival order: bit-reproducible;
+//   * forward apply (summed level): y = res + sum_g act(bn_g(x_g)) in ONE pass, accumulated in fp32, rounded once;
+//   * backward (summed level): dy is read once per pass for all G branches.
+// =====================================================================================================================
+#define BBG_MAX 4
+#define BBG_FIN_BLOCKS 64   // row slices per group in the finalize
+#define BBG_CNT_INTS 64     // ticket counters at the start of the workspace (zero on entry, left zero on exit)
+
+struct CnBBnGroupArgs {
+  const bf16_t* x[BBG_MAX];
+  const bf16_t* dy[BBG_MAX];
+  const float* gamma[BBG_MAX];
+  const float* beta[BBG_MAX];
+  float* mean[BBG_MAX];
+  float* rstd[BBG_MAX];
+  float* running_mean[BBG_MAX];
+  float* running_var[BBG_MAX];
+  bf16_t* y[BBG_MAX];
+  bf16_t* dx[BBG_MAX];
+  float* dgamma[BBG_MAX];
+  float* dbeta[BBG_MAX];
+  const float* rows[BBG_MAX];  // finalize input: [nrows][2][C] fp32 partial rows of group g
+  int accumulate_dx[BBG_MAX];
+  const bf16_t* res;
+  long ldx, lddy, ldy, lddx, ldr;
+  long P, rows_per_block;
+  int G, C, act, training, nrows;
+  long row_pitch;   // floats between consecutive partial rows of one group
+  float eps, momentum;
+  float* coef;      // [G][2][C]
+  double* slices;   // [G][BBG_FIN_BLOCKS][2C] finalize scratch
+  int* counters;    // [G] tickets
+};
+
+// agent-scope (write-through / L2-bypassing) accesses for data handed between workgroups inside one launch
+__device__ __forceinline__ void bbg_store_agent(double* p, double v) {
+  __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ double bbg_load_agent(const double* p) {
+  return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// MODE 0 (forward): columns = {sum x, sum x^2}[C]  -> mean / rstd (+ running statistics)
+// MODE 1 (backward): columns = {sum dz, sum dz*xhat}[C] -> coef = column / count; dgamma += col1, dbeta += col0
+// grid (BBG_FIN_BLOCKS, G); block b sums rows [b*rpb, (b+1)*rpb) of its group, column by column (coalesced).
+template <int MODE>
+__global__ __launch_bounds__(256) void cn_bbn_group_finalize_kernel(const CnBBnGroupArgs a) {
+  __shared__ int s_last;
+  const int g = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
+  const int W2 = 2 * a.C;
+  const float* __restrict__ rows = a.rows[g];
+  const int rpb = (a.nrows + nb - 1) / nb;
+  const int r0 = b * rpb, r1 = r0 + rpb < a.nrows ? r0 + rpb : a.nrows;
+  double* slice = a.slices + ((long)g * nb + b) * W2;
+  for (int col = threadIdx.x; col < W2; col += 256) {
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    int r = r0;
+    const long rp = a.row_pitch;
+    for (; r + 3 < r1; r += 4) {
+      s0 += rows[(long)r * rp + col];
+      s1 += rows[(long)(r + 1) * rp + col];
+      s2 += rows[(long)(r + 2) * rp + col];
+      s3 += rows[(long)(r + 3) * rp + col];
+    }
+    for (; r < r1; ++r) s0 += rows[(long)r * rp + col];
+    bbg_store_agent(slice + col, (s0 + s1) + (s2 + s3));
+  }
+  // publish: every storing wave drains its write-through stores, the block meets, one lane draws the ticket
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int t = __hip_atomic_fetch_add(a.counters + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = (t == nb - 1);
+    if (t == nb - 1) __hip_atomic_store(a.counters + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+  }
+  __syncthreads();
+  if (!s_last) return;
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (compiler ordering only: the loads below are agent-scope)
+  const double count = (double)a.P;
+  const double* gs = a.slices + (long)g * nb * W2;
+  for (int c = threadIdx.x; c < a.C; c += 256) {
+    double v0 = 0.0, v1 = 0.0;
+    for (int k = 0; k < nb; ++k) {  // fixed order: slice 0, 1, 2, ...
+      v0 += bbg_load_agent(gs + (long)k * W2 + c);
+      v1 += bbg_load_agent(gs + (long)k * W2 + a.C + c);
+    }
+    if (MODE == 0) {
+      const double md = v0 / count;
+      double var = v1 / count - md * md;
+      if (var < 0.0) var = 0.0;
+      a.mean[g][c] = (float)md;
+      a.rstd[g][c] = (float)(1.0 / sqrt(var + (double)a.eps));
+      if (a.running_mean[g] != nullptr) {
+        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+        a.running_mean[g][c] = (1.f - a.momentum) * a.running_mean[g][c] + a.momentum * (float)md;
+        a.running_var[g][c] = (1.f - a.momentum) * a.running_var[g][c] + a.momentum * (float)unbiased;
+      }
+    } else {
+      float* coef = a.coef + (long)g * W2;
+      coef[c] = a.training ? (float)(v0 / count) : 0.f;
+      coef[a.C + c] = a.training ? (float)(v1 / count) : 0.f;
+      a.dgamma[g][c] += (float)v1;
+      a.dbeta[g][c] += (float)v0;
+    }
+  }
+}
+
+// eval mode: mean / rstd from the running statistics (no batch statistics, no ticket)
+__global__ __launch_bounds__(256) void cn_bbn_group_eval_stats_kernel(const CnBBnGroupArgs a) {
+  const int g = blockIdx.y;
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  if (c < a.C) {
+    a.mean[g][c] = a.running_mean[g][c];
+    a.rstd[g][c] = 1.0f / sqrtf(a.running_var[g][c] + a.eps);
+  }
+}
+
+// Per-channel partial sums over pixels for GS groups handled by ONE thread (GS = 2: the summed level, dy shared), or
+// group blockIdx.y (GS = 1). MODE as cn_bbn_partial_kernel. part rows: [(blk * G + g) * 2 + k][C] -> the finalize
+// reads group g's rows with a row stride of G (a.rows[g] = part + g * 2C, nrows rows of 2C * G floats apart).
+template <int MODE, int GS>
+__global__ __launch_bounds__(256) void cn_bbn_group_partial_kernel(const CnBBnGroupArgs a, float* __restrict__ part) {
+  __shared__ float red[256 * 16];
+  const int C = a.C, C8 = C >> 3;
+  const int R = 256 / C8;
+  const int tid = threadIdx.x;
+  const int row = tid / C8, cg = tid - row * C8;
+  const bool live = row < R;
+  const int g0 = GS == 1 ? blockIdx.y : 0;
+  float a1[GS][8], a2[GS][8], m[GS][8], rs[GS][8], ga[GS][8], be[GS][8];
+#pragma unroll
+  for (int q = 0; q < GS; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      a1[q][j] = a2[q][j] = 0.f;
+      if (MODE == 1 && live) {
+        const int c = cg * 8 + j;
+        m[q][j] = a.mean[g0 + q][c]; rs[q][j] = a.rstd[g0 + q][c];
+        ga[q][j] = a.gamma[g0 + q][c]; be[q][j] = a.beta[g0 + q][c];
+      }
+    }
+  const long p0 = blockIdx.x * a.rows_per_block;
+  const long p1 = p0 + a.rows_per_block < a.P ? p0 + a.rows_per_block : a.P;
+  if (live) {
+    const bool shared_dy = GS > 1;  // the summed level: one dy for every branch
+    for (long p = p0 + row; p < p1; p += R) {
+      u32x4 xr[GS], dr[GS];
+#pragma unroll
+      for (int q = 0; q < GS; ++q) xr[q] = *reinterpret_cast<const u32x4*>(a.x[g0 + q] + p * a.ldx + cg * 8);
+      if (MODE == 1) {
+        dr[0] = *reinterpret_cast<const u32x4*>(a.dy[g0] + p * a.lddy + cg * 8);
+#pragma unroll
+        for (int q = 1; q < GS; ++q)
+          dr[q] = shared_dy ? dr[0] : *reinterpret_cast<const u32x4*>(a.dy[g0 + q] + p * a.lddy + cg * 8);
+      }
+#pragma unroll
+      for (int q = 0; q < GS; ++q) {
+        float xv[8];
+        cn_unpack8(xr[q], xv);
+        if (MODE == 0) {
+#pragma unroll
+          for (int j = 0; j < 8; ++j) { a1[q][j] += xv[j]; a2[q][j] += xv[j] * xv[j]; }
+        } else {
+          float dv[8];
+          cn_unpack8(dr[q], dv);
+#pragma unroll
+          for (int j = 0; j < 8; ++j) {
+            const float xh = (xv[j] - m[q][j]) * rs[q][j];
+            float dz = dv[j];
+            if (a.act == 1) dz *= cn_silu_grad(ga[q][j] * xh + be[q][j]);
+            a1[q][j] += dz;
+            a2[q][j] += dz * xh;
+          }
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int q = 0; q < GS; ++q) {
+    if (q > 0) __syncthreads();
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = a1[q][j]; red[tid * 16 + 8 + j] = a2[q][j]; }
+    __syncthreads();
+    for (int idx = tid; idx < C8 * 16; idx += 256) {
+      const int g2 = idx >> 4, j = idx & 15;
+      float s = 0.f;
+      for (int r = 0; r < R; ++r) s += red[(r * C8 + g2) * 16 + j];
+      part[(((long)blockIdx.x * a.G + g0 + q) * 2 + (j >> 3)) * C + g2 * 8 + (j & 7)] = s;
+    }
+  }
+}
+
+// Forward apply. GS >= 1 with a.G == GS summed in the thread: y[0] = res + sum_g act(bn_g(x_g)); GS == 0: plain,
+// group = blockIdx.y: y[g] = act(bn_g(x_g)).
+template <int GS>
+__global__ __launch_bounds__(256) void cn_bbn_group_apply_fwd_kernel(const CnBBnGroupArgs a) {
+  constexpr int NG = GS == 0 ? 1 : GS;
+  const int C8 = a.C >> 3;
+  const int R = 256 / C8;
+  const int tid = threadIdx.x;
+  const int row = tid / C8, cg = tid - row * C8;
+  if (row >= R) return;
+  const int g0 = GS == 0 ? blockIdx.y : 0;
+  float sc[NG][8], sh[NG][8];
+#pragma unroll
+  for (int q = 0; q < NG; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cg * 8 + j;
+      const float r_ = a.rstd[g0 + q][c];
+      sc[q][j] = a.gamma[g0 + q][c] * r_;
+      sh[q][j] = a.beta[g0 + q][c] - a.mean[g0 + q][c] * sc[q][j];
+    }
+  const long p0 = blockIdx.x * a.rows_per_block;
+  const long p1 = p0 + a.rows_per_block < a.P ? p0 + a.rows_per_block : a.P;
+  const bf16_t* __restrict__ res = a.res;
+  bf16_t* __restrict__ y = a.y[g0];
+  const u32x4 z4 = {0u, 0u, 0u, 0u};
+  auto one = [&](long p, const u32x4* xr, const u32x4& rr) {
+    float o[8];
+    if (res != nullptr) cn_unpack8(rr, o);
+    else {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) o[j] = 0.f;
+    }
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      float xv[8];
+      cn_unpack8(xr[q], xv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        float z = xv[j] * sc[q][j] + sh[q][j];
+        if (a.act == 1) z = cn_silu(z);
+        o[j] += z;
+      }
+    }
+    *reinterpret_cast<u32x4*>(y + p * a.ldy + cg * 8) = cn_pack8(o);
+  };
+  long p = p0 + row;
+  for (; p + R < p1; p += 2 * R) {  // two pixels in flight: 2 * (NG + 1) sixteen-byte loads before the first use
+    u32x4 xa[NG], xb[NG];
+#pragma unroll
+    for (int q = 0; q < NG; ++q) {
+      xa[q] = *reinterpret_cast<const u32x4*>(a.x[g0 + q] + p * a.ldx + cg * 8);
+      xb[q] = *reinterpret_cast<const u32x4*>(a.x[g0 + q] + (p + R) * a.ldx + cg * 8);
+    }
+    const u32x4 ra = res != nullptr ? *reinterpret_cast<const u32x4*>(res + p * a.ldr + cg * 8) : z4;
+    const u32x4 rb = res != nullptr ? *reinterpret_cast<const u32x4*>(res + (p + R) * a.ldr + cg * 8) : z4;
+    one(p, xa, ra);
+    one(p + R, xb, rb);
+  }
+  if (p < p1) {
+    u32x4 xa[NG];
+#pragma unroll
+    for (int q = 0; q < NG; ++q) xa[q] = *reinterpret_cast<const u32x4*>(a.x[g0 + q] + p * a.ldx + cg * 8);
+    const u32x4 ra = res != nullptr ? *reinterpret_cast<const u32x4*>(res + p * a.ldr + cg * 8) : z4;
+    one(p, xa, ra);
+  }
+}
+
+// Backward apply: dx_g (+)= gamma*rstd*(dz - coef0 - xhat*coef1). GS = 2: both branches of a summed level in the
+// thread (dy read once); GS = 1: group blockIdx.y.
+template <int GS>
+__global__ __launch_bounds__(256) void cn_bbn_group_apply_bwd_kernel(const CnBBnGroupArgs a) {
+  const int C = a.C, C8 = C >> 3;
+  const int R = 256 / C8;
+  const int tid = threadIdx.x;
+  const int row = tid / C8, cg = tid - row * C8;
+  if (row >= R) return;
+  const int g0 = GS == 1 ? blockIdx.y : 0;
+  float sc[GS][8], sh[GS][8], m[GS][8], rs[GS][8], c0[GS][8], c1[GS][8];
+#pragma unroll
+  for (int q = 0; q < GS; ++q)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      const int c = cg * 8 + j;
+      m[q][j] = a.mean[g0 + q][c]; rs[q][j] = a.rstd[g0 + q][c];
+      sc[q][j] = a.gamma[g0 + q][c] * rs[q][j];
+      sh[q][j] = a.beta[g0 + q][c] - m[q][j] * sc[q][j];
+      c0[q][j] = a.coef[(long)(g0 + q) * 2 * C + c];
+      c1[q][j] = a.coef[(long)(g0 + q) * 2 * C + C + c];
+    }
+  const long p0 = blockIdx.x * a.rows_per_block;
+  const long p1 = p0 + a.rows_per_block < a.P ? p0 + a.rows_per_block : a.P;
+  for (long p = p0 + row; p < p1; p += R) {
+    u32x4 xr[GS], dr[GS], orr[GS];
+#pragma unroll
+    for (int q = 0; q < GS; ++q) {
+      xr[q] = *reinterpret_cast<const u32x4*>(a.x[g0 + q] + p * a.ldx + cg * 8);
+      if (q == 0 || GS == 1) dr[q] = *reinterpret_cast<const u32x4*>(a.dy[g0 + q] + p * a.lddy + cg * 8);
+      else dr[q] = dr[0];
+      if (a.dx[g0 + q] != nullptr && a.accumulate_dx[g0 + q])
+        orr[q] = *reinterpret_cast<const u32x4*>(a.dx[g0 + q] + p * a.lddx + cg * 8);
+    }
+#pragma unroll
+    for (int q = 0; q < GS; ++q) {
+      if (a.dx[g0 + q] == nullptr) continue;
+      float xv[8], dv[8], o[8];
+      cn_unpack8(xr[q], xv);
+      cn_unpack8(dr[q], dv);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const float xh = (xv[j] - m[q][j]) * rs[q][j];
+        float dz = dv[j];
+        if (a.act == 1) dz *= cn_silu_grad(xv[j] * sc[q][j] + sh[q][j]);
+        o[j] = sc[q][j] * (dz - c0[q][j] - xh * c1[q][j]);
+      }
+      if (a.accumulate_dx[g0 + q]) {
+        float ov[8];
+        cn_unpack8(orr[q], ov);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) o[j] += ov[j];
+      }
+      *reinterpret_cast<u32x4*>(a.dx[g0 + q] + p * a.lddx + cg * 8) = cn_pack8(o);
+    }
+  }
+}
+
+// Workspace of the grouped calls (floats): BBG_CNT_INTS ticket counters (ZERO on entry; every launch leaves them zero),
+// the finalize slices (fp64), the backward coefficients, the per-block partial rows.
+static inline long bbg_slices_off() { return BBG_CNT_INTS; }                                          // 8-byte aligned
+static inline long bbg_coef_off(int G, int C) { return bbg_slices_off() + (long)G * BBG_FIN_BLOCKS * 2 * C * 2; }
+static inline long bbg_part_off(int G, int C) { return bbg_coef_off(G, C) + (long)G * 2 * C; }
+extern "C" long cn_bn_group_workspace_floats_bf16(int G, int C) {
+  return bbg_part_off(G, C) + (long)BBN_MAX_BLOCKS * G * 2 * C;
+}
+
+static void bbg_common(CnBBnGroupArgs& a, int G, const void* const* xs, long ldx, const float* const* gammas,
+                       const float* const* betas, float* const* means, float* const* rstds, float* ws, long P, int C,
+                       int act, int training) {
+  a.G = G; a.C = C; a.P = P; a.act = act; a.training = training; a.ldx = ldx;
+  for (int g = 0; g < G; ++g) {
+    a.x[g] = (const bf16_t*)xs[g]; a.gamma[g] = gammas[g]; a.beta[g] = betas[g];
+    a.mean[g] = means[g]; a.rstd[g] = rstds[g];
+  }
+  a.counters = reinterpret_cast<int*>(ws);
+  a.slices = reinterpret_cast<double*>(ws + bbg_slices_off());
+  a.coef = ws + bbg_coef_off(G, C);
+}
+
+// ys: G outputs (sum_outputs == 0) or ys[0] = res + sum_g act(bn_g(xs[g])) (sum_outputs != 0; res nullable).
+// conv_sums (nullable, training): per-group `stats` rows of the convolution epilogue (conv_rows rows of [2][C]).
+extern "C" int cn_bn_act_group_fwd_bf16(int G, const void* const* xs, long ldx, const float* const* gammas,
+                                        const float* const* betas, float* const* running_means,
+                                        float* const* running_vars, const void* res, long ldr, void* const* ys,
+                                        long ldy, float* const* means, float* const* rstds, float* ws, long P, int C,
+                                        int training, float momentum, float eps, int act, int sum_outputs,
+                                        const float* const* conv_sums, int conv_rows, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (P <= 0 || C <= 0) return CN_OK;
+  if (G < 1 || G > BBG_MAX || (C & 7) || C > 2048) return CN_ERR_ARG;
+  if (res != nullptr && !sum_outputs) return CN_ERR_ARG;
+  CnBBnGroupArgs a = {};
+  bbg_common(a, G, xs, ldx, gammas, betas, means, rstds, ws, P, C, act, training);
+  a.eps = eps; a.momentum = momentum; a.res = (const bf16_t*)res; a.ldr = ldr; a.ldy = ldy;
+  for (int g = 0; g < G; ++g) {
+    a.running_mean[g] = running_means ? running_means[g] : nullptr;
+    a.running_var[g] = running_vars ? running_vars[g] : nullptr;
+    a.y[g] = (bf16_t*)ys[sum_outputs ? 0 : g];
+    if (!training && (a.running_mean[g] == nullptr || a.running_var[g] == nullptr)) return CN_ERR_ARG;
+  }
+  if (training) {
+    const bool fused = conv_sums != nullptr && conv_rows > 0;
+    if (fused) {
+      for (int g = 0; g < G; ++g) a.rows[g] = conv_sums[g];
+      a.nrows = conv_rows;
+      a.row_pitch = 2L * C;
+    } else {
+      int nblk;
+      long rows;
+      bbn_grid(P, C, nblk, rows);
+      a.rows_per_block = rows;
+      float* part = ws + bbg_part_off(G, C);
+      CN_LAUNCH((cn_bbn_group_partial_kernel<0, 1>), dim3(nblk, G), dim3(256), 0, stream, a, part);
+      // the partial rows of the G groups are interleaved ([blk][g][2][C]): group g's matrix starts at part + g * 2C
+      // with a row pitch of G * 2C floats
+      for (int g = 0; g < G; ++g) a.rows[g] = part + (long)g * 2 * C;
+      a.nrows = nblk;
+      a.row_pitch = 2L * C * G;
+    }
+    const int fb = a.nrows < BBG_FIN_BLOCKS ? a.nrows : BBG_FIN_BLOCKS;
+    CN_LAUNCH((cn_bbn_group_finalize_kernel<0>), dim3(fb, G), dim3(256), 0, stream, a);
+  } else {
+    CN_LAUNCH(cn_bbn_group_eval_stats_kernel, dim3((C + 255) / 256, G), dim3(256), 0, stream, a);
+  }
+  int ablk;
+  long arows;
+  bbn_apply_grid(P, C, ablk, arows);
+  a.rows_per_block = arows;
+  if (!sum_outputs) {
+    CN_LAUNCH((cn_bbn_group_apply_fwd_kernel<0>), dim3(ablk, G), dim3(256), 0, stream, a);
+  } else {
+    switch (G) {
+      case 1: CN_LAUNCH((cn_bbn_group_apply_fwd_kernel<1>), dim3(ablk), dim3(256), 0, stream, a); break;
+      case 2: CN_LAUNCH((cn_bbn_group_apply_fwd_kernel<2>), dim3(ablk), dim3(256), 0, stream, a); break;
+      case 3: CN_LAUNCH((cn_bbn_group_apply_fwd_kernel<3>), dim3(ablk), dim3(256), 0, stream, a); break;
+      default: CN_LAUNCH((cn_bbn_group_apply_fwd_kernel<4>), dim3(ablk), dim3(256), 0, stream, a); break;
+    }
+  }
+  return cn_check_launch();
+}
+
+// dys[g]: gradient of output g (shared_dy != 0: the summed level, every dys[g] is the same tensor and is read once).
+// dxs[g] nullable; dgamma / dbeta ACCUMULATED.
+extern "C" int cn_bn_act_group_bwd_bf16(int G, const void* const* xs, long ldx, const void* const* dys, long lddy,
+                                        const float* const* means, const float* const* rstds,
+                                        const float* const* gammas, const float* const* betas, void* const* dxs,
+                                        long lddx, const int* accumulate_dx, float* const* dgammas,
+                                        float* const* dbetas, float* ws, long P, int C, int training, int act,
+                                        void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (P <= 0 || C <= 0) return CN_OK;
+  if (G < 1 || G > BBG_MAX || (C & 7) || C > 2048) return CN_ERR_ARG;
+  CnBBnGroupArgs a = {};
+  bbg_common(a, G, xs, ldx, gammas, betas, const_cast<float* const*>(means), const_cast<float* const*>(rstds), ws, P, C,
+             act, training);
+  a.lddy = lddy; a.lddx = lddx;
+  bool shared = G == 2;
+  bool any_dx = false;
+  for (int g = 0; g < G; ++g) {
+    a.dy[g] = (const bf16_t*)dys[g]; a.dx[g] = (bf16_t*)dxs[g]; a.accumulate_dx[g] = accumulate_dx[g];
+    a.dgamma[g] = dgammas[g]; a.dbeta[g] = dbetas[g];
+    if (dys[g] != dys[0]) shared = false;
+    any_dx = any_dx || dxs[g] != nullptr;
+  }
+  int nblk;
+  long rows;
+  bbn_grid(P, C, nblk, rows);
+  a.rows_per_block = rows;
+  float* part = ws + bbg_part_off(G, C);
+  if (shared) CN_LAUNCH((cn_bbn_group_partial_kernel<1, 2>), dim3(nblk), dim3(256), 0, stream, a, part);
+  else CN_LAUNCH((cn_bbn_group_partial_kernel<1, 1>), dim3(nblk, G), dim3(256), 0, stream, a, part);
+  // the partial rows of the G groups are interleaved ([blk][g][2][C]): group g's matrix starts at part + g * 2C with
+  // a row pitch of G * 2C floats
+  a.nrows = nblk;
+  a.row_pitch = 2L * C * G;
+  for (int g = 0; g < G; ++g) a.rows[g] = part + (long)g * 2 * C;
+  const int fb = nblk < BBG_FIN_BLOCKS ? nblk : BBG_FIN_BLOCKS;
+  CN_LAUNCH((cn_bbn_group_finalize_kernel<1>), dim3(fb, G), dim3(256), 0, stream, a);
+  if (any_dx) {
+    int ablk;
+    long arows;
+    bbn_apply_grid(P, C, ablk, arows);
+    a.rows_per_block = arows;
+    if (shared) CN_LAUNCH((cn_bbn_group_apply_bwd_kernel<2>), dim3(ablk), dim3(256), 0, stream, a);
+    else CN_LAUNCH((cn_bbn_group_apply_bwd_kernel<1>), dim3(ablk, G), dim3(256), 0, stream, a);
+  }
+  return cn_check_launch();
+}
+
 // ---- LayerNorm over the channel axis (rows of the NHWC image) -------------------------------------------------
 // C8 = C/8 lanes share a pixel (C8 a power of two <= 64); statistics by lane shuffles, two-pass in registers.
 template <int C8>

@@ -557,8 +557,9 @@ static inline unsigned long long nab_thresh(float p) {
 // entry point serves backward (x := dy, accumulate into dx).
 __global__ __launch_bounds__(256) void cn_bdropout_kernel(const bf16_t* __restrict__ x, long ldx, bf16_t* __restrict__ y,
                                                          long ldy, long P, int C, int HW, unsigned long long thresh,
-                                                         float scale, unsigned long long seed, int channelwise,
+                                                         float scale, unsigned long long seed_, const unsigned long long* __restrict__ step, int channelwise,
                                                          int accumulate) {
+  const unsigned long long seed = cn_step_seed(seed_, step);
   const int groups = C >> 3;
   const long n = P * groups;
   for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256L) {
@@ -586,7 +587,8 @@ __global__ __launch_bounds__(256) void cn_bdropout_kernel(const bf16_t* __restri
 }
 
 extern "C" int cn_dropout_bf16(const void* x, long ldx, void* y, long ldy, int B, int C, int HW, float p,
-                               unsigned long long seed, int channelwise, int accumulate, void* stream) {
+                               unsigned long long seed, const unsigned long long* step, int channelwise, int accumulate,
+                               void* stream) {
   if (B <= 0 || C <= 0 || HW <= 0) return CN_OK;
   if (!(p >= 0.f && p < 1.f) || (C & 7)) return CN_ERR_ARG;
   const long P = (long)B * HW;
@@ -594,7 +596,7 @@ extern "C" int cn_dropout_bf16(const void* x, long ldx, void* y, long ldy, int B
   long blocks = (n + 255) / 256;
   if (blocks > 16384) blocks = 16384;
   CN_LAUNCH(cn_bdropout_kernel, dim3((unsigned)blocks), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
-            (bf16_t*)y, ldy, P, C, HW, nab_thresh(p), 1.0f / (1.0f - p), seed, channelwise, accumulate);
+            (bf16_t*)y, ldy, P, C, HW, nab_thresh(p), 1.0f / (1.0f - p), seed, step, channelwise, accumulate);
   return cn_check_launch();
 }
 
@@ -624,7 +626,8 @@ __global__ __launch_bounds__(256) void cn_bna_fwd_kernel(const bf16_t* __restric
                                                         bf16_t* __restrict__ out, long ldo, float* __restrict__ attn,
                                                         int B, int C, int heads, int H, int W, int dil, float scale,
                                                         unsigned long long dthresh, float dscale,
-                                                        unsigned long long dseed) {
+                                                        unsigned long long dseed_, const unsigned long long* __restrict__ dstep) {
+  const unsigned long long dseed = cn_step_seed(dseed_, dstep);
   const int HW = H * W;
   const long n = (long)B * HW * heads;
   const long i = blockIdx.x * 256L + threadIdx.x;
@@ -682,7 +685,8 @@ __global__ __launch_bounds__(256) void cn_bna_bwd_q_kernel(const bf16_t* __restr
                                                           bf16_t* __restrict__ dqkv, long lddq, int B, int C,
                                                           int heads, int H, int W, int dil, float scale,
                                                           unsigned long long dthresh, float dscale,
-                                                          unsigned long long dseed) {
+                                                          unsigned long long dseed_, const unsigned long long* __restrict__ dstep) {
+  const unsigned long long dseed = cn_step_seed(dseed_, dstep);
   const int HW = H * W;
   const long n = (long)B * HW * heads;
   const long i = blockIdx.x * 256L + threadIdx.x;
@@ -740,7 +744,8 @@ __global__ __launch_bounds__(256) void cn_bna_bwd_kv_kernel(const bf16_t* __rest
                                                            bf16_t* __restrict__ dqkv, long lddq, int B, int C,
                                                            int heads, int H, int W, int dil, float scale,
                                                            unsigned long long dthresh, float dscale,
-                                                           unsigned long long dseed) {
+                                                           unsigned long long dseed_, const unsigned long long* __restrict__ dstep) {
+  const unsigned long long dseed = cn_step_seed(dseed_, dstep);
   const int HW = H * W;
   const long n = (long)B * HW * heads;
   const long i = blockIdx.x * 256L + threadIdx.x;
@@ -798,7 +803,7 @@ __global__ __launch_bounds__(256) void cn_bna_bwd_kv_kernel(const bf16_t* __rest
 
 extern "C" int cn_na2d_fwd_bf16(const void* qkv, long ldq, void* out, long ldo, float* attn, int B, int C, int heads,
                                 int H, int W, int kernel_size, int dilation, float attn_drop, unsigned long long seed,
-                                void* stream_) {
+                                const unsigned long long* step, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (kernel_size != NAB_K || heads <= 0 || C % heads != 0) return CN_ERR_ARG;
   if (kernel_size * dilation > H || kernel_size * dilation > W) return CN_ERR_ARG;
@@ -808,14 +813,15 @@ extern "C" int cn_na2d_fwd_bf16(const void* qkv, long ldq, void* out, long ldo, 
   const dim3 grid((unsigned)((n + 255) / 256));
   if (!(attn_drop >= 0.f && attn_drop < 1.f)) return CN_ERR_ARG;
   NAB_DISPATCH(D, cn_bna_fwd_kernel, (const bf16_t*)qkv, ldq, (bf16_t*)out, ldo, attn, B, C, heads, H, W, dilation,
-               scale, nab_thresh(attn_drop), 1.0f / (1.0f - attn_drop), seed);
+               scale, nab_thresh(attn_drop), 1.0f / (1.0f - attn_drop), seed, step);
   return cn_check_launch();
 }
 
 // dqkv bf16 [B][H][W][3C] fully overwritten; dattn: scratch of attn's size.
 extern "C" int cn_na2d_bwd_bf16(const void* qkv, long ldq, const void* dout, long ldo, const float* attn, float* dattn,
                                 void* dqkv, long lddq, int B, int C, int heads, int H, int W, int kernel_size,
-                                int dilation, float attn_drop, unsigned long long seed, void* stream_) {
+                                int dilation, float attn_drop, unsigned long long seed, const unsigned long long* step,
+                                void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (kernel_size != NAB_K || heads <= 0 || C % heads != 0) return CN_ERR_ARG;
   const int D = C / heads;
@@ -826,8 +832,8 @@ extern "C" int cn_na2d_bwd_bf16(const void* qkv, long ldq, const void* dout, lon
   const unsigned long long th = nab_thresh(attn_drop);
   const float ds = 1.0f / (1.0f - attn_drop);
   NAB_DISPATCH(D, cn_bna_bwd_q_kernel, (const bf16_t*)qkv, ldq, (const bf16_t*)dout, ldo, attn, dattn, (bf16_t*)dqkv,
-               lddq, B, C, heads, H, W, dilation, scale, th, ds, seed);
+               lddq, B, C, heads, H, W, dilation, scale, th, ds, seed, step);
   NAB_DISPATCH(D, cn_bna_bwd_kv_kernel, (const bf16_t*)qkv, ldq, (const bf16_t*)dout, ldo, attn, dattn, (bf16_t*)dqkv,
-               lddq, B, C, heads, H, W, dilation, scale, th, ds, seed);
+               lddq, B, C, heads, H, W, dilation, scale, th, ds, seed, step);
   return cn_check_launch();
 }

@@ -24,6 +24,13 @@ static inline int cn_check_launch() {
 extern long g_cn_launches;
 #define CN_LAUNCH(...) do { __atomic_fetch_add(&g_cn_launches, 1L, __ATOMIC_RELAXED); hipLaunchKernelGGL(__VA_ARGS__); } while (0)
 
+// Dropout seeds: `seed` is a launch argument (constant inside a recorded launch plan); `step` (nullable) points at a
+// device word the host bumps once per training step (cn_rng_advance_u64), so that a REPLAYED plan draws fresh masks
+// every step and the eager step -- same word, same bump -- draws identical ones.
+__device__ __forceinline__ unsigned long long cn_step_seed(unsigned long long seed, const unsigned long long* step) {
+  return step != nullptr ? seed + (*step) * 0xD1B54A32D192ED03ull : seed;
+}
+
 static inline int cn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
 
 // ---- XCD-aware block order -------------------------------------------------------------------------------

@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void cn_na2d_fwd_kernel(const float* __restric
                                                          float* __restrict__ out, long obs,
                                                          float* __restrict__ attn, int B, int C, int heads, int H,
                                                          int W, int dil, float scale, unsigned long long dthresh,
-                                                         float dscale, unsigned long long dseed) {
+                                                         float dscale, unsigned long long dseed_, const unsigned long long* __restrict__ dstep) {
+  const unsigned long long dseed = cn_step_seed(dseed_, dstep);
   const int HW = H * W;
   int bx, h, b;
   if (!cn_xcd_block((HW + 255) / 256, heads, ((HW + 255) / 256) * heads * B, bx, h, b)) return;
@@ -112,7 +113,8 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_q_kernel(const float* __restr
                                                            float* __restrict__ dattn, float* __restrict__ dqkv,
                                                            long dqbs, int B, int C, int heads, int H, int W, int dil,
                                                            float scale, unsigned long long dthresh, float dscale,
-                                                           unsigned long long dseed) {
+                                                           unsigned long long dseed_, const unsigned long long* __restrict__ dstep) {
+  const unsigned long long dseed = cn_step_seed(dseed_, dstep);
   const int HW = H * W;
   int bx, h, b;
   if (!cn_xcd_block((HW + 255) / 256, heads, ((HW + 255) / 256) * heads * B, bx, h, b)) return;
@@ -174,7 +176,8 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_kv_kernel(const float* __rest
                                                             float* __restrict__ dqkv, long dqbs, int B, int C,
                                                             int heads, int H, int W, int dil, float scale,
                                                             unsigned long long dthresh, float dscale,
-                                                            unsigned long long dseed) {
+                                                            unsigned long long dseed_, const unsigned long long* __restrict__ dstep) {
+  const unsigned long long dseed = cn_step_seed(dseed_, dstep);
   const int HW = H * W;
   int bx, h, b;
   if (!cn_xcd_block((HW + 255) / 256, heads, ((HW + 255) / 256) * heads * B, bx, h, b)) return;
@@ -242,7 +245,7 @@ static unsigned long long na_thresh(float p) {
 
 extern "C" int cn_na2d_fwd_f32(const float* qkv, long qbs, float* out, long obs, float* attn, int B, int C,
                                int heads, int H, int W, int kernel_size, int dilation, float attn_drop,
-                               unsigned long long seed, void* stream_) {
+                               unsigned long long seed, const unsigned long long* step, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (kernel_size != NA_K || heads <= 0 || C % heads != 0) return CN_ERR_ARG;
   if (kernel_size * dilation > H || kernel_size * dilation > W) return CN_ERR_ARG;
@@ -251,7 +254,7 @@ extern "C" int cn_na2d_fwd_f32(const float* qkv, long qbs, float* out, long obs,
   dim3 grid(cn_xcd_grid((long)((H * W + 255) / 256) * heads * B));  // XCD-aware order, decoded in the kernels
   if (!(attn_drop >= 0.f && attn_drop < 1.f)) return CN_ERR_ARG;
   NA_DISPATCH(D, cn_na2d_fwd_kernel, qkv, qbs, out, obs, attn, B, C, heads, H, W, dilation, scale,
-              na_thresh(attn_drop), 1.0f / (1.0f - attn_drop), seed);
+              na_thresh(attn_drop), 1.0f / (1.0f - attn_drop), seed, step);
   return cn_check_launch();
 }
 
@@ -259,7 +262,7 @@ extern "C" int cn_na2d_fwd_f32(const float* qkv, long qbs, float* out, long obs,
 extern "C" int cn_na2d_bwd_f32(const float* qkv, long qbs, const float* dout, long dobs, const float* attn,
                                float* dattn, float* dqkv, long dqbs, int B, int C, int heads, int H, int W,
                                int kernel_size, int dilation, float attn_drop, unsigned long long seed,
-                               void* stream_) {
+                               const unsigned long long* step, void* stream_) {
   hipStream_t stream = (hipStream_t)stream_;
   if (kernel_size != NA_K || heads <= 0 || C % heads != 0) return CN_ERR_ARG;
   const int D = C / heads;
@@ -269,8 +272,8 @@ extern "C" int cn_na2d_bwd_f32(const float* qkv, long qbs, const float* dout, lo
   const unsigned long long th = na_thresh(attn_drop);
   const float ds = 1.0f / (1.0f - attn_drop);
   NA_DISPATCH(D, cn_na2d_bwd_q_kernel, qkv, qbs, dout, dobs, attn, dattn, dqkv, dqbs, B, C, heads, H, W, dilation,
-              scale, th, ds, seed);
+              scale, th, ds, seed, step);
   NA_DISPATCH(D, cn_na2d_bwd_kv_kernel, qkv, qbs, dout, dobs, attn, dattn, dqkv, dqbs, B, C, heads, H, W, dilation,
-              scale, th, ds, seed);
+              scale, th, ds, seed, step);
   return cn_check_launch();
 }

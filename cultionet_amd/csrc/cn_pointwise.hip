@@ -466,8 +466,9 @@ __device__ __forceinline__ unsigned long long cn_splitmix64(unsigned long long z
 
 __global__ __launch_bounds__(256) void cn_dropout_kernel(const float* __restrict__ x, long xbs, float* __restrict__ y,
                                                         long ybs, int C, int L, unsigned long long thresh,
-                                                        float scale, unsigned long long seed, int channelwise,
+                                                        float scale, unsigned long long seed_, const unsigned long long* __restrict__ step, int channelwise,
                                                         int accumulate) {
+  const unsigned long long seed = cn_step_seed(seed_, step);
   const int c = blockIdx.y, b = blockIdx.z;
   const unsigned long long plane = (unsigned long long)b * C + c;
   const float* xp = x + b * xbs + (long)c * L;
@@ -482,7 +483,8 @@ __global__ __launch_bounds__(256) void cn_dropout_kernel(const float* __restrict
 }
 
 extern "C" int cn_dropout_f32(const float* x, long xbs, float* y, long ybs, int B, int C, int L, float p,
-                              unsigned long long seed, int channelwise, int accumulate, void* stream) {
+                              unsigned long long seed, const unsigned long long* step, int channelwise, int accumulate,
+                              void* stream) {
   if (B <= 0 || C <= 0 || L <= 0) return CN_OK;
   if (!(p >= 0.f && p < 1.f)) return CN_ERR_ARG;
   const double t = (double)p * 18446744073709551616.0;  // p * 2^64
@@ -490,7 +492,17 @@ extern "C" int cn_dropout_f32(const float* x, long xbs, float* y, long ybs, int 
   int bx = (L + 1023) / 1024;
   if (bx < 1) bx = 1;
   CN_LAUNCH(cn_dropout_kernel, dim3(bx, C, B), dim3(256), 0, (hipStream_t)stream, x, xbs, y, ybs, C, L,
-                     thresh, 1.0f / (1.0f - p), seed, channelwise, accumulate);
+                     thresh, 1.0f / (1.0f - p), seed, step, channelwise, accumulate);
+  return cn_check_launch();
+}
+
+__global__ void cn_rng_advance_kernel(unsigned long long* word, unsigned long long value, int set) {
+  if (threadIdx.x == 0 && blockIdx.x == 0) *word = set ? value : *word + value;
+}
+
+extern "C" int cn_rng_advance_u64(unsigned long long* word, unsigned long long value, int set, void* stream) {
+  if (word == nullptr) return CN_ERR_ARG;
+  CN_LAUNCH(cn_rng_advance_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, word, value, set);
   return cn_check_launch();
 }
 

@@ -526,7 +526,8 @@ class HipTrainer:
         self.lit = lit
         # replay=True: forward + loss + backward run from a recorded launch plan after the first steps
         # (cultionet_amd/replay.py): the Python of a step drops from ~8-10 ms to ~1.5 ms, which is what bounds the step at
-        # the reference's default batch of 4 in mixed precision. Needs dropout == 0 and no communicator (else eager).
+        # the reference's default batch of 4 in mixed precision. Dropout replays too (the per-step part of the mask
+        # seeds is a device word the plan's first launch bumps); a communicator keeps the step eager.
         self.replay = bool(replay)
         self._plan = None
         self._plan_key = None
@@ -569,7 +570,7 @@ class HipTrainer:
 
     def forward_backward(self, batch: Data) -> torch.Tensor:
         """Forward + loss + backward; leaves d(loss)/d(params) in store.flat_grad. Returns the loss (1-elem tensor)."""
-        if self.replay and self.comm is None and self.model.training and not self._has_dropout():
+        if self.replay and self.comm is None and self.model.training:
             from . import replay as R
 
             key = R.step_key(self, batch)
@@ -580,14 +581,11 @@ class HipTrainer:
             if self._plan_key != key:  # new shapes / stream: two eager steps first (workspaces grow, packs are built)
                 self._plan_key, self._eager_steps, self._plan = key, 0, None
             if self._eager_steps >= 2:  # everything lazily created exists by now: record this step
-                self._plan = R.record_step(self, batch, self._forward_backward_eager)
+                plan = R.record_step(self, batch, self._forward_backward_eager)
+                self._plan = plan if plan.key is not None else None  # (None: a scratch buffer moved while recording)
                 return self.total
         self._eager_steps += 1
         return self._forward_backward_eager(batch)
-
-    def _has_dropout(self) -> bool:
-        return any(isinstance(m, (torch.nn.Dropout, torch.nn.Dropout2d)) and m.p > 0 for m in self.model.modules()) or \
-            any(getattr(m, "attn_drop", 0.0) > 0 or getattr(m, "proj_drop", 0.0) > 0 for m in self.model.modules())
 
     def _forward_backward_eager(self, batch: Data) -> torch.Tensor:
         from . import _lib

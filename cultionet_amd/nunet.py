@@ -172,9 +172,20 @@ class TowerUNet(nn.Module):
                                         and m.num_batches_tracked is not None]
         return st
 
+    def has_dropout(self) -> bool:
+        """Any Dropout2d / Dropout / natten attn_drop / proj_drop with p > 0 (fixed at construction: cached)."""
+        hd = self.__dict__.get("_cn_has_dropout")
+        if hd is None:
+            hd = any(isinstance(m, (nn.Dropout, nn.Dropout2d)) and m.p > 0 for m in self.modules()) or \
+                any(getattr(m, "attn_drop", 0.0) > 0 or getattr(m, "proj_drop", 0.0) > 0 for m in self.modules())
+            self.__dict__["_cn_has_dropout"] = hd
+        return hd
+
     def forward_vars(self, x: E.Var) -> T.Dict[str, E.Var]:
         """Engine-level forward: x is a Var over [B, C*T, H, W]; returns {distance, edge, crop} Vars."""
         E.current_store().refresh()  # torch optimizers / checkpoint loads since the last pack (drop-in mode)
+        if self.training and self.has_dropout():
+            E.begin_rng_step(x.t.device)  # fresh dropout masks for this step (device step word; see engine.manual_seed)
         emb = self.pre_unet(x)
         enc = self.encoder(emb)
         dec = self.decoder(enc)

@@ -27,6 +27,9 @@ from . import _lib
 from . import engine as E
 
 
+MAX_PLANS = 4  # per model: (input shape, precision) slots kept alive
+
+
 class ForwardPlan:
     __slots__ = ("calls", "pool", "x", "outputs", "key", "keep")
 
@@ -51,7 +54,7 @@ def _bn_signature(model) -> int:
 def _key(model, store, x: torch.Tensor, bf16: bool):
     store.refresh()
     return (tuple(x.shape), x.dtype, bool(bf16), id(store), store.version, E._bn_stats_epoch, _bn_signature(model),
-            torch.cuda.current_stream(x.device).cuda_stream, E._EVAL_FUSION)
+            torch.cuda.current_stream(x.device).cuda_stream, E._EVAL_FUSION, E.workspace_epoch())
 
 
 def plan_input(model, shape: T.Sequence[int], bf16: bool, device) -> T.Optional[torch.Tensor]:
@@ -71,6 +74,8 @@ def forward(model, x: torch.Tensor, bf16: bool, run: T.Callable[[torch.Tensor], 
     key = _key(model, store, x, bf16)
     plan = plans.get(slot)
     if plan is not None and plan.key == key:
+        if len(plans) > 1:  # most recently used last (the cache is a small LRU, see below)
+            plans[slot] = plans.pop(slot)
         if x.data_ptr() != plan.x.data_ptr():
             plan.x.copy_(x)
         for fn, args in plan.calls:
@@ -93,6 +98,7 @@ def forward(model, x: torch.Tensor, bf16: bool, run: T.Callable[[torch.Tensor], 
         plan.calls.append((fn, args))
         return rc
 
+    epoch0 = E.workspace_epoch()
     with torch.cuda.use_mem_pool(plan.pool):
         plan.x = torch.empty_like(x)
         plan.x.copy_(x)
@@ -102,8 +108,15 @@ def forward(model, x: torch.Tensor, bf16: bool, run: T.Callable[[torch.Tensor], 
         finally:
             _lib.call = orig
         plan.outputs = dict(outs)
+    if E.workspace_epoch() != epoch0:  # a scratch buffer moved while recording: stale pointers, do not keep the plan
+        return plan.outputs
     plan.key = _key(model, store, x, bf16)  # (recording may have refreshed packed weights: the key after it)
+    plans.pop(slot, None)
     plans[slot] = plan
+    # a plan owns a private memory pool with the whole activation set of its batch (GBs for a packed window batch):
+    # keep the MAX_PLANS most recently used shapes (full batch + ragged tail, both precisions), drop the rest
+    while len(plans) > MAX_PLANS:
+        plans.pop(next(iter(plans)))
     return plan.outputs
 
 
@@ -121,8 +134,9 @@ def forward(model, x: torch.Tensor, bf16: bool, run: T.Callable[[torch.Tensor], 
 #     (torch.empty / empty_like / zeros_like are wrapped), so each kernel of the step has buffers of its own; the price
 #     is memory (the sum of a step's allocations instead of its peak), which is what 288 GB are for;
 #   * the optimizer (clip + AdamW: two launches with per-step scalars) stays outside the plan.
-# Valid for one (batch shapes, precision, stream, store, loss kind); dropout > 0 (per-step seeds) and a communicator
-# (per-bucket collectives) fall back to the eager step. Bit-exact w.r.t. the eager step except where the eager step itself
+# Valid for one (batch shapes, precision, stream, store, loss kind, scratch-buffer epoch); a communicator (per-bucket
+# collectives) falls back to the eager step. Dropout > 0 replays: the per-step part of every mask seed is a device word
+# that the plan's first launch bumps (engine.begin_rng_step), the recorded seed arguments are the per-call constants. Bit-exact w.r.t. the eager step except where the eager step itself
 # is not (float-atomic parameter-gradient sums): tests/test_replay_train_gpu.py.
 # ---------------------------------------------------------------------------------------------------------------------
 class StepPlan:
@@ -141,7 +155,8 @@ class StepPlan:
 def step_key(trainer, batch) -> tuple:
     x, y, bd = batch.x, batch.y, batch.bdist
     return (tuple(x.shape), x.dtype, tuple(y.shape), y.dtype, tuple(bd.shape), bd.dtype, trainer.bf16, id(trainer.store),
-            str(trainer.lit.loss_name), torch.cuda.current_stream(x.device).cuda_stream, E._OVERLAP_WGRAD)
+            str(trainer.lit.loss_name), torch.cuda.current_stream(x.device).cuda_stream, E._OVERLAP_WGRAD,
+            E.workspace_epoch())
 
 
 def record_step(trainer, batch, eager: T.Callable) -> StepPlan:
@@ -154,6 +169,7 @@ def record_step(trainer, batch, eager: T.Callable) -> StepPlan:
     lib = _lib.load()
     orig_call = _lib.call
     ops = plan.ops
+    epoch0 = E.workspace_epoch()
 
     def recording(name: str, *args):
         fn = getattr(lib, name)
@@ -164,20 +180,31 @@ def record_step(trainer, batch, eager: T.Callable) -> StepPlan:
         return rc
 
     wrapped = {}
+    import threading
+
+    tid = threading.get_ident()
 
     def keepalive(fname):
         real = getattr(torch, fname)
 
         def f(*a, **k):
             t = real(*a, **k)
-            plan.keep.append(t)
+            if threading.get_ident() == tid:  # (a loader / pin-memory thread allocating meanwhile is not the step's)
+                plan.keep.append(t)
             return t
 
         wrapped[fname] = real
         setattr(torch, fname, f)
 
     with torch.cuda.use_mem_pool(plan.pool):
-        plan.inputs = (torch.empty_like(batch.x), torch.empty_like(batch.y), torch.empty_like(batch.bdist))
+        # the plan's inputs in the CANONICAL form the loss / forward kernels consume (x fp32, labels int64, distances
+        # fp32, all dense): `dst.copy_(src)` of every replayed step then does any cast / re-striding on the device, and no
+        # torch conversion kernel (y.long(), .contiguous() -- which a launch plan cannot see) sits between the plan's
+        # input buffers and the recorded launches
+        dev = batch.x.device
+        plan.inputs = (torch.empty(tuple(batch.x.shape), dtype=torch.float32, device=dev),
+                       torch.empty(tuple(batch.y.shape), dtype=torch.int64, device=dev),
+                       torch.empty(tuple(batch.bdist.shape), dtype=torch.float32, device=dev))
         for dst, src in zip(plan.inputs, (batch.x, batch.y, batch.bdist)):
             dst.copy_(src)
         pb = Data(x=plan.inputs[0], y=plan.inputs[1], bdist=plan.inputs[2])
@@ -194,7 +221,9 @@ def record_step(trainer, batch, eager: T.Callable) -> StepPlan:
             for fname, real in wrapped.items():
                 setattr(torch, fname, real)
     plan.outputs = dict(trainer.last_outputs)
-    plan.key = step_key(trainer, batch)
+    # a scratch buffer that was (re)allocated WHILE recording leaves stale pointers in the earlier entries: no key, so
+    # the caller drops this plan and records again once the buffers have settled
+    plan.key = step_key(trainer, batch) if E.workspace_epoch() == epoch0 else None
     plan.n_calls = sum(1 for o in ops if o[0] == 0)
     return plan
 

@@ -207,12 +207,13 @@ int cn_sca_apply_bwd_f32(const float* dy, long dybs, const float* out, long obs,
 /* ---- natten.NeighborhoodAttention2D core (convolution.py:341-350; natten 0.17.1 na2d_qk ->
  * softmax -> na2d_av, kernel 3, dilation d, no rpb). qkv [B][3C][H][W] with channel
  * (which*C + head*D + d); attn [B][heads][9][H][W] saved probabilities; dattn same-size scratch.
- * attn_drop in [0,1): dropout on the probabilities (mask recomputed from `seed`, as cn_dropout_f32). */
+ * attn_drop in [0,1): dropout on the probabilities (mask recomputed from `seed` / `step`, as cn_dropout_f32). */
 int cn_na2d_fwd_f32(const float* qkv, long qbs, float* out, long obs, float* attn, int B, int C, int heads, int H,
-                    int W, int kernel_size, int dilation, float attn_drop, unsigned long long seed, void* stream);
+                    int W, int kernel_size, int dilation, float attn_drop, unsigned long long seed,
+                    const unsigned long long* step, void* stream);
 int cn_na2d_bwd_f32(const float* qkv, long qbs, const float* dout, long dobs, const float* attn, float* dattn,
                     float* dqkv, long dqbs, int B, int C, int heads, int H, int W, int kernel_size, int dilation,
-                    float attn_drop, unsigned long long seed, void* stream);
+                    float attn_drop, unsigned long long seed, const unsigned long long* step, void* stream);
 
 /* ---- F.interpolate(mode="bilinear", align_corners=True) (nn/functional.py:72-81) ------------ */
 int cn_bilinear_fwd_f32(const float* x, long xbs, float* y, long ybs, int B, int C, int Hi, int Wi, int Ho, int Wo,
@@ -227,9 +228,15 @@ int cn_fill_f32(float* p, long n, float v, void* stream);
 
 /* ---- nn.Dropout2d / nn.Dropout (convolution.py:495,511; natten attn_drop, proj_drop) -------------
  * y (+)= x * keep / (1-p); keep = splitmix64(seed + index) >= p*2^64 is recomputed, never stored: call
- * again with x := dy (same seed) for the backward pass. channelwise != 0: one draw per (b, c) plane. */
+ * again with x := dy (same seed) for the backward pass. channelwise != 0: one draw per (b, c) plane.
+ * `step` (nullable): device word added to the seed as seed + *step * 0xD1B54A32D192ED03 -- the per-step part of the
+ * seed lives in HBM so that a recorded launch plan (constant arguments) draws fresh masks every step; the reference
+ * draws from torch's global generator, which advances per step the same way (nn.Dropout2d, convolution.py:495). */
 int cn_dropout_f32(const float* x, long xbs, float* y, long ybs, int B, int C, int L, float p,
-                   unsigned long long seed, int channelwise, int accumulate, void* stream);
+                   unsigned long long seed, const unsigned long long* step, int channelwise, int accumulate,
+                   void* stream);
+/* *word = set ? value : *word + value (one thread): bumps the dropout step word on the launch stream. */
+int cn_rng_advance_u64(unsigned long long* word, unsigned long long value, int set, void* stream);
 
 /* ---- F.adaptive_max_pool2d (pool_by_max=True, convolution.py:499-503) -------------------------
  * idx: int32 [B][C][Ho][Wo] flat argmax inside the input plane (kept for backward). */
@@ -338,7 +345,8 @@ int cn_conv2d_fwd_bf16(const void* x, long ldx, const void* wp, const float* bia
 int cn_conv2d_fwd_grouped_bf16(int G, const void* const* xs, long ldx, const void* const* wps,
                                const float* const* biases /*nullable*/, void* const* ys, long ldy, int B, int Cin,
                                int Hin, int Win, int Cout, int KH, int KW, int stride, const int* pads,
-                               const int* dils, int accumulate, void* stream);
+                               const int* dils, int accumulate, float* const* stats /*nullable: G row sets*/,
+                               void* stream);
 int cn_conv2d_bwd_data_bf16(const void* dy, long lddy, const void* wp_t, void* dx, long lddx, int B, int Cin, int Hin,
                             int Win, int Cout, int KH, int KW, int stride, int pad, int dil, int accumulate,
                             void* stream);
@@ -376,6 +384,29 @@ int cn_bn_act_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const
                        const float* gamma, const float* beta, void* dx /*nullable*/, long lddx, float* dgamma,
                        float* dbeta, float* ws, long P, int C, int training, int act, int accumulate_dx, void* stream);
 
+/* Grouped BatchNorm2d(+SiLU) on the mixed-precision path: the G (<= 4) BatchNorm layers of one ResidualAConv level
+ * (convolution.py:376-395) over G same-shaped bf16 NHWC tensors, one launch per pass; pointer arguments ending in `s`
+ * are HOST arrays of G device pointers. sum_outputs != 0: ys[0] = res + sum_g act(bn_g(xs[g])) in ONE pass (fp32
+ * accumulation, one rounding); else ys[g] = act(bn_g(xs[g])), res must be NULL. conv_sums (nullable, training): per
+ * group the `stats` rows of cn_conv2d_fwd[_grouped]_bf16 (conv_rows rows each). The batch statistics are finalized by
+ * ONE launch: coalesced column sums of the partial rows whose per-block slices are combined by the last-arriving
+ * block (device ticket; fixed summation order, bit-reproducible). ws: cn_bn_group_workspace_floats_bf16(G, C) floats
+ * whose first 64 ints are ticket counters: ZERO before the first call (every call leaves them zero).
+ * Backward: dys[g] = gradient of output g (after a summed forward the same pointer G times: read once per pass);
+ * dxs[g] nullable; accumulate_dx: HOST array of G flags; dgammas / dbetas ACCUMULATED. */
+long cn_bn_group_workspace_floats_bf16(int G, int C);
+int cn_bn_act_group_fwd_bf16(int G, const void* const* xs, long ldx, const float* const* gammas,
+                             const float* const* betas, float* const* running_means, float* const* running_vars,
+                             const void* res /*nullable*/, long ldr, void* const* ys, long ldy, float* const* means,
+                             float* const* rstds, float* ws, long P, int C, int training, float momentum, float eps,
+                             int act, int sum_outputs, const float* const* conv_sums /*nullable*/, int conv_rows,
+                             void* stream);
+int cn_bn_act_group_bwd_bf16(int G, const void* const* xs, long ldx, const void* const* dys, long lddy,
+                             const float* const* means, const float* const* rstds, const float* const* gammas,
+                             const float* const* betas, void* const* dxs, long lddx, const int* accumulate_dx,
+                             float* const* dgammas, float* const* dbetas, float* ws, long P, int C, int training,
+                             int act, void* stream);
+
 /* bias gradients: out[c] (+)= sum_p x[p][c]; ws: cn_bn_workspace_floats_bf16(C) floats */
 int cn_channel_sum_bf16(const void* x, long ldx, long P, int C, float* out, int accumulate, float* ws, void* stream);
 
@@ -405,15 +436,16 @@ int cn_bilinear_bwd_bf16(const void* dy, long lddy, void* dx, long lddx, int B, 
 
 /* NeighborhoodAttention2D core: qkv [B][H][W][3C], out [B][H][W][C]; attn / dattn fp32 [B][heads][9][H][W]. */
 int cn_na2d_fwd_bf16(const void* qkv, long ldq, void* out, long ldo, float* attn, int B, int C, int heads, int H, int W,
-                     int kernel_size, int dilation, float attn_drop, unsigned long long seed, void* stream);
+                     int kernel_size, int dilation, float attn_drop, unsigned long long seed,
+                     const unsigned long long* step, void* stream);
 int cn_na2d_bwd_bf16(const void* qkv, long ldq, const void* dout, long ldo, const float* attn, float* dattn, void* dqkv,
                      long lddq, int B, int C, int heads, int H, int W, int kernel_size, int dilation, float attn_drop,
-                     unsigned long long seed, void* stream);
+                     unsigned long long seed, const unsigned long long* step, void* stream);
 
 /* nn.Dropout2d (channelwise) / nn.Dropout on bf16 NHWC activations [B*HW rows][C], the same counter-based masks as
  * cn_dropout_f32 (convolution.py:495,511; natten proj_drop); backward = the same call on dy with accumulate. */
 int cn_dropout_bf16(const void* x, long ldx, void* y, long ldy, int B, int C, int HW, float p, unsigned long long seed,
-                    int channelwise, int accumulate, void* stream);
+                    const unsigned long long* step, int channelwise, int accumulate, void* stream);
 
 /* ---- diagnostics: per-launch HIP-event timing of the contraction kernels (bench.py roofline) ---
  * begin() starts recording event pairs around every implicit-GEMM / weight-gradient launch on the

@@ -175,6 +175,16 @@ def main():
             out["meta"] = np.array([8, 2, 28, 28, int(mask), 11])
             save(name + ".npz", out)
         return
+    if "--bf16-h64-only" in sys.argv:
+        # the reference CLI's default operating point (model.py:52,56,86; scripts/args.yml:220-226,248-254): hidden 64,
+        # batch 4, 16-mixed -- under CPU bf16 autocast, plus the fp32 twin of the same case
+        args = (64, 4, 100, 100, True)
+        a = _train_case(ns, *args, autocast=True)
+        f = _train_case(ns, *args, autocast=False)
+        for k in ("distance", "edge", "crop", "loss", "dloss", "eloss", "closs", "grad_norms"):
+            a["fp32_" + k] = f[k]
+        save("train_bf16_h64_b4_100.npz", a)
+        return
     if "--bf16-only" in sys.argv:
         # mixed-precision fixtures (BASELINE configs[2]): the reference under CPU bf16 autocast, plus the fp32 run of
         # the SAME case so the tests can state the tolerance relative to the reference's own bf16 deviation

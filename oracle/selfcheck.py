@@ -43,12 +43,18 @@ def smoke_check(device: str = "cuda:0", hidden: int = 8, B: int = 2, H: int = 28
     assert dl <= tol, f"loss mismatch: hip {float(loss.item()):.7f} vs oracle {float(loss_ref.item()):.7f}"
     store = trainer.store
     model = lit.cultionet_model.mask_model
-    worst = 0.0
-    for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
-        g = store.grad_of(p).cpu()
-        scale = max(1.0, float(pr.grad.abs().max()))
-        worst = max(worst, float((g - pr.grad).abs().max()) / scale)
-    assert worst <= 1e-3, f"gradient mismatch {worst:.3e}"
+    # gradient error RELATIVE to each parameter's own gradient norm (gradients here are of order 1e-4..1e-2: an absolute
+    # bound would pass a wrong one); the floor -- 1e-3 of the largest per-parameter norm -- only keeps parameters whose
+    # true gradient is rounding noise (e.g. a bias in front of a BatchNorm) from dividing by ~0. Same 2e-3 as -m gpu.
+    pairs = [(n, store.grad_of(p).cpu().double(), pr.grad.double())
+             for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters())]
+    floor = 1e-3 * max(float(gr.norm()) for _, _, gr in pairs)
+    worst, worst_name = 0.0, ""
+    for n, g, gr in pairs:
+        rel = float((g - gr).norm()) / max(float(gr.norm()), floor)
+        if rel > worst:
+            worst, worst_name = rel, n
+    assert worst <= 2e-3, f"gradient mismatch {worst:.3e} (relative to the parameter's gradient norm) at {worst_name}"
     trainer.optimizer_step()
     torch.cuda.synchronize()
     print(f"smoke ok: loss {float(loss.item()):.6f} (|d|={dl:.2e}), worst rel grad err {worst:.2e}")

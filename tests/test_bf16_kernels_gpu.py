@@ -341,13 +341,13 @@ def test_na2d_bf16(shape, heads, dil):
     out = _empty_nhwc(B, C, H, W)
     at = torch.empty((B, heads, 9, H, W), device=dev)
     _lib.call("cn_na2d_fwd_bf16", qg.data_ptr(), _ld(qg), out.data_ptr(), _ld(out), at.data_ptr(), B, C, heads, H, W, 3,
-              dil, 0.0, 0, _s())
+              dil, 0.0, 0, None, _s())
     _close(out, outr, 6e-3, "out")
     dyg = _nhwc(dy)
     dq = _empty_nhwc(B, 3 * C, H, W)
     dat = torch.empty_like(at)
     _lib.call("cn_na2d_bwd_bf16", qg.data_ptr(), _ld(qg), dyg.data_ptr(), _ld(dyg), at.data_ptr(), dat.data_ptr(),
-              dq.data_ptr(), _ld(dq), B, C, heads, H, W, 3, dil, 0.0, 0, _s())
+              dq.data_ptr(), _ld(dq), B, C, heads, H, W, 3, dil, 0.0, 0, None, _s())
     _close(dq, qr.grad, 8e-3, "dqkv")
 
 
@@ -368,30 +368,30 @@ def test_na2d_bf16_attention_dropout(shape, heads, dil):
     o32 = torch.empty((B, C, H, W), device=dev)
     a32 = torch.empty((B, heads, 9, H, W), device=dev)
     _lib.call("cn_na2d_fwd_f32", q32.data_ptr(), 3 * C * H * W, o32.data_ptr(), C * H * W, a32.data_ptr(), B, C, heads,
-              H, W, 3, dil, p, seed, _s())
+              H, W, 3, dil, p, seed, None, _s())
     dy32 = dy.to(dev)
     da32 = torch.empty_like(a32)
     dq32 = torch.empty_like(q32)
     _lib.call("cn_na2d_bwd_f32", q32.data_ptr(), 3 * C * H * W, dy32.data_ptr(), C * H * W, a32.data_ptr(),
-              da32.data_ptr(), dq32.data_ptr(), 3 * C * H * W, B, C, heads, H, W, 3, dil, p, seed, _s())
+              da32.data_ptr(), dq32.data_ptr(), 3 * C * H * W, B, C, heads, H, W, 3, dil, p, seed, None, _s())
     # bf16 NHWC kernels
     qg = _nhwc(qkv)
     out = _empty_nhwc(B, C, H, W)
     at = torch.empty((B, heads, 9, H, W), device=dev)
     _lib.call("cn_na2d_fwd_bf16", qg.data_ptr(), _ld(qg), out.data_ptr(), _ld(out), at.data_ptr(), B, C, heads, H, W, 3,
-              dil, p, seed, _s())
+              dil, p, seed, None, _s())
     _close(at, a32, 1e-5, "saved probabilities (undropped)")
     _close(out, o32, 6e-3, "out")
     # the dropout is real: without it the output differs
     out0 = _empty_nhwc(B, C, H, W)
     _lib.call("cn_na2d_fwd_bf16", qg.data_ptr(), _ld(qg), out0.data_ptr(), _ld(out0), at.data_ptr(), B, C, heads, H, W, 3,
-              dil, 0.0, 0, _s())
+              dil, 0.0, 0, None, _s())
     assert (out0.float() - out.float()).abs().max() > 0.05
     dyg = _nhwc(dy)
     dq = _empty_nhwc(B, 3 * C, H, W)
     dat = torch.empty_like(at)
     _lib.call("cn_na2d_bwd_bf16", qg.data_ptr(), _ld(qg), dyg.data_ptr(), _ld(dyg), at.data_ptr(), dat.data_ptr(),
-              dq.data_ptr(), _ld(dq), B, C, heads, H, W, 3, dil, p, seed, _s())
+              dq.data_ptr(), _ld(dq), B, C, heads, H, W, 3, dil, p, seed, None, _s())
     _close(dq, dq32, 8e-3, "dqkv")
 
 
@@ -408,10 +408,10 @@ def test_dropout_bf16_draws_the_fp32_masks(channelwise):
     x32 = x.to(dev)
     y32 = torch.empty_like(x32)
     cw = 1 if channelwise else 0
-    _lib.call("cn_dropout_f32", x32.data_ptr(), C * H * W, y32.data_ptr(), C * H * W, B, C, H * W, p, seed, cw, 0, _s())
+    _lib.call("cn_dropout_f32", x32.data_ptr(), C * H * W, y32.data_ptr(), C * H * W, B, C, H * W, p, seed, None, cw, 0, _s())
     xg = _nhwc(x, ld=C + 8)
     y = _empty_nhwc(B, C, H, W, ld=C + 16)
-    _lib.call("cn_dropout_bf16", xg.data_ptr(), _ld(xg), y.data_ptr(), _ld(y), B, C, H * W, p, seed, cw, 0, _s())
+    _lib.call("cn_dropout_bf16", xg.data_ptr(), _ld(xg), y.data_ptr(), _ld(y), B, C, H * W, p, seed, None, cw, 0, _s())
     torch.cuda.synchronize()
     assert torch.equal(y.float().cpu() != 0, y32.cpu() != 0)
     _close(y, y32, 4e-3, "y")
@@ -419,7 +419,7 @@ def test_dropout_bf16_draws_the_fp32_masks(channelwise):
     assert abs(frac - (1 - p)) < (0.15 if channelwise else 0.03), frac
     base = _r(_rand(B, C, H, W, seed=6))
     acc = _nhwc(base)
-    _lib.call("cn_dropout_bf16", xg.data_ptr(), _ld(xg), acc.data_ptr(), _ld(acc), B, C, H * W, p, seed, cw, 1, _s())
+    _lib.call("cn_dropout_bf16", xg.data_ptr(), _ld(xg), acc.data_ptr(), _ld(acc), B, C, H * W, p, seed, None, cw, 1, _s())
     _close(acc, y32.cpu() + base, 8e-3, "accumulate")
 
 

@@ -36,7 +36,10 @@ def _setup(g):
     return lit, batch
 
 
-@pytest.mark.parametrize("name", ["train_bf16_h8_b2_28", "train_bf16_h32_b1_100", "train_bf16_h32_b4_100"])
+# train_bf16_h64_b4_100: the reference CLI's DEFAULT operating point -- hidden 64, batch 4, 16-mixed (model.py:52,56,86;
+# scripts/args.yml:220-226,248-254) -- from the real reference (oracle/make_golden.py --bf16-h64-only)
+@pytest.mark.parametrize("name", ["train_bf16_h8_b2_28", "train_bf16_h32_b1_100", "train_bf16_h32_b4_100",
+                                  "train_bf16_h64_b4_100"])
 def test_bf16_train_step_matches_reference(golden_dir, name):
     from cultionet_amd import engine as E
     from cultionet_amd.lightning import HipTrainer

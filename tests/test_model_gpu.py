@@ -166,6 +166,36 @@ def test_large_tile_eval(golden_dir):
         assert np.abs(p.double().sum(dim=(0, 1, 3)).numpy() - g[f"{k}_rowsum"]).max() <= TOL * W
 
 
+def test_large_tile_eval_bf16_mixed_vs_reference(golden_dir):
+    """BASELINE configs[4] in the reference's DEFAULT predict precision (16-mixed, model.py:415): the fused
+    one-launch-per-ConvBlock2d inference path (cn_conv2d_fwd_fused_bf16 + cn_bn_fold_f32) at [1,4,25,256,256] against
+    the REAL reference's fp32 fixture -- crop and row sums, at the bf16 tolerances stated in tests/test_bf16_model_gpu.py
+    (probability maps: mean |d| <= 6e-3, max |d| <= 8e-2 against the fp32 reference)."""
+    g = np.load(os.path.join(golden_dir, "eval_h32_b1_4x25x256.npz"))
+    from oracle.selfcheck import build_pair
+    from oracle import towerunet_oracle as O
+    from oracle.make_golden import calibrate_bn
+    from cultionet_amd import engine as E
+
+    hidden, B, C, Tn, H, W, seed = (int(v) for v in g["meta"])
+    lit, _ = build_pair(hidden=hidden, in_channels=C, in_time=Tn)
+    model = lit.cultionet_model.mask_model
+    xc, _, _ = O.seeded_batch(B, channels=C, time=Tn, height=H, width=W, seed=seed + 1000)
+    calibrate_bn(model, lambda: model(xc.cuda()))  # fp32 calibration pass, as the fixture's generator did
+    x, _, _ = O.seeded_batch(B, channels=C, time=Tn, height=H, width=W, seed=seed)
+    assert E._EVAL_FUSION
+    with torch.no_grad(), torch.autocast("cuda", dtype=torch.bfloat16):
+        pred = model(x.cuda())
+    for k in KEYS:
+        p = pred[k].float().cpu()
+        d = np.abs(p[:, :, :64, :64].numpy() - g[f"{k}_crop"])
+        assert d.max() > 0.0  # the bf16 path really ran
+        assert d.mean() <= 6e-3 and d.max() <= 8e-2, (k, d.mean(), d.max())
+        rs = np.abs(p.double().sum(dim=(0, 1, 3)).numpy() - g[f"{k}_rowsum"])  # sums of W = 256 probabilities per row
+        assert rs.max() <= 6e-3 * W, (k, rs.max())
+        assert abs(float(p.double().sum()) - float(g[f"{k}_sum"])) <= 6e-3 * H * W, k
+
+
 def test_adamw_step_matches_oracle(golden_dir):
     """One full native step (clip 1.0 + AdamW) vs torch on the CPU oracle: parameter deltas."""
     from cultionet_amd.lightning import HipTrainer
