@@ -110,6 +110,9 @@ SIGNATURES = {
     "cn_na2d_fwd_bf16": [P, L, P, L, P, I, I, I, I, I, I, I, F, U64, P, P],
     "cn_na2d_bwd_bf16": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, F, U64, P, P],
     "cn_dropout_bf16": [P, L, P, L, I, I, I, F, U64, P, I, I, P],
+    "cn_pretime_workspace_floats": [I, I, I, I, I, I],
+    "cn_pretime_fwd_f32": [P, L, P, P, P, L, I, I, I, I, I, I, I, P, F, P, L, P],
+    "cn_pretime_bwd_f32": [P, L, P, P, P, L, I, P, I, I, I, I, I, I, P, F, P, L, P],
     "cn_window_chips_f32": [P, I, P, P, I, I, I, I, I, I, I, P, P, F, F, F, P],
     "cn_stitch_predictions_u16": [P, P, P, P, P, I, I, I, I, I, I, F, P],
     "cn_profile_begin": [],
@@ -168,7 +171,7 @@ def call(name: str, *args) -> int:
 
 
 LONG_RESULT = {"cn_launch_count", "cn_bconv_packed_elems", "cn_bwgrad_workspace_floats", "cn_bn_workspace_floats_bf16",
-               "cn_bn_group_workspace_floats_bf16"}
+               "cn_bn_group_workspace_floats_bf16", "cn_pretime_workspace_floats"}
 
 
 def query(name: str, *args) -> int:

@@ -6,7 +6,9 @@
 // nn.LayerNorm around NeighborhoodAttention2D, convolution.py:338-353).
 // A thread owns ONE 8-channel group (16 bytes) and walks pixels, so its per-channel constants and partial sums live
 // in registers and every access is a full 16-byte lane load of a contiguous pixel row.
+#include <cstdlib>
 #include "cn_bf16.h"
+#include "cn_ticket.h"
 
 #define BBN_MAX_BLOCKS 512
 
@@ -275,7 +277,7 @@ static inline void bbn_grid(long P, int C, int& nblk, long& rows) {
 }
 
 // Floats of scratch for the calls below: per-block partial sums + backward coefficients.
-extern "C" long cn_bn_workspace_floats_bf16(int C) { return (long)BBN_MAX_BLOCKS * 2 * C + 2 * C; }
+extern "C" long cn_bn_workspace_floats_bf16(int C) { return (long)BBN_MAX_BLOCKS * 2 * C + 2 * C + 4096 + 128L * C; }
 
 // y = act(bn(x)) (+ res). x, res, y: bf16 [P][C] rows with pixel strides; C % 8 == 0, C <= 2048.
 // training: batch statistics (saved to mean / rstd, running stats updated); else running statistics.
@@ -350,7 +352,8 @@ extern "C" int cn_bn_act_bwd_bf16(const void* x, long ldx, const void* dy, long 
 // =====================================================================================================================
 #define BBG_MAX 4
 #define BBG_FIN_BLOCKS 64   // row slices per group in the finalize
-#define BBG_CNT_INTS 64     // ticket counters at the start of the workspace (zero on entry, left zero on exit)
+#define BBG_CNT_INTS 512    // ticket counters at the start of the workspace (zero on entry, left zero on exit):
+                            // one per (group, 32-channel group): 4 x 64 at most
 
 struct CnBBnGroupArgs {
   const bf16_t* x[BBG_MAX];
@@ -374,8 +377,8 @@ struct CnBBnGroupArgs {
   long row_pitch;   // floats between consecutive partial rows of one group
   float eps, momentum;
   float* coef;      // [G][2][C]
-  double* slices;   // [G][BBG_FIN_BLOCKS][2C] finalize scratch
-  int* counters;    // [G] tickets
+  double* slices;   // [G][ceil(C/32)][BBG_FIN_BLOCKS][64] finalize scratch
+  int* counters;    // [G][ceil(C/32)] tickets
 };
 
 // agent-scope (write-through / L2-bypassing) accesses for data handed between workgroups inside one launch
@@ -386,69 +389,98 @@ __device__ __forceinline__ double bbg_load_agent(const double* p) {
   return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+// The finalize arithmetic of one channel (shared by the stand-alone finalize kernel and the ticketed partial kernel).
+template <int MODE>
+__device__ __forceinline__ void bbg_finish_channel(const CnBBnGroupArgs& a, int g, int c, double v0, double v1) {
+  const double count = (double)a.P;
+  if (MODE == 0) {
+    const double md = v0 / count;
+    double var = v1 / count - md * md;
+    if (var < 0.0) var = 0.0;
+    a.mean[g][c] = (float)md;
+    a.rstd[g][c] = (float)(1.0 / sqrt(var + (double)a.eps));
+    if (a.running_mean[g] != nullptr) {
+      const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+      a.running_mean[g][c] = (1.f - a.momentum) * a.running_mean[g][c] + a.momentum * (float)md;
+      a.running_var[g][c] = (1.f - a.momentum) * a.running_var[g][c] + a.momentum * (float)unbiased;
+    }
+  } else {
+    float* coef = a.coef + (long)g * 2 * a.C;
+    coef[c] = a.training ? (float)(v0 / count) : 0.f;
+    coef[a.C + c] = a.training ? (float)(v1 / count) : 0.f;
+    a.dgamma[g][c] += (float)v1;
+    a.dbeta[g][c] += (float)v0;
+  }
+}
+
 // MODE 0 (forward): columns = {sum x, sum x^2}[C]  -> mean / rstd (+ running statistics)
 // MODE 1 (backward): columns = {sum dz, sum dz*xhat}[C] -> coef = column / count; dgamma += col1, dbeta += col0
-// grid (BBG_FIN_BLOCKS, G); block b sums rows [b*rpb, (b+1)*rpb) of its group, column by column (coalesced).
+// grid (NB row slices, ceil(C / 32) channel groups, G). A block = 64 columns (32 channels x {stat 0, stat 1}: two
+// 128-byte segments per row) x 4 row lanes: every thread has ALL its loads in flight at once (<= 16), so the whole
+// reduction is two load latencies deep -- the first version (one thread per column walking 40 rows, then 64 slices, four
+// and two loads at a time) took 23 us per launch, all of it dependent round trips.
+#define BBG_ROW_LOADS 16  // rows per thread and batch in phase 1
 template <int MODE>
 __global__ __launch_bounds__(256) void cn_bbn_group_finalize_kernel(const CnBBnGroupArgs a) {
+  __shared__ double red[4][64];
   __shared__ int s_last;
-  const int g = blockIdx.y, b = blockIdx.x, nb = gridDim.x;
-  const int W2 = 2 * a.C;
-  const float* __restrict__ rows = a.rows[g];
+  const int g = blockIdx.z, cgp = blockIdx.y, b = blockIdx.x, nb = gridDim.x, ncg = gridDim.y;
+  const int q = threadIdx.x & 63, rl = threadIdx.x >> 6;
+  const int ch = cgp * 32 + (q & 31), stat = q >> 5;
+  const bool live = ch < a.C;
+  // (a dead channel of a ragged last group reads channel C - 1 and discards it: no predicated loads, see below)
+  const float* __restrict__ rows = a.rows[g] + (long)stat * a.C + (live ? ch : a.C - 1);
   const int rpb = (a.nrows + nb - 1) / nb;
   const int r0 = b * rpb, r1 = r0 + rpb < a.nrows ? r0 + rpb : a.nrows;
-  double* slice = a.slices + ((long)g * nb + b) * W2;
-  for (int col = threadIdx.x; col < W2; col += 256) {
-    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
-    int r = r0;
-    const long rp = a.row_pitch;
-    for (; r + 3 < r1; r += 4) {
-      s0 += rows[(long)r * rp + col];
-      s1 += rows[(long)(r + 1) * rp + col];
-      s2 += rows[(long)(r + 2) * rp + col];
-      s3 += rows[(long)(r + 3) * rp + col];
+  const long rp = a.row_pitch;
+  double acc = 0.0;
+  for (int rb = r0 + rl; rb < r1; rb += 4 * BBG_ROW_LOADS) {
+    float v[BBG_ROW_LOADS];
+#pragma unroll
+    for (int i = 0; i < BBG_ROW_LOADS; ++i) {
+      // clamped, never predicated: a per-element "load or zero" makes hipcc branch around every load and wait for it
+      const int r = rb + 4 * i;
+      v[i] = rows[(long)(r < r1 ? r : r1 - 1) * rp];
     }
-    for (; r < r1; ++r) s0 += rows[(long)r * rp + col];
-    bbg_store_agent(slice + col, (s0 + s1) + (s2 + s3));
+#pragma unroll
+    for (int i = 0; i < BBG_ROW_LOADS; ++i) acc += (rb + 4 * i < r1) ? (double)v[i] : 0.0;
   }
-  // publish: every storing wave drains its write-through stores, the block meets, one lane draws the ticket
+  red[rl][q] = acc;
+  __syncthreads();
+  double* slices = a.slices + (((long)g * ncg + cgp) * nb) * 64;  // [nb][64] of this (group, channel group)
+  if (rl == 0) bbg_store_agent(slices + (long)b * 64 + q, (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]));
+  // publish: the storing wave drains its write-through stores, the block meets, one lane draws the ticket
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  int* counter = a.counters + g * ncg + cgp;
   if (threadIdx.x == 0) {
-    const int t = __hip_atomic_fetch_add(a.counters + g, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const int t = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     s_last = (t == nb - 1);
-    if (t == nb - 1) __hip_atomic_store(a.counters + g, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // next launch
+    if (t == nb - 1) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // for the next launch
   }
   __syncthreads();
   if (!s_last) return;
   __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");  // (compiler ordering only: the loads below are agent-scope)
-  const double count = (double)a.P;
-  const double* gs = a.slices + (long)g * nb * W2;
-  for (int c = threadIdx.x; c < a.C; c += 256) {
-    double v0 = 0.0, v1 = 0.0;
-    for (int k = 0; k < nb; ++k) {  // fixed order: slice 0, 1, 2, ...
-      v0 += bbg_load_agent(gs + (long)k * W2 + c);
-      v1 += bbg_load_agent(gs + (long)k * W2 + a.C + c);
+  // the last arriver: slices k = rl, rl + 4, ... (fixed order), all loads of a batch in flight together
+  double tot = 0.0;
+  for (int kb = rl; kb < nb; kb += 4 * BBG_ROW_LOADS) {
+    double v[BBG_ROW_LOADS];
+#pragma unroll
+    for (int i = 0; i < BBG_ROW_LOADS; ++i) {
+      const int k = kb + 4 * i;
+      v[i] = bbg_load_agent(slices + (long)(k < nb ? k : nb - 1) * 64 + q);
     }
-    if (MODE == 0) {
-      const double md = v0 / count;
-      double var = v1 / count - md * md;
-      if (var < 0.0) var = 0.0;
-      a.mean[g][c] = (float)md;
-      a.rstd[g][c] = (float)(1.0 / sqrt(var + (double)a.eps));
-      if (a.running_mean[g] != nullptr) {
-        const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
-        a.running_mean[g][c] = (1.f - a.momentum) * a.running_mean[g][c] + a.momentum * (float)md;
-        a.running_var[g][c] = (1.f - a.momentum) * a.running_var[g][c] + a.momentum * (float)unbiased;
-      }
-    } else {
-      float* coef = a.coef + (long)g * W2;
-      coef[c] = a.training ? (float)(v0 / count) : 0.f;
-      coef[a.C + c] = a.training ? (float)(v1 / count) : 0.f;
-      a.dgamma[g][c] += (float)v1;
-      a.dbeta[g][c] += (float)v0;
-    }
+#pragma unroll
+    for (int i = 0; i < BBG_ROW_LOADS; ++i) tot += (kb + 4 * i < nb) ? v[i] : 0.0;
   }
+  __syncthreads();
+  red[rl][q] = tot;
+  __syncthreads();
+  if (threadIdx.x >= 32 || !live) return;
+  // threads 0..31: channel ch, v0 = column of stat 0, v1 = column of stat 1
+  const double v0 = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+  const double v1 = (red[0][32 + q] + red[1][32 + q]) + (red[2][32 + q] + red[3][32 + q]);
+  bbg_finish_channel<MODE>(a, g, ch, v0, v1);
 }
 
 // eval mode: mean / rstd from the running statistics (no batch statistics, no ticket)
@@ -461,12 +493,19 @@ __global__ __launch_bounds__(256) void cn_bbn_group_eval_stats_kernel(const CnBB
   }
 }
 
-// Per-channel partial sums over pixels for GS groups handled by ONE thread (GS = 2: the summed level, dy shared), or
-// group blockIdx.y (GS = 1). MODE as cn_bbn_partial_kernel. part rows: [(blk * G + g) * 2 + k][C] -> the finalize
-// reads group g's rows with a row stride of G (a.rows[g] = part + g * 2C, nrows rows of 2C * G floats apart).
+struct CnBBnTickets { CnTicket2 t[BBG_MAX]; };
+
+// Per-channel sums over pixels AND their finalize in one launch: GS groups handled by ONE thread (GS = 2: the summed
+// level, dy shared), or group blockIdx.y (GS = 1). Every block stores its row {k}[C] of group g write-through; the
+// two-level last-block reduction (cn_t2_reduce, one ticket domain per group) hands the column totals to the last
+// arriver, which finishes the channels: MODE 0 mean / rstd / running statistics, MODE 1 backward coefficients and
+// dgamma / dbeta. No stand-alone finalize launch.
 template <int MODE, int GS>
-__global__ __launch_bounds__(256) void cn_bbn_group_partial_kernel(const CnBBnGroupArgs a, float* __restrict__ part) {
-  __shared__ float red[256 * 16];
+__global__ __launch_bounds__(256) void cn_bbn_group_partial_kernel(const CnBBnGroupArgs a, const CnBBnTickets tks) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);                    // 256 * 16 floats
+  double* tot = reinterpret_cast<double*>(smem + 256 * 16 * 4);    // 2C doubles
+  __shared__ int s_flag;
   const int C = a.C, C8 = C >> 3;
   const int R = 256 / C8;
   const int tid = threadIdx.x;
@@ -489,10 +528,50 @@ __global__ __launch_bounds__(256) void cn_bbn_group_partial_kernel(const CnBBnGr
   const long p1 = p0 + a.rows_per_block < a.P ? p0 + a.rows_per_block : a.P;
   if (live) {
     const bool shared_dy = GS > 1;  // the summed level: one dy for every branch
-    for (long p = p0 + row; p < p1; p += R) {
+    auto accum = [&](int q, const u32x4& xq, const u32x4& dq) {
+      float xv[8];
+      cn_unpack8(xq, xv);
+      if (MODE == 0) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { a1[q][j] += xv[j]; a2[q][j] += xv[j] * xv[j]; }
+      } else {
+        float dv[8];
+        cn_unpack8(dq, dv);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float xh = (xv[j] - m[q][j]) * rs[q][j];
+          float dz = dv[j];
+          if (a.act == 1) dz *= cn_silu_grad(ga[q][j] * xh + be[q][j]);
+          a1[q][j] += dz;
+          a2[q][j] += dz * xh;
+        }
+      }
+    };
+    const u32x4 z4 = {0u, 0u, 0u, 0u};
+    long p = p0 + row;
+    if (GS == 1) {
+      // two pixels per iteration: both 16-byte loads (four in MODE 1) are in flight before either is consumed
+      const bf16_t* __restrict__ xp = a.x[g0];
+      const bf16_t* __restrict__ dp = a.dy[g0];
+      for (; p + R < p1; p += 2 * R) {
+        const u32x4 xa = *reinterpret_cast<const u32x4*>(xp + p * a.ldx + cg * 8);
+        const u32x4 xb = *reinterpret_cast<const u32x4*>(xp + (p + R) * a.ldx + cg * 8);
+        u32x4 da = z4, db = z4;
+        if (MODE == 1) {
+          da = *reinterpret_cast<const u32x4*>(dp + p * a.lddy + cg * 8);
+          db = *reinterpret_cast<const u32x4*>(dp + (p + R) * a.lddy + cg * 8);
+        }
+        accum(0, xa, da);
+        accum(0, xb, db);
+      }
+    }
+    for (; p < p1; p += R) {
       u32x4 xr[GS], dr[GS];
 #pragma unroll
-      for (int q = 0; q < GS; ++q) xr[q] = *reinterpret_cast<const u32x4*>(a.x[g0 + q] + p * a.ldx + cg * 8);
+      for (int q = 0; q < GS; ++q) {
+        xr[q] = *reinterpret_cast<const u32x4*>(a.x[g0 + q] + p * a.ldx + cg * 8);
+        dr[q] = z4;
+      }
       if (MODE == 1) {
         dr[0] = *reinterpret_cast<const u32x4*>(a.dy[g0] + p * a.lddy + cg * 8);
 #pragma unroll
@@ -500,30 +579,13 @@ __global__ __launch_bounds__(256) void cn_bbn_group_partial_kernel(const CnBBnGr
           dr[q] = shared_dy ? dr[0] : *reinterpret_cast<const u32x4*>(a.dy[g0 + q] + p * a.lddy + cg * 8);
       }
 #pragma unroll
-      for (int q = 0; q < GS; ++q) {
-        float xv[8];
-        cn_unpack8(xr[q], xv);
-        if (MODE == 0) {
-#pragma unroll
-          for (int j = 0; j < 8; ++j) { a1[q][j] += xv[j]; a2[q][j] += xv[j] * xv[j]; }
-        } else {
-          float dv[8];
-          cn_unpack8(dr[q], dv);
-#pragma unroll
-          for (int j = 0; j < 8; ++j) {
-            const float xh = (xv[j] - m[q][j]) * rs[q][j];
-            float dz = dv[j];
-            if (a.act == 1) dz *= cn_silu_grad(ga[q][j] * xh + be[q][j]);
-            a1[q][j] += dz;
-            a2[q][j] += dz * xh;
-          }
-        }
-      }
+      for (int q = 0; q < GS; ++q) accum(q, xr[q], dr[q]);
     }
   }
 #pragma unroll
   for (int q = 0; q < GS; ++q) {
-    if (q > 0) __syncthreads();
+    const CnTicket2& tk = tks.t[g0 + q];
+    __syncthreads();
 #pragma unroll
     for (int j = 0; j < 8; ++j) { red[tid * 16 + j] = a1[q][j]; red[tid * 16 + 8 + j] = a2[q][j]; }
     __syncthreads();
@@ -531,8 +593,10 @@ __global__ __launch_bounds__(256) void cn_bbn_group_partial_kernel(const CnBBnGr
       const int g2 = idx >> 4, j = idx & 15;
       float s = 0.f;
       for (int r = 0; r < R; ++r) s += red[(r * C8 + g2) * 16 + j];
-      part[(((long)blockIdx.x * a.G + g0 + q) * 2 + (j >> 3)) * C + g2 * 8 + (j & 7)] = s;
+      cn_t2_store(tk, blockIdx.x, (j >> 3) * C + g2 * 8 + (j & 7), s);
     }
+    if (cn_t2_reduce(tk, blockIdx.x, &s_flag, tot))
+      for (int c = tid; c < C; c += 256) bbg_finish_channel<MODE>(a, g0 + q, c, tot[c], tot[C + c]);
   }
 }
 
@@ -662,13 +726,32 @@ __global__ __launch_bounds__(256) void cn_bbn_group_apply_bwd_kernel(const CnBBn
   }
 }
 
-// Workspace of the grouped calls (floats): BBG_CNT_INTS ticket counters (ZERO on entry; every launch leaves them zero),
-// the finalize slices (fp64), the backward coefficients, the per-block partial rows.
-static inline long bbg_slices_off() { return BBG_CNT_INTS; }                                          // 8-byte aligned
-static inline long bbg_coef_off(int G, int C) { return bbg_slices_off() + (long)G * BBG_FIN_BLOCKS * 2 * C * 2; }
-static inline long bbg_part_off(int G, int C) { return bbg_coef_off(G, C) + (long)G * 2 * C; }
+// Workspace of the grouped calls (floats). HEAD (fixed, whatever G and C are -- the engine hands ONE buffer to calls of
+// every shape): BBG_CNT_INTS finalize tickets + BBG_MAX * CN_T2_COUNTERS tickets of the statistics passes, ZERO on
+// entry, left zero by every launch. BODY: finalize slices (fp64), backward coefficients, per-block rows.
+static inline long bbg_slices_off() { return BBG_CNT_INTS + BBG_MAX * CN_T2_COUNTERS; }               // 8-byte aligned
+static inline long bbg_coef_off(int G, int C) {
+  return bbg_slices_off() + (long)G * ((C + 31) / 32) * BBG_FIN_BLOCKS * 64 * 2;  // doubles
+}
+static inline long bbg_part_off(int G, int C) { return (bbg_coef_off(G, C) + (long)G * 2 * C + 63) / 64 * 64; }
+static inline long bbg_domain_floats(int C) { return (cn_t2_body_floats(BBN_MAX_BLOCKS, 2 * C) + 63) / 64 * 64; }
 extern "C" long cn_bn_group_workspace_floats_bf16(int G, int C) {
-  return bbg_part_off(G, C) + (long)BBN_MAX_BLOCKS * G * 2 * C;
+  return bbg_part_off(G, C) + (long)G * bbg_domain_floats(C);
+}
+static inline CnBBnTickets bbg_tickets(float* ws, int G, int C, int nblk) {
+  CnBBnTickets t = {};
+  for (int g = 0; g < G; ++g)
+    t.t[g] = cn_t2_carve(reinterpret_cast<int*>(ws) + BBG_CNT_INTS + g * CN_T2_COUNTERS,
+                         ws + bbg_part_off(G, C) + (long)g * bbg_domain_floats(C), nblk, 2 * C);
+  return t;
+}
+static inline size_t bbg_partial_shmem(int C) { return 256 * 16 * 4 + (size_t)2 * C * 8; }
+
+// row slices of the finalize: >= 4 rows per block (one per row lane), at most BBG_FIN_BLOCKS
+static inline int bbg_fin_blocks(int nrows) {
+  int nb = (nrows + 3) / 4;
+  if (nb > BBG_FIN_BLOCKS) nb = BBG_FIN_BLOCKS;
+  return nb < 1 ? 1 : nb;
 }
 
 static void bbg_common(CnBBnGroupArgs& a, int G, const void* const* xs, long ldx, const float* const* gammas,
@@ -711,21 +794,16 @@ extern "C" int cn_bn_act_group_fwd_bf16(int G, const void* const* xs, long ldx, 
       for (int g = 0; g < G; ++g) a.rows[g] = conv_sums[g];
       a.nrows = conv_rows;
       a.row_pitch = 2L * C;
-    } else {
+      CN_LAUNCH((cn_bbn_group_finalize_kernel<0>), dim3(bbg_fin_blocks(a.nrows), (C + 31) / 32, G), dim3(256), 0,
+                stream, a);
+    } else {  // no conv-epilogue rows: a statistics pass over x that finishes itself (ticketed)
       int nblk;
       long rows;
       bbn_grid(P, C, nblk, rows);
       a.rows_per_block = rows;
-      float* part = ws + bbg_part_off(G, C);
-      CN_LAUNCH((cn_bbn_group_partial_kernel<0, 1>), dim3(nblk, G), dim3(256), 0, stream, a, part);
-      // the partial rows of the G groups are interleaved ([blk][g][2][C]): group g's matrix starts at part + g * 2C
-      // with a row pitch of G * 2C floats
-      for (int g = 0; g < G; ++g) a.rows[g] = part + (long)g * 2 * C;
-      a.nrows = nblk;
-      a.row_pitch = 2L * C * G;
+      CN_LAUNCH((cn_bbn_group_partial_kernel<0, 1>), dim3(nblk, G), dim3(256), bbg_partial_shmem(C), stream, a,
+                bbg_tickets(ws, G, C, nblk));
     }
-    const int fb = a.nrows < BBG_FIN_BLOCKS ? a.nrows : BBG_FIN_BLOCKS;
-    CN_LAUNCH((cn_bbn_group_finalize_kernel<0>), dim3(fb, G), dim3(256), 0, stream, a);
   } else {
     CN_LAUNCH(cn_bbn_group_eval_stats_kernel, dim3((C + 255) / 256, G), dim3(256), 0, stream, a);
   }
@@ -761,7 +839,12 @@ extern "C" int cn_bn_act_group_bwd_bf16(int G, const void* const* xs, long ldx, 
   bbg_common(a, G, xs, ldx, gammas, betas, const_cast<float* const*>(means), const_cast<float* const*>(rstds), ws, P, C,
              act, training);
   a.lddy = lddy; a.lddx = lddx;
-  bool shared = G == 2;
+  // dy shared by the two branches of a summed level: the in-thread form (one read of dy for both branches) measured
+  // SLOWER than one grid row per branch (partial 49 vs 31 us, apply 42 vs 24 us at 32 x 100^2 x 128: 143-149 VGPRs, three
+  // waves per SIMD with one pixel in flight each -- latency-bound, and the second read of dy comes out of the Infinity
+  // Cache anyway). Kept behind CN_BBN_SHARED_DY=1 for experiments.
+  static const bool allow_shared = getenv("CN_BBN_SHARED_DY") != nullptr;
+  bool shared = G == 2 && allow_shared;
   bool any_dx = false;
   for (int g = 0; g < G; ++g) {
     a.dy[g] = (const bf16_t*)dys[g]; a.dx[g] = (bf16_t*)dxs[g]; a.accumulate_dx[g] = accumulate_dx[g];
@@ -773,16 +856,10 @@ extern "C" int cn_bn_act_group_bwd_bf16(int G, const void* const* xs, long ldx, 
   long rows;
   bbn_grid(P, C, nblk, rows);
   a.rows_per_block = rows;
-  float* part = ws + bbg_part_off(G, C);
-  if (shared) CN_LAUNCH((cn_bbn_group_partial_kernel<1, 2>), dim3(nblk), dim3(256), 0, stream, a, part);
-  else CN_LAUNCH((cn_bbn_group_partial_kernel<1, 1>), dim3(nblk, G), dim3(256), 0, stream, a, part);
-  // the partial rows of the G groups are interleaved ([blk][g][2][C]): group g's matrix starts at part + g * 2C with
-  // a row pitch of G * 2C floats
-  a.nrows = nblk;
-  a.row_pitch = 2L * C * G;
-  for (int g = 0; g < G; ++g) a.rows[g] = part + (long)g * 2 * C;
-  const int fb = nblk < BBG_FIN_BLOCKS ? nblk : BBG_FIN_BLOCKS;
-  CN_LAUNCH((cn_bbn_group_finalize_kernel<1>), dim3(fb, G), dim3(256), 0, stream, a);
+  // statistics pass + its finalize (coefficients, dgamma / dbeta) in ONE launch: the last-arriving block finishes
+  const CnBBnTickets tks = bbg_tickets(ws, G, C, nblk);
+  if (shared) CN_LAUNCH((cn_bbn_group_partial_kernel<1, 2>), dim3(nblk), dim3(256), bbg_partial_shmem(C), stream, a, tks);
+  else CN_LAUNCH((cn_bbn_group_partial_kernel<1, 1>), dim3(nblk, G), dim3(256), bbg_partial_shmem(C), stream, a, tks);
   if (any_dx) {
     int ablk;
     long arows;
@@ -941,14 +1018,54 @@ extern "C" int cn_layernorm_c_bwd_bf16(const void* x, long ldx, const void* dy, 
   return cn_check_launch();
 }
 
-// bias gradients on the bf16 path: out[c] (+)= sum_p x[p][c]. ws: cn_bn_workspace_floats_bf16(C) floats.
-__global__ __launch_bounds__(256) void cn_bsum_finalize_kernel(const float* __restrict__ part, int nblk, int C,
-                                                              float* __restrict__ out, int accumulate) {
-  const int c = blockIdx.x * BBN_FIN_CH + (threadIdx.x >> 6), sub = threadIdx.x & 63;
-  double s, ss;
-  bbn_combine(part, nblk, C, c, sub, s, ss);
-  if (c >= C || sub != 0) return;
-  out[c] = accumulate ? out[c] + (float)s : (float)s;
+// bias gradients on the bf16 path: out[c] (+)= sum_p x[p][c] in ONE launch: per-block column sums (<= 512 blocks),
+// combined by the two-level last-block reduction above. ws: cn_bn_workspace_floats_bf16(C) floats whose leading words
+// are the ticket counters: ZERO before the first call (every call leaves them zero).
+__global__ __launch_bounds__(256) void cn_bsum_ticket_kernel(const bf16_t* __restrict__ x, long ldx, long P, int C,
+                                                            long rows_per_block, const CnTicket2 tk,
+                                                            float* __restrict__ out, int accumulate) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+  float* red = reinterpret_cast<float*>(smem);                 // 256 * 8 floats
+  double* tot = reinterpret_cast<double*>(smem + 256 * 8 * 4);  // C doubles
+  __shared__ int s_flag;
+  const int C8 = C >> 3;
+  const int R = 256 / C8;
+  const int tid = threadIdx.x;
+  const int row = tid / C8, cg = tid - row * C8;
+  float a1[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) a1[j] = 0.f;
+  const long p0 = blockIdx.x * rows_per_block;
+  const long p1 = p0 + rows_per_block < P ? p0 + rows_per_block : P;
+  if (row < R) {
+    long p = p0 + row;
+    for (; p + R < p1; p += 2 * R) {
+      const u32x4 xa = *reinterpret_cast<const u32x4*>(x + p * ldx + cg * 8);
+      const u32x4 xb = *reinterpret_cast<const u32x4*>(x + (p + R) * ldx + cg * 8);
+      float va[8], vb[8];
+      cn_unpack8(xa, va);
+      cn_unpack8(xb, vb);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a1[j] += va[j] + vb[j];
+    }
+    if (p < p1) {
+      float va[8];
+      cn_unpack8(*reinterpret_cast<const u32x4*>(x + p * ldx + cg * 8), va);
+#pragma unroll
+      for (int j = 0; j < 8; ++j) a1[j] += va[j];
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) red[tid * 8 + j] = a1[j];
+  __syncthreads();
+  for (int c = tid; c < C; c += 256) {
+    const int g2 = c >> 3, j = c & 7;
+    float sum = 0.f;
+    for (int r = 0; r < R; ++r) sum += red[(r * C8 + g2) * 8 + j];
+    cn_t2_store(tk, blockIdx.x, c, sum);
+  }
+  if (!cn_t2_reduce(tk, blockIdx.x, &s_flag, tot)) return;
+  for (int c = tid; c < C; c += 256) out[c] = accumulate ? out[c] + (float)tot[c] : (float)tot[c];
 }
 
 extern "C" int cn_channel_sum_bf16(const void* x, long ldx, long P, int C, float* out, int accumulate, float* ws,
@@ -959,8 +1076,9 @@ extern "C" int cn_channel_sum_bf16(const void* x, long ldx, long P, int C, float
   int nblk;
   long rows;
   bbn_grid(P, C, nblk, rows);
-  CN_LAUNCH((cn_bbn_partial_kernel<0>), dim3(nblk), dim3(256), 0, stream, (const bf16_t*)x, ldx, nullptr, 0L,
-                     nullptr, nullptr, nullptr, nullptr, P, C, 0, rows, ws);
-  CN_LAUNCH(cn_bsum_finalize_kernel, dim3((C + BBN_FIN_CH - 1) / BBN_FIN_CH), dim3(256), 0, stream, ws, nblk, C, out, accumulate);
+  const CnTicket2 tk = cn_t2_carve(reinterpret_cast<int*>(ws), ws + CN_T2_COUNTERS, nblk, C);
+  const size_t shmem = 256 * 8 * 4 + (size_t)C * 8;
+  CN_LAUNCH(cn_bsum_ticket_kernel, dim3(nblk), dim3(256), shmem, stream, (const bf16_t*)x, ldx, P, C, rows, tk, out,
+            accumulate);
   return cn_check_launch();
 }

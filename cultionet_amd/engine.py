@@ -920,6 +920,113 @@ def time_conv(x: Var, mod, tin: int) -> Var:
     return yv
 
 
+_pt_ws: T.Dict[T.Tuple, torch.Tensor] = {}
+_PRETIME_FUSED = os.environ.get("CN_PRETIME_FUSED", "1") == "1"  # diagnostic: 0 = the generic kernels (rounds 1-3)
+
+
+def _pretime_ws(need: int, dev: torch.device) -> torch.Tensor:
+    """Scratch of the fused PreTimeReduction calls, one per (device, stream): zero-filled once (ticket counters at its
+    head; every launch leaves them zero)."""
+    key = (dev, _stream())
+    ws = _pt_ws.get(key)
+    if ws is None or ws.numel() < need:
+        if ws is not None:
+            torch.cuda.synchronize(dev)
+        ws = _pt_ws[key] = torch.zeros(need, dtype=torch.float32, device=dev)
+        _bump_ws_epoch()
+    return ws
+
+
+def pretime_reduction(x: Var, pre, in_channels: int, in_time: int) -> T.Optional[Var]:
+    """PreTimeReduction (models/nunet.py:60-105) through the fused kernel family cn_pretime_*: both Conv3d stacks, their
+    BatchNorm3d / BatchNorm2d, the branch sum and the LayerNorm, recomputed from x in every pass (3 launches forward in
+    training, 1 in inference, 3 backward -- on the weight-gradient side stream: the stage has parameter gradients only).
+    Writes fp32 NCHW, or bf16 NHWC directly when the mixed-precision region is on. Returns None for shapes / settings the
+    fused kernels do not cover (the caller keeps the generic op-by-op path)."""
+    import ctypes
+
+    if not _PRETIME_FUSED:
+        return None
+    tape = current_tape()
+    xt = _check(x.t)
+    if is16(xt) or x.req or not xt.is_contiguous():
+        return None
+    B, CT, H, W = xt.shape
+    C, Tn = in_channels, in_time
+    br = (pre.conv3, pre.conv5)
+    ln = pre.layer_norm[1]
+    Cout = ln.weight.shape[0]
+    HW = H * W
+    training = bool(pre.training)
+    bn3 = [b.seq[1] for b in br]
+    bn2 = [b.seq[5] for b in br]
+    if CT != C * Tn or any(b.momentum is None for b in bn3 + bn2) or \
+            bn3[0].eps != bn3[1].eps or bn2[0].eps != bn2[1].eps or bn3[0].momentum != bn3[1].momentum or \
+            bn2[0].momentum != bn2[1].momentum or any(b.running_mean is None for b in bn3 + bn2) or \
+            any(b.training != training for b in bn3 + bn2):
+        return None
+    with_bwd = 1 if tape.enabled else 0
+    need = int(_lib.query("cn_pretime_workspace_floats", B, C, Tn, HW, Cout, with_bwd))
+    if need < 0:
+        return None
+    dev = xt.device
+    bf16 = bf16_enabled()
+    if bf16:
+        y = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2)
+        ystride, kind = Cout, 1
+    else:
+        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=dev)
+        ystride, kind = Cout * HW, 0
+    plist = []
+    for b, b3, b2 in zip(br, bn3, bn2):
+        plist += [b.seq[0].weight, b.seq[3].weight, b3.weight, b3.bias, b3.running_mean, b3.running_var, b2.weight,
+                  b2.bias, b2.running_mean, b2.running_var]
+    plist += [ln.weight, ln.bias]
+    params = (ctypes.c_void_p * 22)(*[t.data_ptr() for t in plist])
+    stats_t = torch.empty(2 * (2 * C + 2 * Cout), dtype=torch.float32, device=dev)
+    offs, o = [], 0
+    for _ in range(2):
+        for n in (C, C, Cout, Cout):
+            offs.append(o)
+            o += n
+    stats = (ctypes.c_void_p * 8)(*[stats_t[i:].data_ptr() for i in offs])
+    bnc = (ctypes.c_float * 4)(float(bn3[0].eps), float(bn3[0].momentum), float(bn2[0].eps), float(bn2[0].momentum))
+    _note_bn_update(training)
+    ws = _pretime_ws(need, dev)
+    _lib.call("cn_pretime_fwd_f32", xt.data_ptr(), bstride(xt), params, stats, y.data_ptr(), ystride, kind, B, C, Tn, HW,
+              Cout, 1 if training else 0, bnc, float(ln.eps), ws.data_ptr(), ws.numel(), _stream())
+    yv = Var(y, tape.enabled)
+    if tape.enabled:
+        store = current_store()
+        glist = []
+        for b, b3, b2 in zip(br, bn3, bn2):
+            glist += [b.seq[0].weight, b.seq[3].weight, b3.weight, b3.bias, b2.weight, b2.bias]
+        glist += [ln.weight, ln.bias]
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            if bf16:
+                dstride = ld(dy)
+                if not _dense16(dy):
+                    raise RuntimeError("pretime_reduction: the output gradient must be a dense NHWC buffer")
+            else:
+                if not dy.is_contiguous():
+                    raise RuntimeError("pretime_reduction: the output gradient must be dense NCHW")
+                dstride = Cout * HW
+            grads = (ctypes.c_void_p * 14)(*[store.grad_of(p).data_ptr() for p in glist])
+            with side_stream(xt, dy, stats_t):  # parameter gradients only: off the data-gradient chain
+                wsb = _pretime_ws(need, dev)
+                _lib.call("cn_pretime_bwd_f32", xt.data_ptr(), bstride(xt), params, stats, dy.data_ptr(), dstride, kind,
+                          grads, B, C, Tn, HW, Cout, 1 if training else 0, bnc, float(ln.eps), wsb.data_ptr(),
+                          wsb.numel(), _stream())
+            yv.grad = None
+
+        tape.add(bwd, tuple(glist))
+    return yv
+
+
 ACT_NONE, ACT_SILU = 0, 1
 
 # bumped by every train-mode BatchNorm forward (the kernels update running_mean / running_var in place, which torch's
@@ -1685,7 +1792,9 @@ def _ws16(need: int, dev: torch.device, pool_name: str = "wgrad") -> T.Tuple[int
     if ws is None or ws.numel() < need:
         if ws is not None:  # growing: the old buffer may still be in use by launches in flight on either stream
             torch.cuda.synchronize(dev)
-        ws = pool[key] = torch.empty(need, dtype=torch.float32, device=dev)
+        # zero-filled: the single-launch reductions keep their ticket counters in the first words of these buffers
+        # (zero on entry, left zero on exit)
+        ws = pool[key] = torch.zeros(need, dtype=torch.float32, device=dev)
         _bump_ws_epoch()
     return ws.data_ptr(), ws.numel()
 

@@ -83,6 +83,11 @@ class PreTimeReduction(nn.Module):
         self.layer_norm = nn.Sequential(_Marker(), nn.LayerNorm(out_channels), _Marker())
 
     def forward(self, x: E.Var) -> E.Var:
+        # the whole stage as one fused kernel family (3 launches forward, 1 in inference, 3 backward on the side stream);
+        # writes bf16 NHWC directly inside the mixed-precision region
+        y = E.pretime_reduction(x, self, self.conv3.in_channels, self.conv3.in_time)
+        if y is not None:
+            return y
         x3 = self.conv3(x)
         s = self.conv5(x, residual=x3)  # x3 + x5 fused into conv5's last BN+SiLU
         y = E.layer_norm_c(s, self.layer_norm[1])

@@ -390,8 +390,10 @@ int cn_bn_act_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const
  * accumulation, one rounding); else ys[g] = act(bn_g(xs[g])), res must be NULL. conv_sums (nullable, training): per
  * group the `stats` rows of cn_conv2d_fwd[_grouped]_bf16 (conv_rows rows each). The batch statistics are finalized by
  * ONE launch: coalesced column sums of the partial rows whose per-block slices are combined by the last-arriving
- * block (device ticket; fixed summation order, bit-reproducible). ws: cn_bn_group_workspace_floats_bf16(G, C) floats
- * whose first 64 ints are ticket counters: ZERO before the first call (every call leaves them zero).
+ * block (device ticket; fixed summation order, bit-reproducible); statistics passes over x / dy (backward, or a forward
+ * without conv_sums) finish themselves the same way (two-level last-block reduction): no finalize launch.
+ * ws: cn_bn_group_workspace_floats_bf16(G, C) floats holding ticket counters: ZERO-FILLED before its first use (every
+ * call leaves the counters zero), not shared with calls in flight on another stream.
  * Backward: dys[g] = gradient of output g (after a summed forward the same pointer G times: read once per pass);
  * dxs[g] nullable; accumulate_dx: HOST array of G flags; dgammas / dbetas ACCUMULATED. */
 long cn_bn_group_workspace_floats_bf16(int G, int C);
@@ -407,7 +409,9 @@ int cn_bn_act_group_bwd_bf16(int G, const void* const* xs, long ldx, const void*
                              float* const* dgammas, float* const* dbetas, float* ws, long P, int C, int training,
                              int act, void* stream);
 
-/* bias gradients: out[c] (+)= sum_p x[p][c]; ws: cn_bn_workspace_floats_bf16(C) floats */
+/* bias gradients: out[c] (+)= sum_p x[p][c] in ONE launch (two-level last-block reduction); ws:
+ * cn_bn_workspace_floats_bf16(C) floats, ZERO-FILLED before its first use (ticket counters; left zero by every call), not
+ * the buffer handed to cn_bn_act_*_bf16 (those write partial rows over its head) */
 int cn_channel_sum_bf16(const void* x, long ldx, long P, int C, float* out, int accumulate, float* ws, void* stream);
 
 /* nn.LayerNorm over channels (rows of the NHWC image), + residual; statistics recomputed in backward.
@@ -446,6 +450,27 @@ int cn_na2d_bwd_bf16(const void* qkv, long ldq, const void* dout, long ldo, cons
  * cn_dropout_f32 (convolution.py:495,511; natten proj_drop); backward = the same call on dy with accumulate. */
 int cn_dropout_bf16(const void* x, long ldx, void* y, long ldy, int B, int C, int HW, float p, unsigned long long seed,
                     const unsigned long long* step, int channelwise, int accumulate, void* stream);
+
+/* ---- PreTimeReduction (models/nunet.py:18-105) fused: both Conv3d stacks (k = 3, 5: Conv3d(C->C,(k,1,1)) -> BatchNorm3d
+ * -> SiLU -> Conv3d(C->Cout,(T-k+1,1,1)) -> BatchNorm2d -> SiLU), their sum and the LayerNorm over Cout, recomputed from
+ * x [B][C*T][HW] (batch stride xbs) in every pass: training forward = 3 launches (+ 1 weight transpose), backward = 3,
+ * inference = 1; every pass finishes its own cross-block reduction (last-block tickets, fixed summation order).
+ * params: HOST array of 22 device pointers: per branch (k = 3, then k = 5) {wa [C][C][k], wb [Cout][C][T-k+1], gamma3,
+ * beta3, running_mean3, running_var3 (nullable in training), gamma2, beta2, running_mean2, running_var2}, then
+ * {ln_gamma, ln_beta}. stats: HOST array of 8 device pointers: per branch {mean3 [C], rstd3 [C], mean2 [Cout], rstd2
+ * [Cout]}: written by a training forward, read by backward. bn: HOST {eps3, momentum3, eps2, momentum2}.
+ * y / dy: out_kind 0 = fp32 NCHW (stride = batch stride), 1 = bf16 NHWC (stride = pixel stride, Cout innermost).
+ * grads: HOST array of 14 device pointers: per branch {dwa, dwb, dgamma3, dbeta3, dgamma2, dbeta2}, then {d ln_gamma,
+ * d ln_beta}; ACCUMULATED. ws: cn_pretime_workspace_floats(...) floats, ZERO-FILLED before its first use (ticket
+ * counters at its head; every call leaves them zero); -1 = shape outside the fused kernel (C <= 8, 8 <= Cout <= 64,
+ * Cout % 8 == 0, T >= 5, every pass's LDS image within 160 KiB): the caller keeps its generic path. */
+long cn_pretime_workspace_floats(int B, int C, int T, int HW, int Cout, int with_backward);
+int cn_pretime_fwd_f32(const float* x, long xbs, const void* const* params, float* const* stats, void* y, long y_stride,
+                       int out_kind, int B, int C, int T, int HW, int Cout, int training, const float* bn, float eps_ln,
+                       float* ws, long ws_floats, void* stream);
+int cn_pretime_bwd_f32(const float* x, long xbs, const void* const* params, float* const* stats, const void* dy,
+                       long dy_stride, int out_kind, float* const* grads, int B, int C, int T, int HW, int Cout,
+                       int training, const float* bn, float eps_ln, float* ws, long ws_floats, void* stream);
 
 /* ---- diagnostics: per-launch HIP-event timing of the contraction kernels (bench.py roofline) ---
  * begin() starts recording event pairs around every implicit-GEMM / weight-gradient launch on the

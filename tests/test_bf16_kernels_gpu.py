@@ -281,6 +281,182 @@ def test_bn_act_bf16(shape, act, res, train):
     _close(db, bn.bias.grad, 2e-3, "dbeta", abs_=1e-3)
 
 
+def _tab(ptrs):
+    return (ctypes.c_void_p * len(ptrs))(*ptrs)
+
+
+_SHARED_WS = {}
+
+
+def _shared_group_ws(need):
+    """ONE zero-initialised workspace shared by every grouped-BatchNorm case of this module, as the engine shares one
+    buffer between calls of every (G, C): the ticket counters must sit where no other shape ever writes row data."""
+    ws = _SHARED_WS.get("ws")
+    if ws is None or ws.numel() < need:
+        ws = _SHARED_WS["ws"] = torch.zeros(max(need, 8 << 20), device=_dev())
+    return ws
+
+
+@pytest.mark.parametrize("shape,G,summed,act,res,train",
+                         [((2, 16, 20, 20), 2, True, 1, True, True), ((2, 128, 25, 25), 2, True, 1, True, True),
+                          ((3, 64, 50, 50), 2, False, 1, False, True), ((1, 480, 13, 13), 1, True, 0, False, True),
+                          ((2, 32, 28, 28), 2, True, 1, True, False), ((2, 8, 28, 28), 3, True, 1, True, True),
+                          ((2, 24, 17, 19), 4, False, 1, False, True), ((8, 128, 100, 100), 2, True, 1, True, True),
+                          ((2, 40, 30, 30), 3, False, 0, False, True)])
+def test_bn_act_group_bf16(shape, G, summed, act, res, train):
+    """cn_bn_act_group_{fwd,bwd}_bf16: G BatchNorm(+SiLU) layers in one launch per pass, ONE finalize launch (coalesced
+    column sums + last-block ticket). Summed mode = the ResUNet-a level `res + sum_g SiLU(BN_g(x_g))` (convolution.py:
+    376-395) with its shared dy in backward; plain mode = G independent outputs / gradients. Against torch fp32 on the
+    same bf16-rounded operands; two calls back to back also check that the ticket counters return to zero."""
+    from cultionet_amd import _lib
+
+    B, C, H, W = shape
+    P = B * H * W
+    dev = _dev()
+    xs = [_r(_rand(*shape, seed=10 + g) * (1.0 + 0.3 * g) + 0.2 * g) for g in range(G)]
+    r = _r(_rand(*shape, seed=2)) if res else None
+    bns = []
+    for g in range(G):
+        bn = torch.nn.BatchNorm2d(C)
+        with torch.no_grad():
+            bn.weight.copy_(1 + 0.1 * _rand(C, seed=30 + g))
+            bn.bias.copy_(0.1 * _rand(C, seed=40 + g))
+            bn.running_mean.copy_(0.2 * _rand(C, seed=50 + g))
+            bn.running_var.copy_(1 + 0.1 * _rand(C, seed=60 + g).abs())
+        bn.train(train)
+        bns.append(bn)
+    rm0 = [bn.running_mean.clone() for bn in bns]
+    rv0 = [bn.running_var.clone() for bn in bns]
+    xr = [x.clone().requires_grad_(True) for x in xs]
+    outs = []
+    for g in range(G):
+        z = bns[g](xr[g])
+        outs.append(F.silu(z) if act else z)
+    if summed:
+        yr = sum(outs) + (r if res else 0.0)
+        dy = _r(_rand(*shape, seed=7))
+        yr.backward(dy)
+        dys = [dy] * G
+    else:
+        dys = [_r(_rand(*shape, seed=70 + g)) for g in range(G)]
+        torch.autograd.backward(outs, dys)
+    xg = [_nhwc(x, ld=C + 8) for x in xs]
+    rg = _nhwc(r, ld=C + 16) if res else None
+    ys = [_empty_nhwc(B, C, H, W) for _ in range(1 if summed else G)]
+    gam = [bn.weight.detach().to(dev) for bn in bns]
+    bet = [bn.bias.detach().to(dev) for bn in bns]
+    rm, rv = [t.to(dev) for t in rm0], [t.to(dev) for t in rv0]
+    mean, rstd = torch.empty((G, C), device=dev), torch.empty((G, C), device=dev)
+    ws = _shared_group_ws(_lib.query("cn_bn_group_workspace_floats_bf16", G, C))
+    for rep in range(2):  # twice: the second call finds the counters as the first left them (zero)
+        if rep == 1:
+            for g in range(G):
+                rm[g].copy_(rm0[g])
+                rv[g].copy_(rv0[g])
+        _lib.call("cn_bn_act_group_fwd_bf16", G, _tab([t.data_ptr() for t in xg]), _ld(xg[0]),
+                  _tab([t.data_ptr() for t in gam]), _tab([t.data_ptr() for t in bet]),
+                  _tab([t.data_ptr() for t in rm]), _tab([t.data_ptr() for t in rv]),
+                  rg.data_ptr() if res else None, _ld(rg) if res else 0,
+                  _tab([(ys[0] if summed else ys[g]).data_ptr() for g in range(G)]), _ld(ys[0]),
+                  _tab([mean[g].data_ptr() for g in range(G)]), _tab([rstd[g].data_ptr() for g in range(G)]),
+                  ws.data_ptr(), P, C, 1 if train else 0, 0.1, bns[0].eps, act, 1 if summed else 0, None, 0, _s())
+        if summed:
+            _close(ys[0], yr, 6e-3, "y")
+        else:
+            for g in range(G):
+                _close(ys[g], outs[g], 6e-3, f"y{g}")
+        if train:
+            for g in range(G):
+                _close(rm[g], bns[g].running_mean, 1e-4, "running_mean", abs_=1e-5)
+                _close(rv[g], bns[g].running_var, 1e-4, "running_var", abs_=1e-5)
+    assert int(ws[:768].view(torch.int32).abs().sum()) == 0  # tickets back to zero
+    dyg = [_nhwc(dys[0])] * G if summed else [_nhwc(d) for d in dys]
+    base = _r(_rand(*shape, seed=99))
+    dxs = [_empty_nhwc(B, C, H, W) for _ in range(G)]
+    dxs[-1] = _nhwc(base)  # the last group ACCUMULATES into an existing gradient
+    accs = [0] * (G - 1) + [1]
+    dg = [torch.zeros(C, device=dev) for _ in range(G)]
+    db = [torch.zeros(C, device=dev) for _ in range(G)]
+    _lib.call("cn_bn_act_group_bwd_bf16", G, _tab([t.data_ptr() for t in xg]), _ld(xg[0]),
+              _tab([t.data_ptr() for t in dyg]), _ld(dyg[0]), _tab([mean[g].data_ptr() for g in range(G)]),
+              _tab([rstd[g].data_ptr() for g in range(G)]), _tab([t.data_ptr() for t in gam]),
+              _tab([t.data_ptr() for t in bet]), _tab([t.data_ptr() for t in dxs]), _ld(dxs[0]),
+              (ctypes.c_int * G)(*accs), _tab([t.data_ptr() for t in dg]), _tab([t.data_ptr() for t in db]),
+              ws.data_ptr(), P, C, 1 if train else 0, act, _s())
+    for g in range(G):
+        want = xr[g].grad + (base if accs[g] else 0.0)
+        _close(dxs[g], want, 8e-3, f"dx{g}")
+        _close(dg[g], bns[g].weight.grad, 2e-3, f"dgamma{g}", abs_=1e-3)
+        _close(db[g], bns[g].bias.grad, 2e-3, f"dbeta{g}", abs_=1e-3)
+    assert int(ws[:768].view(torch.int32).abs().sum()) == 0
+
+
+@pytest.mark.parametrize("P,C,ldx", [(5000, 128, 136), (37, 8, 8), (320000, 128, 128), (700, 480, 480)])
+def test_channel_sum_bf16_single_launch(P, C, ldx):
+    """Bias gradients on the mixed-precision path: per-channel sums over pixels in ONE launch (last-block ticket),
+    accumulate and overwrite forms, twice in a row on the same workspace (the counter returns to zero)."""
+    from cultionet_amd import _lib
+
+    dev = _dev()
+    x = _r(_rand(P, C, seed=3) + 0.25)
+    buf = torch.zeros((P, ldx), dtype=BF, device=dev)
+    buf[:, :C] = x.to(BF).to(dev)
+    ws = torch.zeros(_lib.query("cn_bn_workspace_floats_bf16", C), device=dev)
+    want = x.double().sum(0)
+    out = torch.full((C,), 3.0, device=dev)
+    _lib.call("cn_channel_sum_bf16", buf.data_ptr(), ldx, P, C, out.data_ptr(), 0, ws.data_ptr(), _s())
+    _close(out, want, 2e-3, "sum", abs_=2e-3 * float(x.abs().max()) * P ** 0.5)
+    _lib.call("cn_channel_sum_bf16", buf.data_ptr(), ldx, P, C, out.data_ptr(), 1, ws.data_ptr(), _s())
+    _close(out, 2 * want, 2e-3, "accumulated", abs_=4e-3 * float(x.abs().max()) * P ** 0.5)
+    assert int(ws[:16].view(torch.int32).abs().sum()) == 0
+
+
+def test_conv_group_bf16_statistics_feed_the_grouped_batchnorm():
+    """cn_conv2d_fwd_grouped_bf16 with per-conv statistics rows (two convolutions of one shape in ONE launch, as the
+    dilation branches of a ResidualAConv level) -> cn_bn_act_group_fwd_bf16(conv_sums=...): the BatchNorm batch
+    statistics come from the conv epilogues' rows, no pass over the conv outputs."""
+    from cultionet_amd import _lib
+
+    dev = _dev()
+    B, Cin, H, W, Cout, G = 2, 32, 50, 50, 64, 2
+    P = B * H * W
+    x = _r(_rand(B, Cin, H, W, seed=1))
+    ws_ = [_r(_rand(Cout, Cin, 3, 3, seed=2 + g) * 0.1) for g in range(G)]
+    pads, dils = [1, 2], [1, 2]
+    ref = [F.conv2d(x, ws_[g], padding=pads[g], dilation=dils[g]) for g in range(G)]
+    xg = _nhwc(x)
+    wps = [_pack(w.to(dev), 9, Cin, Cout, 9, Cin * 9, 1) for w in ws_]
+    ys = [_empty_nhwc(B, Cout, H, W) for _ in range(G)]
+    rows = _lib.query("cn_conv2d_stats_rows_bf16", B, H, W, Cout, 3, 3, 1, max(pads), max(dils))
+    stats = [torch.full((rows, 2, Cout), float("nan"), device=dev) for _ in range(G)]
+    _lib.call("cn_conv2d_fwd_grouped_bf16", G, _tab([xg.data_ptr()] * G), _ld(xg), _tab([w.data_ptr() for w in wps]),
+              None, _tab([y.data_ptr() for y in ys]), _ld(ys[0]), B, Cin, H, W, Cout, 3, 3, 1,
+              (ctypes.c_int * G)(*pads), (ctypes.c_int * G)(*dils), 0, _tab([t.data_ptr() for t in stats]), _s())
+    for g in range(G):
+        _close(ys[g], ref[g], 6e-3, f"conv{g}")
+        _close(stats[g][:, 0].sum(0), ref[g].sum(dim=(0, 2, 3)), 2e-3, "sum", abs_=2e-2 * float(ref[g].abs().max()))
+        _close(stats[g][:, 1].sum(0), (ref[g] ** 2).sum(dim=(0, 2, 3)), 2e-3, "sumsq")
+    bns = [torch.nn.BatchNorm2d(Cout).train() for _ in range(G)]
+    yr = sum(F.silu(bns[g](ref[g])) for g in range(G))
+    gam = [bn.weight.detach().to(dev) for bn in bns]
+    bet = [bn.bias.detach().to(dev) for bn in bns]
+    rm = [torch.zeros(Cout, device=dev) for _ in range(G)]
+    rv = [torch.ones(Cout, device=dev) for _ in range(G)]
+    mean, rstd = torch.empty((G, Cout), device=dev), torch.empty((G, Cout), device=dev)
+    out = _empty_nhwc(B, Cout, H, W)
+    ws = torch.zeros(_lib.query("cn_bn_group_workspace_floats_bf16", G, Cout), device=dev)
+    _lib.call("cn_bn_act_group_fwd_bf16", G, _tab([y.data_ptr() for y in ys]), _ld(ys[0]),
+              _tab([t.data_ptr() for t in gam]), _tab([t.data_ptr() for t in bet]), _tab([t.data_ptr() for t in rm]),
+              _tab([t.data_ptr() for t in rv]), None, 0, _tab([out.data_ptr()] * G), _ld(out),
+              _tab([mean[g].data_ptr() for g in range(G)]), _tab([rstd[g].data_ptr() for g in range(G)]),
+              ws.data_ptr(), P, Cout, 1, 0.1, 1e-5, 1, 1, _tab([t.data_ptr() for t in stats]), rows, _s())
+    # (the statistics are those of the fp32 conv results, the normalised tensor is their bf16 rounding: 1.2e-2)
+    _close(out, yr, 1.2e-2, "sum of SiLU(BN(conv))")
+    for g in range(G):
+        _close(rm[g], bns[g].running_mean, 2e-3, "running_mean", abs_=1e-4)
+        _close(mean[g], ref[g].mean(dim=(0, 2, 3)), 2e-3, "mean", abs_=1e-4)
+
+
 @pytest.mark.parametrize("shape,res", [((2, 32, 20, 20), False), ((2, 128, 25, 25), True), ((1, 8, 13, 13), True),
                                        ((2, 256, 9, 9), False)])
 def test_layernorm_c_bf16(shape, res):
