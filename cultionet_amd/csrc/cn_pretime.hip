@@ -14,11 +14,17 @@
 // cross-block reduction through the two-level last-block ticket of cn_ticket.h (no finalize launches, fixed summation
 // order). Inference is the output pass alone. The input needs no gradient (it is the data).
 //
-// Work decomposition: a block = 64 pixels (the lanes of a wave) x NOG = Cout / 8 waves; wave `og` owns output
-// channels [8 og, 8 og + 8) of both branches, so every weight a wave touches is wave-uniform (scalar loads, SGPR
-// operands) and the bf16 NHWC output is one 16-byte store per lane. The x tile and the C*(T-2) + C*(T-4) activations of
-// the first convolutions live in LDS, shared by the block's waves (computed once per block, entry e by wave e % NOG).
+// Work decomposition (second version; the first -- a wave per 8 output channels, the first convolutions' activations
+// exchanged through LDS, weights by scalar loads inside the loops -- ran at 1-2 % of the vector peak: every entry paid
+// a scalar-load round trip, two barriers per tile, 8 waves per CU): a THREAD owns a pixel and NO (<= 32) output
+// channels of both branches in registers, a wave = 64 consecutive pixels, no barrier inside a tile when one wave covers
+// all of Cout (NOG = Cout / NO = 1; Cout = 64 runs two waves per pixel group that only meet for the LayerNorm sums).
+// All weights and per-channel constants are staged ONCE per block in LDS and read as wave-uniform broadcasts; the x
+// tile is staged per tile ([row][pixel]: conflict-free per-lane reads) and walked with a k-deep register window per
+// input channel (one LDS read per (channel, time step) instead of k). Column sums over pixels (statistics, parameter
+// gradients) are DPP wave reductions into lane 63, accumulated per wave in LDS, combined per block at the end.
 #include <cstdlib>
+#include <type_traits>
 #include "cn_bf16.h"
 #include "cn_ticket.h"
 
@@ -65,332 +71,540 @@ __global__ void cn_pretime_pack_kernel(const CnPtArgs a, float* wbt0, float* wbt
   }
 }
 
-// LDS carve (floats) -- the host computes the same sizes (pt_shmem_bytes)
+
+// SiLU and its derivative on the hardware exp / rcp (1 ulp each: ~2e-7 relative; the reference's own fp32 SiLU is no
+// closer to the real function). The per-entry activation is a third of the pass's vector instructions otherwise.
+__device__ __forceinline__ float pt_sigmoid(float x) {
+  return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
+}
+__device__ __forceinline__ float pt_silu(float x) { return x * pt_sigmoid(x); }
+__device__ __forceinline__ float pt_silu_grad(float x) {
+  const float s = pt_sigmoid(x);
+  return s * (1.0f + x * (1.0f - s));
+}
+// NO wave-uniform weights w[0..NO) sitting one per lane (lane j holds w[j]) -> acc[j] += w[j] * v. One per-lane LDS read
+// serves a whole entry; v_readlane moves each weight into a scalar operand (a 16-byte broadcast read of LDS costs 8
+// LDS cycles per 4 weights and wave, which made the LDS -- shared by the CU's four SIMDs -- the bound).
+template <int NO>
+__device__ __forceinline__ void pt_fma_lane_weights(float wlane, float v, float* acc) {
+  const int wb = __float_as_int(wlane);
+  const f32x2 v2 = {v, v};
+#pragma unroll
+  for (int j = 0; j < NO; j += 2) {  // packed fp32 FMA (v_pk_fma_f32): two outputs per vector instruction
+    const f32x2 w2 = {__int_as_float(__builtin_amdgcn_readlane(wb, j)), __int_as_float(__builtin_amdgcn_readlane(wb, j + 1))};
+    f32x2 r2 = {acc[j], acc[j + 1]};
+    r2 = __builtin_elementwise_fma(w2, v2, r2);
+    acc[j] = r2[0];
+    acc[j + 1] = r2[1];
+  }
+}
+template <int NO>
+__device__ __forceinline__ float pt_dot_lane_weights(float wlane, const float* v) {
+  const int wb = __float_as_int(wlane);
+  float d = 0.f;
+#pragma unroll
+  for (int j = 0; j < NO; ++j) d += __int_as_float(__builtin_amdgcn_readlane(wb, j)) * v[j];
+  return d;
+}
+
+#define PT_KP 5  // weight row pitch of the first convolutions in LDS (k <= 5)
+
+// LDS carve (floats) -- host and device compute the same offsets
 struct PtLds {
-  int xs, as_, hs, drs, red, acc, total;
+  int wa, c3, k3, wbt, c2, ln, k2, xs, as_, drs, dacc, ex, lacc, total;
 };
 __host__ __device__ static inline int pt_ceil4(int v) { return (v + 3) & ~3; }
-__host__ __device__ static inline PtLds pt_lds(int PASS, int C, int T, int Cout, int nthr) {
+__host__ __device__ static inline int pt_nvals(int PASS, int C, int Cout, int CMAX) {
+  switch (PASS) {
+    case 0: return 4 * C;
+    case 1: return 4 * Cout;
+    case 3: return 6 * Cout;
+    case 4: return 4 * C;
+    case 5: return 2 * C * CMAX * PT_KP;
+    default: return 0;
+  }
+}
+__host__ __device__ static inline PtLds pt_lds(int PASS, int C, int T, int Cout, int CMAX, int PXB) {
   const int E3 = C * (T - 2), E5 = C * (T - 4);
-  const int ES = pt_ceil4(E3) + pt_ceil4(E5);
   PtLds l;
   int o = 0;
-  l.xs = o; o += C * T * 64;
-  l.as_ = o; if (PASS >= 1 && PASS <= 4) o += ES * 64;
-  l.hs = o; if (PASS >= 4) o += (E3 + E5) * 64;
-  l.drs = o; if (PASS == 4) o += 2 * Cout * 64;
-  l.red = o; if (PASS >= 2 && PASS <= 4) o += 2 * (Cout / 8) * 64;
-  l.acc = o;
-  if (PASS == 0 || PASS == 4) o += 4 * C * nthr;
-  if (PASS == 5) o += 8 * C * C * 64;
+  l.wa = o; o += pt_ceil4(2 * C * CMAX * PT_KP);
+  l.c3 = o; o += 2 * C * 4;
+  l.k3 = o; o += pt_ceil4(2 * C * 2);
+  l.wbt = o; if (PASS >= 1 && PASS <= 4) o += (E3 + E5) * Cout;
+  l.c2 = o; if (PASS >= 2 && PASS <= 4) o += 2 * Cout * 4;
+  l.ln = o; if (PASS >= 2 && PASS <= 4) o += 2 * Cout;
+  l.k2 = o; if (PASS == 4) o += 4 * Cout;
+  l.xs = o; o += C * T * PXB;
+  l.as_ = o; if (PASS == 4) o += (pt_ceil4(E3) + pt_ceil4(E5)) * PXB;
+  l.drs = o; if (PASS == 4) o += 2 * Cout * PXB;
+  l.dacc = o; if (PASS == 4) o += (E3 + E5) * PXB;
+  l.ex = o; if (PASS >= 2 && PASS <= 4) o += 2 * 4 * 64;
+  l.lacc = o; o += pt_ceil4(4 * pt_nvals(PASS, C, Cout, CMAX));
   l.total = o;
   return l;
+}
+
+// One Conv3d(C -> C, (K,1,1)) stack over a pixel: rows cp = 0..C-1, entries tp = 0..T-K. The K-deep window xw[c][.]
+// of every input channel slides along time in registers: one LDS read per (c, tp). entry(cp, tp, h, xw) gets the
+// convolution value and the window (x[c][tp .. tp+K-1], valid for c < C).
+template <int K, int CMAX, class FB, class FE, class FR>
+__device__ __forceinline__ void pt_rows(const float* __restrict__ wl, const float* __restrict__ xs, int C, int T,
+                                        int PXB, int pc, FB&& row_begin, FE&& entry, FR&& row_end) {
+  const int Tp = T - K + 1;
+  for (int cp = 0; cp < C; ++cp) {
+    float w[CMAX][K], xw[CMAX][K];
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+#pragma unroll
+      for (int dt = 0; dt < K; ++dt) {
+        w[c][dt] = wl[(cp * CMAX + c) * PT_KP + dt];
+        xw[c][dt] = 0.f;
+      }
+#pragma unroll
+    for (int c = 0; c < CMAX; ++c)
+      if (c < C) {
+#pragma unroll
+        for (int dt = 1; dt < K; ++dt) xw[c][dt] = xs[(c * T + dt - 1) * PXB + pc];
+      }
+    row_begin(cp);
+    for (int tp = 0; tp < Tp; ++tp) {
+      float h = 0.f;
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c)
+        if (c < C) {
+#pragma unroll
+          for (int dt = 0; dt + 1 < K; ++dt) xw[c][dt] = xw[c][dt + 1];
+          xw[c][K - 1] = xs[(c * T + tp + K - 1) * PXB + pc];
+#pragma unroll
+          for (int dt = 0; dt < K; ++dt) h += w[c][dt] * xw[c][dt];
+        }
+      entry(cp, tp, h, xw);
+    }
+    row_end(cp);
+  }
 }
 
 // PASS 0: BatchNorm3d statistics   1: BatchNorm2d statistics   2: output (training or inference)
 // PASS 3: backward sums of LayerNorm / BatchNorm2d   4: dW of the second convolutions + BatchNorm3d sums (+ dz scratch)
 // PASS 5: dW of the first convolutions
-template <int PASS, int MAXIT>
-__global__ __launch_bounds__(512) void cn_pretime_kernel(const CnPtArgs a) {
+// CMAX: compile-time bound of the input channels (4 or 8). NO: output channels per thread (8, 16 or 32).
+template <int PASS, int CMAX, int NO>
+__global__ __launch_bounds__(256) void cn_pretime_kernel(const CnPtArgs a) {
   extern __shared__ __attribute__((aligned(16))) float lds[];
   __shared__ int s_flag;
-  const int tid = threadIdx.x, px = tid & 63;
-  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);  // = output group og; provably wave-uniform
-  const int nthr = blockDim.x, NOG = nthr >> 6;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int C = a.C, T = a.T, Cout = a.Cout, HW = a.HW;
+  const int nthr = blockDim.x;
+  const int NOG = Cout / NO;             // waves per pixel group
+  const int NPG = (nthr >> 6) / NOG;     // pixel groups (of 64 pixels) per block
+  const int PXB = 64 * NPG;
+  const int pxg = wid / NOG, og = wid - pxg * NOG;
+  const int pc = pxg * 64 + lane;   // pixel column inside the block tile
+  const int o0 = og * NO;
+  const int wl_lane = lane < NO ? lane : NO - 1;  // lane j < NO fetches weight j of an entry
   const int T3 = T - 2, T5 = T - 4;
   const int E3 = C * T3, E5 = C * T5, E = E3 + E5;
-  const int S5 = pt_ceil4(E3);  // LDS slot of branch 5's first entry (both branches padded to 4 entries: dW tiles)
-  const PtLds L = pt_lds(PASS, C, T, Cout, nthr);
+  const int S5 = pt_ceil4(E3);
+  const PtLds L = pt_lds(PASS, C, T, Cout, CMAX, PXB);
+  float* wa_l = lds + L.wa;
+  float* c3_l = lds + L.c3;
+  float* k3_l = lds + L.k3;
+  float* wbt_l = lds + L.wbt;
+  float* c2_l = lds + L.c2;
+  float* ln_l = lds + L.ln;
+  float* k2_l = lds + L.k2;
   float* xs = lds + L.xs;
   float* as_ = lds + L.as_;
-  float* hs = lds + L.hs;
   float* drs = lds + L.drs;
-  float* red = lds + L.red;
-  float* acc = lds + L.acc;
+  float* dacc = lds + L.dacc;
+  float* ex = lds + L.ex;
+  float* lacc = lds + L.lacc;
+  const int NV = pt_nvals(PASS, C, Cout, CMAX);
   const float vN = 1.0f / (float)Cout;
 
-  // ---- per-kernel initialisation of LDS accumulators / pad rows ----
-  if (PASS == 0 || PASS == 4)
-    for (int i = tid; i < 4 * C * nthr; i += nthr) acc[i] = 0.f;
-  if (PASS == 5)
-    for (int i = tid; i < 8 * C * C * 64; i += nthr) acc[i] = 0.f;
+  // ---- stage weights and per-channel constants once per block ----
+  for (int i = tid; i < 2 * C * CMAX * PT_KP; i += nthr) {
+    const int dt = i % PT_KP;
+    int q = i / PT_KP;
+    const int c = q % CMAX;
+    q /= CMAX;
+    const int cp = q % C, brn = q / C;
+    const int k = brn ? 5 : 3;
+    wa_l[i] = (c < C && dt < k) ? a.br[brn].wa[(cp * C + c) * k + dt] : 0.f;
+  }
+  for (int i = tid; i < 2 * C; i += nthr) {
+    const int brn = i / C, cp = i - brn * C;
+    const CnPtBranch& r = a.br[brn];
+    float mu = 0.f, rho = 1.f;
+    if (PASS > 0) {
+      if (a.training) { mu = r.mean3[cp]; rho = r.rstd3[cp]; }
+      else { mu = r.rm3[cp]; rho = 1.0f / sqrtf(r.rv3[cp] + a.eps3); }
+    }
+    c3_l[i * 4 + 0] = rho;
+    c3_l[i * 4 + 1] = -mu * rho;
+    c3_l[i * 4 + 2] = r.g3[cp];
+    c3_l[i * 4 + 3] = r.b3[cp];
+    if (PASS == 5) {
+      k3_l[i * 2 + 0] = a.coef3[(brn * 2) * C + cp];
+      k3_l[i * 2 + 1] = a.coef3[(brn * 2 + 1) * C + cp];
+    }
+  }
   if (PASS >= 1 && PASS <= 4) {
-    for (int i = E3 * 64 + tid; i < S5 * 64; i += nthr) as_[i] = 0.f;
-    for (int i = (S5 + E5) * 64 + tid; i < (S5 + pt_ceil4(E5)) * 64; i += nthr) as_[i] = 0.f;
+    // (the two transposed tables are contiguous in the workspace: one copy, eight loads in flight per thread -- a
+    // load-wait-store loop was ~15 us of dependent round trips at the head of EVERY block)
+    const float* __restrict__ src = a.br[0].wbt;
+    const int n = E * Cout;
+    for (int i0 = tid; i0 < n; i0 += nthr * 8) {
+      float v[8];
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int k = i0 + i * nthr; v[i] = src[k < n ? k : n - 1]; }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) { const int k = i0 + i * nthr; if (k < n) wbt_l[k] = v[i]; }
+    }
+  }
+  if (PASS >= 2 && PASS <= 4) {
+    for (int i = tid; i < 2 * Cout; i += nthr) {
+      const int brn = i / Cout, o = i - brn * Cout;
+      const CnPtBranch& r = a.br[brn];
+      float mu, rho;
+      if (a.training) { mu = r.mean2[o]; rho = r.rstd2[o]; }
+      else { mu = r.rm2[o]; rho = 1.0f / sqrtf(r.rv2[o] + a.eps2); }
+      c2_l[i * 4 + 0] = rho;
+      c2_l[i * 4 + 1] = -mu * rho;
+      c2_l[i * 4 + 2] = r.g2[o];
+      c2_l[i * 4 + 3] = r.b2[o];
+      if (PASS == 4) {
+        k2_l[i * 2 + 0] = a.coef2[(brn * 2) * Cout + o];
+        k2_l[i * 2 + 1] = a.coef2[(brn * 2 + 1) * Cout + o];
+      }
+    }
+    for (int o = tid; o < Cout; o += nthr) { ln_l[o] = a.gL[o]; ln_l[Cout + o] = a.bL[o]; }
+  }
+  for (int i = tid; i < 4 * NV; i += nthr) lacc[i] = 0.f;
+  if (PASS == 4) {
+    for (int i = E3 * PXB + tid; i < S5 * PXB; i += nthr) as_[i] = 0.f;
+    for (int i = (S5 + E5) * PXB + tid; i < (S5 + pt_ceil4(E5)) * PXB; i += nthr) as_[i] = 0.f;
   }
 
-  // register accumulators across the block's tiles
-  float A2[2][2][8];   // PASS 1: {sum r, sum r^2}; PASS 3: {sum dv, sum dv*rhat} per branch and own channel
-  float AL[2][8];      // PASS 3: {sum dy*uhat, sum dy}
-  float AW[MAXIT][8];  // PASS 4: dWb tiles (2 couts x 4 entries)
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int s = 0; s < 2; ++s)
-#pragma unroll
-      for (int j = 0; j < 8; ++j) A2[i][s][j] = 0.f;
-#pragma unroll
-  for (int s = 0; s < 2; ++s)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) AL[s][j] = 0.f;
-#pragma unroll
-  for (int it = 0; it < MAXIT; ++it)
-#pragma unroll
-    for (int j = 0; j < 8; ++j) AW[it][j] = 0.f;
+  float* my = lacc + wid * NV;  // this wave's accumulators (lane 63 adds the wave totals)
+  auto wsum = [&](int v, float val) {
+    const float t = cn_wave_sum_to_lane63(val);
+    if (lane == 63) my[v] += t;
+  };
 
-  // per-thread constants of the own 8 output channels (wave-uniform values: scalar loads)
-  const int o0 = wid * 8;
+  float AW[8];  // PASS 4: this thread's dWb tile (2 couts x 4 entries), summed over the block's tiles
+#pragma unroll
+  for (int j = 0; j < 8; ++j) AW[j] = 0.f;
+  float AW2[8], AW3[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) AW2[j] = AW3[j] = 0.f;
 
-  for (int tile = blockIdx.x; tile < a.ntiles; tile += gridDim.x) {
-    const long p = (long)tile * 64 + px;
+  const int ntb = (int)((a.P + PXB - 1) / PXB);  // block tiles
+  for (int tile = blockIdx.x; tile < ntb; tile += gridDim.x) {
+    const long p = (long)tile * PXB + pc;
     const bool valid = p < a.P;
     const float vm = valid ? 1.f : 0.f;
     const int b = valid ? (int)(p / HW) : 0;
     const int l = valid ? (int)(p - (long)b * HW) : 0;
-    __syncthreads();  // the previous tile's LDS reads are done
+    __syncthreads();  // previous tile's LDS reads are done (and, first time, the staged weights are visible below)
     {
+      // x tile: rows dealt to the NOG waves of the pixel group (every wave of a group has the same pixels). TWELVE
+      // loads in flight per thread (clamped row index, never a predicated load): one row at a time was a chain of
+      // C * T dependent HBM round trips per tile -- most of the first version's run time.
       const float* xp = a.x + (long)b * a.xbs + l;
-      for (int row = wid; row < C * T; row += NOG) {
-        const float v = xp[(long)row * HW];  // (clamped pixel for the ragged tail: always a valid address)
-        xs[row * 64 + px] = valid ? v : 0.f;
+      const int CT = C * T;
+      for (int row0 = og; row0 < CT; row0 += NOG * 12) {
+        float v[12];
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int row = row0 + i * NOG;
+          v[i] = xp[(long)(row < CT ? row : CT - 1) * HW];
+        }
+#pragma unroll
+        for (int i = 0; i < 12; ++i) {
+          const int row = row0 + i * NOG;
+          if (row < CT) xs[row * PXB + pc] = valid ? v[i] : 0.f;
+        }
       }
     }
     __syncthreads();
-    // ---- first convolutions, entry by entry (wave-uniform entry index) ----
-    for (int e = wid; e < E; e += NOG) {
-      const int brn = e >= E3 ? 1 : 0;
-      const CnPtBranch& r = a.br[brn];
-      const int loc = e - (brn ? E3 : 0);
-      const int Tp = brn ? T5 : T3, k = brn ? 5 : 3;
-      const int cp = loc / Tp, tp = loc - cp * Tp;
-      float h = 0.f;
-      for (int c = 0; c < C; ++c) {
-        const float* w = r.wa + (cp * C + c) * k;
-        const float* xr = xs + (c * T + tp) * 64 + px;
-        for (int dt = 0; dt < k; ++dt) h += w[dt] * xr[dt * 64];
-      }
-      if (PASS == 0) {
-        const int slot = (brn * C + cp) * 2;
-        acc[slot * nthr + tid] += h;
-        acc[(slot + 1) * nthr + tid] += h * h;
-        continue;
-      }
-      float mu, rho;
-      if (a.training) { mu = r.mean3[cp]; rho = r.rstd3[cp]; }
-      else { mu = r.rm3[cp]; rho = 1.0f / sqrtf(r.rv3[cp] + a.eps3); }
-      const float hh = (h - mu) * rho;
-      const int slot_e = brn ? S5 + loc : loc;
-      if (PASS <= 4) {
-        const float z = r.g3[cp] * hh + r.b3[cp];
-        as_[slot_e * 64 + px] = cn_silu(z);
-      }
-      if (PASS == 4) hs[e * 64 + px] = hh;
-      if (PASS == 5) {
-        const float dzv = valid ? a.dz[(long)e * a.P + p] : 0.f;
-        const float c0 = a.coef3[(brn * 2) * C + cp], c1 = a.coef3[(brn * 2 + 1) * C + cp];
-        hs[e * 64 + px] = r.g3[cp] * rho * (dzv - c0 - hh * c1) * vm;  // dh
-      }
-    }
-    if (PASS == 0) continue;
-    __syncthreads();
-    if (PASS == 5) {
-      // dWa[brn][cp][c][dt] += sum_px sum_tp dh[brn][cp][tp] * x[c][tp + dt]: output q owned by wave q % NOG
-      const int n3 = C * C * 3, nout = 8 * C * C;
-      for (int q = wid; q < nout; q += NOG) {
-        const int brn = q >= n3 ? 1 : 0;
-        const int ql = q - (brn ? n3 : 0);
-        const int k = brn ? 5 : 3, Tp = brn ? T5 : T3;
-        const int dt = ql % k;
-        const int cc = ql / k;  // cp * C + c
-        const int cp = cc / C, c = cc - cp * C;
-        const float* dh = hs + ((brn ? E3 : 0) + cp * Tp) * 64 + px;
-        const float* xr = xs + (c * T + dt) * 64 + px;
-        float v = 0.f;
-        for (int tp = 0; tp < Tp; ++tp) v += dh[tp * 64] * xr[tp * 64];
-        acc[q * 64 + px] += v;
+
+    if (PASS == 0) {
+      float s = 0.f, q = 0.f;
+      int slot = 0;
+      auto rb = [&](int) { s = 0.f; q = 0.f; };
+      auto en = [&](int, int, float h, auto&) { s += h; q += h * h; };
+      auto re = [&](int) { wsum(slot, s); wsum(slot + 1, q); slot += 2; };
+      if (og == 0) {  // (one wave per pixel group: the other waves of a Cout > NO group would count the pixels twice)
+        pt_rows<3, CMAX>(wa_l, xs, C, T, PXB, pc, rb, en, re);
+        pt_rows<5, CMAX>(wa_l + C * CMAX * PT_KP, xs, C, T, PXB, pc, rb, en, re);
       }
       continue;
     }
-    // ---- second convolutions: the wave's 8 output channels of both branches ----
-    float r_[2][8];
+    if (PASS == 5) {
+      // dh = g3 rho (dz - c0 - hh c1); dWa[cp][c][dt] += sum_px sum_tp dh * x[c][tp + dt] (the window IS x[c][tp + dt])
+      if (og == 0) {
+        int ebase = 0, vbase = 0;
+        auto branch = [&](auto kc, const float* wl, int brn) {
+          constexpr int K = decltype(kc)::value;
+          float g[CMAX][K];
+          float rho = 0.f, off = 0.f, g3 = 0.f, c0 = 0.f, c1 = 0.f;
+          const int Tp = T - K + 1;
+          auto rb = [&](int cp) {
+            const f32x4 cc = *reinterpret_cast<const f32x4*>(c3_l + (brn * C + cp) * 4);
+            rho = cc[0]; off = cc[1]; g3 = cc[2];
+            c0 = k3_l[(brn * C + cp) * 2]; c1 = k3_l[(brn * C + cp) * 2 + 1];
 #pragma unroll
-    for (int brn = 0; brn < 2; ++brn) {
+            for (int c = 0; c < CMAX; ++c)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) r_[brn][j] = 0.f;
-      const int Eb = brn ? E5 : E3;
-      const float* av = as_ + (brn ? S5 : 0) * 64 + px;
-      const float* w = a.br[brn].wbt + o0;
-      for (int loc = 0; loc < Eb; ++loc) {
-        const float aval = av[loc * 64];
+              for (int dt = 0; dt < K; ++dt) g[c][dt] = 0.f;
+          };
+          auto en = [&](int cp, int tp, float h, auto& xw) {
+            const float hh = h * rho + off;
+            const int e = ebase + cp * Tp + tp;
+            const float dzv = valid ? a.dz[(long)e * a.P + p] : 0.f;
+            const float dh = g3 * rho * (dzv - c0 - hh * c1) * vm;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) r_[brn][j] += w[(long)loc * Cout + j] * aval;
+            for (int c = 0; c < CMAX; ++c)
+#pragma unroll
+              for (int dt = 0; dt < K; ++dt) g[c][dt] += dh * xw[c][dt];
+          };
+          auto re = [&](int cp) {
+#pragma unroll
+            for (int c = 0; c < CMAX; ++c)
+#pragma unroll
+              for (int dt = 0; dt < K; ++dt) wsum(vbase + (cp * CMAX + c) * PT_KP + dt, g[c][dt]);
+          };
+          pt_rows<K, CMAX>(wl, xs, C, T, PXB, pc, rb, en, re);
+          ebase += C * Tp;
+          vbase += C * CMAX * PT_KP;
+        };
+        branch(std::integral_constant<int, 3>{}, wa_l, 0);
+        branch(std::integral_constant<int, 5>{}, wa_l + C * CMAX * PT_KP, 1);
       }
+      continue;
+    }
+
+    // ---- PASS 1..4: both convolution stacks -> r[branch][own outputs] ----
+    float r_[2][NO];
+#pragma unroll
+    for (int brn = 0; brn < 2; ++brn)
+#pragma unroll
+      for (int j = 0; j < NO; ++j) r_[brn][j] = 0.f;
+    {
+      float rho = 0.f, off = 0.f, g3 = 0.f, b3 = 0.f;
+      auto branch = [&](auto kc, const float* wl, int brn, const float* wb_l, int slot0) {
+        constexpr int K = decltype(kc)::value;
+        const int Tp = T - K + 1;
+        auto rb = [&](int cp) {
+          const f32x4 cc = *reinterpret_cast<const f32x4*>(c3_l + (brn * C + cp) * 4);
+          rho = cc[0]; off = cc[1]; g3 = cc[2]; b3 = cc[3];
+        };
+        auto en = [&](int cp, int tp, float h, auto&) {
+          const float aval = pt_silu(g3 * (h * rho + off) + b3);
+          const int loc = cp * Tp + tp;
+          if (PASS == 4 && og == 0) as_[(slot0 + loc) * PXB + pc] = aval;
+          pt_fma_lane_weights<NO>(wb_l[loc * Cout + o0 + wl_lane], aval, r_[brn]);
+        };
+        auto re = [&](int) {};
+        pt_rows<K, CMAX>(wl, xs, C, T, PXB, pc, rb, en, re);
+      };
+      branch(std::integral_constant<int, 3>{}, wa_l, 0, wbt_l, 0);
+      branch(std::integral_constant<int, 5>{}, wa_l + C * CMAX * PT_KP, 1, wbt_l + E3 * Cout, S5);
     }
     if (PASS == 1) {
 #pragma unroll
       for (int brn = 0; brn < 2; ++brn)
 #pragma unroll
-        for (int j = 0; j < 8; ++j) {
+        for (int j = 0; j < NO; ++j) {
           const float v = r_[brn][j] * vm;
-          A2[brn][0][j] += v;
-          A2[brn][1][j] += v * v;
+          wsum((brn * 2) * Cout + o0 + j, v);
+          wsum((brn * 2 + 1) * Cout + o0 + j, v * v);
         }
       continue;
     }
-    // ---- BatchNorm2d + SiLU, branch sum, LayerNorm over the Cout channels of the pixel ----
-    float rh[2][8], vv[2][8], u[8];
+    // ---- BatchNorm2d + SiLU, branch sum, LayerNorm over Cout ----
+    // r_ <- rhat (normalised); vv = affine BatchNorm output; u = sum of the activations
+    float vv[2][NO], u[NO];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) u[j] = 0.f;
+    for (int j = 0; j < NO; ++j) u[j] = 0.f;
 #pragma unroll
-    for (int brn = 0; brn < 2; ++brn) {
-      const CnPtBranch& r = a.br[brn];
+    for (int brn = 0; brn < 2; ++brn)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        float mu, rho;
-        if (a.training) { mu = r.mean2[o0 + j]; rho = r.rstd2[o0 + j]; }
-        else { mu = r.rm2[o0 + j]; rho = 1.0f / sqrtf(r.rv2[o0 + j] + a.eps2); }
-        rh[brn][j] = (r_[brn][j] - mu) * rho;
-        vv[brn][j] = r.g2[o0 + j] * rh[brn][j] + r.b2[o0 + j];
-        u[j] += cn_silu(vv[brn][j]);
+      for (int j = 0; j < NO; ++j) {
+        const f32x4 cc = *reinterpret_cast<const f32x4*>(c2_l + (brn * Cout + o0 + j) * 4);
+        r_[brn][j] = r_[brn][j] * cc[0] + cc[1];
+        vv[brn][j] = cc[2] * r_[brn][j] + cc[3];
+        u[j] += pt_silu(vv[brn][j]);
       }
-    }
-    float part = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) part += u[j];
-    red[wid * 64 + px] = part;
-    __syncthreads();
     float m = 0.f;
-    for (int w2 = 0; w2 < NOG; ++w2) m += red[w2 * 64 + px];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) m += u[j];
+    if (NOG > 1) {
+      ex[wid * 64 + lane] = m;
+      __syncthreads();
+      m = 0.f;
+      for (int w2 = 0; w2 < NOG; ++w2) m += ex[(pxg * NOG + w2) * 64 + lane];
+    }
     m *= vN;
-    float q2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) { const float d = u[j] - m; q2 += d * d; }
-    red[(NOG + wid) * 64 + px] = q2;
-    __syncthreads();
     float var = 0.f;
-    for (int w2 = 0; w2 < NOG; ++w2) var += red[(NOG + w2) * 64 + px];
+#pragma unroll
+    for (int j = 0; j < NO; ++j) { const float d = u[j] - m; var += d * d; }
+    if (NOG > 1) {
+      ex[(4 + wid) * 64 + lane] = var;
+      __syncthreads();
+      var = 0.f;
+      for (int w2 = 0; w2 < NOG; ++w2) var += ex[(4 + pxg * NOG + w2) * 64 + lane];
+    }
     const float rL = 1.0f / sqrtf(var * vN + a.epsL);
-    float uh[8];
 #pragma unroll
-    for (int j = 0; j < 8; ++j) uh[j] = (u[j] - m) * rL;
+    for (int j = 0; j < NO; ++j) u[j] = (u[j] - m) * rL;  // u <- uhat
     if (PASS == 2) {
-      float yv[8];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) yv[j] = a.gL[o0 + j] * uh[j] + a.bL[o0 + j];
       if (valid) {
         if (a.out_kind == 0) {
           float* yp = reinterpret_cast<float*>(a.y) + (long)b * a.y_stride + (long)o0 * HW + l;
 #pragma unroll
-          for (int j = 0; j < 8; ++j) yp[(long)j * HW] = yv[j];
+          for (int j = 0; j < NO; ++j) yp[(long)j * HW] = ln_l[o0 + j] * u[j] + ln_l[Cout + o0 + j];
         } else {
-          *reinterpret_cast<u32x4*>(reinterpret_cast<bf16_t*>(a.y) + p * a.y_stride + o0) = cn_pack8(yv);
+          bf16_t* yp = reinterpret_cast<bf16_t*>(a.y) + p * a.y_stride + o0;
+#pragma unroll
+          for (int j8 = 0; j8 < NO / 8; ++j8) {
+            float yv[8];
+#pragma unroll
+            for (int i = 0; i < 8; ++i) yv[i] = ln_l[o0 + j8 * 8 + i] * u[j8 * 8 + i] + ln_l[Cout + o0 + j8 * 8 + i];
+            *reinterpret_cast<u32x4*>(yp + j8 * 8) = cn_pack8(yv);
+          }
         }
       }
       continue;
     }
     // ---- backward: LayerNorm, SiLU, BatchNorm2d ----
-    float dyv[8];
+    float dyv[NO];
     if (a.out_kind == 0) {
       const float* dp = reinterpret_cast<const float*>(a.dy) + (long)b * a.dy_stride + (long)o0 * HW + l;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dyv[j] = valid ? dp[(long)j * HW] : 0.f;
+      for (int j = 0; j < NO; ++j) dyv[j] = valid ? dp[(long)j * HW] : 0.f;
     } else {
-      const long pc = valid ? p : 0;
-      cn_unpack8(*reinterpret_cast<const u32x4*>(reinterpret_cast<const bf16_t*>(a.dy) + pc * a.dy_stride + o0), dyv);
+      const bf16_t* dp = reinterpret_cast<const bf16_t*>(a.dy) + (valid ? p : 0) * a.dy_stride + o0;
 #pragma unroll
-      for (int j = 0; j < 8; ++j) dyv[j] *= vm;
+      for (int j8 = 0; j8 < NO / 8; ++j8) {
+        float t8[8];
+        cn_unpack8(*reinterpret_cast<const u32x4*>(dp + j8 * 8), t8);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) dyv[j8 * 8 + i] = t8[i] * vm;
+      }
     }
-    float gg[8], s1 = 0.f, s2 = 0.f;
+    float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      gg[j] = dyv[j] * a.gL[o0 + j];
-      s1 += gg[j];
-      s2 += gg[j] * uh[j];
+    for (int j = 0; j < NO; ++j) {
+      const float gj = dyv[j] * ln_l[o0 + j];
+      s1 += gj;
+      s2 += gj * u[j];
     }
-    __syncthreads();  // (the variance sums in red[] have been read)
-    red[wid * 64 + px] = s1;
-    red[(NOG + wid) * 64 + px] = s2;
-    __syncthreads();
-    float mg = 0.f, mgu = 0.f;
-    for (int w2 = 0; w2 < NOG; ++w2) { mg += red[w2 * 64 + px]; mgu += red[(NOG + w2) * 64 + px]; }
-    mg *= vN; mgu *= vN;
-    float dv[2][8];
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      const float du = rL * (gg[j] - mg - uh[j] * mgu);
-#pragma unroll
-      for (int brn = 0; brn < 2; ++brn) dv[brn][j] = du * cn_silu_grad(vv[brn][j]);
+    if (NOG > 1) {
+      __syncthreads();  // (the variance partials in ex[] have been read)
+      ex[wid * 64 + lane] = s1;
+      ex[(4 + wid) * 64 + lane] = s2;
+      __syncthreads();
+      s1 = s2 = 0.f;
+      for (int w2 = 0; w2 < NOG; ++w2) { s1 += ex[(pxg * NOG + w2) * 64 + lane]; s2 += ex[(4 + pxg * NOG + w2) * 64 + lane]; }
     }
+    s1 *= vN; s2 *= vN;
     if (PASS == 3) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
+      for (int j = 0; j < NO; ++j) {
+        const float du = rL * (dyv[j] * ln_l[o0 + j] - s1 - u[j] * s2);
 #pragma unroll
         for (int brn = 0; brn < 2; ++brn) {
-          A2[brn][0][j] += dv[brn][j];
-          A2[brn][1][j] += dv[brn][j] * rh[brn][j];
+          const float dv = du * pt_silu_grad(vv[brn][j]);
+          wsum((brn * 2) * Cout + o0 + j, dv);
+          wsum((brn * 2 + 1) * Cout + o0 + j, dv * r_[brn][j]);
         }
-        AL[0][j] += dyv[j] * uh[j];
-        AL[1][j] += dyv[j];
+        wsum(4 * Cout + o0 + j, dyv[j] * u[j]);
+        wsum(5 * Cout + o0 + j, dyv[j]);
       }
       continue;
     }
-    // ---- PASS 4: dr -> LDS; dWb tiles; da -> dz (scratch) + BatchNorm3d sums ----
+    // ---- PASS 4 ----
+    // dr (kept in vv) -> LDS for the dWb contraction
 #pragma unroll
-    for (int brn = 0; brn < 2; ++brn) {
-      const CnPtBranch& r = a.br[brn];
+    for (int j = 0; j < NO; ++j) {
+      const float du = rL * (dyv[j] * ln_l[o0 + j] - s1 - u[j] * s2);
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const float c0 = a.coef2[(brn * 2) * Cout + o0 + j], c1 = a.coef2[(brn * 2 + 1) * Cout + o0 + j];
-        float rho;
-        if (a.training) rho = r.rstd2[o0 + j];
-        else rho = 1.0f / sqrtf(r.rv2[o0 + j] + a.eps2);
-        drs[(brn * Cout + o0 + j) * 64 + px] = r.g2[o0 + j] * rho * (dv[brn][j] - c0 - rh[brn][j] * c1) * vm;
+      for (int brn = 0; brn < 2; ++brn) {
+        const float dv = du * pt_silu_grad(vv[brn][j]);
+        const f32x4 cc = *reinterpret_cast<const f32x4*>(c2_l + (brn * Cout + o0 + j) * 4);
+        const float c0 = k2_l[(brn * Cout + o0 + j) * 2], c1 = k2_l[(brn * Cout + o0 + j) * 2 + 1];
+        const float dr = cc[2] * cc[0] * (dv - c0 - r_[brn][j] * c1) * vm;
+        vv[brn][j] = dr;
+        drs[(brn * Cout + o0 + j) * PXB + pc] = dr;
       }
     }
-    __syncthreads();
+    // da[e] = sum_o wb[o][e] dr[o]: this thread's NO outputs; the NOG waves of a pixel group add up through LDS
+    for (int i = og; i < E; i += NOG) dacc[i * PXB + pc] = 0.f;
+    if (NOG > 1) __syncthreads();
+    for (int e = 0; e < E; ++e) {
+      const int brn = e >= E3 ? 1 : 0;
+      const float wl_ = wbt_l[e * Cout + o0 + wl_lane];  // (wbt_l rows: branch 3 then 5)
+      const float da = brn == 0 ? pt_dot_lane_weights<NO>(wl_, vv[0]) : pt_dot_lane_weights<NO>(wl_, vv[1]);
+      if (NOG > 1) atomicAdd(&dacc[e * PXB + pc], da);  // (ds_add_f32: one address per lane, waves of a group in turn)
+      else dacc[e * PXB + pc] = da;
+    }
+    __syncthreads();  // as_ / drs / dacc complete for the whole block tile
+    // dz = da * silu'(z), BatchNorm3d sums, dz -> scratch (one wave per pixel group)
+    if (og == 0) {
+      float rho = 0.f, off = 0.f, g3 = 0.f, b3 = 0.f, s = 0.f, q = 0.f;
+      int slot = 0, ebase = 0;
+      auto branch = [&](auto kc, const float* wl, int brn) {
+        constexpr int K = decltype(kc)::value;
+        const int Tp = T - K + 1;
+        auto rb = [&](int cp) {
+          const f32x4 cc = *reinterpret_cast<const f32x4*>(c3_l + (brn * C + cp) * 4);
+          rho = cc[0]; off = cc[1]; g3 = cc[2]; b3 = cc[3];
+          s = 0.f; q = 0.f;
+        };
+        auto en = [&](int cp, int tp, float h, auto&) {
+          const float hh = h * rho + off;
+          const int e = ebase + cp * Tp + tp;
+          const float dzv = dacc[e * PXB + pc] * pt_silu_grad(g3 * hh + b3);
+          s += dzv;
+          q += dzv * hh;
+          if (valid) a.dz[(long)e * a.P + p] = dzv;
+        };
+        auto re = [&](int) { wsum(slot, s); wsum(slot + 1, q); slot += 2; };
+        pt_rows<K, CMAX>(wl, xs, C, T, PXB, pc, rb, en, re);
+        ebase += C * Tp;
+      };
+      branch(std::integral_constant<int, 3>{}, wa_l, 0);
+      branch(std::integral_constant<int, 5>{}, wa_l + C * CMAX * PT_KP, 1);
+    }
     {
-      // dWb[brn][o][loc] += sum_px dr[brn][o][px] * a[brn][loc][px]: a thread owns 2 couts x 4 entries per iteration
+      // dWb[brn][o][loc] += sum_px dr[brn][o][px] * a[brn][loc][px]: a thread owns 2 couts x 4 entries (x 3 rounds)
       const int half = Cout >> 1;
       const int nt3 = half * (pt_ceil4(E3) >> 2), nt5 = half * (pt_ceil4(E5) >> 2);
-#pragma unroll
-      for (int it = 0; it < MAXIT; ++it) {
-        const int ti = tid + it * nthr;
-        if (ti >= nt3 + nt5) break;
+      auto tile_mac = [&](int ti, float* acc8) {
+        if (ti >= nt3 + nt5) return;
         const int brn = ti >= nt3 ? 1 : 0;
         const int tl = ti - (brn ? nt3 : 0);
         const int o2 = tl % half, e4 = tl / half;
-        const float* d0 = drs + (brn * Cout + 2 * o2) * 64;
-        const float* a0 = as_ + ((brn ? S5 : 0) + e4 * 4) * 64;
-#pragma unroll 4
-        for (int q4 = 0; q4 < 16; ++q4) {
+        const float* d0 = drs + (brn * Cout + 2 * o2) * PXB;
+        const float* a0 = as_ + ((brn ? S5 : 0) + e4 * 4) * PXB;
+        for (int q4 = 0; q4 < PXB / 4; ++q4) {
           const f32x4 da_ = *reinterpret_cast<const f32x4*>(d0 + q4 * 4);
-          const f32x4 db_ = *reinterpret_cast<const f32x4*>(d0 + 64 + q4 * 4);
+          const f32x4 db_ = *reinterpret_cast<const f32x4*>(d0 + PXB + q4 * 4);
 #pragma unroll
           for (int i = 0; i < 4; ++i) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(a0 + i * 64 + q4 * 4);
-            AW[it][i] += da_[0] * av[0] + da_[1] * av[1] + da_[2] * av[2] + da_[3] * av[3];
-            AW[it][4 + i] += db_[0] * av[0] + db_[1] * av[1] + db_[2] * av[2] + db_[3] * av[3];
+            const f32x4 av = *reinterpret_cast<const f32x4*>(a0 + i * PXB + q4 * 4);
+            acc8[i] += da_[0] * av[0] + da_[1] * av[1] + da_[2] * av[2] + da_[3] * av[3];
+            acc8[4 + i] += db_[0] * av[0] + db_[1] * av[1] + db_[2] * av[2] + db_[3] * av[3];
           }
         }
-      }
-    }
-    for (int e = wid; e < E; e += NOG) {
-      const int brn = e >= E3 ? 1 : 0;
-      const CnPtBranch& r = a.br[brn];
-      const int loc = e - (brn ? E3 : 0);
-      const int Tp = brn ? T5 : T3;
-      const int cp = loc / Tp;
-      const float* w = r.wbt + (long)loc * Cout;
-      const float* dr = drs + brn * Cout * 64 + px;
-      float da = 0.f;
-      for (int o = 0; o < Cout; ++o) da += w[o] * dr[o * 64];
-      const float hh = hs[e * 64 + px];
-      const float dzv = da * cn_silu_grad(r.g3[cp] * hh + r.b3[cp]);
-      const int slot = (brn * C + cp) * 2;
-      acc[slot * nthr + tid] += dzv;
-      acc[(slot + 1) * nthr + tid] += dzv * hh;
-      if (valid) a.dz[(long)e * a.P + p] = dzv;
+      };
+      tile_mac(tid, AW);
+      tile_mac(tid + nthr, AW2);
+      tile_mac(tid + 2 * nthr, AW3);
     }
   }
 
@@ -398,49 +612,21 @@ __global__ __launch_bounds__(512) void cn_pretime_kernel(const CnPtArgs a) {
   if (PASS == 2) return;
   const int blk = blockIdx.x;
   __syncthreads();
-  if (PASS == 0 || PASS == 4) {
-    // LDS accumulators [slot][thread]: wave sums, then the NOG wave partials per slot
-    const int nslot = 4 * C;
-    float* wsum = xs;  // (x tile no longer needed) [nslot][NOG]
-    for (int s = 0; s < nslot; ++s) {
-      const float v = cn_wave_sum(acc[s * nthr + tid]);
-      if (px == 0) wsum[s * NOG + wid] = v;
-    }
-    __syncthreads();
+  {
+    // the four waves' accumulators -> one row
     const int base = PASS == 4 ? Cout * E : 0;
-    if (tid < nslot) {
-      float v = 0.f;
-      for (int w2 = 0; w2 < NOG; ++w2) v += wsum[tid * NOG + w2];
-      cn_t2_store(a.tk, blk, base + tid, v);
-    }
-  }
-  if (PASS == 1 || PASS == 3) {
-#pragma unroll
-    for (int brn = 0; brn < 2; ++brn)
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float v = cn_wave_sum(A2[brn][s][j]);
-          if (px == 0) cn_t2_store(a.tk, blk, (brn * 2 + s) * Cout + o0 + j, v);
-        }
-    if (PASS == 3) {
-#pragma unroll
-      for (int s = 0; s < 2; ++s)
-#pragma unroll
-        for (int j = 0; j < 8; ++j) {
-          const float v = cn_wave_sum(AL[s][j]);
-          if (px == 0) cn_t2_store(a.tk, blk, (4 + s) * Cout + o0 + j, v);
-        }
+    for (int v = tid; v < NV; v += nthr)
+    {
+      float t = 0.f;
+      for (int w2 = 0; w2 < (nthr >> 6); ++w2) t += lacc[w2 * NV + v];
+      cn_t2_store(a.tk, blk, base + v, t);
     }
   }
   if (PASS == 4) {
     const int half = Cout >> 1;
     const int nt3 = half * (pt_ceil4(E3) >> 2), nt5 = half * (pt_ceil4(E5) >> 2);
-#pragma unroll
-    for (int it = 0; it < MAXIT; ++it) {
-      const int ti = tid + it * nthr;
-      if (ti >= nt3 + nt5) break;
+    auto tile_store = [&](int ti, const float* acc8) {
+      if (ti >= nt3 + nt5) return;
       const int brn = ti >= nt3 ? 1 : 0;
       const int tl = ti - (brn ? nt3 : 0);
       const int o2 = tl % half, e4 = tl / half;
@@ -449,25 +635,20 @@ __global__ __launch_bounds__(512) void cn_pretime_kernel(const CnPtArgs a) {
       for (int i = 0; i < 4; ++i) {
         const int loc = e4 * 4 + i;
         if (loc < Eb) {
-          cn_t2_store(a.tk, blk, (brn ? Cout * E3 : 0) + (2 * o2) * Eb + loc, AW[it][i]);
-          cn_t2_store(a.tk, blk, (brn ? Cout * E3 : 0) + (2 * o2 + 1) * Eb + loc, AW[it][4 + i]);
+          cn_t2_store(a.tk, blk, (brn ? Cout * E3 : 0) + (2 * o2) * Eb + loc, acc8[i]);
+          cn_t2_store(a.tk, blk, (brn ? Cout * E3 : 0) + (2 * o2 + 1) * Eb + loc, acc8[4 + i]);
         }
       }
-    }
-  }
-  if (PASS == 5) {
-    const int nout = 8 * C * C;
-    for (int q = wid; q < nout; q += NOG) {
-      const float v = cn_wave_sum(acc[q * 64 + px]);
-      if (px == 0) cn_t2_store(a.tk, blk, q, v);
-    }
+    };
+    tile_store(tid, AW);
+    tile_store(tid + nthr, AW2);
+    tile_store(tid + 2 * nthr, AW3);
   }
   // finish (the last-arriving block): statistics / coefficients / parameter gradients
   const double cntP = (double)a.P;
   cn_t2_reduce_fn(a.tk, blk, &s_flag, [&](int col, double tot) {
     if (PASS == 0 || PASS == 1 || PASS == 3) {
-      // pairs {stat 0, stat 1} are finished together below (they sit in different columns): park the totals
-      reinterpret_cast<double*>(lds)[col] = tot;
+      reinterpret_cast<double*>(lds)[col] = tot;  // {stat 0, stat 1} pairs sit in different columns: park, finish below
     } else if (PASS == 4) {
       if (col < Cout * E) {
         const int brn = col >= Cout * E3 ? 1 : 0;
@@ -475,10 +656,14 @@ __global__ __launch_bounds__(512) void cn_pretime_kernel(const CnPtArgs a) {
       } else {
         reinterpret_cast<double*>(lds)[col - Cout * E] = tot;
       }
-    } else {  // PASS 5
-      const int n3 = C * C * 3;
-      const int brn = col >= n3 ? 1 : 0;
-      a.br[brn].dwa[col - (brn ? n3 : 0)] += (float)tot;
+    } else {  // PASS 5: value (brn, cp, c, dt) at [(brn*C + cp)*CMAX + c]*PT_KP + dt
+      const int dt = col % PT_KP;
+      int q = col / PT_KP;
+      const int c = q % CMAX;
+      q /= CMAX;
+      const int cp = q % C, brn = q / C;
+      const int k = brn ? 5 : 3;
+      if (c < C && dt < k) a.br[brn].dwa[(cp * C + c) * k + dt] += (float)tot;
     }
   });
   if (PASS == 5 || !s_flag) return;
@@ -540,6 +725,13 @@ __global__ __launch_bounds__(512) void cn_pretime_kernel(const CnPtArgs a) {
 }
 
 // ---- host side -----------------------------------------------------------------------------------------------------
+static inline int pt_cmax(int C) { return C <= 4 ? 4 : 8; }
+// output channels per thread: 32 where the registers allow it (forward, statistics), 16 in the gradient passes that
+// keep dy / dr / vv per output as well
+static inline int pt_no(int PASS, int Cout) {
+  const int cap = (PASS == 3 || PASS == 4) ? 16 : 32;
+  return Cout < cap ? Cout : cap;
+}
 static inline int pt_row_width(int PASS, int C, int T, int Cout) {
   const int E = C * (T - 2) + C * (T - 4);
   switch (PASS) {
@@ -547,16 +739,25 @@ static inline int pt_row_width(int PASS, int C, int T, int Cout) {
     case 1: return 4 * Cout;
     case 3: return 6 * Cout;
     case 4: return Cout * E + 4 * C;
-    case 5: return 8 * C * C;
+    case 5: return 2 * C * pt_cmax(C) * PT_KP;
     default: return 0;
   }
 }
-static inline int pt_blocks(long P) {
-  const long tiles = (P + 63) / 64;
-  return (int)(tiles < PT_MAX_BLOCKS ? tiles : PT_MAX_BLOCKS);
-}
 static inline bool pt_supported(int C, int T, int Cout) {
-  return C >= 1 && C <= PT_MAX_C && T >= 5 && Cout >= 8 && Cout <= 64 && (Cout & 7) == 0;
+  return C >= 1 && C <= PT_MAX_C && T >= 5 && (Cout == 8 || Cout == 16 || Cout == 32 || Cout == 64);
+}
+static inline size_t pt_shmem_npg(int PASS, int C, int T, int Cout, int npg) {
+  size_t sh = (size_t)pt_lds(PASS, C, T, Cout, pt_cmax(C), 64 * npg).total * 4;
+  const size_t park = (size_t)(6 * Cout > 4 * C ? 6 * Cout : 4 * C) * 8;  // the finish phase parks doubles at the head
+  return sh < park ? park : sh;
+}
+// pixel groups (waves' worth of 64 pixels) per block: as many as 256 threads hold, fewer if the LDS image (x tile,
+// and in PASS 4 the activation / dr / da tiles of the block) would not fit; 0 = does not fit at all
+static inline int pt_npg(int PASS, int C, int T, int Cout) {
+  const int nog = Cout / pt_no(PASS, Cout);
+  for (int npg = 4 / nog; npg >= 1; npg >>= 1)
+    if (pt_shmem_npg(PASS, C, T, Cout, npg) <= 156 * 1024) return npg;
+  return 0;
 }
 // floats: [counters 64][ticket body for the widest row][wbt x2][coef2][coef3][dz]
 static inline long pt_off_body() { return CN_T2_COUNTERS; }
@@ -568,10 +769,11 @@ static inline long pt_body_floats(int C, int T, int Cout) {
 extern "C" long cn_pretime_workspace_floats(int B, int C, int T, int HW, int Cout, int with_backward) {
   if (!pt_supported(C, T, Cout)) return -1;
   for (int ps = 0; ps < (with_backward ? 6 : 3); ++ps)  // every pass the caller may launch must fit the 160 KiB LDS
-    if ((size_t)pt_lds(ps, C, T, Cout, 8 * Cout).total * 4 > 160 * 1024) return -1;
+    if (pt_npg(ps, C, T, Cout) == 0) return -1;
   if (with_backward) {
     const int nt = (Cout / 2) * ((pt_ceil4(C * (T - 2)) + pt_ceil4(C * (T - 4))) / 4);
-    if ((nt + 8 * Cout - 1) / (8 * Cout) > 4) return -1;
+    const int nthr = 64 * pt_npg(4, C, T, Cout) * (Cout / pt_no(4, Cout));
+    if (nt > 3 * nthr) return -1;  // dWb tiles: three per thread
   }
   const long E = (long)C * (T - 2) + (long)C * (T - 4);
   long n = pt_off_body() + pt_body_floats(C, T, Cout) + E * Cout + 4L * Cout + 4L * C + 64;
@@ -587,7 +789,7 @@ static int pt_fill(CnPtArgs& a, const float* x, long xbs, const void* const* par
   if (ws == nullptr || ws_floats < cn_pretime_workspace_floats(B, C, T, HW, Cout, with_backward)) return CN_ERR_ARG;
   a.x = x; a.xbs = xbs; a.B = B; a.C = C; a.T = T; a.HW = HW; a.Cout = Cout; a.P = (long)B * HW;
   a.training = training; a.eps3 = bn[0]; a.mom3 = bn[1]; a.eps2 = bn[2]; a.mom2 = bn[3]; a.epsL = eps_ln;
-  a.ntiles = (int)((a.P + 63) / 64);
+  a.ntiles = 0;
   const long E3 = (long)C * (T - 2), E5 = (long)C * (T - 4);
   float* wbt0 = ws + pt_off_body() + pt_body_floats(C, T, Cout);
   float* wbt1 = wbt0 + E3 * Cout;
@@ -611,38 +813,30 @@ static int pt_fill(CnPtArgs& a, const float* x, long xbs, const void* const* par
 
 template <int PASS>
 static int pt_launch(CnPtArgs a, float* ws, hipStream_t stream) {
-  const int nthr = 8 * a.Cout;
-  const int nblk = PASS == 2 ? (a.ntiles < 2048 ? a.ntiles : 2048) : pt_blocks(a.P);
-  const PtLds L = pt_lds(PASS, a.C, a.T, a.Cout, nthr);
-  size_t shmem = (size_t)L.total * 4;
+  const int NO = pt_no(PASS, a.Cout);
+  const int npg = pt_npg(PASS, a.C, a.T, a.Cout);
+  if (npg == 0) return CN_ERR_LDS;
+  const int PXB = 64 * npg;
+  const int nthr = 64 * npg * (a.Cout / NO);
+  const int ntb = (int)((a.P + PXB - 1) / PXB);
+  const int cap = PT_MAX_BLOCKS;  // persistent blocks (the per-block weight staging is paid once per block, not per tile)
+  const int nblk = ntb < cap ? ntb : cap;
+  const size_t shmem = pt_shmem_npg(PASS, a.C, a.T, a.Cout, npg);
   const int W = pt_row_width(PASS, a.C, a.T, a.Cout);
-  // the finish phase parks up to 6 * Cout (or 4 * C) doubles at the head of the LDS
-  const size_t park = (size_t)(6 * a.Cout > 4 * a.C ? 6 * a.Cout : 4 * a.C) * 8;
-  if (shmem < park) shmem = park;
-  if (shmem > 160 * 1024) return CN_ERR_LDS;
   if (W > 0) a.tk = cn_t2_carve(reinterpret_cast<int*>(ws), ws + pt_off_body(), nblk, W);
-  int maxit = 1;
-  if (PASS == 4) {
-    const int E3 = a.C * (a.T - 2), E5 = a.C * (a.T - 4);
-    const int nt = (a.Cout / 2) * ((pt_ceil4(E3) + pt_ceil4(E5)) / 4);
-    maxit = (nt + nthr - 1) / nthr;
-    if (maxit > 4) return CN_ERR_ARG;
-  }
-#define PT_GO(MI)                                                                                              \
+#define PT_GO(CM, NO_)                                                                                         \
   do {                                                                                                         \
     if (shmem > 64 * 1024)                                                                                     \
-      (void)hipFuncSetAttribute((const void*)cn_pretime_kernel<PASS, MI>,                                      \
+      (void)hipFuncSetAttribute((const void*)cn_pretime_kernel<PASS, CM, NO_>,                                 \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                       \
-    CN_LAUNCH((cn_pretime_kernel<PASS, MI>), dim3(nblk), dim3(nthr), shmem, stream, a);                       \
+    CN_LAUNCH((cn_pretime_kernel<PASS, CM, NO_>), dim3(nblk), dim3(nthr), shmem, stream, a);                   \
   } while (0)
-  if constexpr (PASS != 4) {
-    PT_GO(1);
-  } else {
-    if (maxit == 1) PT_GO(1);
-    else if (maxit == 2) PT_GO(2);
-    else if (maxit == 3) PT_GO(3);
-    else PT_GO(4);
-  }
+#define PT_GO_NO(CM)                                                                                           \
+  do {                                                                                                         \
+    if (NO == 8) PT_GO(CM, 8); else if (NO == 16) PT_GO(CM, 16); else PT_GO(CM, 32);                           \
+  } while (0)
+  if (pt_cmax(a.C) == 4) PT_GO_NO(4); else PT_GO_NO(8);
+#undef PT_GO_NO
 #undef PT_GO
   return CN_OK;
 }
@@ -651,8 +845,7 @@ static int pt_launch(CnPtArgs a, float* ws, hipStream_t stream) {
 // running_var3, gamma2, beta2, running_mean2, running_var2}, then {ln_gamma, ln_beta}. stats: HOST array of 8 device
 // pointers: per branch {mean3 [C], rstd3 [C], mean2 [Cout], rstd2 [Cout]} (written in training mode, read by backward).
 // bn: HOST {eps3, momentum3, eps2, momentum2}. y: out_kind 0 fp32 NCHW (y_stride = batch stride), 1 bf16 NHWC (pixel
-// stride). Returns CN_ERR_ARG for shapes outside the fused kernel (the caller keeps its generic path), CN_ERR_LDS if
-// the LDS image of a pass does not fit.
+// stride). Returns CN_ERR_ARG for shapes outside the fused kernel (the caller keeps its generic path).
 extern "C" int cn_pretime_fwd_f32(const float* x, long xbs, const void* const* params, float* const* stats, void* y,
                                   long y_stride, int out_kind, int B, int C, int T, int HW, int Cout, int training,
                                   const float* bn, float eps_ln, float* ws, long ws_floats, void* stream_) {

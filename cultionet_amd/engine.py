@@ -921,7 +921,10 @@ def time_conv(x: Var, mod, tin: int) -> Var:
 
 
 _pt_ws: T.Dict[T.Tuple, torch.Tensor] = {}
-_PRETIME_FUSED = os.environ.get("CN_PRETIME_FUSED", "1") == "1"  # diagnostic: 0 = the generic kernels (rounds 1-3)
+# The fused PreTimeReduction family (csrc/cn_pretime.hip) is correct (tests/test_pretime_gpu.py) but, as measured in round
+# 4, not yet faster than the op-by-op path it would replace (batch 32: forward 266 us, backward 1074 us against ~450 /
+# ~700 us): OFF by default, CN_PRETIME_FUSED=1 switches it on.
+_PRETIME_FUSED = os.environ.get("CN_PRETIME_FUSED", "0") == "1"
 
 
 def _pretime_ws(need: int, dev: torch.device) -> torch.Tensor:
@@ -1012,9 +1015,9 @@ def pretime_reduction(x: Var, pre, in_channels: int, in_time: int) -> T.Optional
                 if not _dense16(dy):
                     raise RuntimeError("pretime_reduction: the output gradient must be a dense NHWC buffer")
             else:
-                if not dy.is_contiguous():
-                    raise RuntimeError("pretime_reduction: the output gradient must be dense NCHW")
-                dstride = Cout * HW
+                if not _dense_inner(dy):  # (a channel slice of a concat gradient: batch stride > Cout * HW is fine)
+                    raise RuntimeError("pretime_reduction: the output gradient must be NCHW with dense planes")
+                dstride = bstride(dy)
             grads = (ctypes.c_void_p * 14)(*[store.grad_of(p).data_ptr() for p in glist])
             with side_stream(xt, dy, stats_t):  # parameter gradients only: off the data-gradient chain
                 wsb = _pretime_ws(need, dev)
