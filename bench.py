@@ -62,7 +62,7 @@ def parse():
     ap.add_argument("--no-extras", action="store_true", help="skip the streaming-kernel pass and the predict block")
     ap.add_argument("--cpu-steps", type=int, default=4)
     ap.add_argument("--cpu-threads", type=int, default=0, help="0 = best of the documented sweep (16)")
-    ap.add_argument("--child", choices=("train", "predict"), default=None,
+    ap.add_argument("--child", choices=("train", "predict", "default_point"), default=None,
                     help="internal: one block of the default line in a process of its own (see run_child)")
     ap.add_argument("--dry-run", action="store_true",
                     help="launch + rendezvous check only (gloo, no GPU, no kernels): what tests/test_bench_launch.py runs")
@@ -298,6 +298,60 @@ def predict_block(dev, hidden: int, cpu: bool, threads: int):
             dtc = (time.perf_counter() - t0) / 2
         out["cpu_baseline"] = {"value": 256 * 256 / dtc, "unit": "pixels/s", "cores": cores, "kind": "port",
                                "sample": "2 eval forwards of one [1,4,25,256,256] tile (1 warm-up discarded)"}
+    return out
+
+
+def default_point_block(dev, steps: int, warmup: int):
+    """The reference CLI's DEFAULT operating point as a first-class measurement: hidden_channels 64, batch_size 4,
+    precision 16-mixed, dropout 0.1 (model.py:52,56,59,86; scripts/args.yml:220-226,248-254) -- the native step through
+    HipTrainer(replay=True) (forward + loss + backward from a recorded launch plan; dropout masks from the device step
+    word, so the plan draws fresh masks every step), with the eager step of the same trainer class beside it."""
+    import torch
+
+    from cultionet_amd import _lib
+    from cultionet_amd import synthetic as O
+    from cultionet_amd.data import Data
+    from cultionet_amd.lightning import CultionetLitModel, HipTrainer
+
+    hidden, B = 64, 4
+    x, y, bdist = O.seeded_batch(B, seed=7)
+    batch = Data(x=x.to(dev), y=y.to(dev), bdist=bdist.to(dev), lon=torch.zeros(B, device=dev),
+                 lat=torch.zeros(B, device=dev))
+    out = {"workload": f"TowerUNet train step at the reference CLI's defaults: hidden {hidden}, batch {B} x [3,12,100,100], "
+                       "bf16 mixed precision, dropout 0.1, HipTrainer(replay=True)", "unit": "chips/s"}
+    train_gflop = 3.0 * FWD_GFLOP_PER_CHIP[hidden]
+    for tag, replay in (("eager", False), ("replay", True)):
+        lit = CultionetLitModel(in_channels=3, in_time=12, hidden_channels=hidden, dropout=0.1)
+        model = lit.cultionet_model.mask_model
+        model.load_state_dict(O.seeded_state_dict(model.state_dict()))
+        lit = lit.to(dev).train()
+        tr = HipTrainer(lit, gradient_clip_val=1.0, precision="bf16-mixed", replay=replay)
+        for _ in range(max(warmup, 4)):  # (a plan is recorded on the third step)
+            loss = tr.training_step(batch)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            loss = tr.training_step(batch)
+        t1 = time.perf_counter()
+        torch.cuda.synchronize()
+        dt = (time.perf_counter() - t0) / steps
+        _lib.query("cn_launch_count", 1)
+        tr.training_step(batch)
+        launches = _lib.query("cn_launch_count", 1)
+        torch.cuda.synchronize()
+        rec = {"value": B / dt, "ms_per_step": dt * 1e3, "host_enqueue_ms": (t1 - t0) / steps * 1e3,
+               "kernel_launches_per_step": launches, "loss": float(loss.item()),
+               "replayed": bool(replay and tr._plan is not None),
+               "roofline": {"bound": "mfma", "achieved": B / dt * train_gflop / 1e3, "peak": PEAK_TFLOPS["bf16"],
+                            "unit": "TFLOP/s", "frac": B / dt * train_gflop / 1e3 / PEAK_TFLOPS["bf16"],
+                            "note": "end to end: algorithmic train FLOP of the chips per second"}}
+        if replay:
+            out.update(rec)
+        else:
+            out["eager"] = rec
+        del tr, lit, model
+        torch.cuda.empty_cache()
+    out["speedup_vs_eager"] = out["value"] / out["eager"]["value"]
     return out
 
 
@@ -674,6 +728,9 @@ def main():
 
     _lib.load()
     TrainLeg.rccl_ranks = rccl_ranks
+    if args.child == "default_point":
+        print(json.dumps(default_point_block(dev, min(args.steps, 30), args.warmup)), flush=True)
+        return
     if args.child == "predict":  # the predict block alone (child of a default run)
         print(json.dumps(predict_block(dev, args.hidden, not args.no_cpu_baseline, args.cpu_threads)), flush=True)
         return
@@ -763,6 +820,11 @@ def main():
                 out["predict"] = {"error": repr(e)}
         else:
             out["predict"] = predict_block(dev, args.hidden, not args.no_cpu_baseline, args.cpu_threads)
+        try:  # the reference CLI's default operating point (hidden 64, batch 4, 16-mixed, dropout 0.1), replayed
+            out["default_point"] = run_child("default_point", args) if not use_dist else \
+                default_point_block(dev, min(args.steps, 30), args.warmup)
+        except Exception as e:
+            out["default_point"] = {"error": repr(e)}
     if rank == 0:
         # scalars of the extra blocks inside `config` (the driver's record keeps `config` whole, the blocks by name only)
         cfg = out["config"]

