@@ -4,25 +4,26 @@
 //                                            -> Conv3d(C -> Cout, (T-k+1,1,1)) -> BatchNorm2d -> SiLU
 //                          LayerNorm_Cout(branch3 + branch5)                       -> y [B, Cout, H, W]
 //
-// Everything between the two BatchNorm reductions is per pixel: 36 inputs (C = 3, T = 12), ~2.4k multiply-adds, 32
-// outputs. Rounds 1-3 ran the stage as ~40 launches of the generic kernels (banded 1x1 contractions through the MFMA
-// path at 19 TFLOP/s, BatchNorm3d as a 3-channel view, BatchNorm2d, LayerNorm, conversions): 1.15 ms of the 16 ms
-// mixed-precision step and ~0.6 ms of the fp32 step for 0.1 % of the FLOPs. Here the chain is RECOMPUTED from x in
-// every pass instead of being stored (x is 144 bytes per pixel; the intermediates would be 900): three forward passes
-// (BatchNorm3d statistics, BatchNorm2d statistics, output) and three backward passes (LayerNorm / BatchNorm2d sums,
-// second-conv weight gradients + BatchNorm3d sums, first-conv weight gradients), each ONE launch that finishes its own
-// cross-block reduction through the two-level last-block ticket of cn_ticket.h (no finalize launches, fixed summation
-// order). Inference is the output pass alone. The input needs no gradient (it is the data).
+// Everything between the BatchNorm reductions is per pixel: 36 inputs (C = 3, T = 12), ~2.4k multiply-adds, 32 outputs.
+// Rounds 1-3 ran the stage as ~40 launches of the generic kernels (banded 1x1 contractions through the MFMA path at 19
+// TFLOP/s, BatchNorm3d as a 3-channel view, BatchNorm2d, LayerNorm, conversions): 1.15 ms of the 16 ms mixed-precision
+// step and ~0.6 ms of the fp32 step for 0.1 % of the FLOPs. Here the chain is RECOMPUTED from x in every pass instead of
+// being stored (x is 144 bytes per pixel; the intermediates would be 900): three forward passes (BatchNorm3d
+// statistics, BatchNorm2d statistics, output) and three backward passes (LayerNorm / BatchNorm2d sums, second-conv
+// weight gradients + BatchNorm3d sums, first-conv weight gradients), each ONE launch that finishes its own cross-block
+// reduction through the two-level last-block ticket of cn_ticket.h (no finalize launches, fixed summation order).
+// Inference is the output pass alone. The input needs no gradient (it is the data).
 //
-// Work decomposition (second version; the first -- a wave per 8 output channels, the first convolutions' activations
-// exchanged through LDS, weights by scalar loads inside the loops -- ran at 1-2 % of the vector peak: every entry paid
-// a scalar-load round trip, two barriers per tile, 8 waves per CU): a THREAD owns a pixel and NO (<= 32) output
-// channels of both branches in registers, a wave = 64 consecutive pixels, no barrier inside a tile when one wave covers
-// all of Cout (NOG = Cout / NO = 1; Cout = 64 runs two waves per pixel group that only meet for the LayerNorm sums).
-// All weights and per-channel constants are staged ONCE per block in LDS and read as wave-uniform broadcasts; the x
-// tile is staged per tile ([row][pixel]: conflict-free per-lane reads) and walked with a k-deep register window per
-// input channel (one LDS read per (channel, time step) instead of k). Column sums over pixels (statistics, parameter
-// gradients) are DPP wave reductions into lane 63, accumulated per wave in LDS, combined per block at the end.
+// Third version of the work decomposition (round 4; the first two, measured: DESIGN section 4c). A WAVE owns 32
+// pixels: lane l works on pixel l % 32 and on the entries (time steps) of parity l / 32 of the first convolutions, so
+// the pair of activations a[2s], a[2s + 1] a wave produces per step IS the B operand (K = 2) of
+// v_mfma_f32_32x32x2_f32, and the second convolution -- the one dense contraction of the stage, 73 % of its multiply-adds
+// -- runs on the matrix pipe with the weights as A operand (one conflict-free LDS read per lane and step): the
+// accumulator comes out as [32 pixels] x [16 output channels per lane], 16 registers per branch instead of one per
+// output. The backward contractions use the same pipe: da = W^T dr with the accumulator registers of dr as B operand
+// as they are, and dWb = dr a^T over the pixels with both operands read transposed out of LDS. Column sums over pixels
+// (statistics, parameter gradients) are DPP half-wave reductions. All weights and per-channel constants are staged once
+// per block in LDS; blocks are persistent over the pixel tiles.
 #include <cstdlib>
 #include <type_traits>
 #include "cn_bf16.h"
@@ -30,11 +31,13 @@
 
 #define PT_MAX_BLOCKS 512
 #define PT_MAX_C 8
+#define PT_PXB 128  // pixels per block tile: 4 waves x 32
+#define PT_KP 5     // weight row pitch of the first convolutions in LDS (k <= 5)
+#define PT_LP 33    // pitch of the per-wave [row][32 pixels] transposition tiles (conflict-free both ways)
 
 struct CnPtBranch {
   const float* wa;   // [C][C][k]       Conv3d(C -> C, (k,1,1)).weight
   const float* wb;   // [Cout][C][Tp]   Conv3d(C -> Cout, (Tp,1,1)).weight
-  const float* wbt;  // [C*Tp][Cout]    transposed copy (workspace; cn_pretime_pack_kernel)
   const float* g3; const float* b3; float* rm3; float* rv3; float* mean3; float* rstd3;  // BatchNorm3d(C)
   const float* g2; const float* b2; float* rm2; float* rv2; float* mean2; float* rstd2;  // BatchNorm2d(Cout)
   float* dwa; float* dwb; float* dg3; float* db3; float* dg2; float* db2;                // gradients (accumulated)
@@ -55,25 +58,12 @@ struct CnPtArgs {
   float* coef2;  // [2 branches][2][Cout]
   float* coef3;  // [2 branches][2][C]
   float* dz;     // [E][P]
+  float* img;    // the table image (pt_lds layout up to .xs): weights in operand order, per-channel constants
   CnTicket2 tk;
   int ntiles;
 };
 
-__global__ void cn_pretime_pack_kernel(const CnPtArgs a, float* wbt0, float* wbt1) {
-  for (int brn = 0; brn < 2; ++brn) {
-    const CnPtBranch& r = a.br[brn];
-    float* dst = brn ? wbt1 : wbt0;
-    const int E = a.C * r.Tp;
-    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < E * a.Cout; i += gridDim.x * blockDim.x) {
-      const int loc = i / a.Cout, o = i - loc * a.Cout;
-      dst[i] = r.wb[(long)o * E + loc];
-    }
-  }
-}
-
-
-// SiLU and its derivative on the hardware exp / rcp (1 ulp each: ~2e-7 relative; the reference's own fp32 SiLU is no
-// closer to the real function). The per-entry activation is a third of the pass's vector instructions otherwise.
+// SiLU and its derivative on the hardware exp / rcp (1 ulp each: ~2e-7 relative).
 __device__ __forceinline__ float pt_sigmoid(float x) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(-1.4426950408889634f * x));
 }
@@ -82,38 +72,23 @@ __device__ __forceinline__ float pt_silu_grad(float x) {
   const float s = pt_sigmoid(x);
   return s * (1.0f + x * (1.0f - s));
 }
-// NO wave-uniform weights w[0..NO) sitting one per lane (lane j holds w[j]) -> acc[j] += w[j] * v. One per-lane LDS read
-// serves a whole entry; v_readlane moves each weight into a scalar operand (a 16-byte broadcast read of LDS costs 8
-// LDS cycles per 4 weights and wave, which made the LDS -- shared by the CU's four SIMDs -- the bound).
-template <int NO>
-__device__ __forceinline__ void pt_fma_lane_weights(float wlane, float v, float* acc) {
-  const int wb = __float_as_int(wlane);
-  const f32x2 v2 = {v, v};
-#pragma unroll
-  for (int j = 0; j < NO; j += 2) {  // packed fp32 FMA (v_pk_fma_f32): two outputs per vector instruction
-    const f32x2 w2 = {__int_as_float(__builtin_amdgcn_readlane(wb, j)), __int_as_float(__builtin_amdgcn_readlane(wb, j + 1))};
-    f32x2 r2 = {acc[j], acc[j + 1]};
-    r2 = __builtin_elementwise_fma(w2, v2, r2);
-    acc[j] = r2[0];
-    acc[j + 1] = r2[1];
-  }
+__device__ __forceinline__ f32x16 pt_mfma(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
 }
-template <int NO>
-__device__ __forceinline__ float pt_dot_lane_weights(float wlane, const float* v) {
-  const int wb = __float_as_int(wlane);
-  float d = 0.f;
-#pragma unroll
-  for (int j = 0; j < NO; ++j) d += __int_as_float(__builtin_amdgcn_readlane(wb, j)) * v[j];
-  return d;
+// Sum over the 32 lanes of each half-wave (DPP, no LDS): the totals land in lanes 31 and 63.
+__device__ __forceinline__ float pt_half_sum(float v) {
+  v = cn_dpp_add<0x111, 0xf>(v);  // row_shr:1
+  v = cn_dpp_add<0x112, 0xf>(v);  // row_shr:2
+  v = cn_dpp_add<0x114, 0xf>(v);  // row_shr:4
+  v = cn_dpp_add<0x118, 0xf>(v);  // row_shr:8  -> lane 15 of each row holds the row total
+  v = cn_dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
+  return v;
 }
+// accumulator register j of lane (pixel, half) of a 32x32 tile holds output row 8 (j / 4) + 4 half + j % 4
+__device__ __forceinline__ int pt_row(int j, int half) { return 8 * (j >> 2) + 4 * half + (j & 3); }
 
-#define PT_KP 5  // weight row pitch of the first convolutions in LDS (k <= 5)
-
-// LDS carve (floats) -- host and device compute the same offsets
-struct PtLds {
-  int wa, c3, k3, wbt, c2, ln, k2, xs, as_, drs, dacc, ex, lacc, total;
-};
-__host__ __device__ static inline int pt_ceil4(int v) { return (v + 3) & ~3; }
+__host__ __device__ static inline int pt_ceil32(int v) { return (v + 31) & ~31; }
+__host__ __device__ static inline int pt_steps(int C, int T) { return C * ((T - 2 + 1) / 2) + C * ((T - 4 + 1) / 2); }
 __host__ __device__ static inline int pt_nvals(int PASS, int C, int Cout, int CMAX) {
   switch (PASS) {
     case 0: return 4 * C;
@@ -124,62 +99,194 @@ __host__ __device__ static inline int pt_nvals(int PASS, int C, int Cout, int CM
     default: return 0;
   }
 }
-__host__ __device__ static inline PtLds pt_lds(int PASS, int C, int T, int Cout, int CMAX, int PXB) {
+// LDS carve (floats) -- host and device compute the same offsets
+struct PtLds {
+  int wa, c3, k3, wA, wB, c2, ln, k2, xs, as_, drs, lacc, total;
+};
+__host__ __device__ static inline PtLds pt_lds(int PASS, int C, int T, int Cout, int CMAX) {
   const int E3 = C * (T - 2), E5 = C * (T - 4);
+  const int CP = pt_ceil32(Cout);
+  const int EP = pt_ceil32(E3) + pt_ceil32(E5);
   PtLds l;
   int o = 0;
-  l.wa = o; o += pt_ceil4(2 * C * CMAX * PT_KP);
+  l.wa = o; o += (2 * C * CMAX * PT_KP + 3) & ~3;
   l.c3 = o; o += 2 * C * 4;
-  l.k3 = o; o += pt_ceil4(2 * C * 2);
-  l.wbt = o; if (PASS >= 1 && PASS <= 4) o += (E3 + E5) * Cout;
-  l.c2 = o; if (PASS >= 2 && PASS <= 4) o += 2 * Cout * 4;
-  l.ln = o; if (PASS >= 2 && PASS <= 4) o += 2 * Cout;
-  l.k2 = o; if (PASS == 4) o += 4 * Cout;
-  l.xs = o; o += C * T * PXB;
-  l.as_ = o; if (PASS == 4) o += (pt_ceil4(E3) + pt_ceil4(E5)) * PXB;
-  l.drs = o; if (PASS == 4) o += 2 * Cout * PXB;
-  l.dacc = o; if (PASS == 4) o += (E3 + E5) * PXB;
-  l.ex = o; if (PASS >= 2 && PASS <= 4) o += 2 * 4 * 64;
-  l.lacc = o; o += pt_ceil4(4 * pt_nvals(PASS, C, Cout, CMAX));
+  l.k3 = o; o += (2 * C * 2 + 3) & ~3;
+  // (the tables up to here form the IMAGE every block copies from global memory in one batched pass; its layout does
+  // not depend on PASS, only how much of it a pass copies: pt_img_floats)
+  l.wA = o; o += pt_steps(C, T) * 2 * CP;
+  l.c2 = o; o += 2 * CP * 4;
+  l.ln = o; o += 2 * CP;
+  l.k2 = o; o += 2 * CP * 2;
+  l.wB = o; if (PASS == 4) o += CP * EP;
+  o = (o + 3) & ~3;
+  l.xs = o; o += C * (T + 6) * PT_PXB;  // (T + PT_TPAD rows per channel)
+  l.as_ = o; if (PASS == 4) o += 4 * EP * PT_LP;       // per wave: a[entry][pixel], later da[entry][pixel]
+  l.drs = o; if (PASS == 4) o += 4 * 2 * CP * PT_LP;   // per wave: dr[branch][cout][pixel]
+  l.lacc = o; o += (4 * pt_nvals(PASS, C, Cout, CMAX) + 3) & ~3;
   l.total = o;
   return l;
 }
 
-// One Conv3d(C -> C, (K,1,1)) stack over a pixel: rows cp = 0..C-1, entries tp = 0..T-K. The K-deep window xw[c][.]
-// of every input channel slides along time in registers: one LDS read per (c, tp). entry(cp, tp, h, xw) gets the
-// convolution value and the window (x[c][tp .. tp+K-1], valid for c < C).
+// Builds the table image (once per forward / backward call). mode 0: training forward (batch statistics do not exist
+// yet: the finishing blocks of PASS 0 / 1 write c3 / c2), 1: inference (running statistics), 2: backward (saved
+// statistics; PASS 3 / 4 finishers add k2 / k3).
+template <int CMAX>
+__global__ __launch_bounds__(256) void cn_pretime_pack_kernel(const CnPtArgs a, int mode) {
+  const int C = a.C, T = a.T, Cout = a.Cout;
+  const int CP = pt_ceil32(Cout);
+  const int T3 = T - 2, T5 = T - 4, E3 = C * T3, E5 = C * T5;
+  const int EP3 = pt_ceil32(E3), EP = EP3 + pt_ceil32(E5);
+  const int NS3 = C * ((T3 + 1) >> 1);
+  const PtLds L = pt_lds(4, C, T, Cout, CMAX);
+  float* img = a.img;
+  const int gt = blockIdx.x * 256 + threadIdx.x, gn = gridDim.x * 256;
+  for (int i = gt; i < 2 * C * CMAX * PT_KP; i += gn) {
+    const int dt = i % PT_KP;
+    int q = i / PT_KP;
+    const int c = q % CMAX;
+    q /= CMAX;
+    const int cp = q % C, brn = q / C;
+    const int k = brn ? 5 : 3;
+    img[L.wa + i] = (c < C && dt < k) ? a.br[brn].wa[(cp * C + c) * k + dt] : 0.f;
+  }
+  for (int i = gt; i < 2 * C; i += gn) {
+    const int brn = i / C, cp = i - brn * C;
+    const CnPtBranch& r = a.br[brn];
+    float mu = 0.f, rho = 1.f;
+    if (mode == 1) { mu = r.rm3[cp]; rho = 1.0f / sqrtf(r.rv3[cp] + a.eps3); }
+    if (mode == 2) {
+      if (a.training) { mu = r.mean3[cp]; rho = r.rstd3[cp]; }
+      else { mu = r.rm3[cp]; rho = 1.0f / sqrtf(r.rv3[cp] + a.eps3); }
+    }
+    img[L.c3 + i * 4 + 0] = rho;
+    img[L.c3 + i * 4 + 1] = -mu * rho;
+    img[L.c3 + i * 4 + 2] = r.g3[cp];
+    img[L.c3 + i * 4 + 3] = r.b3[cp];
+    img[L.k3 + i * 2 + 0] = 0.f;
+    img[L.k3 + i * 2 + 1] = 0.f;
+  }
+  // A operands of the second convolutions: wA[step][half][cout] = wb[cout][cp][2 s + half] (0 beyond the row / Cout)
+  for (int i = gt; i < pt_steps(C, T) * 2 * CP; i += gn) {
+    const int o = i % CP;
+    int q = i / CP;
+    const int hf = q & 1;
+    int gs = q >> 1;
+    const int brn = gs >= NS3 ? 1 : 0;
+    gs -= brn ? NS3 : 0;
+    const int Tp = brn ? T5 : T3;
+    const int nsr = (Tp + 1) >> 1;
+    const int cp = gs / nsr, tp = 2 * (gs - cp * nsr) + hf;
+    img[L.wA + i] = (o < Cout && tp < Tp) ? a.br[brn].wb[((long)o * C + cp) * Tp + tp] : 0.f;
+  }
+  // wB[cout][entry slot] (branch 3 entries at [0, E3), branch 5 at [EP3, EP3 + E5), zeros elsewhere)
+  for (int i = gt; i < CP * EP; i += gn) {
+    const int es = i % EP, o = i / EP;
+    const int brn = es >= EP3 ? 1 : 0;
+    const int loc = es - (brn ? EP3 : 0);
+    const int Eb = brn ? E5 : E3;
+    img[L.wB + i] = (o < Cout && loc < Eb) ? a.br[brn].wb[(long)o * Eb + loc] : 0.f;
+  }
+  for (int i = gt; i < 2 * CP; i += gn) {
+    const int brn = i / CP, o = i - brn * CP;
+    const CnPtBranch& r = a.br[brn];
+    float mu = 0.f, rho = 0.f, g2 = 0.f, b2 = 0.f;
+    if (o < Cout) {
+      g2 = r.g2[o]; b2 = r.b2[o];
+      if (mode == 1 || (mode == 2 && !a.training)) { mu = r.rm2[o]; rho = 1.0f / sqrtf(r.rv2[o] + a.eps2); }
+      else if (mode == 2) { mu = r.mean2[o]; rho = r.rstd2[o]; }
+    }
+    img[L.c2 + i * 4 + 0] = rho;
+    img[L.c2 + i * 4 + 1] = -mu * rho;
+    img[L.c2 + i * 4 + 2] = g2;
+    img[L.c2 + i * 4 + 3] = b2;
+    img[L.k2 + i * 2 + 0] = 0.f;
+    img[L.k2 + i * 2 + 1] = 0.f;
+  }
+  for (int o = gt; o < CP; o += gn) {
+    img[L.ln + o] = o < Cout ? a.gL[o] : 0.f;
+    img[L.ln + CP + o] = o < Cout ? a.bL[o] : 0.f;
+  }
+}
+
+// floats of the table image a pass needs in LDS (PASS 4 also takes wB, the last table)
+__host__ __device__ static inline int pt_img_floats(int PASS, int C, int T, int Cout, int CMAX) {
+  const PtLds l = pt_lds(4, C, T, Cout, CMAX);
+  return PASS == 4 ? l.xs : l.wB;
+}
+
+#define PT_TPAD 6  // pad rows per channel of the x tile: window reads past the last time step need no clamp
+
+// One Conv3d(C -> C, (K,1,1)) stack over a pixel, two time steps per wave step: lane half h works on tp = 2 s + h.
+// The K-deep window xw[c][.] of every input channel slides along time in registers: per (channel, step) ONE pointer
+// add and two LDS reads with immediate offsets (the first version rebuilt every address -- multiply, clamp, select --
+// and spent three quarters of the pass's vector instructions on it). xs is [C][T + PT_TPAD][128 pixels].
+// entry(cp, tp, live, h, xw): h = convolution value at tp (finite garbage when !live: tp beyond the row).
+// Diagnostic build (-DPT_STAMP): s_memtime stamps of wave 0 of block 0 of the LAST pass launched, read back with
+// cn_pretime_read_stamps (tools/pretime_stamps.py). Never compiled into the shipped library.
+#ifdef PT_STAMP
+__device__ unsigned long long pt_stamps[32];
+#define PT_ST(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) pt_stamps[(i)] = __builtin_amdgcn_s_memtime(); } while (0)
+extern "C" int cn_pretime_read_stamps(unsigned long long* out) {
+  return hipMemcpyFromSymbol(out, HIP_SYMBOL(pt_stamps), sizeof(unsigned long long) * 32) == hipSuccess ? 0 : -2;
+}
+#else
+#define PT_ST(i) do { } while (0)
+#endif
+
+extern __shared__ __attribute__((aligned(16))) float pt_smem[];  // the one dynamic LDS array of the pass kernels
+#define SM(i) pt_smem[(i)]
+
 template <int K, int CMAX, class FB, class FE, class FR>
-__device__ __forceinline__ void pt_rows(const float* __restrict__ wl, const float* __restrict__ xs, int C, int T,
-                                        int PXB, int pc, FB&& row_begin, FE&& entry, FR&& row_end) {
+__device__ __forceinline__ void pt_rows(int wl, int xs, int C, int T, int pcol, int half, FB&& row_begin, FE&& entry,
+                                        FR&& row_end) {
   const int Tp = T - K + 1;
+  const int NS = (Tp + 1) >> 1;
+  const int TS = T + PT_TPAD;
   for (int cp = 0; cp < C; ++cp) {
+    // NO per-channel branches: channels c >= C carry zero weights (the table image pads them) and re-read channel 0,
+    // so every loop below is straight-line code -- with `if (c < C)` around each channel the compiler emitted one basic
+    // block per channel, each ending in s_waitcnt lgkmcnt(0): C exposed LDS round trips per step, ~1000 cycles a step.
     float w[CMAX][K], xw[CMAX][K];
+    int xp[CMAX];  // LDS offsets (every shared-memory access indexes the one __shared__ array: a float* threaded
+                   // through lambdas and arrays degraded to FLAT loads with 64-bit address arithmetic)
 #pragma unroll
-    for (int c = 0; c < CMAX; ++c)
+    for (int c = 0; c < CMAX; ++c) {
+      xp[c] = xs + ((c < C ? c : 0) * TS + half) * PT_PXB + pcol;  // &x[c][half][pixel]
 #pragma unroll
       for (int dt = 0; dt < K; ++dt) {
-        w[c][dt] = wl[(cp * CMAX + c) * PT_KP + dt];
-        xw[c][dt] = 0.f;
+        w[c][dt] = SM(wl + ((cp * CMAX + c) * PT_KP + dt));
+        xw[c][dt] = SM(xp[c] + dt * PT_PXB);
       }
-#pragma unroll
-    for (int c = 0; c < CMAX; ++c)
-      if (c < C) {
-#pragma unroll
-        for (int dt = 1; dt < K; ++dt) xw[c][dt] = xs[(c * T + dt - 1) * PXB + pc];
-      }
+    }
     row_begin(cp);
-    for (int tp = 0; tp < Tp; ++tp) {
-      float h = 0.f;
+    for (int s = 0; s < NS; ++s) {
+      const int tp = 2 * s + half;
+      // the two new window values per channel for the NEXT step are fetched first: their LDS latency hides under this
+      // step's arithmetic (pad rows beyond T: never a clamp)
+      float n0[CMAX], n1[CMAX];
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) {
+        n0[c] = SM(xp[c] + K * PT_PXB);        // x[c][tp + K]
+        n1[c] = SM(xp[c] + (K + 1) * PT_PXB);  // x[c][tp + K + 1]
+        xp[c] += 2 * PT_PXB;
+      }
+      float h0 = 0.f, h1 = 0.f;  // two partial sums: half the length of the dependent FMA chain
 #pragma unroll
       for (int c = 0; c < CMAX; ++c)
-        if (c < C) {
 #pragma unroll
-          for (int dt = 0; dt + 1 < K; ++dt) xw[c][dt] = xw[c][dt + 1];
-          xw[c][K - 1] = xs[(c * T + tp + K - 1) * PXB + pc];
-#pragma unroll
-          for (int dt = 0; dt < K; ++dt) h += w[c][dt] * xw[c][dt];
+        for (int dt = 0; dt < K; ++dt) {
+          if ((c + dt) & 1) h1 += w[c][dt] * xw[c][dt];
+          else h0 += w[c][dt] * xw[c][dt];
         }
-      entry(cp, tp, h, xw);
+      entry(cp, tp, tp < Tp, h0 + h1, xw);
+#pragma unroll
+      for (int c = 0; c < CMAX; ++c) {
+#pragma unroll
+        for (int dt = 0; dt + 2 < K; ++dt) xw[c][dt] = xw[c][dt + 2];
+        xw[c][K - 2] = n0[c];
+        xw[c][K - 1] = n1[c];
+      }
     }
     row_end(cp);
   }
@@ -188,461 +295,477 @@ __device__ __forceinline__ void pt_rows(const float* __restrict__ wl, const floa
 // PASS 0: BatchNorm3d statistics   1: BatchNorm2d statistics   2: output (training or inference)
 // PASS 3: backward sums of LayerNorm / BatchNorm2d   4: dW of the second convolutions + BatchNorm3d sums (+ dz scratch)
 // PASS 5: dW of the first convolutions
-// CMAX: compile-time bound of the input channels (4 or 8). NO: output channels per thread (8, 16 or 32).
-template <int PASS, int CMAX, int NO>
-__global__ __launch_bounds__(256) void cn_pretime_kernel(const CnPtArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float lds[];
+// CMAX: compile-time bound of the input channels (4 or 8). MT: 32-channel tiles of Cout (1 or 2). NE: 32-entry tiles per
+// branch (PASS 4 only; 1..3).
+template <int PASS, int CMAX, int MT, int NE>
+#ifndef PT_MINB
+#define PT_MINB 1
+#endif
+__global__ __launch_bounds__(256, PT_MINB) void cn_pretime_kernel(const CnPtArgs a) {
+  float* const lds = pt_smem;  // (only for the block-cooperative copy at the top and the parked doubles at the end)
   __shared__ int s_flag;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int l32 = lane & 31, half = lane >> 5;
   const int C = a.C, T = a.T, Cout = a.Cout, HW = a.HW;
-  const int nthr = blockDim.x;
-  const int NOG = Cout / NO;             // waves per pixel group
-  const int NPG = (nthr >> 6) / NOG;     // pixel groups (of 64 pixels) per block
-  const int PXB = 64 * NPG;
-  const int pxg = wid / NOG, og = wid - pxg * NOG;
-  const int pc = pxg * 64 + lane;   // pixel column inside the block tile
-  const int o0 = og * NO;
-  const int wl_lane = lane < NO ? lane : NO - 1;  // lane j < NO fetches weight j of an entry
+  constexpr int CP = 32 * MT;
+  const int pcol = wid * 32 + l32;  // pixel column inside the block tile
   const int T3 = T - 2, T5 = T - 4;
   const int E3 = C * T3, E5 = C * T5, E = E3 + E5;
-  const int S5 = pt_ceil4(E3);
-  const PtLds L = pt_lds(PASS, C, T, Cout, CMAX, PXB);
-  float* wa_l = lds + L.wa;
-  float* c3_l = lds + L.c3;
-  float* k3_l = lds + L.k3;
-  float* wbt_l = lds + L.wbt;
-  float* c2_l = lds + L.c2;
-  float* ln_l = lds + L.ln;
-  float* k2_l = lds + L.k2;
-  float* xs = lds + L.xs;
-  float* as_ = lds + L.as_;
-  float* drs = lds + L.drs;
-  float* dacc = lds + L.dacc;
-  float* ex = lds + L.ex;
-  float* lacc = lds + L.lacc;
+  const int EP3 = pt_ceil32(E3), EP = EP3 + pt_ceil32(E5);
+  const int NS3 = C * ((T3 + 1) >> 1);  // wave steps of branch 3
+  const PtLds L = pt_lds(PASS, C, T, Cout, CMAX);
+  const int wa_l = L.wa;
+  const int c3_l = L.c3;
+  const int k3_l = L.k3;
+  const int wA_l = L.wA;
+  const int wB_l = L.wB;
+  const int c2_l = L.c2;
+  const int ln_l = L.ln;
+  const int k2_l = L.k2;
+  const int xs = L.xs;
+  const int as_w = L.as_ + wid * EP * PT_LP;
+  const int drs_w = L.drs + wid * 2 * CP * PT_LP;
+  const int lacc = L.lacc;
   const int NV = pt_nvals(PASS, C, Cout, CMAX);
   const float vN = 1.0f / (float)Cout;
 
-  // ---- stage weights and per-channel constants once per block ----
-  for (int i = tid; i < 2 * C * CMAX * PT_KP; i += nthr) {
-    const int dt = i % PT_KP;
-    int q = i / PT_KP;
-    const int c = q % CMAX;
-    q /= CMAX;
-    const int cp = q % C, brn = q / C;
-    const int k = brn ? 5 : 3;
-    wa_l[i] = (c < C && dt < k) ? a.br[brn].wa[(cp * C + c) * k + dt] : 0.f;
-  }
-  for (int i = tid; i < 2 * C; i += nthr) {
-    const int brn = i / C, cp = i - brn * C;
-    const CnPtBranch& r = a.br[brn];
-    float mu = 0.f, rho = 1.f;
-    if (PASS > 0) {
-      if (a.training) { mu = r.mean3[cp]; rho = r.rstd3[cp]; }
-      else { mu = r.rm3[cp]; rho = 1.0f / sqrtf(r.rv3[cp] + a.eps3); }
-    }
-    c3_l[i * 4 + 0] = rho;
-    c3_l[i * 4 + 1] = -mu * rho;
-    c3_l[i * 4 + 2] = r.g3[cp];
-    c3_l[i * 4 + 3] = r.b3[cp];
-    if (PASS == 5) {
-      k3_l[i * 2 + 0] = a.coef3[(brn * 2) * C + cp];
-      k3_l[i * 2 + 1] = a.coef3[(brn * 2 + 1) * C + cp];
-    }
-  }
-  if (PASS >= 1 && PASS <= 4) {
-    // (the two transposed tables are contiguous in the workspace: one copy, eight loads in flight per thread -- a
-    // load-wait-store loop was ~15 us of dependent round trips at the head of EVERY block)
-    const float* __restrict__ src = a.br[0].wbt;
-    const int n = E * Cout;
-    for (int i0 = tid; i0 < n; i0 += nthr * 8) {
-      float v[8];
+  PT_ST(0);
+  // ---- the table image -> LDS, once per block: 16-byte loads, four in flight per thread (building the tables in
+  // every block -- index arithmetic plus dependent scalar-indexed loads -- was ~25 us at the head of each block) ----
+  {
+    const int n4 = (pt_img_floats(PASS, C, T, Cout, CMAX) + 3) >> 2;
+    const f32x4* __restrict__ src = reinterpret_cast<const f32x4*>(a.img);
+    f32x4* dst = reinterpret_cast<f32x4*>(lds);
+    for (int i0 = tid; i0 < n4; i0 += 256 * 4) {
+      f32x4 v[4];
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int k = i0 + i * nthr; v[i] = src[k < n ? k : n - 1]; }
+      for (int i = 0; i < 4; ++i) { const int k = i0 + i * 256; v[i] = src[k < n4 ? k : n4 - 1]; }
 #pragma unroll
-      for (int i = 0; i < 8; ++i) { const int k = i0 + i * nthr; if (k < n) wbt_l[k] = v[i]; }
+      for (int i = 0; i < 4; ++i) { const int k = i0 + i * 256; if (k < n4) dst[k] = v[i]; }
     }
   }
-  if (PASS >= 2 && PASS <= 4) {
-    for (int i = tid; i < 2 * Cout; i += nthr) {
-      const int brn = i / Cout, o = i - brn * Cout;
-      const CnPtBranch& r = a.br[brn];
-      float mu, rho;
-      if (a.training) { mu = r.mean2[o]; rho = r.rstd2[o]; }
-      else { mu = r.rm2[o]; rho = 1.0f / sqrtf(r.rv2[o] + a.eps2); }
-      c2_l[i * 4 + 0] = rho;
-      c2_l[i * 4 + 1] = -mu * rho;
-      c2_l[i * 4 + 2] = r.g2[o];
-      c2_l[i * 4 + 3] = r.b2[o];
-      if (PASS == 4) {
-        k2_l[i * 2 + 0] = a.coef2[(brn * 2) * Cout + o];
-        k2_l[i * 2 + 1] = a.coef2[(brn * 2 + 1) * Cout + o];
-      }
-    }
-    for (int o = tid; o < Cout; o += nthr) { ln_l[o] = a.gL[o]; ln_l[Cout + o] = a.bL[o]; }
-  }
-  for (int i = tid; i < 4 * NV; i += nthr) lacc[i] = 0.f;
-  if (PASS == 4) {
-    for (int i = E3 * PXB + tid; i < S5 * PXB; i += nthr) as_[i] = 0.f;
-    for (int i = (S5 + E5) * PXB + tid; i < (S5 + pt_ceil4(E5)) * PXB; i += nthr) as_[i] = 0.f;
+  for (int i = tid; i < 4 * NV; i += 256) SM(lacc + (i)) = 0.f;
+  for (int i = tid; i < C * PT_TPAD * PT_PXB; i += 256) {  // the pad rows of the x tile (never written again)
+    const int c = i / (PT_TPAD * PT_PXB), r = i - c * (PT_TPAD * PT_PXB);
+    SM(xs + ((c * (T + PT_TPAD) + T) * PT_PXB + r)) = 0.f;
   }
 
-  float* my = lacc + wid * NV;  // this wave's accumulators (lane 63 adds the wave totals)
-  auto wsum = [&](int v, float val) {
+  const int my = lacc + wid * NV;  // this wave's accumulators (LDS offset)
+  auto wsum = [&](int v, float val) {  // full-wave sum (both halves belong to the same value)
     const float t = cn_wave_sum_to_lane63(val);
-    if (lane == 63) my[v] += t;
+    if (lane == 63) SM(my + (v)) += t;
+  };
+  auto hsum = [&](int v, float val, bool on) {  // per-half sum: lanes 31 / 63 own different values v
+    const float t = pt_half_sum(val);
+    if (l32 == 31 && on) SM(my + (v)) += t;
   };
 
-  float AW[8];  // PASS 4: this thread's dWb tile (2 couts x 4 entries), summed over the block's tiles
+  f32x16 accW[2][MT][NE];  // PASS 4: dWb accumulators (cout x entry tiles), summed over the wave's tiles
+  if (PASS == 4) {
 #pragma unroll
-  for (int j = 0; j < 8; ++j) AW[j] = 0.f;
-  float AW2[8], AW3[8];
+    for (int brn = 0; brn < 2; ++brn)
 #pragma unroll
-  for (int j = 0; j < 8; ++j) AW2[j] = AW3[j] = 0.f;
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int et = 0; et < NE; ++et)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) accW[brn][mt][et][j] = 0.f;
+  }
 
-  const int ntb = (int)((a.P + PXB - 1) / PXB);  // block tiles
+  PT_ST(1);
+  const int ntb = (int)((a.P + PT_PXB - 1) / PT_PXB);
+  int st_i = 2;
   for (int tile = blockIdx.x; tile < ntb; tile += gridDim.x) {
-    const long p = (long)tile * PXB + pc;
+    if (st_i < 26) { PT_ST(st_i); ++st_i; }
+    const long p = (long)tile * PT_PXB + pcol;
     const bool valid = p < a.P;
     const float vm = valid ? 1.f : 0.f;
     const int b = valid ? (int)(p / HW) : 0;
     const int l = valid ? (int)(p - (long)b * HW) : 0;
-    __syncthreads();  // previous tile's LDS reads are done (and, first time, the staged weights are visible below)
+    __syncthreads();  // previous tile's LDS reads are done (first time: the staged weights become visible)
     {
-      // x tile: rows dealt to the NOG waves of the pixel group (every wave of a group has the same pixels). TWELVE
-      // loads in flight per thread (clamped row index, never a predicated load): one row at a time was a chain of
-      // C * T dependent HBM round trips per tile -- most of the first version's run time.
+      // x tile: the two halves of a wave load alternate rows of the wave's 32 pixels; twelve loads in flight per lane
       const float* xp = a.x + (long)b * a.xbs + l;
       const int CT = C * T;
-      for (int row0 = og; row0 < CT; row0 += NOG * 12) {
+      for (int row0 = half; row0 < CT; row0 += 24) {
         float v[12];
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
-          const int row = row0 + i * NOG;
+          const int row = row0 + 2 * i;
           v[i] = xp[(long)(row < CT ? row : CT - 1) * HW];
         }
 #pragma unroll
         for (int i = 0; i < 12; ++i) {
-          const int row = row0 + i * NOG;
-          if (row < CT) xs[row * PXB + pc] = valid ? v[i] : 0.f;
+          const int row = row0 + 2 * i;
+          const int c = row / T;  // (row = c * T + t -> LDS row c * (T + PT_TPAD) + t)
+          if (row < CT) SM(xs + ((row + c * PT_TPAD) * PT_PXB + pcol)) = valid ? v[i] : 0.f;
         }
       }
     }
     __syncthreads();
+    if (st_i < 26) { PT_ST(st_i); ++st_i; }
 
     if (PASS == 0) {
       float s = 0.f, q = 0.f;
       int slot = 0;
       auto rb = [&](int) { s = 0.f; q = 0.f; };
-      auto en = [&](int, int, float h, auto&) { s += h; q += h * h; };
+      auto en = [&](int, int, bool live, float h, auto&) { if (live) { s += h; q += h * h; } };
       auto re = [&](int) { wsum(slot, s); wsum(slot + 1, q); slot += 2; };
-      if (og == 0) {  // (one wave per pixel group: the other waves of a Cout > NO group would count the pixels twice)
-        pt_rows<3, CMAX>(wa_l, xs, C, T, PXB, pc, rb, en, re);
-        pt_rows<5, CMAX>(wa_l + C * CMAX * PT_KP, xs, C, T, PXB, pc, rb, en, re);
-      }
+      pt_rows<3, CMAX>(wa_l, xs, C, T, pcol, half, rb, en, re);
+      pt_rows<5, CMAX>(wa_l + C * CMAX * PT_KP, xs, C, T, pcol, half, rb, en, re);
       continue;
     }
     if (PASS == 5) {
       // dh = g3 rho (dz - c0 - hh c1); dWa[cp][c][dt] += sum_px sum_tp dh * x[c][tp + dt] (the window IS x[c][tp + dt])
-      if (og == 0) {
-        int ebase = 0, vbase = 0;
-        auto branch = [&](auto kc, const float* wl, int brn) {
-          constexpr int K = decltype(kc)::value;
-          float g[CMAX][K];
-          float rho = 0.f, off = 0.f, g3 = 0.f, c0 = 0.f, c1 = 0.f;
-          const int Tp = T - K + 1;
-          auto rb = [&](int cp) {
-            const f32x4 cc = *reinterpret_cast<const f32x4*>(c3_l + (brn * C + cp) * 4);
-            rho = cc[0]; off = cc[1]; g3 = cc[2];
-            c0 = k3_l[(brn * C + cp) * 2]; c1 = k3_l[(brn * C + cp) * 2 + 1];
+      int ebase = 0, vbase = 0;
+      auto branch = [&](auto kc, int wl, int brn) {
+        constexpr int K = decltype(kc)::value;
+        float g[CMAX][K];
+        float rho = 0.f, off = 0.f, g3 = 0.f, c0 = 0.f, c1 = 0.f;
+        const int Tp = T - K + 1;
+        auto rb = [&](int cp) {
+          const f32x4 cc = *reinterpret_cast<const f32x4*>(&SM(c3_l + (brn * C + cp) * 4));
+          rho = cc[0]; off = cc[1]; g3 = cc[2];
+          c0 = SM(k3_l + ((brn * C + cp) * 2)); c1 = SM(k3_l + ((brn * C + cp) * 2 + 1));
 #pragma unroll
-            for (int c = 0; c < CMAX; ++c)
+          for (int c = 0; c < CMAX; ++c)
 #pragma unroll
-              for (int dt = 0; dt < K; ++dt) g[c][dt] = 0.f;
-          };
-          auto en = [&](int cp, int tp, float h, auto& xw) {
-            const float hh = h * rho + off;
-            const int e = ebase + cp * Tp + tp;
-            const float dzv = valid ? a.dz[(long)e * a.P + p] : 0.f;
-            const float dh = g3 * rho * (dzv - c0 - hh * c1) * vm;
-#pragma unroll
-            for (int c = 0; c < CMAX; ++c)
-#pragma unroll
-              for (int dt = 0; dt < K; ++dt) g[c][dt] += dh * xw[c][dt];
-          };
-          auto re = [&](int cp) {
-#pragma unroll
-            for (int c = 0; c < CMAX; ++c)
-#pragma unroll
-              for (int dt = 0; dt < K; ++dt) wsum(vbase + (cp * CMAX + c) * PT_KP + dt, g[c][dt]);
-          };
-          pt_rows<K, CMAX>(wl, xs, C, T, PXB, pc, rb, en, re);
-          ebase += C * Tp;
-          vbase += C * CMAX * PT_KP;
+            for (int dt = 0; dt < K; ++dt) g[c][dt] = 0.f;
         };
-        branch(std::integral_constant<int, 3>{}, wa_l, 0);
-        branch(std::integral_constant<int, 5>{}, wa_l + C * CMAX * PT_KP, 1);
-      }
+        auto en = [&](int cp, int tp, bool live, float h, auto& xw) {
+          const float hh = h * rho + off;
+          const int e = ebase + cp * Tp + (live ? tp : 0);
+          const float dzv = (valid && live) ? a.dz[(long)e * a.P + p] : 0.f;
+          const float dh = (valid && live) ? g3 * rho * (dzv - c0 - hh * c1) : 0.f;
+#pragma unroll
+          for (int c = 0; c < CMAX; ++c)
+#pragma unroll
+            for (int dt = 0; dt < K; ++dt) g[c][dt] += dh * xw[c][dt];
+        };
+        auto re = [&](int cp) {
+#pragma unroll
+          for (int c = 0; c < CMAX; ++c)
+#pragma unroll
+            for (int dt = 0; dt < K; ++dt) wsum(vbase + (cp * CMAX + c) * PT_KP + dt, g[c][dt]);
+        };
+        pt_rows<K, CMAX>(wl, xs, C, T, pcol, half, rb, en, re);
+        ebase += C * Tp;
+        vbase += C * CMAX * PT_KP;
+      };
+      branch(std::integral_constant<int, 3>{}, wa_l, 0);
+      branch(std::integral_constant<int, 5>{}, wa_l + C * CMAX * PT_KP, 1);
       continue;
     }
 
-    // ---- PASS 1..4: both convolution stacks -> r[branch][own outputs] ----
-    float r_[2][NO];
+    // ---- PASS 1..4: first convolutions -> SiLU(BatchNorm3d) -> second convolutions on the matrix pipe ----
+    f32x16 acc[2][MT];
 #pragma unroll
     for (int brn = 0; brn < 2; ++brn)
 #pragma unroll
-      for (int j = 0; j < NO; ++j) r_[brn][j] = 0.f;
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) acc[brn][mt][j] = 0.f;
     {
       float rho = 0.f, off = 0.f, g3 = 0.f, b3 = 0.f;
-      auto branch = [&](auto kc, const float* wl, int brn, const float* wb_l, int slot0) {
+      int gs = 0;
+      auto branch = [&](auto kc, int wl, auto bc, int slot0) {
         constexpr int K = decltype(kc)::value;
+        constexpr int brn = decltype(bc)::value;
         const int Tp = T - K + 1;
         auto rb = [&](int cp) {
-          const f32x4 cc = *reinterpret_cast<const f32x4*>(c3_l + (brn * C + cp) * 4);
+          const f32x4 cc = *reinterpret_cast<const f32x4*>(&SM(c3_l + (brn * C + cp) * 4));
           rho = cc[0]; off = cc[1]; g3 = cc[2]; b3 = cc[3];
         };
-        auto en = [&](int cp, int tp, float h, auto&) {
-          const float aval = pt_silu(g3 * (h * rho + off) + b3);
-          const int loc = cp * Tp + tp;
-          if (PASS == 4 && og == 0) as_[(slot0 + loc) * PXB + pc] = aval;
-          pt_fma_lane_weights<NO>(wb_l[loc * Cout + o0 + wl_lane], aval, r_[brn]);
+        auto en = [&](int cp, int tp, bool live, float h, auto&) {
+          const float aval = live ? pt_silu(g3 * (h * rho + off) + b3) : 0.f;
+          if (PASS == 4 && live) SM(as_w + ((slot0 + cp * Tp + tp) * PT_LP + l32)) = aval * vm;
+          const int wv = wA_l + (gs * 2 + half) * CP + l32;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) acc[brn][mt] = pt_mfma(SM(wv + (mt * 32)), aval, acc[brn][mt]);
+          ++gs;
         };
         auto re = [&](int) {};
-        pt_rows<K, CMAX>(wl, xs, C, T, PXB, pc, rb, en, re);
+        pt_rows<K, CMAX>(wl, xs, C, T, pcol, half, rb, en, re);
       };
-      branch(std::integral_constant<int, 3>{}, wa_l, 0, wbt_l, 0);
-      branch(std::integral_constant<int, 5>{}, wa_l + C * CMAX * PT_KP, 1, wbt_l + E3 * Cout, S5);
+      branch(std::integral_constant<int, 3>{}, wa_l, std::integral_constant<int, 0>{}, 0);
+      branch(std::integral_constant<int, 5>{}, wa_l + C * CMAX * PT_KP, std::integral_constant<int, 1>{}, EP3);
     }
+    if (st_i < 26) { PT_ST(st_i); ++st_i; }
+    // this lane: pixel l32, output channels o(mt, j) = 32 mt + pt_row(j, half)
     if (PASS == 1) {
 #pragma unroll
       for (int brn = 0; brn < 2; ++brn)
 #pragma unroll
-        for (int j = 0; j < NO; ++j) {
-          const float v = r_[brn][j] * vm;
-          wsum((brn * 2) * Cout + o0 + j, v);
-          wsum((brn * 2 + 1) * Cout + o0 + j, v * v);
-        }
+        for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            const int o = mt * 32 + pt_row(j, half);
+            const float v = acc[brn][mt][j] * vm;
+            hsum((brn * 2) * Cout + o, v, o < Cout);
+            hsum((brn * 2 + 1) * Cout + o, v * v, o < Cout);
+          }
       continue;
     }
     // ---- BatchNorm2d + SiLU, branch sum, LayerNorm over Cout ----
-    // r_ <- rhat (normalised); vv = affine BatchNorm output; u = sum of the activations
-    float vv[2][NO], u[NO];
-#pragma unroll
-    for (int j = 0; j < NO; ++j) u[j] = 0.f;
-#pragma unroll
-    for (int brn = 0; brn < 2; ++brn)
-#pragma unroll
-      for (int j = 0; j < NO; ++j) {
-        const f32x4 cc = *reinterpret_cast<const f32x4*>(c2_l + (brn * Cout + o0 + j) * 4);
-        r_[brn][j] = r_[brn][j] * cc[0] + cc[1];
-        vv[brn][j] = cc[2] * r_[brn][j] + cc[3];
-        u[j] += pt_silu(vv[brn][j]);
-      }
+    // acc <- rhat (normalised); vv = affine BatchNorm output; u = sum of the activations (0 for padded channels)
+    f32x16 vv[2][MT], u[MT];
     float m = 0.f;
 #pragma unroll
-    for (int j = 0; j < NO; ++j) m += u[j];
-    if (NOG > 1) {
-      ex[wid * 64 + lane] = m;
-      __syncthreads();
-      m = 0.f;
-      for (int w2 = 0; w2 < NOG; ++w2) m += ex[(pxg * NOG + w2) * 64 + lane];
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int o = mt * 32 + pt_row(j, half);
+        float uj = 0.f;
+#pragma unroll
+        for (int brn = 0; brn < 2; ++brn) {
+          const f32x4 cc = *reinterpret_cast<const f32x4*>(&SM(c2_l + (brn * CP + o) * 4));
+          acc[brn][mt][j] = acc[brn][mt][j] * cc[0] + cc[1];
+          vv[brn][mt][j] = cc[2] * acc[brn][mt][j] + cc[3];
+          uj += pt_silu(vv[brn][mt][j]);
+        }
+        uj = o < Cout ? uj : 0.f;
+        u[mt][j] = uj;
+        m += uj;
+      }
+    m += __shfl_xor(m, 32, 64);
     m *= vN;
     float var = 0.f;
 #pragma unroll
-    for (int j = 0; j < NO; ++j) { const float d = u[j] - m; var += d * d; }
-    if (NOG > 1) {
-      ex[(4 + wid) * 64 + lane] = var;
-      __syncthreads();
-      var = 0.f;
-      for (int w2 = 0; w2 < NOG; ++w2) var += ex[(4 + pxg * NOG + w2) * 64 + lane];
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int o = mt * 32 + pt_row(j, half);
+        const float d = o < Cout ? u[mt][j] - m : 0.f;
+        var += d * d;
+      }
+    var += __shfl_xor(var, 32, 64);
     const float rL = 1.0f / sqrtf(var * vN + a.epsL);
 #pragma unroll
-    for (int j = 0; j < NO; ++j) u[j] = (u[j] - m) * rL;  // u <- uhat
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int o = mt * 32 + pt_row(j, half);
+        u[mt][j] = o < Cout ? (u[mt][j] - m) * rL : 0.f;  // u <- uhat
+      }
     if (PASS == 2) {
       if (valid) {
         if (a.out_kind == 0) {
-          float* yp = reinterpret_cast<float*>(a.y) + (long)b * a.y_stride + (long)o0 * HW + l;
+          float* yp = reinterpret_cast<float*>(a.y) + (long)b * a.y_stride + l;
 #pragma unroll
-          for (int j = 0; j < NO; ++j) yp[(long)j * HW] = ln_l[o0 + j] * u[j] + ln_l[Cout + o0 + j];
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const int o = mt * 32 + pt_row(j, half);
+              if (o < Cout) yp[(long)o * HW] = SM(ln_l + (o)) * u[mt][j] + SM(ln_l + (CP + o));
+            }
         } else {
-          bf16_t* yp = reinterpret_cast<bf16_t*>(a.y) + p * a.y_stride + o0;
+          bf16_t* yp = reinterpret_cast<bf16_t*>(a.y) + p * a.y_stride;
 #pragma unroll
-          for (int j8 = 0; j8 < NO / 8; ++j8) {
-            float yv[8];
+          for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-            for (int i = 0; i < 8; ++i) yv[i] = ln_l[o0 + j8 * 8 + i] * u[j8 * 8 + i] + ln_l[Cout + o0 + j8 * 8 + i];
-            *reinterpret_cast<u32x4*>(yp + j8 * 8) = cn_pack8(yv);
-          }
+            for (int q = 0; q < 4; ++q) {  // four consecutive channels 32 mt + 8 q + 4 half + (0..3): one 8-byte store
+              const int o = mt * 32 + 8 * q + 4 * half;
+              if (o < Cout) {
+                u32x2 pk;
+                pk[0] = cn_pack_bf16(SM(ln_l + (o)) * u[mt][4 * q] + SM(ln_l + (CP + o)), SM(ln_l + (o + 1)) * u[mt][4 * q + 1] + SM(ln_l + (CP + o + 1)));
+                pk[1] = cn_pack_bf16(SM(ln_l + (o + 2)) * u[mt][4 * q + 2] + SM(ln_l + (CP + o + 2)),
+                                     SM(ln_l + (o + 3)) * u[mt][4 * q + 3] + SM(ln_l + (CP + o + 3)));
+                *reinterpret_cast<u32x2*>(yp + o) = pk;
+              }
+            }
         }
       }
       continue;
     }
     // ---- backward: LayerNorm, SiLU, BatchNorm2d ----
-    float dyv[NO];
+    f32x16 dyv[MT];
     if (a.out_kind == 0) {
-      const float* dp = reinterpret_cast<const float*>(a.dy) + (long)b * a.dy_stride + (long)o0 * HW + l;
+      const float* dp = reinterpret_cast<const float*>(a.dy) + (long)b * a.dy_stride + l;
 #pragma unroll
-      for (int j = 0; j < NO; ++j) dyv[j] = valid ? dp[(long)j * HW] : 0.f;
+      for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int o = mt * 32 + pt_row(j, half);
+          dyv[mt][j] = (valid && o < Cout) ? dp[(long)(o < Cout ? o : 0) * HW] : 0.f;
+        }
     } else {
-      const bf16_t* dp = reinterpret_cast<const bf16_t*>(a.dy) + (valid ? p : 0) * a.dy_stride + o0;
+      const bf16_t* dp = reinterpret_cast<const bf16_t*>(a.dy) + (valid ? p : 0) * a.dy_stride;
 #pragma unroll
-      for (int j8 = 0; j8 < NO / 8; ++j8) {
-        float t8[8];
-        cn_unpack8(*reinterpret_cast<const u32x4*>(dp + j8 * 8), t8);
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int i = 0; i < 8; ++i) dyv[j8 * 8 + i] = t8[i] * vm;
-      }
+        for (int q = 0; q < 4; ++q) {
+          const int o = mt * 32 + 8 * q + 4 * half;
+          const u32x2 pk = *reinterpret_cast<const u32x2*>(dp + (o < Cout ? o : 0));
+          const float on = (valid && o < Cout) ? 1.f : 0.f;
+          dyv[mt][4 * q] = cn_bf16_lo(pk[0]) * on;
+          dyv[mt][4 * q + 1] = cn_bf16_hi(pk[0]) * on;
+          dyv[mt][4 * q + 2] = cn_bf16_lo(pk[1]) * on;
+          dyv[mt][4 * q + 3] = cn_bf16_hi(pk[1]) * on;
+        }
     }
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
-    for (int j = 0; j < NO; ++j) {
-      const float gj = dyv[j] * ln_l[o0 + j];
-      s1 += gj;
-      s2 += gj * u[j];
-    }
-    if (NOG > 1) {
-      __syncthreads();  // (the variance partials in ex[] have been read)
-      ex[wid * 64 + lane] = s1;
-      ex[(4 + wid) * 64 + lane] = s2;
-      __syncthreads();
-      s1 = s2 = 0.f;
-      for (int w2 = 0; w2 < NOG; ++w2) { s1 += ex[(pxg * NOG + w2) * 64 + lane]; s2 += ex[(4 + pxg * NOG + w2) * 64 + lane]; }
-    }
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int o = mt * 32 + pt_row(j, half);
+        const float gj = dyv[mt][j] * SM(ln_l + (o));
+        s1 += gj;
+        s2 += gj * u[mt][j];
+      }
+    s1 += __shfl_xor(s1, 32, 64);
+    s2 += __shfl_xor(s2, 32, 64);
     s1 *= vN; s2 *= vN;
     if (PASS == 3) {
 #pragma unroll
-      for (int j = 0; j < NO; ++j) {
-        const float du = rL * (dyv[j] * ln_l[o0 + j] - s1 - u[j] * s2);
+      for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-        for (int brn = 0; brn < 2; ++brn) {
-          const float dv = du * pt_silu_grad(vv[brn][j]);
-          wsum((brn * 2) * Cout + o0 + j, dv);
-          wsum((brn * 2 + 1) * Cout + o0 + j, dv * r_[brn][j]);
+        for (int j = 0; j < 16; ++j) {
+          const int o = mt * 32 + pt_row(j, half);
+          const bool on = o < Cout;
+          const float du = on ? rL * (dyv[mt][j] * SM(ln_l + (o)) - s1 - u[mt][j] * s2) : 0.f;
+#pragma unroll
+          for (int brn = 0; brn < 2; ++brn) {
+            const float dv = du * pt_silu_grad(vv[brn][mt][j]);
+            hsum((brn * 2) * Cout + o, dv, on);
+            hsum((brn * 2 + 1) * Cout + o, dv * acc[brn][mt][j], on);
+          }
+          hsum(4 * Cout + o, dyv[mt][j] * u[mt][j], on);
+          hsum(5 * Cout + o, dyv[mt][j], on);
         }
-        wsum(4 * Cout + o0 + j, dyv[j] * u[j]);
-        wsum(5 * Cout + o0 + j, dyv[j]);
-      }
       continue;
     }
     // ---- PASS 4 ----
-    // dr (kept in vv) -> LDS for the dWb contraction
+    // dr (kept in vv), and transposed into LDS [cout][pixel] for the dWb contraction
 #pragma unroll
-    for (int j = 0; j < NO; ++j) {
-      const float du = rL * (dyv[j] * ln_l[o0 + j] - s1 - u[j] * s2);
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-      for (int brn = 0; brn < 2; ++brn) {
-        const float dv = du * pt_silu_grad(vv[brn][j]);
-        const f32x4 cc = *reinterpret_cast<const f32x4*>(c2_l + (brn * Cout + o0 + j) * 4);
-        const float c0 = k2_l[(brn * Cout + o0 + j) * 2], c1 = k2_l[(brn * Cout + o0 + j) * 2 + 1];
-        const float dr = cc[2] * cc[0] * (dv - c0 - r_[brn][j] * c1) * vm;
-        vv[brn][j] = dr;
-        drs[(brn * Cout + o0 + j) * PXB + pc] = dr;
+      for (int j = 0; j < 16; ++j) {
+        const int o = mt * 32 + pt_row(j, half);
+        const float du = o < Cout ? rL * (dyv[mt][j] * SM(ln_l + (o)) - s1 - u[mt][j] * s2) : 0.f;
+#pragma unroll
+        for (int brn = 0; brn < 2; ++brn) {
+          const float dv = du * pt_silu_grad(vv[brn][mt][j]);
+          const f32x4 cc = *reinterpret_cast<const f32x4*>(&SM(c2_l + (brn * CP + o) * 4));
+          const float c0 = SM(k2_l + ((brn * CP + o) * 2)), c1 = SM(k2_l + ((brn * CP + o) * 2 + 1));
+          const float dr = cc[2] * cc[0] * (dv - c0 - acc[brn][mt][j] * c1) * vm;
+          vv[brn][mt][j] = dr;
+          SM(drs_w + ((brn * CP + o) * PT_LP + l32)) = dr;
+        }
+      }
+    // dWb[cout][entry] += sum_px dr[cout][px] a[entry][px]: K = pixels, two per step; A = dr^T, B = a^T out of LDS
+#pragma unroll
+    for (int brn = 0; brn < 2; ++brn) {
+      const int ab = as_w + (brn ? EP3 : 0) * PT_LP;
+      const int db = drs_w + brn * CP * PT_LP;
+      const int net = ((brn ? E5 : E3) + 31) >> 5;
+      for (int t = 0; t < 16; ++t) {
+        const int px = 2 * t + half;
+#pragma unroll
+        for (int et = 0; et < NE; ++et) {
+          if (et < net) {
+            const float bv = SM(ab + ((et * 32 + l32) * PT_LP + px));
+#pragma unroll
+            for (int mt = 0; mt < MT; ++mt)
+              accW[brn][mt][et] = pt_mfma(SM(db + ((mt * 32 + l32) * PT_LP + px)), bv, accW[brn][mt][et]);
+          }
+        }
       }
     }
-    // da[e] = sum_o wb[o][e] dr[o]: this thread's NO outputs; the NOG waves of a pixel group add up through LDS
-    for (int i = og; i < E; i += NOG) dacc[i * PXB + pc] = 0.f;
-    if (NOG > 1) __syncthreads();
-    for (int e = 0; e < E; ++e) {
-      const int brn = e >= E3 ? 1 : 0;
-      const float wl_ = wbt_l[e * Cout + o0 + wl_lane];  // (wbt_l rows: branch 3 then 5)
-      const float da = brn == 0 ? pt_dot_lane_weights<NO>(wl_, vv[0]) : pt_dot_lane_weights<NO>(wl_, vv[1]);
-      if (NOG > 1) atomicAdd(&dacc[e * PXB + pc], da);  // (ds_add_f32: one address per lane, waves of a group in turn)
-      else dacc[e * PXB + pc] = da;
+    // da[entry][px] = sum_cout wb[cout][entry] dr[cout][px]: K = couts, the accumulator registers of dr ARE the B
+    // operands (k-step (mt, j): couts 32 mt + pt_row(j, 0) and + pt_row(j, 1)); result transposed through LDS into
+    // the (pixel, entry parity) layout of the first convolutions (it replaces a[][] in as_w)
+#pragma unroll
+    for (int brn = 0; brn < 2; ++brn) {
+      const int net = ((brn ? E5 : E3) + 31) >> 5;
+#pragma unroll
+      for (int et = 0; et < NE; ++et) {
+        if (et < net) {
+          f32x16 da;
+#pragma unroll
+          for (int j = 0; j < 16; ++j) da[j] = 0.f;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+              const int o = mt * 32 + pt_row(j, half);
+              da = pt_mfma(SM(wB_l + (o * EP + (brn ? EP3 : 0) + et * 32 + l32)), vv[brn][mt][j], da);
+            }
+#pragma unroll
+          for (int j = 0; j < 16; ++j)
+            SM(as_w + (((brn ? EP3 : 0) + et * 32 + pt_row(j, half)) * PT_LP + l32)) = da[j];
+        }
+      }
     }
-    __syncthreads();  // as_ / drs / dacc complete for the whole block tile
-    // dz = da * silu'(z), BatchNorm3d sums, dz -> scratch (one wave per pixel group)
-    if (og == 0) {
+    // dz = da * silu'(z), BatchNorm3d sums, dz -> scratch
+    {
       float rho = 0.f, off = 0.f, g3 = 0.f, b3 = 0.f, s = 0.f, q = 0.f;
       int slot = 0, ebase = 0;
-      auto branch = [&](auto kc, const float* wl, int brn) {
+      auto branch = [&](auto kc, int wl, int brn, int slot0) {
         constexpr int K = decltype(kc)::value;
         const int Tp = T - K + 1;
         auto rb = [&](int cp) {
-          const f32x4 cc = *reinterpret_cast<const f32x4*>(c3_l + (brn * C + cp) * 4);
+          const f32x4 cc = *reinterpret_cast<const f32x4*>(&SM(c3_l + (brn * C + cp) * 4));
           rho = cc[0]; off = cc[1]; g3 = cc[2]; b3 = cc[3];
           s = 0.f; q = 0.f;
         };
-        auto en = [&](int cp, int tp, float h, auto&) {
-          const float hh = h * rho + off;
-          const int e = ebase + cp * Tp + tp;
-          const float dzv = dacc[e * PXB + pc] * pt_silu_grad(g3 * hh + b3);
-          s += dzv;
-          q += dzv * hh;
-          if (valid) a.dz[(long)e * a.P + p] = dzv;
+        auto en = [&](int cp, int tp, bool live, float h, auto&) {
+          if (live) {
+            const float hh = h * rho + off;
+            const int loc = cp * Tp + tp;
+            const float dzv = SM(as_w + ((slot0 + loc) * PT_LP + l32)) * pt_silu_grad(g3 * hh + b3);
+            s += dzv;
+            q += dzv * hh;
+            if (valid) a.dz[(long)(ebase + loc) * a.P + p] = dzv;
+          }
         };
         auto re = [&](int) { wsum(slot, s); wsum(slot + 1, q); slot += 2; };
-        pt_rows<K, CMAX>(wl, xs, C, T, PXB, pc, rb, en, re);
+        pt_rows<K, CMAX>(wl, xs, C, T, pcol, half, rb, en, re);
         ebase += C * Tp;
       };
-      branch(std::integral_constant<int, 3>{}, wa_l, 0);
-      branch(std::integral_constant<int, 5>{}, wa_l + C * CMAX * PT_KP, 1);
-    }
-    {
-      // dWb[brn][o][loc] += sum_px dr[brn][o][px] * a[brn][loc][px]: a thread owns 2 couts x 4 entries (x 3 rounds)
-      const int half = Cout >> 1;
-      const int nt3 = half * (pt_ceil4(E3) >> 2), nt5 = half * (pt_ceil4(E5) >> 2);
-      auto tile_mac = [&](int ti, float* acc8) {
-        if (ti >= nt3 + nt5) return;
-        const int brn = ti >= nt3 ? 1 : 0;
-        const int tl = ti - (brn ? nt3 : 0);
-        const int o2 = tl % half, e4 = tl / half;
-        const float* d0 = drs + (brn * Cout + 2 * o2) * PXB;
-        const float* a0 = as_ + ((brn ? S5 : 0) + e4 * 4) * PXB;
-        for (int q4 = 0; q4 < PXB / 4; ++q4) {
-          const f32x4 da_ = *reinterpret_cast<const f32x4*>(d0 + q4 * 4);
-          const f32x4 db_ = *reinterpret_cast<const f32x4*>(d0 + PXB + q4 * 4);
-#pragma unroll
-          for (int i = 0; i < 4; ++i) {
-            const f32x4 av = *reinterpret_cast<const f32x4*>(a0 + i * PXB + q4 * 4);
-            acc8[i] += da_[0] * av[0] + da_[1] * av[1] + da_[2] * av[2] + da_[3] * av[3];
-            acc8[4 + i] += db_[0] * av[0] + db_[1] * av[1] + db_[2] * av[2] + db_[3] * av[3];
-          }
-        }
-      };
-      tile_mac(tid, AW);
-      tile_mac(tid + nthr, AW2);
-      tile_mac(tid + 2 * nthr, AW3);
+      branch(std::integral_constant<int, 3>{}, wa_l, 0, 0);
+      branch(std::integral_constant<int, 5>{}, wa_l + C * CMAX * PT_KP, 1, EP3);
     }
   }
 
   // ---- block row -> two-level last-block reduction -> finish ----
+  PT_ST(30);
   if (PASS == 2) return;
   const int blk = blockIdx.x;
   __syncthreads();
   {
-    // the four waves' accumulators -> one row
     const int base = PASS == 4 ? Cout * E : 0;
-    for (int v = tid; v < NV; v += nthr)
-    {
-      float t = 0.f;
-      for (int w2 = 0; w2 < (nthr >> 6); ++w2) t += lacc[w2 * NV + v];
-      cn_t2_store(a.tk, blk, base + v, t);
-    }
+    for (int v = tid; v < NV; v += 256)
+      cn_t2_store(a.tk, blk, base + v, (SM(lacc + (v)) + SM(lacc + (NV + v))) + (SM(lacc + (2 * NV + v)) + SM(lacc + (3 * NV + v))));
   }
   if (PASS == 4) {
-    const int half = Cout >> 1;
-    const int nt3 = half * (pt_ceil4(E3) >> 2), nt5 = half * (pt_ceil4(E5) >> 2);
-    auto tile_store = [&](int ti, const float* acc8) {
-      if (ti >= nt3 + nt5) return;
-      const int brn = ti >= nt3 ? 1 : 0;
-      const int tl = ti - (brn ? nt3 : 0);
-      const int o2 = tl % half, e4 = tl / half;
-      const int Eb = brn ? E5 : E3;
+    // the four waves' dWb tiles -> LDS (wave-private slabs over the dead x / a / dr regions) -> summed in wave order
+    const int slab = L.xs;
+    const int W4 = Cout * E;
+    __syncthreads();
+    for (int w2 = 0; w2 < 4; ++w2) {
+      if (wid == w2) {
 #pragma unroll
-      for (int i = 0; i < 4; ++i) {
-        const int loc = e4 * 4 + i;
-        if (loc < Eb) {
-          cn_t2_store(a.tk, blk, (brn ? Cout * E3 : 0) + (2 * o2) * Eb + loc, acc8[i]);
-          cn_t2_store(a.tk, blk, (brn ? Cout * E3 : 0) + (2 * o2 + 1) * Eb + loc, acc8[4 + i]);
+        for (int brn = 0; brn < 2; ++brn) {
+          const int Eb = brn ? E5 : E3;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+            for (int et = 0; et < NE; ++et)
+#pragma unroll
+              for (int j = 0; j < 16; ++j) {
+                const int o = mt * 32 + pt_row(j, half), e = et * 32 + l32;
+                if (o < Cout && e < Eb) {
+                  const int col = (brn ? Cout * E3 : 0) + o * Eb + e;
+                  SM(slab + (col)) = w2 == 0 ? accW[brn][mt][et][j] : SM(slab + (col)) + accW[brn][mt][et][j];
+                }
+              }
         }
       }
-    };
-    tile_store(tid, AW);
-    tile_store(tid + nthr, AW2);
-    tile_store(tid + 2 * nthr, AW3);
+      __syncthreads();
+    }
+    for (int col = tid; col < W4; col += 256) cn_t2_store(a.tk, blk, col, SM(slab + (col)));
   }
   // finish (the last-arriving block): statistics / coefficients / parameter gradients
   const double cntP = (double)a.P;
@@ -670,7 +793,7 @@ __global__ __launch_bounds__(256) void cn_pretime_kernel(const CnPtArgs a) {
   __syncthreads();
   const double* tot = reinterpret_cast<const double*>(lds);
   if (PASS == 0 || PASS == 4) {
-    for (int i = tid; i < 2 * C; i += nthr) {
+    for (int i = tid; i < 2 * C; i += 256) {
       const int brn = i / C, cp = i - brn * C;
       const CnPtBranch& r = a.br[brn];
       const double v0 = tot[(brn * C + cp) * 2], v1 = tot[(brn * C + cp) * 2 + 1];
@@ -681,6 +804,12 @@ __global__ __launch_bounds__(256) void cn_pretime_kernel(const CnPtArgs a) {
         if (var < 0.0) var = 0.0;
         r.mean3[cp] = (float)md;
         r.rstd3[cp] = (float)(1.0 / sqrt(var + (double)a.eps3));
+        {  // the next passes' table image
+          const PtLds LI = pt_lds(4, C, T, Cout, CMAX);
+          const float rho = (float)(1.0 / sqrt(var + (double)a.eps3));
+          a.img[LI.c3 + (brn * C + cp) * 4 + 0] = rho;
+          a.img[LI.c3 + (brn * C + cp) * 4 + 1] = -(float)md * rho;
+        }
         if (r.rm3 != nullptr) {
           const double unb = cnt > 1.0 ? var * cnt / (cnt - 1.0) : var;
           r.rm3[cp] = (1.f - a.mom3) * r.rm3[cp] + a.mom3 * (float)md;
@@ -689,12 +818,17 @@ __global__ __launch_bounds__(256) void cn_pretime_kernel(const CnPtArgs a) {
       } else {
         a.coef3[(brn * 2) * C + cp] = a.training ? (float)(v0 / cnt) : 0.f;
         a.coef3[(brn * 2 + 1) * C + cp] = a.training ? (float)(v1 / cnt) : 0.f;
+        {
+          const PtLds LI = pt_lds(4, C, T, Cout, CMAX);
+          a.img[LI.k3 + (brn * C + cp) * 2 + 0] = a.training ? (float)(v0 / cnt) : 0.f;
+          a.img[LI.k3 + (brn * C + cp) * 2 + 1] = a.training ? (float)(v1 / cnt) : 0.f;
+        }
         r.dg3[cp] += (float)v1;
         r.db3[cp] += (float)v0;
       }
     }
   } else {  // PASS 1 / 3: columns [(brn*2 + stat)*Cout + o] (+ LayerNorm parameter gradients in PASS 3)
-    for (int i = tid; i < 2 * Cout; i += nthr) {
+    for (int i = tid; i < 2 * Cout; i += 256) {
       const int brn = i / Cout, o = i - brn * Cout;
       const CnPtBranch& r = a.br[brn];
       const double v0 = tot[(brn * 2) * Cout + o], v1 = tot[(brn * 2 + 1) * Cout + o];
@@ -704,6 +838,12 @@ __global__ __launch_bounds__(256) void cn_pretime_kernel(const CnPtArgs a) {
         if (var < 0.0) var = 0.0;
         r.mean2[o] = (float)md;
         r.rstd2[o] = (float)(1.0 / sqrt(var + (double)a.eps2));
+        {
+          const PtLds LI = pt_lds(4, C, T, Cout, CMAX);
+          const float rho = (float)(1.0 / sqrt(var + (double)a.eps2));
+          a.img[LI.c2 + (brn * CP + o) * 4 + 0] = rho;
+          a.img[LI.c2 + (brn * CP + o) * 4 + 1] = -(float)md * rho;
+        }
         if (r.rm2 != nullptr) {
           const double unb = cntP > 1.0 ? var * cntP / (cntP - 1.0) : var;
           r.rm2[o] = (1.f - a.mom2) * r.rm2[o] + a.mom2 * (float)md;
@@ -712,12 +852,17 @@ __global__ __launch_bounds__(256) void cn_pretime_kernel(const CnPtArgs a) {
       } else {
         a.coef2[(brn * 2) * Cout + o] = a.training ? (float)(v0 / cntP) : 0.f;
         a.coef2[(brn * 2 + 1) * Cout + o] = a.training ? (float)(v1 / cntP) : 0.f;
+        {
+          const PtLds LI = pt_lds(4, C, T, Cout, CMAX);
+          a.img[LI.k2 + (brn * CP + o) * 2 + 0] = a.training ? (float)(v0 / cntP) : 0.f;
+          a.img[LI.k2 + (brn * CP + o) * 2 + 1] = a.training ? (float)(v1 / cntP) : 0.f;
+        }
         r.dg2[o] += (float)v1;
         r.db2[o] += (float)v0;
       }
     }
     if (PASS == 3)
-      for (int o = tid; o < Cout; o += nthr) {
+      for (int o = tid; o < Cout; o += 256) {
         a.dgL[o] += (float)tot[4 * Cout + o];
         a.dbL[o] += (float)tot[5 * Cout + o];
       }
@@ -726,12 +871,6 @@ __global__ __launch_bounds__(256) void cn_pretime_kernel(const CnPtArgs a) {
 
 // ---- host side -----------------------------------------------------------------------------------------------------
 static inline int pt_cmax(int C) { return C <= 4 ? 4 : 8; }
-// output channels per thread: 32 where the registers allow it (forward, statistics), 16 in the gradient passes that
-// keep dy / dr / vv per output as well
-static inline int pt_no(int PASS, int Cout) {
-  const int cap = (PASS == 3 || PASS == 4) ? 16 : 32;
-  return Cout < cap ? Cout : cap;
-}
 static inline int pt_row_width(int PASS, int C, int T, int Cout) {
   const int E = C * (T - 2) + C * (T - 4);
   switch (PASS) {
@@ -744,22 +883,20 @@ static inline int pt_row_width(int PASS, int C, int T, int Cout) {
   }
 }
 static inline bool pt_supported(int C, int T, int Cout) {
-  return C >= 1 && C <= PT_MAX_C && T >= 5 && (Cout == 8 || Cout == 16 || Cout == 32 || Cout == 64);
+  return C >= 1 && C <= PT_MAX_C && T >= 5 && Cout >= 8 && Cout <= 64 && (Cout & 7) == 0;
 }
-static inline size_t pt_shmem_npg(int PASS, int C, int T, int Cout, int npg) {
-  size_t sh = (size_t)pt_lds(PASS, C, T, Cout, pt_cmax(C), 64 * npg).total * 4;
+static inline int pt_ne(int C, int T) { return (pt_ceil32(C * (T - 2)) >> 5); }  // entry tiles of the longer branch
+static inline size_t pt_shmem(int PASS, int C, int T, int Cout) {
+  size_t sh = (size_t)pt_lds(PASS, C, T, Cout, pt_cmax(C)).total * 4;
+  if (PASS == 4) {  // the end-of-kernel slab of the dWb tiles overlays the x / a / dr regions
+    const PtLds L = pt_lds(PASS, C, T, Cout, pt_cmax(C));
+    const size_t slab = (size_t)(L.xs + Cout * (C * (T - 2) + C * (T - 4))) * 4;
+    sh = sh < slab ? slab : sh;
+  }
   const size_t park = (size_t)(6 * Cout > 4 * C ? 6 * Cout : 4 * C) * 8;  // the finish phase parks doubles at the head
   return sh < park ? park : sh;
 }
-// pixel groups (waves' worth of 64 pixels) per block: as many as 256 threads hold, fewer if the LDS image (x tile,
-// and in PASS 4 the activation / dr / da tiles of the block) would not fit; 0 = does not fit at all
-static inline int pt_npg(int PASS, int C, int T, int Cout) {
-  const int nog = Cout / pt_no(PASS, Cout);
-  for (int npg = 4 / nog; npg >= 1; npg >>= 1)
-    if (pt_shmem_npg(PASS, C, T, Cout, npg) <= 156 * 1024) return npg;
-  return 0;
-}
-// floats: [counters 64][ticket body for the widest row][wbt x2][coef2][coef3][dz]
+// floats: [counters 64][ticket body for the widest row][coef2][coef3][dz]
 static inline long pt_off_body() { return CN_T2_COUNTERS; }
 static inline long pt_body_floats(int C, int T, int Cout) {
   int w = 0;
@@ -769,14 +906,13 @@ static inline long pt_body_floats(int C, int T, int Cout) {
 extern "C" long cn_pretime_workspace_floats(int B, int C, int T, int HW, int Cout, int with_backward) {
   if (!pt_supported(C, T, Cout)) return -1;
   for (int ps = 0; ps < (with_backward ? 6 : 3); ++ps)  // every pass the caller may launch must fit the 160 KiB LDS
-    if (pt_npg(ps, C, T, Cout) == 0) return -1;
-  if (with_backward) {
-    const int nt = (Cout / 2) * ((pt_ceil4(C * (T - 2)) + pt_ceil4(C * (T - 4))) / 4);
-    const int nthr = 64 * pt_npg(4, C, T, Cout) * (Cout / pt_no(4, Cout));
-    if (nt > 3 * nthr) return -1;  // dWb tiles: three per thread
-  }
+    if (pt_shmem(ps, C, T, Cout) > 160 * 1024) return -1;
+  // dWb accumulator registers of the gradient pass: up to three 32-entry tiles per branch at Cout <= 32; the two-tile
+  // Cout = 64 instantiation spills (1 KB per lane) and is left to the generic path for now
+  if (with_backward && (pt_ne(C, T) > 3 || Cout > 32)) return -1;
   const long E = (long)C * (T - 2) + (long)C * (T - 4);
-  long n = pt_off_body() + pt_body_floats(C, T, Cout) + E * Cout + 4L * Cout + 4L * C + 64;
+  long n = pt_off_body() + pt_body_floats(C, T, Cout) + 4L * pt_ceil32(Cout) + 4L * C + 128 +
+           ((pt_lds(4, C, T, Cout, pt_cmax(C)).xs + 63) / 64 * 64);
   if (with_backward) n += E * (long)B * HW;
   return n;
 }
@@ -790,12 +926,10 @@ static int pt_fill(CnPtArgs& a, const float* x, long xbs, const void* const* par
   a.x = x; a.xbs = xbs; a.B = B; a.C = C; a.T = T; a.HW = HW; a.Cout = Cout; a.P = (long)B * HW;
   a.training = training; a.eps3 = bn[0]; a.mom3 = bn[1]; a.eps2 = bn[2]; a.mom2 = bn[3]; a.epsL = eps_ln;
   a.ntiles = 0;
-  const long E3 = (long)C * (T - 2), E5 = (long)C * (T - 4);
-  float* wbt0 = ws + pt_off_body() + pt_body_floats(C, T, Cout);
-  float* wbt1 = wbt0 + E3 * Cout;
-  a.coef2 = wbt1 + E5 * Cout;
-  a.coef3 = a.coef2 + 4L * Cout;
-  a.dz = a.coef3 + 4L * C + (64 - (4 * C) % 64) % 64;
+  a.coef2 = ws + pt_off_body() + pt_body_floats(C, T, Cout);
+  a.coef3 = a.coef2 + 4L * pt_ceil32(Cout);
+  a.img = a.coef3 + 64;
+  a.dz = a.img + (pt_lds(4, C, T, Cout, pt_cmax(C)).xs + 63) / 64 * 64;
   for (int brn = 0; brn < 2; ++brn) {
     CnPtBranch& r = a.br[brn];
     const void* const* p = params + brn * 10;
@@ -803,7 +937,6 @@ static int pt_fill(CnPtArgs& a, const float* x, long xbs, const void* const* par
     r.g3 = (const float*)p[2]; r.b3 = (const float*)p[3]; r.rm3 = (float*)p[4]; r.rv3 = (float*)p[5];
     r.g2 = (const float*)p[6]; r.b2 = (const float*)p[7]; r.rm2 = (float*)p[8]; r.rv2 = (float*)p[9];
     r.mean3 = stats[brn * 4 + 0]; r.rstd3 = stats[brn * 4 + 1]; r.mean2 = stats[brn * 4 + 2]; r.rstd2 = stats[brn * 4 + 3];
-    r.wbt = brn ? wbt1 : wbt0;
     r.k = brn ? 5 : 3; r.Tp = T - r.k + 1;
     if (!training && (r.rm3 == nullptr || r.rv3 == nullptr || r.rm2 == nullptr || r.rv2 == nullptr)) return CN_ERR_ARG;
   }
@@ -813,30 +946,32 @@ static int pt_fill(CnPtArgs& a, const float* x, long xbs, const void* const* par
 
 template <int PASS>
 static int pt_launch(CnPtArgs a, float* ws, hipStream_t stream) {
-  const int NO = pt_no(PASS, a.Cout);
-  const int npg = pt_npg(PASS, a.C, a.T, a.Cout);
-  if (npg == 0) return CN_ERR_LDS;
-  const int PXB = 64 * npg;
-  const int nthr = 64 * npg * (a.Cout / NO);
-  const int ntb = (int)((a.P + PXB - 1) / PXB);
-  const int cap = PT_MAX_BLOCKS;  // persistent blocks (the per-block weight staging is paid once per block, not per tile)
-  const int nblk = ntb < cap ? ntb : cap;
-  const size_t shmem = pt_shmem_npg(PASS, a.C, a.T, a.Cout, npg);
+  const int ntb = (int)((a.P + PT_PXB - 1) / PT_PXB);
+  const int nblk = ntb < PT_MAX_BLOCKS ? ntb : PT_MAX_BLOCKS;  // persistent blocks: weights are staged once per block
+  const size_t shmem = pt_shmem(PASS, a.C, a.T, a.Cout);
+  if (shmem > 160 * 1024) return CN_ERR_LDS;
   const int W = pt_row_width(PASS, a.C, a.T, a.Cout);
   if (W > 0) a.tk = cn_t2_carve(reinterpret_cast<int*>(ws), ws + pt_off_body(), nblk, W);
-#define PT_GO(CM, NO_)                                                                                         \
+  const int MT = a.Cout > 32 ? 2 : 1;
+  const int NE = PASS == 4 ? pt_ne(a.C, a.T) : 1;
+#define PT_GO(CM, MT_, NE_)                                                                                    \
   do {                                                                                                         \
     if (shmem > 64 * 1024)                                                                                     \
-      (void)hipFuncSetAttribute((const void*)cn_pretime_kernel<PASS, CM, NO_>,                                 \
+      (void)hipFuncSetAttribute((const void*)cn_pretime_kernel<PASS, CM, MT_, NE_>,                            \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                       \
-    CN_LAUNCH((cn_pretime_kernel<PASS, CM, NO_>), dim3(nblk), dim3(nthr), shmem, stream, a);                   \
+    CN_LAUNCH((cn_pretime_kernel<PASS, CM, MT_, NE_>), dim3(nblk), dim3(256), shmem, stream, a);              \
   } while (0)
-#define PT_GO_NO(CM)                                                                                           \
+#define PT_GO_MT(CM)                                                                                           \
   do {                                                                                                         \
-    if (NO == 8) PT_GO(CM, 8); else if (NO == 16) PT_GO(CM, 16); else PT_GO(CM, 32);                           \
+    if constexpr (PASS == 4) {                                                                                 \
+      if (MT == 2) PT_GO(CM, 2, 1);                                                                            \
+      else if (NE == 1) PT_GO(CM, 1, 1); else if (NE == 2) PT_GO(CM, 1, 2); else PT_GO(CM, 1, 3);              \
+    } else {                                                                                                   \
+      if (MT == 2) PT_GO(CM, 2, 1); else PT_GO(CM, 1, 1);                                                      \
+    }                                                                                                          \
   } while (0)
-  if (pt_cmax(a.C) == 4) PT_GO_NO(4); else PT_GO_NO(8);
-#undef PT_GO_NO
+  if (pt_cmax(a.C) == 4) PT_GO_MT(4); else PT_GO_MT(8);
+#undef PT_GO_MT
 #undef PT_GO
   return CN_OK;
 }
@@ -854,8 +989,8 @@ extern "C" int cn_pretime_fwd_f32(const float* x, long xbs, const void* const* p
   int rc = pt_fill(a, x, xbs, params, stats, B, C, T, HW, Cout, training, bn, eps_ln, ws, ws_floats, 0);
   if (rc != CN_OK) return rc;
   a.y = y; a.y_stride = y_stride; a.out_kind = out_kind;
-  CN_LAUNCH(cn_pretime_pack_kernel, dim3(8), dim3(256), 0, stream, a, const_cast<float*>(a.br[0].wbt),
-            const_cast<float*>(a.br[1].wbt));
+  if (pt_cmax(C) == 4) CN_LAUNCH(cn_pretime_pack_kernel<4>, dim3(8), dim3(256), 0, stream, a, training ? 0 : 1);
+  else CN_LAUNCH(cn_pretime_pack_kernel<8>, dim3(8), dim3(256), 0, stream, a, training ? 0 : 1);
   if (training) {
     if ((rc = pt_launch<0>(a, ws, stream)) != CN_OK) return rc;
     if ((rc = pt_launch<1>(a, ws, stream)) != CN_OK) return rc;
@@ -865,8 +1000,7 @@ extern "C" int cn_pretime_fwd_f32(const float* x, long xbs, const void* const* p
 }
 
 // grads: HOST array of 14 device pointers: per branch {dwa, dwb, dgamma3, dbeta3, dgamma2, dbeta2}, then
-// {d ln_gamma, d ln_beta}; all ACCUMULATED. dy in the layout of y. The workspace must be the one of the forward call
-// (with_backward = 1 sizing) only for its transposed weights, which are re-made here.
+// {d ln_gamma, d ln_beta}; all ACCUMULATED. dy in the layout of y.
 extern "C" int cn_pretime_bwd_f32(const float* x, long xbs, const void* const* params, float* const* stats,
                                   const void* dy, long dy_stride, int out_kind, float* const* grads, int B, int C, int T,
                                   int HW, int Cout, int training, const float* bn, float eps_ln, float* ws,
@@ -882,8 +1016,8 @@ extern "C" int cn_pretime_bwd_f32(const float* x, long xbs, const void* const* p
     r.dwa = g[0]; r.dwb = g[1]; r.dg3 = g[2]; r.db3 = g[3]; r.dg2 = g[4]; r.db2 = g[5];
   }
   a.dgL = grads[12]; a.dbL = grads[13];
-  CN_LAUNCH(cn_pretime_pack_kernel, dim3(8), dim3(256), 0, stream, a, const_cast<float*>(a.br[0].wbt),
-            const_cast<float*>(a.br[1].wbt));
+  if (pt_cmax(C) == 4) CN_LAUNCH(cn_pretime_pack_kernel<4>, dim3(8), dim3(256), 0, stream, a, 2);
+  else CN_LAUNCH(cn_pretime_pack_kernel<8>, dim3(8), dim3(256), 0, stream, a, 2);
   if ((rc = pt_launch<3>(a, ws, stream)) != CN_OK) return rc;
   if ((rc = pt_launch<4>(a, ws, stream)) != CN_OK) return rc;
   if ((rc = pt_launch<5>(a, ws, stream)) != CN_OK) return rc;

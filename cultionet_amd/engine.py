@@ -921,10 +921,10 @@ def time_conv(x: Var, mod, tin: int) -> Var:
 
 
 _pt_ws: T.Dict[T.Tuple, torch.Tensor] = {}
-# The fused PreTimeReduction family (csrc/cn_pretime.hip) is correct (tests/test_pretime_gpu.py) but, as measured in round
-# 4, not yet faster than the op-by-op path it would replace (batch 32: forward 266 us, backward 1074 us against ~450 /
-# ~700 us): OFF by default, CN_PRETIME_FUSED=1 switches it on.
-_PRETIME_FUSED = os.environ.get("CN_PRETIME_FUSED", "0") == "1"
+# The fused PreTimeReduction family (csrc/cn_pretime.hip). CN_PRETIME_FUSED = "infer" (default): the
+# inference forward only (one launch instead of ~12); "1": training too (measured 1 % SLOWER end to end in round 4: its
+# three backward passes are the tail of the step, 620 us against the ~430 us of the op-by-op tail); "0": never.
+_PRETIME_FUSED = os.environ.get("CN_PRETIME_FUSED", "infer")
 
 
 def _pretime_ws(need: int, dev: torch.device) -> torch.Tensor:
@@ -948,9 +948,9 @@ def pretime_reduction(x: Var, pre, in_channels: int, in_time: int) -> T.Optional
     fused kernels do not cover (the caller keeps the generic op-by-op path)."""
     import ctypes
 
-    if not _PRETIME_FUSED:
-        return None
     tape = current_tape()
+    if _PRETIME_FUSED == "0" or (_PRETIME_FUSED != "1" and (tape.enabled or pre.training)):
+        return None
     xt = _check(x.t)
     if is16(xt) or x.req or not xt.is_contiguous():
         return None

@@ -81,6 +81,42 @@ def test_native_train_step_matches_reference(golden_dir, name, kw):
     assert int(sd[k0 + "num_batches_tracked"]) == 1
 
 
+@pytest.mark.parametrize("name", ["train_h8_b2_28_masked", "train_h32_b1_100", "train_h32_b8_100"])
+def test_native_train_step_with_fused_pretime_matches_reference(golden_dir, name, monkeypatch):
+    """The same step with the fused PreTimeReduction kernel family (cn_pretime_*) switched on for TRAINING
+    (CN_PRETIME_FUSED=1; by default it serves inference only): loss, maps, masks and every gradient norm -- including
+    the eighteen PreTimeReduction parameters whose gradients the three fused backward passes produce -- against the
+    reference fixtures at the same tolerances."""
+    from cultionet_amd import engine as E
+    from cultionet_amd.lightning import HipTrainer
+
+    monkeypatch.setattr(E, "_PRETIME_FUSED", "1")
+    g = np.load(os.path.join(golden_dir, name + ".npz"))
+    lit, ref, batch = _setup(g)
+    lit.train()
+    trainer = HipTrainer(lit)
+    calls = []
+    orig = E._lib.call
+    monkeypatch.setattr(E._lib, "call", lambda n, *a: (calls.append(n), orig(n, *a))[1])
+    loss = trainer.forward_backward(batch)
+    torch.cuda.synchronize()
+    assert "cn_pretime_fwd_f32" in calls and "cn_pretime_bwd_f32" in calls  # the fused path really ran
+    assert abs(float(loss.item()) - float(g["loss"])) <= TOL, (float(loss.item()), float(g["loss"]))
+    if all(k in g.files for k in KEYS):
+        _check_outputs(trainer.last_outputs, g)
+    model = lit.cultionet_model.mask_model
+    norms = {n: float(trainer.store.grad_of(p).double().norm()) for n, p in model.named_parameters()}
+    bad = []
+    for n, refn in zip(g["grad_names"], g["grad_norms"]):
+        if abs(norms[str(n)] - refn) > 2e-3 * max(1e-3, abs(refn)) + 1e-6:
+            bad.append((str(n), norms[str(n)], float(refn)))
+    assert not bad, bad[:8]
+    sd = model.state_dict()
+    for k in ("pre_unet.conv3.seq.1.running_mean", "pre_unet.conv5.seq.5.running_var"):
+        assert torch.isfinite(sd[k]).all() and float(sd[k].abs().sum()) > 0
+    assert int(sd["pre_unet.conv3.seq.1.num_batches_tracked"]) == 1
+
+
 @pytest.mark.parametrize("name,kw", [("train_h8_b2_28", {}), ("train_h32_b1_100_masked", {})])
 def test_dropin_forward_calc_loss_backward(golden_dir, name, kw):
     """The LightningModule surface: forward(Data) -> calc_loss -> loss.backward() through torch.autograd."""

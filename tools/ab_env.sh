@@ -1,0 +1,13 @@
+#!/bin/bash
+# Same-box A/B of an environment switch: bash tools/ab_env.sh VAR A B [bench args]  (two rounds each, interleaved)
+VAR=$1; A=$2; B=$3; shift 3
+R=$GRAFT_REPO_ROOT
+for round in 1 2; do
+  for v in $A $B; do
+    for P in bf16 f32; do
+      X=""; [ $P = bf16 ] && X="--dtype bf16"
+      env $VAR=$v python3 $R/bench.py $X --steps 20 --warmup 5 --no-cpu-baseline --no-extras "$@" 2>/dev/null | python3 -c "
+import json,sys; d=json.loads(sys.stdin.readline()); print('$VAR=$v $P', round(d['value'],1), round(d['ms_per_step'],3), d['config']['kernel_launches_per_step'])"
+    done
+  done
+done
