@@ -353,12 +353,14 @@ __global__ __launch_bounds__(256, PT_MINB) void cn_pretime_kernel(const CnPtArgs
 
   const int my = lacc + wid * NV;  // this wave's accumulators (LDS offset)
   auto wsum = [&](int v, float val) {  // full-wave sum (both halves belong to the same value)
+    // (ds_add_f32, no return value: nothing waits for it -- a read-modify-write here exposed one LDS round trip per
+    // VALUE, 100-200 of them per tile; the address belongs to this wave alone, so the order of the adds is the program's)
     const float t = cn_wave_sum_to_lane63(val);
-    if (lane == 63) SM(my + (v)) += t;
+    if (lane == 63) atomicAdd(&SM(my + (v)), t);
   };
   auto hsum = [&](int v, float val, bool on) {  // per-half sum: lanes 31 / 63 own different values v
     const float t = pt_half_sum(val);
-    if (l32 == 31 && on) SM(my + (v)) += t;
+    if (l32 == 31 && on) atomicAdd(&SM(my + (v)), t);
   };
 
   f32x16 accW[2][MT][NE];  // PASS 4: dWb accumulators (cout x entry tiles), summed over the wave's tiles
