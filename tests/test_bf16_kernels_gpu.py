@@ -713,3 +713,35 @@ def test_conv_bn_act_fused_eval_bf16(case):
         _lib.call("cn_conv2d_fwd_fused_bf16", xg.data_ptr(), _ld(xg), wp.data_ptr(), sh.data_ptr(), y2.data_ptr(),
                   _ld(y2), y2.data_ptr(), _ld(y2), B, Cin, H, W, Cout, k, k, s, p, d, act, _s())
         _close(y2, yr, 8e-3, "y in place")
+
+
+@pytest.mark.parametrize("shape", [(128, 128, 3), (130, 72, 3), (128, 480, 1), (8, 128, 3), (256, 40, 1), (512, 256, 3)])
+def test_pack_weights_batched_bf16_matches_single(shape):
+    """The LDS-tiled batched repack (fp32 masters -> bf16 MFMA fragments, all layers in one launch) against the plain
+    gather pack, for the stride patterns of Conv2d fwd / bwd-data and ConvTranspose2d fwd / bwd-data: bit-identical."""
+    import struct
+
+    from cultionet_amd import _lib
+
+    cout, cin, k = shape
+    taps = k * k
+    dev = _dev()
+    w = _rand(cout, cin, k, k, seed=5).to(dev)
+    s = _s()
+    pats = [(cin, cout, taps, cin * taps), (cout, cin, cin * taps, taps),  # conv fwd, conv bwd-data
+            (cout, cin, cin * taps, taps), (cin, cout, taps, cin * taps)]  # convT fwd (w as [Cin=cout][Cout=cin]), bwd
+    singles, outs, buf = [], [], bytearray()
+    for (K, N, sk, sn) in pats:
+        n = _lib.query("cn_bconv_packed_elems", taps, K, N)
+        a = torch.full((n,), float("nan"), dtype=BF, device=dev)
+        b = torch.full((n,), float("nan"), dtype=BF, device=dev)
+        _lib.call("cn_pack_weights_bf16", w.data_ptr(), a.data_ptr(), taps, K, N, sk, sn, 1, s)
+        buf += struct.pack("<QQiiiiiiqqqQ", w.data_ptr(), b.data_ptr(), taps, K, N, (K + 15) // 16, (N + 31) // 32, 0, sk,
+                           sn, 1, 0)
+        singles.append(a)
+        outs.append(b)
+    table = torch.frombuffer(buf, dtype=torch.uint8).clone().to(dev)
+    _lib.call("cn_pack_weights_batched_bf16", table.data_ptr(), len(pats), s)
+    torch.cuda.synchronize()
+    for a, b in zip(singles, outs):
+        assert torch.equal(a.view(torch.int16).cpu(), b.view(torch.int16).cpu())
