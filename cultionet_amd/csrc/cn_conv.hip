@@ -25,6 +25,51 @@
 
 static int cn_reduce_slices(const CnConvGeom& g, hipStream_t stream);
 
+// ---- epilogue shared by the two implicit-GEMM kernels: D[i = cout][j = pixel]; lane = pixel -> coalesced along W.
+// Split-K / summed-group launches store each block's partial tile into its own workspace slice and
+// cn_conv_reduce_kernel sums the slices. (Round 4 measured the alternative -- a per-tile ticket, the block that draws a
+// tile's last ticket summing its slices in index order: 67 launches fewer per fp32 step and 9 % SLOWER end to end,
+// 369 -> 335 chips/s. A tile's slices are 64 KiB x 6..16 read by ONE block with dword loads at memory latency,
+// ~45 us per launch, where the reduce kernel spreads the same bytes over the chip in 8 us. Tickets pay for rows of a few
+// hundred floats -- cn_ticket.h -- not for slabs.)
+template <int TN, int TM>
+__device__ __forceinline__ void cn_igemm_epilogue(const CnConvGeom& g, const f32x16 (&acc)[TN][TM],
+                                                  const bool (&pix_ok)[TM], const int (&out_off)[TM], int co_base,
+                                                  int half, int grp, int split, int b,
+                                                  const float* __restrict__ bias, float* __restrict__ y) {
+  const int HWout = g.Hout * g.Wout;
+  const bool sliced = g.slice_stride != 0;  // split-K partials go to private workspace slices (no atomics)
+  float* yb = sliced ? g.part + (long)(grp * g.splits + split) * g.slice_stride + (long)b * g.Cout * HWout
+                     : y + (long)b * g.ybs;
+  const bool first = split == 0;  // shared_y: every group adds its bias (sum semantics)
+#pragma unroll
+  for (int tn = 0; tn < TN; ++tn) {
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int co = co_base + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (co < g.Cout) {
+        const float bv = (bias != nullptr && first) ? bias[co] : 0.f;
+#pragma unroll
+        for (int tm = 0; tm < TM; ++tm) {
+          if (pix_ok[tm]) {
+            float* dst = yb + (long)co * HWout + out_off[tm];
+            const float v = acc[tn][tm][r] + bv;
+            if (sliced) {
+              *dst = acc[tn][tm][r];
+            } else if (g.atomic_out) {
+              atomicAdd(dst, v);
+            } else if (g.accumulate) {
+              *dst += v;
+            } else {
+              *dst = v;
+            }
+          }
+        }
+      }
+    }
+  }
+}
+
 // Software-pipelined implicit GEMM.
 //   NI_T: halo plane capacity = NI_T*256 floats per channel (register prefetch uses NI_T*KC VGPRs)
 // grid = (tiles over all classes and images, N tiles, K splits)
@@ -201,38 +246,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const CnConvGeom g) 
 #undef CN_PREFETCH
   }
 
-  // ---- epilogue: D[i = cout][j = pixel]; lane = pixel -> coalesced along W
-  const int HWout = g.Hout * g.Wout;
-  const bool sliced = g.slice_stride != 0;  // split-K partials go to private workspace slices (no atomics)
-  float* yb = sliced ? g.part + (long)(grp * g.splits + split) * g.slice_stride + (long)b * g.Cout * HWout
-                     : y + (long)b * g.ybs;
-  const bool first = split == 0;  // shared_y: every group adds its bias (sum semantics)
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = n0 + wn * (TN * 32) + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co < g.Cout) {
-        const float bv = (bias != nullptr && first) ? bias[co] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < 2; ++tm) {
-          if (pix_ok[tm]) {
-            float* dst = yb + (long)co * HWout + out_off[tm];
-            const float v = acc[tn][tm][r] + bv;
-            if (sliced) {
-              *dst = acc[tn][tm][r];
-            } else if (g.atomic_out) {
-              atomicAdd(dst, v);
-            } else if (g.accumulate) {
-              *dst += v;
-            } else {
-              *dst = v;
-            }
-          }
-        }
-      }
-    }
-  }
+  cn_igemm_epilogue<TN, 2>(g, acc, pix_ok, out_off, n0 + wn * (TN * 32), half, grp, split, b, bias, y);
 }
 
 // Same GEMM with 16-byte staging ("flattened rows"): when channel planes are 16-byte aligned (H*W % 4 == 0) the
@@ -249,6 +263,15 @@ __global__ __launch_bounds__(256, (NV <= 1 ? 2 : 1)) void cn_conv_igemm_vec_kern
   constexpr int NT = WAVES_N * TN * 32;
   constexpr int WI = (CN_MAX_TAPS * KC * (NT / 4) + 255) / 256;
   constexpr int VS = NV * 1024;  // LDS channel stride (floats): compile-time so channel-pair offsets are DS immediates
+  // RP == 3: unpadded rows (as RP == 0) over ODD planes (H*W % 4 == 1: 25x25, 13x13, 99x99 ...): plane c starts
+  // (c % 4) floats past a 16-byte boundary, so channel ci of a chunk is fetched from its plane base rounded DOWN
+  // (delta = ci % 4 floats early; the chunk's first channel is a multiple of 4) and its LDS image is laid at channel
+  // stride VS + 1: 16-byte piece e4 of channel ci lands at ci*VS + (ci & ~3) + e4 (aligned), i.e. plane element q at
+  // ci*(VS+1) + q - f0 -- the same image as the aligned kernel's at a channel stride that is still a DS immediate.
+  // The two pieces that straddle a plane's ends are masked element-wise when they are written to LDS.
+  constexpr bool PADR = RP == 1 || RP == 2;
+  constexpr int ODD = RP == 3 ? 1 : 0;
+  constexpr int VSS = VS + ODD;
   extern __shared__ __attribute__((aligned(16))) float smem[];
   float* in_lds = smem;               // [KC][VS]
   float* w_lds = smem + g.w_lds_off;  // [ntaps*KC][NT]
@@ -279,9 +302,9 @@ __global__ __launch_bounds__(256, (NV <= 1 ? 2 : 1)) void cn_conv_igemm_vec_kern
   const int m0 = (tile - b * tiles_per_img) * MT;
   const int Win = g.Win;
   // RP: rows padded in LDS by a zero gap of >= 4 floats (serves both neighbours' halos); pitch % 4 == 0
-  const int pitch = RP ? ((Win + 3) / 4 * 4 + 4) : Win;
+  const int pitch = PADR ? ((Win + 3) / 4 * 4 + 4) : Win;
   if (tid < ntaps) {
-    tap_lds[tid] = RP ? (g.cls[ci_].dy[tid] - min_dy) * pitch + g.cls[ci_].dx[tid]
+    tap_lds[tid] = PADR ? (g.cls[ci_].dy[tid] - min_dy) * pitch + g.cls[ci_].dx[tid]
                       : (g.cls[ci_].dy[tid] - min_dy) * Win + (g.cls[ci_].dx[tid] - min_dx);
     tap_lds[CN_MAX_TAPS + tid] = g.cls[ci_].wt[tid];
     tap_lds[2 * CN_MAX_TAPS + tid] = g.cls[ci_].dx[tid];
@@ -294,7 +317,7 @@ __global__ __launch_bounds__(256, (NV <= 1 ? 2 : 1)) void cn_conv_igemm_vec_kern
   // flattened-row image: RP == false: unpadded, origin `start` aligned down to 16 bytes (shift sh), column
   // overruns masked at read time. RP == true (Win % 4 == 0): whole rows [iy_base, iy_base+rows) x [0, Win), each
   // followed by a 4-float zero gap in LDS, so taps that step over a row end read zeros and need no mask.
-  const int start = RP ? (gy0 * g.is + min_dy) * Win : (gy0 * g.is + min_dy) * Win + min_dx;
+  const int start = PADR ? (gy0 * g.is + min_dy) * Win : (gy0 * g.is + min_dy) * Win + min_dx;
   const int f0 = (start >> 2) << 2;  // aligned down (arithmetic shift: floor)
   const int sh = start - f0;         // 0 when RP == 1; 0 or 2 when RP == 2
 
@@ -303,13 +326,13 @@ __global__ __launch_bounds__(256, (NV <= 1 ? 2 : 1)) void cn_conv_igemm_vec_kern
   int ldst2[NV];  // RP == 2 (Win % 4 == 2): offset of the second half -- a chunk may straddle two rows
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
-    const int e4 = 4 * (tid + i * 256) - (RP ? sh : 0);  // RP: element index relative to the first staged row
-    const int lim = RP ? g.cls[ci_].rows * Win : vplane;
+    const int e4 = 4 * (tid + i * 256) - (PADR ? sh : 0);  // RP: element index relative to the first staged row
+    const int lim = PADR ? g.cls[ci_].rows * Win : vplane;
     ldst[i] = 0;
     ldst2[i] = 0;
     if (e4 + 3 >= 0 && e4 < lim) {
-      const int fq = start + e4 - (RP ? 0 : sh);
-      goff[i] = (fq >= 0 && fq + 3 < HWin) ? fq : -1;
+      const int fq = start + e4 - (PADR ? 0 : sh);
+      goff[i] = (fq >= 0 && (ODD ? fq < HWin : fq + 3 < HWin)) ? fq : -1;  // ODD: fq % 4 == 0, the last piece is partial
       if (RP == 1) {
         const int r = e4 / Win;
         ldst[i] = r * pitch + 4 + (e4 - r * Win);
@@ -326,7 +349,7 @@ __global__ __launch_bounds__(256, (NV <= 1 ? 2 : 1)) void cn_conv_igemm_vec_kern
       goff[i] = -2;
     }
   }
-  if (RP) {  // gaps are never written by the staging: zero the channel images once
+  if (PADR) {  // gaps are never written by the staging: zero the channel images once
     for (int e = tid; e < KC * VS; e += 256) in_lds[e] = 0.f;
   }
 
@@ -339,8 +362,8 @@ __global__ __launch_bounds__(256, (NV <= 1 ? 2 : 1)) void cn_conv_igemm_vec_kern
     pix_ok[tm] = p < Mimg;
     const int pc = pix_ok[tm] ? p : Mimg - 1;
     const int gy = pc / Wg, gx = pc - gy * Wg;
-    pix_lds[tm] = RP ? ((gy - gy0) * g.is) * pitch + 4 + gx * g.is + half * VS
-                     : ((gy - gy0) * g.is) * Win + gx * g.is + sh + half * VS;
+    pix_lds[tm] = PADR ? ((gy - gy0) * g.is) * pitch + 4 + gx * g.is + half * VS
+                     : ((gy - gy0) * g.is) * Win + gx * g.is + sh + half * VSS;
     out_off[tm] = (gy * g.os + oy0) * g.Wout + gx * g.os + ox0;
     unsigned m = 0;
     for (int t = 0; t < ntaps; ++t) {
@@ -395,7 +418,7 @@ __global__ __launch_bounds__(256, (NV <= 1 ? 2 : 1)) void cn_conv_igemm_vec_kern
     const int c0 = (c0_);                                                                                  \
     _Pragma("unroll") for (int ci = 0; ci < KC; ++ci) {                                                    \
       if ((c0 + ci) < g.Cin) { /* wave-uniform */                                                          \
-        const int so = (c0 + ci) * HWin * 4;                                                               \
+        const int so = ODD ? (((c0 + ci) * HWin) & ~3) * 4 : (c0 + ci) * HWin * 4;                                                               \
         _Pragma("unroll") for (int i = 0; i < NV; ++i)                                                     \
             xin[ci][i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, xo[i], so, 0)); \
       } else {                                                                                             \
@@ -417,6 +440,15 @@ __global__ __launch_bounds__(256, (NV <= 1 ? 2 : 1)) void cn_conv_igemm_vec_kern
             if (RP == 2) {
               if (ldst[i] >= 0) *reinterpret_cast<float2*>(in_lds + ci * VS + ldst[i]) = make_float2(xin[ci][i][0], xin[ci][i][1]);
               if (ldst2[i] >= 0) *reinterpret_cast<float2*>(in_lds + ci * VS + ldst2[i]) = make_float2(xin[ci][i][2], xin[ci][i][3]);
+            } else if (ODD) {
+              f32x4 v = xin[ci][i];
+              const int dl = ci & 3;  // floats this channel's pieces start before the plane-relative index (unrolled: a constant)
+              const bool first = dl > 0 && goff[i] == 0;         // first piece: its first dl floats are the previous plane's
+              const bool last = dl < 3 && goff[i] == HWin - 1;   // last piece: only elements 0..dl are inside the plane
+#pragma unroll
+              for (int j = 0; j < 4; ++j)
+                if ((first && j < dl) || (last && j > dl)) v[j] = 0.f;
+              *reinterpret_cast<f32x4*>(in_lds + ci * VS + (ci & ~3) + ldst[i]) = v;
             } else {
               *reinterpret_cast<f32x4*>(in_lds + ci * VS + ldst[i]) = xin[ci][i];
             }
@@ -440,7 +472,7 @@ __global__ __launch_bounds__(256, (NV <= 1 ? 2 : 1)) void cn_conv_igemm_vec_kern
 #pragma unroll
         for (int tm = 0; tm < TM; ++tm) {
           brow[tm] = in_lds + pix_lds[tm] + toff;
-          msk[tm] = RP ? -1 : __builtin_amdgcn_sbfe((int)colmask[tm], t, 1);
+          msk[tm] = PADR ? -1 : __builtin_amdgcn_sbfe((int)colmask[tm], t, 1);
         }
 #pragma unroll
         for (int cp = 0; cp < KC / 2; ++cp) {
@@ -449,7 +481,7 @@ __global__ __launch_bounds__(256, (NV <= 1 ? 2 : 1)) void cn_conv_igemm_vec_kern
           for (int tn = 0; tn < TN; ++tn) a[tn] = wrow[(2 * cp) * NT + tn * 32];
 #pragma unroll
           for (int tm = 0; tm < TM; ++tm)
-            bb[tm] = RP ? brow[tm][(2 * cp) * VS] : __int_as_float(__float_as_int(brow[tm][(2 * cp) * VS]) & msk[tm]);
+            bb[tm] = PADR ? brow[tm][(2 * cp) * VS] : __int_as_float(__float_as_int(brow[tm][(2 * cp) * VSS]) & msk[tm]);
 #pragma unroll
           for (int tn = 0; tn < TN; ++tn)
 #pragma unroll
@@ -461,37 +493,7 @@ __global__ __launch_bounds__(256, (NV <= 1 ? 2 : 1)) void cn_conv_igemm_vec_kern
 #undef CN_PREFETCH_V
   }
 
-  const int HWout = g.Hout * g.Wout;
-  const bool sliced = g.slice_stride != 0;  // split-K partials go to private workspace slices (no atomics)
-  float* yb = sliced ? g.part + (long)(grp * g.splits + split) * g.slice_stride + (long)b * g.Cout * HWout
-                     : y + (long)b * g.ybs;
-  const bool first = split == 0;  // shared_y: every group adds its bias (sum semantics)
-#pragma unroll
-  for (int tn = 0; tn < TN; ++tn) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      const int co = n0 + wn * (TN * 32) + tn * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
-      if (co < g.Cout) {
-        const float bv = (bias != nullptr && first) ? bias[co] : 0.f;
-#pragma unroll
-        for (int tm = 0; tm < TM; ++tm) {
-          if (pix_ok[tm]) {
-            float* dst = yb + (long)co * HWout + out_off[tm];
-            const float v = acc[tn][tm][r] + bv;
-            if (sliced) {
-              *dst = acc[tn][tm][r];
-            } else if (g.atomic_out) {
-              atomicAdd(dst, v);
-            } else if (g.accumulate) {
-              *dst += v;
-            } else {
-              *dst = v;
-            }
-          }
-        }
-      }
-    }
-  }
+  cn_igemm_epilogue<TN, TM>(g, acc, pix_ok, out_off, n0 + wn * (TN * 32), half, grp, split, b, bias, y);
 }
 
 // Wp[t][k][n] = (k < K && n < N) ? w[k*sk + n*sn + t*st] : 0
@@ -902,9 +904,11 @@ static int cn_launch_vec_cfg(const float* x, const float* wp, const float* bias,
   const CnPlan p = cn_plan(g, MT);
   if (p.total_tiles <= 0) return CN_OK;
   // row-padded LDS image (no read-time masks) when rows are whole 16-byte pieces and the padded image fits
-  const int rp = (p.max_rplane <= 4096 && p.max_absdx <= 4) ? (g.Win % 4 == 0 ? 1 : (g.Win % 2 == 0 ? 2 : 0)) : 0;
-  const int img = rp ? p.max_rplane : p.max_vplane;
-  g.w_lds_off = KC * 1024 * (img <= 1024 ? 1 : (img <= 2048 ? 2 : 4));
+  const int rp = g.odd_planes ? 3
+                 : (p.max_rplane <= 4096 && p.max_absdx <= 4) ? (g.Win % 4 == 0 ? 1 : (g.Win % 2 == 0 ? 2 : 0)) : 0;
+  const int img = (rp == 1 || rp == 2) ? p.max_rplane : p.max_vplane;
+  // (odd planes: the channel images sit at stride VS + 1, the last one ends up to 8 floats later)
+  g.w_lds_off = KC * 1024 * (img <= 1024 ? 1 : (img <= 2048 ? 2 : 4)) + (rp == 3 ? 16 : 0);
   const int rc = cn_finish_split(g, p, splits, cps, y, stream);
   if (rc != CN_OK) return rc;
 #define CN_GO(NV_, RP_) \
@@ -918,6 +922,11 @@ static int cn_launch_vec_cfg(const float* x, const float* wp, const float* bias,
     if (img <= 1024) CN_GO(1, 2);
     if (img <= 2048) CN_GO(2, 2);
     CN_GO(4, 2);
+  }
+  if (rp == 3) {
+    if (img <= 1024) CN_GO(1, 3);
+    if (img <= 2048) CN_GO(2, 3);
+    CN_GO(4, 3);
   }
   if (img <= 1024) CN_GO(1, 0);
   if (img <= 2048) CN_GO(2, 0);
@@ -1153,7 +1162,15 @@ int cn_conv_igemm_launch(CnConvGeom& g, hipStream_t stream) {
                        (((long)g.B * g.Cout * g.Hout * g.Wout + 3) / 4 * 4) * g.G * 32 <= g_conv_ws_floats;
   const bool allow_split = dense_out || g.accumulate || ws_fits;
   if (g.G > 1 && g.shared_y && !allow_split) return CN_ERR_ARG;
-  bool vec = (((long)g.Hin * g.Win) % 4 == 0) && (g.xbs % 4 == 0);
+  // 16-byte staging needs every image 16-byte aligned and either aligned planes (H*W % 4 == 0) or the odd-plane variant
+  // (H*W % 4 == 1: every odd square -- 25x25, 13x13, 99x99, 49x49, 97x97)
+  static const bool odd_vec = getenv("CN_ODD_VEC") == nullptr || atoi(getenv("CN_ODD_VEC")) != 0;  // A/B switch
+  const int hw4 = (int)(((long)g.Hin * g.Win) % 4);
+  // (measured per layer at batch 8, same box: 25x25 and 49x49 planes 3-9 % faster than the dword kernel, the stride-4
+  // scatter 25x25 -> 97x97 1.5x; strided gathers from 99x99 -- two float4 pieces per thread and channel -- 20 % slower:
+  // those stay on the dword kernel)
+  g.odd_planes = (hw4 == 1 && odd_vec && !(g.is > 1 && (long)g.Hin * g.Win > 4096)) ? 1 : 0;
+  bool vec = (hw4 == 0 || g.odd_planes) && (g.xbs % 4 == 0);
   // the kernels' buffer loads carry 31-bit byte offsets inside one image / one packed weight tensor
   if ((long)g.Cin * g.Hin * g.Win * 4 >= (1L << 31) || (long)CN_MAX_TAPS * cn_conv_kpad(g.Cin) * g.Npad * 4 >= (1L << 31))
     return CN_ERR_ARG;

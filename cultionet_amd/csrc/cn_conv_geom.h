@@ -35,6 +35,7 @@ struct CnConvGeom {
   // groups: G independent (input, weights, bias, output) sets in one launch; each class names its group
   // (CnConvClass::grp), so groups may differ in taps (dilation). shared_y: all groups sum into one output.
   int G, splits, shared_y;
+  int odd_planes;      // H*W % 4 == 1: the 16-byte staging kernel runs its odd-plane variant (RP == 3)
   float* part;         // split-K partial slices [(grp * splits + split)][B][Cout][Hout][Wout] (slice_stride != 0)
   long slice_stride;
   int grid_x, grid_y;  // logical grid (pixel tiles, N tiles); z = splits. Launched 1-D in XCD-aware order

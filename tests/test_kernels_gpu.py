@@ -74,6 +74,15 @@ CONV_CASES = [
     (8, 576, 50, 50, 128, 3, 1, 1, 1, False),    # tower_b block 0
     (8, 640, 25, 25, 128, 3, 1, 1, 1, False),    # tower_c block 0
     (8, 480, 100, 100, 128, 1, 1, 0, 1, True),   # tower_a skip
+    # odd planes (H*W % 4 == 1) through the 16-byte staging kernel's odd-plane variant: per-channel alignment shifts,
+    # the two partial pieces at a plane's ends, ragged channel chunks, stride 2 from an odd plane, dilation
+    (8, 128, 25, 25, 128, 3, 1, 1, 1, False),    # up_cu / tower_c blocks
+    (8, 256, 13, 13, 256, 3, 1, 1, 1, True),
+    (2, 128, 99, 99, 128, 3, 2, 1, 1, False),    # pool conv from the 99x99 ConvTranspose output
+    (3, 12, 49, 49, 40, 3, 2, 1, 1, True),
+    (2, 20, 25, 25, 24, 3, 1, 2, 2, False),      # dilated, Cin % 8 != 0
+    (1, 9, 5, 5, 7, 3, 1, 1, 1, True),           # plane smaller than one tile, one image
+    (4, 64, 9, 9, 64, 1, 1, 0, 1, True),
 ]
 
 

@@ -30,3 +30,12 @@ torch.cuda.synchronize()
 t2 = time.perf_counter()
 print(f"{prec} batch {bs} replay {rp}: {(t2 - t0) / reps * 1e3:.2f} ms per scene ({HS * HS / ((t2 - t0) / reps) / 1e6:.1f} Mpx/s), "
       f"host enqueue {(t1 - t0) / reps * 1e3:.2f} ms per scene")
+if os.environ.get("CN_PROF_DUMP"):  # per-launch table of the contraction kernels: python tools/layerprof.py $CN_PROF_DUMP 3 bf16
+    import ctypes
+    from cultionet_amd import _lib
+    _lib.call("cn_profile_set_filter", None)
+    _lib.call("cn_profile_begin")
+    for _ in range(3):
+        sp.predict_scene(scene)
+    torch.cuda.synchronize()
+    _lib.call("cn_profile_end", (ctypes.c_double * 24)())
