@@ -632,11 +632,34 @@ __global__ __launch_bounds__(256) void cn_bpack_kernel(const CnBPackDesc* __rest
   for (int tl = blockIdx.x; tl < ts * tm; tl += gridDim.x) {
     const int s0 = (tl / tm) * 32, m0 = (tl % tm) * 32;
     __syncthreads();
-    for (int sr = wave; sr < 32; sr += 4)  // one wave per source row: a contiguous run of 32 * T floats
-      for (int j = lane; j < run; j += 64) {
-        const long mi = (long)m0 * T + j;
-        tile[sr * CNB_PK_PITCH + j] = (s0 + sr < S && mi < (long)M * T) ? d.w[(s0 + sr) * ss + mi] : 0.f;
+    // one wave per source row (a contiguous run of 32 * T <= 288 floats), 8 rows per wave: all 8 x 5 loads of a
+    // thread are issued before the first LDS store (clamped, never predicated -- as a loop of load -> store pairs the
+    // tile took 36 memory latencies: 258 us per step at hidden 64)
+    {
+      constexpr int NJ = (32 * CNB_MAX_TAPS + 63) / 64;
+      float v[8][NJ];
+      const long mlim = (long)M * T;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int sr = wave + 4 * i;
+        const long rowo = (long)(s0 + sr < S ? s0 + sr : S - 1) * ss;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+          const long mi = (long)m0 * T + lane + 64 * jj;
+          v[i][jj] = d.w[rowo + (mi < mlim ? mi : mlim - 1)];
+        }
       }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int sr = wave + 4 * i;
+#pragma unroll
+        for (int jj = 0; jj < NJ; ++jj) {
+          const int j = lane + 64 * jj;
+          const long mi = (long)m0 * T + j;
+          if (j < run) tile[sr * CNB_PK_PITCH + j] = (s0 + sr < S && mi < mlim) ? v[i][jj] : 0.f;
+        }
+      }
+    }
     __syncthreads();
     const int k0 = n_slow ? m0 : s0, n0 = n_slow ? s0 : m0;
     const int nt = n0 >> 5;
