@@ -362,6 +362,7 @@ class ParamStore:
         params = [p for p in module.parameters()]
         if not params:
             raise ValueError("module has no parameters")
+        params = self._with_contiguous_groups(module, params)
         dev = params[0].device
         if dev.type != "cuda":
             raise RuntimeError("ParamStore needs the module on the GPU (call .to('cuda') first)")
@@ -386,6 +387,35 @@ class ParamStore:
         self._pack_table: T.Optional[torch.Tensor] = None
         self._packs16: T.List[T.Tuple] = []    # the same for the bf16 MFMA-fragment copies
         self._pack_table16: T.Optional[torch.Tensor] = None
+
+    @staticmethod
+    def _with_contiguous_groups(module: torch.nn.Module, params: T.List[torch.nn.Parameter]) -> T.List[torch.nn.Parameter]:
+        """Registration order with the members of every declared group made adjacent (at the place of the group's first
+        member). A submodule declares groups through ``cn_contiguous_params()`` -> lists of parameters that one kernel
+        reads / writes as ONE tensor (the three 128 -> 3 head convolutions of a tower: one 128 -> 9 convolution on the
+        views, no concatenated copies of weights or gradients). Members must be multiples of 4 elements (the store pads
+        every slice to 16 bytes: a padded member would break adjacency)."""
+        first_of, member = {}, set()
+        for m in module.modules():
+            fn = getattr(m, "cn_contiguous_params", None)
+            if fn is None:
+                continue
+            for grp in fn():
+                grp = list(grp)
+                if len(grp) < 2 or any(q.numel() % 4 for q in grp) or any(id(q) in member for q in grp):
+                    continue
+                first_of[id(grp[0])] = grp
+                member.update(id(q) for q in grp)
+        if not first_of:
+            return params
+        out = []
+        for q in params:
+            if id(q) in first_of:
+                out.extend(first_of[id(q)])
+            elif id(q) not in member:
+                out.append(q)
+        assert len(out) == len(params)
+        return out
 
     def owns(self, module: torch.nn.Module) -> bool:
         lo, hi = self._base, self._base + self.numel * 4
@@ -2326,12 +2356,13 @@ class _ThinPack16:
     parameters change): the three head streams of a tower run as ONE 128 -> 9 convolution, one 9 -> 128 backward-data
     and one weight-gradient launch instead of three each."""
 
-    __slots__ = ("wcat", "dwcat", "fwd16", "bwd16", "version", "store_id")
+    __slots__ = ("wcat", "dwcat", "fwd16", "bwd16", "version", "store_id", "view")
 
     def __init__(self):
         self.wcat = self.dwcat = self.fwd16 = self.bwd16 = None
         self.version = -1
         self.store_id = 0
+        self.view = False  # wcat is a VIEW of the store's flat buffer (the n weights are adjacent there)
 
 
 def _thin_conv3x3_bf16(x: Var, mods: T.Sequence, grouped: bool, dilation: int, out: T.Optional[torch.Tensor]) -> Var:
@@ -2357,18 +2388,39 @@ def _thin_conv3x3_bf16(x: Var, mods: T.Sequence, grouped: bool, dilation: int, o
     if tw is None or tw.store_id != id(store):
         tw = _ThinPack16()
         tw.store_id = id(store)
-        tw.wcat = torch.empty((CPt, Cin, 3, 3), dtype=torch.float32, device=xt.device)
-        tw.dwcat = torch.empty_like(tw.wcat)
+        per = CP * Cin * 9
+        w0 = mods[0].weight
+        # the store keeps declared groups adjacent (ParamStore._with_contiguous_groups): the n weights ARE one
+        # [n*CP][Cin][3][3] tensor, and so are their gradients -- no concatenated copies, no per-step copy / pack / zero /
+        # copy-back launches (27 per step for the three towers)
+        tw.view = all(m.weight.is_contiguous() and m.weight.data_ptr() == w0.data_ptr() + 4 * per * i
+                      for i, m in enumerate(mods))
         tw.fwd16 = torch.empty(_lib.query("cn_bconv_packed_elems", 9, Cin, CPt), dtype=torch.bfloat16, device=xt.device)
         tw.bwd16 = torch.empty(_lib.query("cn_bconv_packed_elems", 9, CPt, Cin), dtype=torch.bfloat16, device=xt.device)
+        if tw.view:
+            o = (w0.data_ptr() - store._base) // 4
+            tw.wcat = store.flat[o:o + n * per].view(CPt, Cin, 3, 3)
+            tw.dwcat = None  # the flat gradient slice of the moment (the bridge swaps flat_grad): looked up at use
+            s = _stream()
+            _lib.call("cn_pack_weights_bf16", tw.wcat.data_ptr(), tw.fwd16.data_ptr(), 9, Cin, CPt, 9, Cin * 9, 1, s)
+            _lib.call("cn_pack_weights_bf16", tw.wcat.data_ptr(), tw.bwd16.data_ptr(), 9, CPt, Cin, Cin * 9, 9, 1, s)
+            store.register_pack16(tw, "fwd16", tw.fwd16, tw.wcat, 9, Cin, CPt, 9, Cin * 9, 1)
+            store.register_pack16(tw, "bwd16", tw.bwd16, tw.wcat, 9, CPt, Cin, Cin * 9, 9, 1)
+            tw.version = store.version
+        else:
+            tw.wcat = torch.empty((CPt, Cin, 3, 3), dtype=torch.float32, device=xt.device)
+            tw.dwcat = torch.empty_like(tw.wcat)
         mods[0].__dict__["_cn_thin16"] = tw
     if tw.version != store.version:
-        s = _stream()
-        per = CP * Cin * 9
-        for i, m in enumerate(mods):
-            _lib.call("cn_copy_f32", m.weight.data_ptr(), per, tw.wcat[i * CP].data_ptr(), per, 1, per, 0, s)
-        _lib.call("cn_pack_weights_bf16", tw.wcat.data_ptr(), tw.fwd16.data_ptr(), 9, Cin, CPt, 9, Cin * 9, 1, s)
-        _lib.call("cn_pack_weights_bf16", tw.wcat.data_ptr(), tw.bwd16.data_ptr(), 9, CPt, Cin, Cin * 9, 9, 1, s)
+        if tw.view:  # registered with the batched per-step repack: one launch for every layer of the model
+            store.repack_all()
+        else:
+            s = _stream()
+            per = CP * Cin * 9
+            for i, m in enumerate(mods):
+                _lib.call("cn_copy_f32", m.weight.data_ptr(), per, tw.wcat[i * CP].data_ptr(), per, 1, per, 0, s)
+            _lib.call("cn_pack_weights_bf16", tw.wcat.data_ptr(), tw.fwd16.data_ptr(), 9, Cin, CPt, 9, Cin * 9, 1, s)
+            _lib.call("cn_pack_weights_bf16", tw.wcat.data_ptr(), tw.bwd16.data_ptr(), 9, CPt, Cin, Cin * 9, 9, 1, s)
         tw.version = store.version
     _lib.call("cn_conv2d_fwd_bf16", xt.data_ptr(), ld(xt), tw.fwd16.data_ptr(), None, y.data_ptr(), 0, CPt * HW, B, Cin,
               H, W, CPt, 3, 3, 1, dilation, dilation, 0, 1, None, _stream())
@@ -2387,13 +2439,18 @@ def _thin_conv3x3_bf16(x: Var, mods: T.Sequence, grouped: bool, dilation: int, o
                 ss = _stream()
                 need = _lib.query("cn_bwgrad_workspace_floats", B, Cin, H, W, CPt, 3, 3, 1, dilation, dilation, 0)
                 wsp, wsn = _ws16(need, xt.device)
-                _lib.call("cn_fill_f32", tw.dwcat.data_ptr(), tw.dwcat.numel(), 0.0, ss)
-                _lib.call("cn_conv2d_bwd_weight_bf16", xt.data_ptr(), ld(xt), d16.data_ptr(), cp8, tw.dwcat.data_ptr(), B,
-                          Cin, H, W, CPt, 3, 3, 1, dilation, dilation, wsp, wsn, ss)
-                per = CP * Cin * 9
-                for i, m in enumerate(mods):
-                    _lib.call("cn_copy_f32", tw.dwcat[i * CP].data_ptr(), per, store.grad_of(m.weight).data_ptr(), per,
-                              1, per, 1, ss)
+                if tw.view:  # accumulates straight into the flat gradient (zeroed once per step)
+                    _lib.call("cn_conv2d_bwd_weight_bf16", xt.data_ptr(), ld(xt), d16.data_ptr(), cp8,
+                              store.grad_of(tw.wcat).data_ptr(), B, Cin, H, W, CPt, 3, 3, 1, dilation, dilation, wsp,
+                              wsn, ss)
+                else:
+                    _lib.call("cn_fill_f32", tw.dwcat.data_ptr(), tw.dwcat.numel(), 0.0, ss)
+                    _lib.call("cn_conv2d_bwd_weight_bf16", xt.data_ptr(), ld(xt), d16.data_ptr(), cp8,
+                              tw.dwcat.data_ptr(), B, Cin, H, W, CPt, 3, 3, 1, dilation, dilation, wsp, wsn, ss)
+                    per = CP * Cin * 9
+                    for i, m in enumerate(mods):
+                        _lib.call("cn_copy_f32", tw.dwcat[i * CP].data_ptr(), per, store.grad_of(m.weight).data_ptr(),
+                                  per, 1, per, 1, ss)
             if x.req:
                 dx, acc = grad_buffer(x)
                 _lib.call("cn_conv2d_bwd_data_bf16", d16.data_ptr(), cp8, tw.bwd16.data_ptr(), dx.data_ptr(), ld(dx), B,

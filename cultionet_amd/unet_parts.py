@@ -105,6 +105,11 @@ class TowerUNetFinal(nn.Module):
         self.fuse_conv = ConvBlock2d(3, 3, kernel_size=3, padding=1, add_activation=True,
                                      activation_type=activation_type)
 
+    def cn_contiguous_params(self):
+        """The three 128 -> 3 stream weights, kept adjacent in the engine's flat parameter store: the mixed-precision path
+        runs them as one 128 -> 9 convolution on that view (engine._thin_conv3x3_bf16)."""
+        return [[s.conv[0].seq[0].weight for s in (self.dist_conv, self.edge_conv, self.crop_conv)]]
+
     def forward(self, x: E.Var, size=None, suffix: str = "") -> E.Var:
         if size is not None:
             x = self.up_conv(x, size=size)
