@@ -17,6 +17,7 @@ Design (MI355X-first, not torch.autograd):
 from __future__ import annotations
 
 import threading
+import contextlib
 import os
 import typing as T
 
@@ -951,10 +952,13 @@ def time_conv(x: Var, mod, tin: int) -> Var:
 
 
 _pt_ws: T.Dict[T.Tuple, torch.Tensor] = {}
-# The fused PreTimeReduction family (csrc/cn_pretime.hip). CN_PRETIME_FUSED = "infer" (default): the
-# inference forward only (one launch instead of ~12); "1": training too (measured 1 % SLOWER end to end in round 4: its
-# three backward passes are the tail of the step, 620 us against the ~430 us of the op-by-op tail); "0": never.
-_PRETIME_FUSED = os.environ.get("CN_PRETIME_FUSED", "infer")
+# The fused PreTimeReduction family (csrc/cn_pretime.hip). CN_PRETIME_FUSED = "1" (default): training
+# and inference (forward 3 launches / 1 in eval mode instead of ~20, backward 3 instead of ~20; same-box A/B in round 4:
+# bf16 batch 32 at parity with the op-by-op path, fp32 batch 8 +1 %, 32 / 29 launches fewer per step); "infer": the
+# inference forward only; "0": never. CN_PRETIME_BWD = "main" (default) / "side": the stream of the three backward
+# launches -- queued on the weight-gradient stream, behind the encoder's 100 x 100 weight gradients, they cost 1 %.
+_PRETIME_FUSED = os.environ.get("CN_PRETIME_FUSED", "1")
+_PRETIME_BWD = os.environ.get("CN_PRETIME_BWD", "main")
 
 
 def _pretime_ws(need: int, dev: torch.device) -> torch.Tensor:
@@ -1049,7 +1053,11 @@ def pretime_reduction(x: Var, pre, in_channels: int, in_time: int) -> T.Optional
                     raise RuntimeError("pretime_reduction: the output gradient must be NCHW with dense planes")
                 dstride = bstride(dy)
             grads = (ctypes.c_void_p * 14)(*[store.grad_of(p).data_ptr() for p in glist])
-            with side_stream(xt, dy, stats_t):  # parameter gradients only: off the data-gradient chain
+            # parameter gradients only, and the LAST node of the backward. On the compute stream: the weight-gradient
+            # stream still holds the encoder's 100 x 100 weight gradients at this point, behind which these three
+            # launches would queue (CN_PRETIME_BWD=side: measured 1 % slower end to end)
+            ctx = side_stream(xt, dy, stats_t) if _PRETIME_BWD == "side" else contextlib.nullcontext()
+            with ctx:
                 wsb = _pretime_ws(need, dev)
                 _lib.call("cn_pretime_bwd_f32", xt.data_ptr(), bstride(xt), params, stats, dy.data_ptr(), dstride, kind,
                           grads, B, C, Tn, HW, Cout, 1 if training else 0, bnc, float(ln.eps), wsb.data_ptr(),
