@@ -47,7 +47,7 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # MI355X_MICROARCH.md: f32-input M
 PEAK_HBM_GBS = 8000.0
 FAMILY = {0: "cn_conv_igemm*/cn_conv1x1 <NT=128>", 1: "cn_conv_igemm* <NT<=64>", 2: "cn_wgrad* <3x3>",
           3: "cn_wgrad* <1x1>", 4: "cn_bconv_kernel (bf16)", 5: "cn_bwgrad_kernel (bf16)"}
-PMC_FILES = {"f32": "profiles/r04_v1_pmc_traffic_f32.json", "bf16": "profiles/r04_v1_pmc_traffic_bf16.json"}
+PMC_FILES = {"f32": "profiles/r04_v2_pmc_traffic_f32.json", "bf16": "profiles/r04_v2_pmc_traffic_bf16.json"}
 
 
 def parse():
@@ -236,9 +236,10 @@ def predict_block(dev, hidden: int, cpu: bool, threads: int):
                        f"reference CLI's default batch of 4 is reported beside it), hidden {hidden} (BASELINE configs[4])",
            "unit": "pixels/s"}
 
-    def time_scene(prec, bs, n=5, pack=0):
+    def time_scene(prec, bs, n=20, pack=0):
+        # (n = 5 after two warm-up scenes read 49 where 20 scenes read 53-54 Mpx/s: the first replays still page in)
         sp = SlidingWindowPredictor(lit, window_size=100, padding=5, batch_size=bs, precision=prec, pixels_per_launch=pack)
-        for _ in range(2):
+        for _ in range(4):
             sp.predict_scene(scene)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -254,8 +255,8 @@ def predict_block(dev, hidden: int, cpu: bool, threads: int):
         tf = nwin * 110 * 110 * gflop_px / dt / 1e3
         out[tag] = {"ms_per_scene": dt * 1e3, "value": HS * HS / dt, "windows": nwin, "host_enqueue_ms": host * 1e3,
                     "roofline": {"bound": "mfma", "achieved": tf, "peak": peak, "unit": "TFLOP/s", "frac": tf / peak}}
-        dt4, host4 = time_scene(prec, 4, n=3)
-        dt4p, _ = time_scene(prec, 4, n=3, pack=400_000)
+        dt4, host4 = time_scene(prec, 4, n=8)
+        dt4p, _ = time_scene(prec, 4, n=12, pack=400_000)
         out[tag]["batch4"] = {"ms_per_scene": dt4 * 1e3, "value": HS * HS / dt4, "host_enqueue_ms": host4 * 1e3,
                               "note": "the reference CLI's default predict batch size (args.yml:248-254) launched as "
                                       "given: 9 forwards per scene, bound by dispatch latency",
