@@ -83,6 +83,7 @@ SIGNATURES = {
     "cn_pack_weights_scaled_bf16": [P, P, P, I, I, I, L, L, L, P],
     "cn_bn_fold_f32": [P, P, P, P, P, F, I, P, P, P],
     "cn_conv2d_fwd_grouped_bf16": [I, P, L, P, P, P, L, I, I, I, I, I, I, I, I, P, P, I, P, P],
+    "cn_conv2d_fwd_grouped_bnstats_bf16": [I, P, L, P, P, L, I, I, I, I, I, I, I, I, P, P, P, P, P, P, P, F, F, P, L, P, P],
     "cn_conv2d_bwd_data_bf16": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
     "cn_conv2d_bwd_data_grouped_bf16": [I, P, L, P, P, L, I, I, I, I, I, I, I, I, P, P, I, P],
     "cn_conv_transpose2d_fwd_bf16": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, P],

@@ -87,7 +87,8 @@ class ConvBlock2d(nn.Module):
             y = E.conv2d(h, self.seq[2], self.stride, self.padding, self.dilation)
             return E.add(residual, y) if residual is not None else y
         # mixed precision: the conv epilogue hands BatchNorm its batch statistics (no statistics pass over y)
-        y = E.conv2d(x, self.seq[0], self.stride, self.padding, self.dilation, want_stats=self.training)
+        y = E.conv2d(x, self.seq[0], self.stride, self.padding, self.dilation, want_stats=self.training,
+                     bn=self.seq[1] if self.training else None)
         return E.bn_act(y, self.seq[1], self.act, residual=residual, training=self.training)
 
 
@@ -260,11 +261,13 @@ class ResidualAConv(nn.Module):
             # the G dilation branches run level by level: one grouped launch for their first convs (shared input),
             # one for their second convs; out + SiLU(BN(.)) is fused into the last BN of each branch
             blocks1 = [m.block[1] for m in self.res_modules]
+            bn0 = [b.seq[1] for b in blocks0] if self.training else None
+            bn1 = [b.seq[1] for b in blocks1] if self.training else None
             ys = E.conv2d_group([x] * G, [b.seq[0] for b in blocks0], [b.padding for b in blocks0],
-                                [b.dilation for b in blocks0], blocks0[0].stride)
+                                [b.dilation for b in blocks0], blocks0[0].stride, bns=bn0)
             hs = E.bn_act_group(ys, [b.seq[1] for b in blocks0], blocks0[0].act, training=self.training)
             ys = E.conv2d_group(hs, [b.seq[0] for b in blocks1], [b.padding for b in blocks1],
-                                [b.dilation for b in blocks1], blocks1[0].stride)
+                                [b.dilation for b in blocks1], blocks1[0].stride, bns=bn1)
             # skip(x) is recorded AFTER the branches, so in backward its bwd-data is the FIRST writer of dx (plain
             # stores) and the branches' shared-dx launch accumulates onto it: no zero-fill of dx, and no
             # read-modify-write epilogue in the 1x1 GEMM (that ordering cost 165 us at 8 x 480 x 100^2)

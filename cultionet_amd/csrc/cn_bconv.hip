@@ -23,6 +23,7 @@
 #include <cstdlib>
 #include "cn_bf16.h"
 #include "cn_profile.h"
+#include "cn_ticket.h"
 
 #define CNB_MAX_TAPS 9
 #define CNB_MAX_CLASSES 16
@@ -69,6 +70,19 @@ struct CnBGeom {
                   // fp32 results, rows [tile][2][Cout]
                   // (plain stores, one row per tile: same-address float atomics serialise at ~200 ns each and
                   // 2560 tiles x 4 waves of them made a 128->128 conv at 100x100 nine times slower)
+  // In-launch BatchNorm statistics (fin_cnt nullable): the launch FINISHES its per-tile rows itself -- a two-level
+  // last-block ticket per (group, cout block): the last of every 16 tiles sums their rows into a group row (fp64, tile
+  // order), the last group finisher sums the group rows (group order) and writes mean / rstd / running statistics of
+  // its 32 * WN channels. One dependent launch (cn_bbn_group_finalize_kernel, 9 us + its dispatch gap) fewer per
+  // BatchNorm; for launches of <= CN_BNWS_CONV_MAX_TILES tiles per group (a last block reads <= 16 + 63 rows).
+  int* fin_cnt;       // [G * nblk_n][CN_T2_COUNTERS], zero between launches (head of the grouped-BatchNorm workspace)
+  double* fin_grows;  // [G * nblk_n][CN_T2_COUNTERS - 1][64 * WN]
+  float* fin_mean[CNB_MAX_GROUPS];
+  float* fin_rstd[CNB_MAX_GROUPS];
+  float* fin_rmean[CNB_MAX_GROUPS];  // nullable: no running statistics
+  float* fin_rvar[CNB_MAX_GROUPS];
+  float fin_eps, fin_momentum;
+  int fin_tiles;      // tiles of one group
   CnBClass cls[CNB_MAX_CLASSES];
 };
 
@@ -568,7 +582,82 @@ __global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
     const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * hh;
     if (n_live && n < g.Cout && wm == 0) {  // wid = wm * WN + wn: the wm == 0 wave of each cout tile stores the row
       float* row = stats_g + (long)tile * 2 * g.Cout + (jj >= 16 ? g.Cout : 0) + n;
-      *row = tot;
+      if (g.fin_cnt != nullptr) __hip_atomic_store(row, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      else *row = tot;
+    }
+    if (g.fin_cnt != nullptr) {  // block-uniform
+      constexpr int W = 64 * WN;  // this block's columns: {sum, sum of squares} x its 32 * WN couts
+      const int dom = grp * g.nblk_n + nb;
+      int* cnt = g.fin_cnt + dom * CN_T2_COUNTERS;
+      double* grows = g.fin_grows + (long)dom * (CN_T2_COUNTERS - 1) * W;
+      const int ntl = g.fin_tiles, ngr = (ntl + CN_T2_GROUP - 1) / CN_T2_GROUP;
+      const int grpi = tile / CN_T2_GROUP, t0 = grpi * CN_T2_GROUP;
+      const int gn = t0 + CN_T2_GROUP <= ntl ? CN_T2_GROUP : ntl - t0;
+      int* s_flag = reinterpret_cast<int*>(lds);
+      double* tot2 = reinterpret_cast<double*>(lds + 16);
+      const int stat = tid / (32 * WN), cc = tid - stat * (32 * WN);
+      const int nc = nb * (32 * WN) + cc;
+      const long coff = (long)stat * g.Cout + (nc < g.Cout ? nc : g.Cout - 1);  // dead columns re-read the last channel
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();  // the row is on its way to memory; the transposition scratch is dead
+      if (tid == 0) {
+        const int kq = __hip_atomic_fetch_add(cnt + grpi, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        *s_flag = (kq == gn - 1);
+        if (kq == gn - 1) __hip_atomic_store(cnt + grpi, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+      __syncthreads();
+      if (*s_flag) {
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        if (tid < W) {
+          float v[CN_T2_GROUP];
+#pragma unroll
+          for (int i = 0; i < CN_T2_GROUP; ++i)  // clamped, never predicated: all 16 loads in flight together
+            v[i] = __hip_atomic_load(stats_g + (long)(t0 + (i < gn ? i : gn - 1)) * 2 * g.Cout + coff, __ATOMIC_RELAXED,
+                                     __HIP_MEMORY_SCOPE_AGENT);
+          double sd = 0.0;
+#pragma unroll
+          for (int i = 0; i < CN_T2_GROUP; ++i) sd += i < gn ? (double)v[i] : 0.0;
+          __hip_atomic_store(grows + (long)grpi * W + tid, sd, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (tid == 0) {
+          const int kq = __hip_atomic_fetch_add(cnt + CN_T2_COUNTERS - 1, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          *s_flag = (kq == ngr - 1);
+          if (kq == ngr - 1) __hip_atomic_store(cnt + CN_T2_COUNTERS - 1, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+        __syncthreads();
+        if (*s_flag) {
+          __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+          if (tid < W) {
+            double sd = 0.0;
+            for (int k0 = 0; k0 < ngr; k0 += CN_T2_GROUP) {
+              double v[CN_T2_GROUP];
+#pragma unroll
+              for (int i = 0; i < CN_T2_GROUP; ++i)
+                v[i] = __hip_atomic_load(grows + (long)(k0 + i < ngr ? k0 + i : ngr - 1) * W + tid, __ATOMIC_RELAXED,
+                                         __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+              for (int i = 0; i < CN_T2_GROUP; ++i) sd += k0 + i < ngr ? v[i] : 0.0;
+            }
+            tot2[tid] = sd;
+          }
+          __syncthreads();
+          if (tid < 32 * WN && nc < g.Cout) {  // (stat == 0 here: nc is this thread's channel)
+            const double count = (double)g.B * g.Hout * g.Wout;
+            const double md = tot2[tid] / count;
+            double var = tot2[32 * WN + tid] / count - md * md;
+            if (var < 0.0) var = 0.0;
+            g.fin_mean[grp][nc] = (float)md;
+            g.fin_rstd[grp][nc] = (float)(1.0 / sqrt(var + (double)g.fin_eps));
+            if (g.fin_rmean[grp] != nullptr) {
+              const double unbiased = count > 1.0 ? var * count / (count - 1.0) : var;
+              g.fin_rmean[grp][nc] = (1.f - g.fin_momentum) * g.fin_rmean[grp][nc] + g.fin_momentum * (float)md;
+              g.fin_rvar[grp][nc] = (1.f - g.fin_momentum) * g.fin_rvar[grp][nc] + g.fin_momentum * (float)unbiased;
+            }
+          }
+        }
+      }
     }
   }
   CNB_ST(5);
@@ -762,7 +851,15 @@ static void cnb_pick_tile(int Hg, int Wg, int is, int span, int max_pix, int& TH
   }
 }
 
-static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
+// Host request for the in-launch statistics finalize (cn_conv2d_fwd_grouped_bnstats_bf16); `done` reports the decision.
+struct CnBFinReq {
+  float* const* means; float* const* rstds; float* const* rmeans; float* const* rvars;
+  float momentum, eps;
+  float* ws; long ws_floats;  // the grouped-BatchNorm workspace (zero head: cn_ticket.h)
+  int done;
+};
+
+static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops, CnBFinReq* fin = nullptr) {
   // tiles: one (TH, TW) for the launch, from the largest class grid and the widest tap span
   int span = 0, Hg = 1, Wg = 1;
   for (int c = 0; c < g.ncls; ++c) {
@@ -864,6 +961,28 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops) {
   if (g.stats[0] != nullptr && shmem < 4 * 64 * 33 * sizeof(float)) shmem = 4 * 64 * 33 * sizeof(float);
   const dim3 grid(cn_xcd_grid(total)), block(256);
   if (g.stats[0] != nullptr && g.ncls != G) return CN_ERR_ARG;  // one class per group: a tile's row has ONE writer
+  g.fin_cnt = nullptr;
+  if (fin != nullptr) {
+    fin->done = 0;
+    static const bool on = getenv("CN_CONV_BNFIN") == nullptr || atoi(getenv("CN_CONV_BNFIN")) != 0;  // A/B switch
+    const long tiles = (long)g.cls[0].tiles_per_img * g.B;
+    const long domains = (long)G * g.nblk_n;
+    const long grow_doubles = domains * (CN_T2_COUNTERS - 1) * 64 * WN;
+    if (on && g.stats[0] != nullptr && tiles <= CN_BNWS_CONV_MAX_TILES && domains <= CN_BNWS_CONV_DOMAINS &&
+        fin->ws != nullptr && (reinterpret_cast<uintptr_t>(fin->ws) & 7) == 0 &&
+        fin->ws_floats >= CN_BNWS_HEAD_INTS + 2 * grow_doubles) {
+      g.fin_cnt = reinterpret_cast<int*>(fin->ws) + CN_BNWS_CONV_OFF;
+      g.fin_grows = reinterpret_cast<double*>(fin->ws + CN_BNWS_HEAD_INTS);
+      g.fin_tiles = (int)tiles;
+      g.fin_eps = fin->eps; g.fin_momentum = fin->momentum;
+      for (int i = 0; i < G; ++i) {
+        g.fin_mean[i] = fin->means[i]; g.fin_rstd[i] = fin->rstds[i];
+        g.fin_rmean[i] = fin->rmeans ? fin->rmeans[i] : nullptr;
+        g.fin_rvar[i] = fin->rvars ? fin->rvars[i] : nullptr;
+      }
+      fin->done = 1;
+    }
+  }
   const int NPv = np <= 4 ? 4 : (np <= 6 ? 6 : 10);
   if (MPWv == 2)
     cn_prof_name("cn_bconv_kernel<%d, %d, %d, 2>", WN, (KSC == 2 ? NPv : (KSC == 4 ? (NPv <= 6 ? 6 : 10) : 10)), KSC);
@@ -912,7 +1031,7 @@ static int cnb_gather(int G, const bf16_t* const* xs, long ldx, const bf16_t* co
                       void* const* ys, long ldy, long y_bs, int B, int Cin, int Hin, int Win, int Cout, int Hout,
                       int Wout, int KH, int KW, int stride, const int* pads, const int* dils, int accumulate,
                       int out_kind, float* const* stats, hipStream_t stream, int act = 0,
-                      const bf16_t* const* ress = nullptr, long ldres = 0) {
+                      const bf16_t* const* ress = nullptr, long ldres = 0, CnBFinReq* fin = nullptr) {
   if (G < 1 || G > CNB_MAX_GROUPS || KH * KW > CNB_MAX_TAPS || stride < 1) return CN_ERR_ARG;
   if (Hout <= 0 || Wout <= 0 || B <= 0) return CN_OK;
   CnBGeom g = {};
@@ -938,7 +1057,7 @@ static int cnb_gather(int G, const bf16_t* const* xs, long ldx, const bf16_t* co
       }
   }
   const double flops = 2.0 * B * Hout * Wout * (double)Cout * Cin * KH * KW * G;
-  return cnb_launch(g, G, stream, flops);
+  return cnb_launch(g, G, stream, flops, fin);
 }
 
 // Scatter form: out[o] = bias + sum_k src[(o + pad - k*dil)/s] W[k] where divisible (Conv2d backward-data,
@@ -1058,6 +1177,36 @@ extern "C" int cn_conv2d_fwd_grouped_bf16(int G, const void* const* xs, long ldx
       return CN_ERR_ARG;
   return cnb_gather(G, (const bf16_t* const*)xs, ldx, (const bf16_t* const*)wps, biases, ys, ldy, 0, B, Cin, Hin, Win,
                     Cout, Hout, Wout, KH, KW, stride, pads, dils, accumulate, 0, stats, (hipStream_t)stream);
+}
+
+// The same launch (bias-free: ConvBlock2d, convolution.py:71-120) that also FINISHES the BatchNorm batch statistics of
+// its G outputs when it can: *finalized = 1 -> means / rstds (and, when given, the running statistics with `momentum`)
+// are written by the launch and the caller goes straight to cn_bn_act_group_fwd_bf16(..., conv_rows = -1);
+// *finalized = 0 -> only the per-tile rows in `stats` were written (more than 1008 tiles per convolution, or a workspace
+// too small) and the caller passes them to cn_bn_act_group_fwd_bf16 as before. bn_ws: the grouped-BatchNorm workspace
+// of the launch stream (cn_bn_group_workspace_floats_bf16(G, Cout) floats, zero-filled once; its head holds the tickets).
+extern "C" int cn_conv2d_fwd_grouped_bnstats_bf16(int G, const void* const* xs, long ldx, const void* const* wps,
+                                                  void* const* ys, long ldy, int B, int Cin, int Hin, int Win, int Cout,
+                                                  int KH, int KW, int stride, const int* pads, const int* dils,
+                                                  float* const* stats, float* const* means, float* const* rstds,
+                                                  float* const* running_means, float* const* running_vars,
+                                                  float momentum, float eps, float* bn_ws, long bn_ws_floats,
+                                                  int* finalized, void* stream) {
+  if (stride < 1 || G < 1 || G > CNB_MAX_GROUPS || stats == nullptr || means == nullptr || rstds == nullptr ||
+      finalized == nullptr || (running_means == nullptr) != (running_vars == nullptr))
+    return CN_ERR_ARG;
+  const int Hout = (Hin + 2 * pads[0] - dils[0] * (KH - 1) - 1) / stride + 1;
+  const int Wout = (Win + 2 * pads[0] - dils[0] * (KW - 1) - 1) / stride + 1;
+  for (int i = 1; i < G; ++i)
+    if ((Hin + 2 * pads[i] - dils[i] * (KH - 1) - 1) / stride + 1 != Hout ||
+        (Win + 2 * pads[i] - dils[i] * (KW - 1) - 1) / stride + 1 != Wout)
+      return CN_ERR_ARG;
+  CnBFinReq fin = {means, rstds, running_means, running_vars, momentum, eps, bn_ws, bn_ws_floats, 0};
+  const int rc = cnb_gather(G, (const bf16_t* const*)xs, ldx, (const bf16_t* const*)wps, nullptr, ys, ldy, 0, B, Cin, Hin,
+                            Win, Cout, Hout, Wout, KH, KW, stride, pads, dils, 0, 0, stats, (hipStream_t)stream, 0, nullptr,
+                            0, &fin);
+  *finalized = fin.done;
+  return rc;
 }
 
 // Conv2d backward-data: dx [B,Hin,Win,Cin] (+)= scatter(dy [B,Hout,Wout,Cout]); wp_t packed with K = Cout, N = Cin.

@@ -729,14 +729,18 @@ __global__ __launch_bounds__(256) void cn_bbn_group_apply_bwd_kernel(const CnBBn
 // Workspace of the grouped calls (floats). HEAD (fixed, whatever G and C are -- the engine hands ONE buffer to calls of
 // every shape): BBG_CNT_INTS finalize tickets + BBG_MAX * CN_T2_COUNTERS tickets of the statistics passes, ZERO on
 // entry, left zero by every launch. BODY: finalize slices (fp64), backward coefficients, per-block rows.
-static inline long bbg_slices_off() { return BBG_CNT_INTS + BBG_MAX * CN_T2_COUNTERS; }               // 8-byte aligned
+static inline long bbg_slices_off() { return CN_BNWS_HEAD_INTS; }  // 8-byte aligned (cn_ticket.h: the fixed head)
 static inline long bbg_coef_off(int G, int C) {
   return bbg_slices_off() + (long)G * ((C + 31) / 32) * BBG_FIN_BLOCKS * 64 * 2;  // doubles
 }
 static inline long bbg_part_off(int G, int C) { return (bbg_coef_off(G, C) + (long)G * 2 * C + 63) / 64 * 64; }
 static inline long bbg_domain_floats(int C) { return (cn_t2_body_floats(BBN_MAX_BLOCKS, 2 * C) + 63) / 64 * 64; }
 extern "C" long cn_bn_group_workspace_floats_bf16(int G, int C) {
-  return bbg_part_off(G, C) + (long)G * bbg_domain_floats(C);
+  const long own = bbg_part_off(G, C) + (long)G * bbg_domain_floats(C);
+  // a convolution that finishes its own statistics (cn_conv2d_fwd_grouped_bnstats_bf16) parks its group rows at the
+  // start of the body: (CN_T2_COUNTERS - 1) x G x 2 x (couts padded to a 128-cout block) doubles
+  const long conv = bbg_slices_off() + 2L * (CN_T2_COUNTERS - 1) * G * 2 * ((C + 127) / 128 * 128);
+  return own > conv ? own : conv;
 }
 static inline CnBBnTickets bbg_tickets(float* ws, int G, int C, int nblk) {
   CnBBnTickets t = {};
@@ -790,7 +794,10 @@ extern "C" int cn_bn_act_group_fwd_bf16(int G, const void* const* xs, long ldx, 
   }
   if (training) {
     const bool fused = conv_sums != nullptr && conv_rows > 0;
-    if (fused) {
+    if (conv_rows == -1) {
+      // means / rstds (and the running statistics) were written by the convolution launch that produced xs
+      // (cn_conv2d_fwd_grouped_bnstats_bf16 reported `finalized`): nothing to do before the apply
+    } else if (fused) {
       for (int g = 0; g < G; ++g) a.rows[g] = conv_sums[g];
       a.nrows = conv_rows;
       a.row_pitch = 2L * C;

@@ -99,3 +99,14 @@ __device__ __forceinline__ bool cn_t2_reduce(const CnTicket2& t, int blk, int* s
   if (last) __syncthreads();
   return last;
 }
+
+// ---- head of the grouped-BatchNorm workspace (cn_bn_group_workspace_floats_bf16) --------------------------------------
+// ONE zero-filled buffer per (device, stream) serves calls of every shape, so every ticket counter lives at a FIXED
+// place in its head: [CN_BNWS_FIN_INTS finalize tickets][CN_BNWS_T2_DOMAINS x CN_T2_COUNTERS statistics-pass tickets]
+// [CN_BNWS_CONV_DOMAINS x CN_T2_COUNTERS tickets of the convolution launches that finish their own statistics].
+#define CN_BNWS_FIN_INTS 512
+#define CN_BNWS_T2_DOMAINS 4
+#define CN_BNWS_CONV_DOMAINS 64
+#define CN_BNWS_CONV_OFF (CN_BNWS_FIN_INTS + CN_BNWS_T2_DOMAINS * CN_T2_COUNTERS)
+#define CN_BNWS_HEAD_INTS (CN_BNWS_CONV_OFF + CN_BNWS_CONV_DOMAINS * CN_T2_COUNTERS)
+#define CN_BNWS_CONV_MAX_TILES ((CN_T2_COUNTERS - 1) * CN_T2_GROUP)  // 1008 tiles per (group, cout block)

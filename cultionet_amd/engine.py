@@ -126,7 +126,7 @@ def _dense_inner(t: torch.Tensor) -> bool:
 class Var:
     """A device buffer and (during training) its gradient buffer."""
 
-    __slots__ = ("t", "grad", "req", "parent", "stats")
+    __slots__ = ("t", "grad", "req", "parent", "stats", "bnfin")
 
     def __init__(self, t: torch.Tensor, req: bool = False):
         self.t = t
@@ -134,6 +134,7 @@ class Var:
         self.req = req
         self.parent: T.Optional[T.Tuple["Var", int, int]] = None  # channel slice [c0, c1) of another Var
         self.stats: T.Optional[torch.Tensor] = None  # bf16 conv outputs: per-channel {sum, sumsq} from the epilogue
+        self.bnfin = None  # (bn module, mean, rstd): BatchNorm statistics already finished by the producing conv launch
 
     @property
     def shape(self):
@@ -705,12 +706,13 @@ def _pad_ws(*tensors: torch.Tensor) -> T.Tuple[T.Optional[int], int]:
 
 
 def conv2d(x: Var, mod, stride: int = 1, padding: int = 0, dilation: int = 1, out: T.Optional[torch.Tensor] = None,
-           want_stats: bool = False) -> Var:
-    """nn.Conv2d forward (+ tape node for bwd-data, bwd-weight, bias grad)."""
+           want_stats: bool = False, bn=None) -> Var:
+    """nn.Conv2d forward (+ tape node for bwd-data, bwd-weight, bias grad). ``bn``: the BatchNorm2d that follows (training
+    mode, mixed precision): the conv launch finishes its batch statistics when it can (see _bnstats_launch)."""
     tape = current_tape()
     xt = _check(x.t)
     if is16(xt):
-        return _conv2d_bf16(x, mod, stride, padding, dilation, out, want_stats)
+        return _conv2d_bf16(x, mod, stride, padding, dilation, out, want_stats, bn)
     B, Cin, H, W = xt.shape
     w = mod.weight
     Cout = w.shape[0]
@@ -751,7 +753,7 @@ def conv2d(x: Var, mod, stride: int = 1, padding: int = 0, dilation: int = 1, ou
 
 
 def conv2d_group(xs: T.Sequence[Var], mods: T.Sequence, paddings: T.Sequence[int], dilations: T.Sequence[int],
-                 stride: int = 1) -> T.List[Var]:
+                 stride: int = 1, bns: T.Optional[T.Sequence] = None) -> T.List[Var]:
     """G (<= 4) nn.Conv2d of identical shapes (per-conv padding / dilation) in ONE implicit-GEMM launch -- the
     dilation branches of ResidualAConv. ``xs`` may repeat one Var (branches sharing their input: backward sums the
     G input gradients in the same launch). Weight gradients stay one launch per conv."""
@@ -761,7 +763,7 @@ def conv2d_group(xs: T.Sequence[Var], mods: T.Sequence, paddings: T.Sequence[int
     G = len(mods)
     xts = [_check(x.t) for x in xs]
     if is16(xts[0]):  # mixed precision: one grouped launch, each conv with BatchNorm statistics rows from its epilogue
-        return _conv2d_group_bf16(xs, mods, paddings, dilations, stride)
+        return _conv2d_group_bf16(xs, mods, paddings, dilations, stride, bns)
     B, Cin, H, W = xts[0].shape
     w0 = mods[0].weight
     Cout, KH, KW = w0.shape[0], w0.shape[2], w0.shape[3]
@@ -1872,8 +1874,49 @@ def to_bf16(x: Var) -> Var:
     return yv
 
 
+_CONV_BNFIN = os.environ.get("CN_CONV_BNFIN", "1") != "0"
+
+
+def _bnstats_launch(xts, pws, ys, B, Cin, H, W, Cout, KH, KW, stride, paddings, dilations, stats, bns):
+    """A training-mode ConvBlock2d convolution (bias-free, G <= 4 branches) through
+    cn_conv2d_fwd_grouped_bnstats_bf16: the launch writes the per-tile statistics rows AND, for launches of <= 1008 pixel
+    tiles, finishes them (mean / rstd / running statistics) by a last-block ticket -- the dependent finalize launch between
+    the convolution and the BatchNorm apply disappears. Returns per-output (bn, mean, rstd) or None when the launch only
+    wrote the rows."""
+    import ctypes
+
+    G = len(xts)
+    dev = xts[0].device
+    tab = lambda ptrs: (ctypes.c_void_p * G)(*ptrs)
+    means = torch.empty((G, Cout), dtype=torch.float32, device=dev)
+    rstds = torch.empty((G, Cout), dtype=torch.float32, device=dev)
+    has_running = bns[0].running_mean is not None
+    need = int(_lib.query("cn_bn_group_workspace_floats_bf16", G, Cout))
+    ws = _bn_group_ws16(G, Cout, dev)
+    fin = ctypes.c_int(0)
+    _lib.call("cn_conv2d_fwd_grouped_bnstats_bf16", G, tab([t.data_ptr() for t in xts]), ld(xts[0]),
+              tab([p.fwd16.data_ptr() for p in pws]), tab([y.data_ptr() for y in ys]), ld(ys[0]), B, Cin, H, W, Cout, KH,
+              KW, stride, (ctypes.c_int * G)(*paddings), (ctypes.c_int * G)(*dilations),
+              tab([t.data_ptr() for t in stats]), tab([means[g].data_ptr() for g in range(G)]),
+              tab([rstds[g].data_ptr() for g in range(G)]),
+              tab([bn.running_mean.data_ptr() for bn in bns]) if has_running else None,
+              tab([bn.running_var.data_ptr() for bn in bns]) if has_running else None, _bn_momentum(bns[0]),
+              float(bns[0].eps), ws, max(need, 1 << 20), ctypes.byref(fin), _stream())
+    if not fin.value:
+        return None
+    return [(bns[g], means[g], rstds[g]) for g in range(G)]
+
+
+def _bnfin_ok(bns, mods) -> bool:
+    return (_CONV_BNFIN and _GROUP_BF16 and bns is not None and len(bns) == len(mods)
+            and all(m.bias is None for m in mods) and all(bn.training for bn in bns)
+            and all(bn.momentum == bns[0].momentum and bn.eps == bns[0].eps for bn in bns)
+            and all((bn.running_mean is None) == (bns[0].running_mean is None) for bn in bns)
+            and mods[0].weight.shape[0] % 8 == 0)
+
+
 def _conv2d_bf16(x: Var, mod, stride: int, padding: int, dilation: int, out: T.Optional[torch.Tensor],
-                 want_stats: bool) -> Var:
+                 want_stats: bool, bn=None) -> Var:
     tape = current_tape()
     xt = x.t
     B, Cin, H, W = xt.shape
@@ -1889,11 +1932,17 @@ def _conv2d_bf16(x: Var, mod, stride: int, padding: int, dilation: int, out: T.O
     if want_stats:  # one row of {sum, sumsq}[Cout] per pixel tile, written by the conv epilogue (no zero-fill)
         rows = _lib.query("cn_conv2d_stats_rows_bf16", B, H, W, Cout, KH, KW, stride, padding, dilation)
         stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=xt.device)
-    _lib.call("cn_conv2d_fwd_bf16", xt.data_ptr(), ld(xt), pw.fwd16.data_ptr(),
-              bias.data_ptr() if bias is not None else None, y.data_ptr(), ld(y), 0, B, Cin, H, W, Cout, KH, KW, stride,
-              padding, dilation, 0, 0, stats.data_ptr() if stats is not None else None, _stream())
+    bnfin = None
+    if stats is not None and w.dim() == 4 and _bnfin_ok([bn] if bn is not None else None, [mod]):
+        bnfin = _bnstats_launch([xt], [pw], [y], B, Cin, H, W, Cout, KH, KW, stride, [padding], [dilation], [stats], [bn])
+        bnfin = bnfin[0] if bnfin is not None else False  # False: launched (rows only)
+    if bnfin is None:
+        _lib.call("cn_conv2d_fwd_bf16", xt.data_ptr(), ld(xt), pw.fwd16.data_ptr(),
+                  bias.data_ptr() if bias is not None else None, y.data_ptr(), ld(y), 0, B, Cin, H, W, Cout, KH, KW,
+                  stride, padding, dilation, 0, 0, stats.data_ptr() if stats is not None else None, _stream())
     yv = Var(y, tape.enabled)
     yv.stats = stats
+    yv.bnfin = bnfin or None
     if tape.enabled:
         store = current_store()
 
@@ -1925,7 +1974,7 @@ _GROUP_BF16 = os.environ.get("CN_BF16_GROUPED", "1") == "1"  # diagnostic: 0 = b
 
 
 def _conv2d_group_bf16(xs: T.Sequence[Var], mods: T.Sequence, paddings: T.Sequence[int], dilations: T.Sequence[int],
-                       stride: int) -> T.List[Var]:
+                       stride: int, bns: T.Optional[T.Sequence] = None) -> T.List[Var]:
     """The G dilation branches of a ResidualAConv level as ONE bf16 implicit-GEMM launch (G classes of one launch:
     twice the blocks on the small planes, half the launches), every conv with its own BatchNorm statistics rows.
     Backward: weight gradients conv by conv on the side stream; data gradients in one grouped launch when the G inputs
@@ -1941,7 +1990,8 @@ def _conv2d_group_bf16(xs: T.Sequence[Var], mods: T.Sequence, paddings: T.Sequen
     same = all(tuple(t.shape) == (B, Cin, H, W) and ld(t) == ld(xts[0]) for t in xts) and \
         all(tuple(m.weight.shape) == tuple(w0.shape) and (m.bias is None) == (mods[0].bias is None) for m in mods)
     if not _GROUP_BF16 or G < 2 or G > 4 or not same or w0.dim() != 4:
-        return [_conv2d_bf16(x, m, stride, p, d, None, tape.enabled) for x, m, p, d in zip(xs, mods, paddings, dilations)]
+        return [_conv2d_bf16(x, m, stride, p, d, None, tape.enabled, bns[i] if bns is not None else None)
+                for i, (x, m, p, d) in enumerate(zip(xs, mods, paddings, dilations))]
     Cout, KH, KW = w0.shape[0], w0.shape[2], w0.shape[3]
     Ho = (H + 2 * paddings[0] - dilations[0] * (KH - 1) - 1) // stride + 1
     Wo = (W + 2 * paddings[0] - dilations[0] * (KW - 1) - 1) // stride + 1
@@ -1957,13 +2007,21 @@ def _conv2d_group_bf16(xs: T.Sequence[Var], mods: T.Sequence, paddings: T.Sequen
     if tape.enabled:  # (training forward: the tape is on; rows of {sum, sumsq}[Cout] per pixel tile and conv)
         rows = _lib.query("cn_conv2d_stats_rows_bf16", B, H, W, Cout, KH, KW, stride, max(paddings), max(dilations))
         stats = [torch.empty((rows, 2, Cout), dtype=torch.float32, device=xts[0].device) for _ in range(G)]
-    _lib.call("cn_conv2d_fwd_grouped_bf16", G, tab([t.data_ptr() for t in xts]), ld(xts[0]),
-              tab([p.fwd16.data_ptr() for p in pws]), tab([b.data_ptr() for b in biases]) if has_bias else None,
-              tab([y.data_ptr() for y in ys]), ld(ys[0]), B, Cin, H, W, Cout, KH, KW, stride, pads_c, dils_c, 0,
-              tab([t.data_ptr() for t in stats]) if stats is not None else None, _stream())
+    bnfin = None
+    if stats is not None and _bnfin_ok(bns, mods):
+        bnfin = _bnstats_launch(xts, pws, ys, B, Cin, H, W, Cout, KH, KW, stride, list(paddings), list(dilations), stats,
+                                list(bns))
+        if bnfin is None:
+            bnfin = False  # launched, rows only
+    if bnfin is None:
+        _lib.call("cn_conv2d_fwd_grouped_bf16", G, tab([t.data_ptr() for t in xts]), ld(xts[0]),
+                  tab([p.fwd16.data_ptr() for p in pws]), tab([b.data_ptr() for b in biases]) if has_bias else None,
+                  tab([y.data_ptr() for y in ys]), ld(ys[0]), B, Cin, H, W, Cout, KH, KW, stride, pads_c, dils_c, 0,
+                  tab([t.data_ptr() for t in stats]) if stats is not None else None, _stream())
     yvs = [Var(y, tape.enabled) for y in ys]
     for i, v in enumerate(yvs):
         v.stats = stats[i] if stats is not None else None
+        v.bnfin = bnfin[i] if bnfin else None
     if tape.enabled:
         store = current_store()
         shared_in = any(xs[i] is xs[j] for i in range(G) for j in range(i))
@@ -2214,11 +2272,17 @@ def _bn_act_group_bf16(xs: T.Sequence[Var], bns: T.Sequence, act: int, residual:
             raise ValueError("bn_act_group: outs must match the outputs and share their pixel stride")
     else:
         ys = [_new(xts[0].shape, xts[0]) for _ in range(1 if sum_outputs else G)]
-    means = torch.empty((G, C), dtype=torch.float32, device=dev)
-    rstds = torch.empty((G, C), dtype=torch.float32, device=dev)
+    # statistics already finished by the convolution launch that produced xs (_bnstats_launch)?
+    prefin = training and all(x.bnfin is not None and x.bnfin[0] is bn for x, bn in zip(xs, bns))
+    if prefin:
+        means = [x.bnfin[1] for x in xs]
+        rstds = [x.bnfin[2] for x in xs]
+    else:
+        means = torch.empty((G, C), dtype=torch.float32, device=dev)
+        rstds = torch.empty((G, C), dtype=torch.float32, device=dev)
     rt = _check(residual.t) if residual is not None else None
     has_running = bns[0].running_mean is not None
-    sums = [x.stats for x in xs] if (use_batch and has_sums) else None
+    sums = [x.stats for x in xs] if (use_batch and has_sums and not prefin) else None
     ws = _bn_group_ws16(G, C, dev)
     gam, bet = tab([bn.weight.data_ptr() for bn in bns]), tab([bn.bias.data_ptr() for bn in bns])
     mtab, rtab = tab([means[g].data_ptr() for g in range(G)]), tab([rstds[g].data_ptr() for g in range(G)])
@@ -2229,7 +2293,7 @@ def _bn_act_group_bf16(xs: T.Sequence[Var], bns: T.Sequence, act: int, residual:
               tab([(ys[0] if sum_outputs else ys[g]).data_ptr() for g in range(G)]), ld(ys[0]), mtab, rtab, ws, P, C,
               1 if use_batch else 0, _bn_momentum(bns[0]), float(bns[0].eps), act, 1 if sum_outputs else 0,
               tab([t.data_ptr() for t in sums]) if sums is not None else None,
-              sums[0].shape[0] if sums is not None else 0, _stream())
+              -1 if prefin else (sums[0].shape[0] if sums is not None else 0), _stream())
     yvs = [Var(y, tape.enabled) for y in ys]
     if tape.enabled:
         store = current_store()

@@ -347,6 +347,19 @@ int cn_conv2d_fwd_grouped_bf16(int G, const void* const* xs, long ldx, const voi
                                int Hin, int Win, int Cout, int KH, int KW, int stride, const int* pads,
                                const int* dils, int accumulate, float* const* stats /*nullable: G row sets*/,
                                void* stream);
+/* ConvBlock2d in training mode (convolution.py:71-120: Conv2d(bias=False) -> BatchNorm2d): the grouped launch also
+ * FINISHES the BatchNorm batch statistics of its G outputs when it can (a two-level last-block ticket per group and
+ * cout block; <= 1008 pixel tiles per convolution). *finalized = 1: means / rstds [Cout] per group (and the running
+ * statistics, updated with `momentum` as torch does, when given) were written by the launch -- go straight to
+ * cn_bn_act_group_fwd_bf16(..., conv_sums = NULL, conv_rows = -1). *finalized = 0: only the per-tile rows in `stats` were
+ * written -- pass them to cn_bn_act_group_fwd_bf16 as for cn_conv2d_fwd_grouped_bf16. bn_ws: the grouped-BatchNorm
+ * workspace of this stream (cn_bn_group_workspace_floats_bf16(G, Cout) floats, zero-filled once after allocation). */
+int cn_conv2d_fwd_grouped_bnstats_bf16(int G, const void* const* xs, long ldx, const void* const* wps, void* const* ys,
+                                       long ldy, int B, int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride,
+                                       const int* pads, const int* dils, float* const* stats, float* const* means,
+                                       float* const* rstds, float* const* running_means /*nullable*/,
+                                       float* const* running_vars /*nullable*/, float momentum, float eps, float* bn_ws,
+                                       long bn_ws_floats, int* finalized, void* stream);
 int cn_conv2d_bwd_data_bf16(const void* dy, long lddy, const void* wp_t, void* dx, long lddx, int B, int Cin, int Hin,
                             int Win, int Cout, int KH, int KW, int stride, int pad, int dil, int accumulate,
                             void* stream);
@@ -392,6 +405,8 @@ int cn_bn_act_bwd_bf16(const void* x, long ldx, const void* dy, long lddy, const
  * ONE launch: coalesced column sums of the partial rows whose per-block slices are combined by the last-arriving
  * block (device ticket; fixed summation order, bit-reproducible); statistics passes over x / dy (backward, or a forward
  * without conv_sums) finish themselves the same way (two-level last-block reduction): no finalize launch.
+ * conv_rows = -1 (training): means / rstds and the running statistics were already written by the convolution launch
+ * (cn_conv2d_fwd_grouped_bnstats_bf16 with *finalized = 1): apply only.
  * ws: cn_bn_group_workspace_floats_bf16(G, C) floats holding ticket counters: ZERO-FILLED before its first use (every
  * call leaves the counters zero), not shared with calls in flight on another stream.
  * Backward: dys[g] = gradient of output g (after a summed forward the same pointer G times: read once per pass);

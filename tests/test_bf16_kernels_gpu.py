@@ -457,6 +457,79 @@ def test_conv_group_bf16_statistics_feed_the_grouped_batchnorm():
         _close(mean[g], ref[g].mean(dim=(0, 2, 3)), 2e-3, "mean", abs_=1e-4)
 
 
+@pytest.mark.parametrize("B,Cin,H,W,Cout,G,expect", [
+    (2, 32, 50, 50, 64, 2, 1),     # 40 tiles per conv, one cout block
+    (3, 16, 25, 25, 40, 1, 1),     # ragged couts (40 of a 64-cout block), one group
+    (4, 64, 100, 100, 256, 2, 1),  # 313 tiles x 2 cout blocks x 2 groups: 20 ticket groups per domain
+    (2, 8, 13, 13, 8, 4, 1),       # tiny planes, four groups
+    (14, 16, 100, 100, 128, 1, 0),  # 1120 tiles of 128 pixels > 1008: rows only, the caller runs the finalize
+])
+def test_conv_bnstats_bf16_finishes_its_own_batchnorm_statistics(B, Cin, H, W, Cout, G, expect):
+    """cn_conv2d_fwd_grouped_bnstats_bf16: the convolution launch finishes the BatchNorm batch statistics of its outputs
+    (two-level last-block ticket per group and cout block) -- mean / rstd / running statistics against torch's
+    BatchNorm2d on the fp32 convolution, twice in a row on ONE workspace (the tickets must be back at zero), then
+    cn_bn_act_group_fwd_bf16(conv_rows=-1) applies them. Above 1008 tiles the launch reports `finalized = 0`."""
+    from cultionet_amd import _lib
+
+    dev = _dev()
+    P = B * H * W
+    x = _r(_rand(B, Cin, H, W, seed=1))
+    ws_ = [_r(_rand(Cout, Cin, 3, 3, seed=2 + g) * 0.1) for g in range(G)]
+    pads = dils = [1 + (g % 2) for g in range(G)]
+    ref = [F.conv2d(x, ws_[g], padding=pads[g], dilation=dils[g]) for g in range(G)]
+    xg = _nhwc(x)
+    wps = [_pack(w.to(dev), 9, Cin, Cout, 9, Cin * 9, 1) for w in ws_]
+    ys = [_empty_nhwc(B, Cout, H, W) for _ in range(G)]
+    rows = _lib.query("cn_conv2d_stats_rows_bf16", B, H, W, Cout, 3, 3, 1, max(pads), max(dils))
+    stats = [torch.full((rows, 2, Cout), float("nan"), device=dev) for _ in range(G)]
+    bns = [torch.nn.BatchNorm2d(Cout).train() for _ in range(G)]
+    rm = [torch.zeros(Cout, device=dev) for _ in range(G)]
+    rv = [torch.ones(Cout, device=dev) for _ in range(G)]
+    mean = torch.full((G, Cout), float("nan"), device=dev)
+    rstd = torch.full((G, Cout), float("nan"), device=dev)
+    nws = _lib.query("cn_bn_group_workspace_floats_bf16", G, Cout)
+    ws = torch.zeros(nws, device=dev)
+    fin = ctypes.c_int(-7)
+    for rep in range(2):
+        _lib.call("cn_conv2d_fwd_grouped_bnstats_bf16", G, _tab([xg.data_ptr()] * G), _ld(xg),
+                  _tab([w.data_ptr() for w in wps]), _tab([y.data_ptr() for y in ys]), _ld(ys[0]), B, Cin, H, W, Cout, 3, 3,
+                  1, (ctypes.c_int * G)(*pads), (ctypes.c_int * G)(*dils), _tab([t.data_ptr() for t in stats]),
+                  _tab([mean[g].data_ptr() for g in range(G)]), _tab([rstd[g].data_ptr() for g in range(G)]),
+                  _tab([t.data_ptr() for t in rm]), _tab([t.data_ptr() for t in rv]), 0.1, 1e-5, ws.data_ptr(), nws,
+                  ctypes.byref(fin), _s())
+        torch.cuda.synchronize()
+        assert fin.value == expect
+        [bn(r) for bn, r in zip(bns, ref)]  # torch's running statistics move once per repetition too
+        for g in range(G):
+            _close(ys[g], ref[g], 6e-3, f"conv{g}")
+            _close(stats[g][:, 0].sum(0), ref[g].sum(dim=(0, 2, 3)), 2e-3, "sum", abs_=2e-2 * float(ref[g].abs().max()))
+        if not expect:
+            assert torch.isnan(mean).all() and float(rm[0].abs().max()) == 0.0  # untouched: the caller finalizes
+            continue
+        for g in range(G):
+            _close(mean[g], ref[g].mean(dim=(0, 2, 3)), 2e-3, "mean", abs_=1e-4)
+            _close(rstd[g], 1.0 / torch.sqrt(ref[g].var(dim=(0, 2, 3), unbiased=False) + 1e-5), 2e-3, "rstd")
+            _close(rm[g], bns[g].running_mean, 2e-3, f"running_mean rep {rep}", abs_=1e-4)
+            _close(rv[g], bns[g].running_var, 2e-3, f"running_var rep {rep}")
+        head = ws[:_lib.query("cn_bn_group_workspace_floats_bf16", 1, 8)][:4864].view(torch.int32)
+        assert int(head.abs().sum()) == 0  # every ticket counter is back at zero
+    gam = [bn.weight.detach().to(dev) for bn in bns]
+    bet = [bn.bias.detach().to(dev) for bn in bns]
+    out = _empty_nhwc(B, Cout, H, W)
+    rm2, rv2 = [t.clone() for t in rm], [t.clone() for t in rv]
+    _lib.call("cn_bn_act_group_fwd_bf16", G, _tab([y.data_ptr() for y in ys]), _ld(ys[0]),
+              _tab([t.data_ptr() for t in gam]), _tab([t.data_ptr() for t in bet]), _tab([t.data_ptr() for t in rm]),
+              _tab([t.data_ptr() for t in rv]), None, 0, _tab([out.data_ptr()] * G), _ld(out),
+              _tab([mean[g].data_ptr() for g in range(G)]), _tab([rstd[g].data_ptr() for g in range(G)]),
+              ws.data_ptr(), P, Cout, 1, 0.1, 1e-5, 1, 1,
+              None if expect else _tab([t.data_ptr() for t in stats]), -1 if expect else rows, _s())
+    yr = sum(F.silu(F.batch_norm(ref[g], None, None, bns[g].weight, bns[g].bias, True, 0.0, 1e-5)) for g in range(G))
+    _close(out, yr, 1.2e-2, "sum of SiLU(BN(conv))")
+    if expect:  # apply-only: the running statistics are not updated a second time
+        for g in range(G):
+            assert torch.equal(rm[g], rm2[g]) and torch.equal(rv[g], rv2[g])
+
+
 @pytest.mark.parametrize("shape,res", [((2, 32, 20, 20), False), ((2, 128, 25, 25), True), ((1, 8, 13, 13), True),
                                        ((2, 256, 9, 9), False)])
 def test_layernorm_c_bf16(shape, res):
