@@ -251,9 +251,14 @@ class ResidualAConv(nn.Module):
                            num_blocks=num_blocks, batchnorm_first=batchnorm_first) for d in dilations
         ])
 
-    def forward(self, x: E.Var) -> E.Var:
+    def forward(self, x: E.Var, out: T.Optional["torch.Tensor"] = None) -> E.Var:
+        """``out``: where the caller would like the result -- its channel slice of a tower's concat buffer (TowerUNet
+        hands it down so that torch.cat needs no copy). Honoured by the final op of the default paths (the summed
+        BatchNorm of the grouped branches, or the second LayerNorm of the attention branch); every other path returns a
+        buffer of its own and the concat copies as before."""
         G = len(self.res_modules)
         blocks0 = [m.block[0] for m in self.res_modules]
+        sum_out = out if self.attention_weights is None else None  # (with attention the branch sum is an intermediate)
         fused_eval = (not blocks0[0].batchnorm_first
                       and all(E.can_fuse_eval(x, b.seq[1], self.training) for m in self.res_modules for b in m.block))
         if 2 <= G <= 4 and all(len(m.block) == 2 for m in self.res_modules) and not blocks0[0].batchnorm_first \
@@ -271,22 +276,21 @@ class ResidualAConv(nn.Module):
             # skip(x) is recorded AFTER the branches, so in backward its bwd-data is the FIRST writer of dx (plain
             # stores) and the branches' shared-dx launch accumulates onto it: no zero-fill of dx, and no
             # read-modify-write epilogue in the 1x1 GEMM (that ordering cost 165 us at 8 x 480 x 100^2)
-            out = E.conv2d(x, self.skip) if isinstance(self.skip, nn.Conv2d) else x
-            skip = out
-            out = E.bn_act_group(ys, [b.seq[1] for b in blocks1], blocks1[0].act, residual=out, sum_outputs=True,
-                                 training=self.training)
+            skip = E.conv2d(x, self.skip) if isinstance(self.skip, nn.Conv2d) else x
+            res = E.bn_act_group(ys, [b.seq[1] for b in blocks1], blocks1[0].act, residual=skip, sum_outputs=True,
+                                 training=self.training, outs=[sum_out] if sum_out is not None else None)
         else:
-            out = E.conv2d(x, self.skip) if isinstance(self.skip, nn.Conv2d) else x
-            skip = out
+            skip = E.conv2d(x, self.skip) if isinstance(self.skip, nn.Conv2d) else x
+            res = skip
             for layer in self.res_modules:
-                out = layer(x, residual=out)  # out + SiLU(BN(conv(...))) fused in the last block
+                res = layer(x, residual=res)  # out + SiLU(BN(conv(...))) fused in the last block
         if self.attention_weights == AttentionTypes.NATTEN:
             a = E.layer_norm_c(skip, self.attention_conv[1])
             a = self.attention_conv[2](a)
-            out = E.layer_norm_c(a, self.attention_conv[3], residual=out)
+            res = E.layer_norm_c(a, self.attention_conv[3], residual=res, out=out)
         elif self.attention_weights is not None:  # spatial_channel: out *= attention(skip)
-            out = E.spatial_channel_attention(skip, out, self.attention_conv)
-        return out
+            res = E.spatial_channel_attention(skip, res, self.attention_conv)
+        return res
 
 
 class PoolResidualConv(nn.Module):
@@ -322,7 +326,7 @@ class PoolResidualConv(nn.Module):
                                           natten_proj_drop=natten_proj_drop)
         self.dropout_layer = nn.Dropout2d(p=dropout)
 
-    def forward(self, x: E.Var) -> E.Var:
+    def forward(self, x: E.Var, out: T.Optional["torch.Tensor"] = None) -> E.Var:
         if self.pool_first:
             if self.pool_by_max:
                 h, w = x.shape[-2:]
@@ -331,5 +335,9 @@ class PoolResidualConv(nn.Module):
                 x = E.conv2d(x, self.pool_conv, 2, 1, 1)
             else:
                 x = self.pool_conv(x)
-        x = self.res_conv(x)
-        return E.dropout(x, self.dropout_layer.p, channelwise=True, training=self.training)
+        drops = self.training and self.dropout_layer.p > 0.0  # (then Dropout2d is the final op and takes `out`)
+        if isinstance(self.res_conv, ResidualAConv):
+            x = self.res_conv(x, out=None if drops else out)
+        else:
+            x = self.res_conv(x)
+        return E.dropout(x, self.dropout_layer.p, channelwise=True, training=self.training, out=out)

@@ -1230,15 +1230,21 @@ def bn_act_group(xs: T.Sequence[Var], bns: T.Sequence, act: int, residual: T.Opt
     return yvs[0] if sum_outputs else yvs
 
 
-def layer_norm_c(x: Var, ln, residual: T.Optional[Var] = None) -> Var:
+def _out_ok(out: T.Optional[torch.Tensor], like: torch.Tensor) -> bool:
+    """May ``out`` (a channel slice of a concat buffer handed down by TowerUNet) receive a result shaped like ``like``?"""
+    return (out is not None and tuple(out.shape) == tuple(like.shape) and out.dtype == like.dtype
+            and out.device == like.device and (not is16(like) or (_dense16(out) and out.stride(1) == 1)))
+
+
+def layer_norm_c(x: Var, ln, residual: T.Optional[Var] = None, out: T.Optional[torch.Tensor] = None) -> Var:
     """nn.LayerNorm over the channel axis of an NCHW buffer (+ residual)."""
     tape = current_tape()
     xt = _check(x.t)
     if is16(xt):
-        return _layer_norm_c_bf16(x, ln, residual)
+        return _layer_norm_c_bf16(x, ln, residual, out)
     B, C = xt.shape[0], xt.shape[1]
     L = int(xt[0, 0].numel())
-    y = _new(xt.shape, xt)
+    y = out if _out_ok(out, xt) and _dense_inner(out) else _new(xt.shape, xt)
     mu = _new((B, L), xt)
     rstd = _new((B, L), xt)
     rt = residual.t if residual is not None else None
@@ -1750,8 +1756,9 @@ def _next_seed() -> int:
     return ((_rng["seed"] << 16) ^ (_rng["calls"] * 0x9E3779B1)) & 0xFFFFFFFFFFFFFFFF
 
 
-def dropout(x: Var, p: float, channelwise: bool, training: bool) -> Var:
-    """nn.Dropout2d (channelwise) / nn.Dropout; identity in eval mode or for p == 0."""
+def dropout(x: Var, p: float, channelwise: bool, training: bool, out: T.Optional[torch.Tensor] = None) -> Var:
+    """nn.Dropout2d (channelwise) / nn.Dropout; identity in eval mode or for p == 0 (``out`` is then ignored: the caller
+    hands it to the producer of x instead)."""
     if not training or p <= 0.0:
         return x
     tape = current_tape()
@@ -1761,7 +1768,7 @@ def dropout(x: Var, p: float, channelwise: bool, training: bool) -> Var:
     seed = _next_seed()
     stepw = _step_word(xt.device).data_ptr()
     step_fwd = _rng["step"]
-    y = _new(xt.shape, xt)
+    y = out if _out_ok(out, xt) and (is16(xt) or _dense_inner(out)) else _new(xt.shape, xt)
     cw = 1 if channelwise else 0
     if is16(xt):  # mixed precision: the same counter-based masks on the NHWC buffer
         _lib.call("cn_dropout_bf16", xt.data_ptr(), ld(xt), y.data_ptr(), ld(y), B, C, L, float(p), seed, stepw, cw, 0,
@@ -2330,12 +2337,12 @@ def _bn_act_group_bf16(xs: T.Sequence[Var], bns: T.Sequence, act: int, residual:
     return yvs[0] if sum_outputs else yvs
 
 
-def _layer_norm_c_bf16(x: Var, ln, residual: T.Optional[Var]) -> Var:
+def _layer_norm_c_bf16(x: Var, ln, residual: T.Optional[Var], out: T.Optional[torch.Tensor] = None) -> Var:
     tape = current_tape()
     xt = x.t
     B, C, H, W = xt.shape
     P = B * H * W
-    y = _new(xt.shape, xt)
+    y = out if _out_ok(out, xt) else _new(xt.shape, xt)
     rt = _check(residual.t) if residual is not None else None
     _lib.call("cn_layernorm_c_fwd_bf16", xt.data_ptr(), ld(xt), ln.weight.data_ptr(), ln.bias.data_ptr(),
               rt.data_ptr() if rt is not None else None, ld(rt) if rt is not None else 0, y.data_ptr(), ld(y), P, C,

@@ -11,6 +11,7 @@ is collapsed by PreTimeReduction (two Conv3d stacks + BN + SiLU, summed, LayerNo
 """
 from __future__ import annotations
 
+import os
 import typing as T
 
 import torch
@@ -94,6 +95,9 @@ class PreTimeReduction(nn.Module):
         # mixed precision: the time reduction (0.1 % of the FLOPs, fp32 input chips) stays fp32; its output enters the
         # bf16 NHWC region here and the tower heads leave it again (engine._thin_conv3x3_bf16)
         return E.to_bf16(y) if E.bf16_enabled() else y
+
+
+_CAT_IN_PLACE = os.environ.get("CN_CAT_IN_PLACE", "1") != "0"  # A/B switch: concat inputs produced in place
 
 
 class TowerUNet(nn.Module):
@@ -192,9 +196,17 @@ class TowerUNet(nn.Module):
         if self.training and self.has_dropout():
             E.begin_rng_step(x.t.device)  # fresh dropout masks for this step (device step word; see engine.manual_seed)
         emb = self.pre_unet(x)
-        enc = self.encoder(emb)
-        dec = self.decoder(enc)
-        tow = self.tower_fusion(encoded=enc, decoded=dec)
+        # the towers' concat buffers exist before the encoder / decoder run: x_a / x_b / x_c and x_au / x_bu / x_cu are
+        # produced in their channel slices (no concat copies of the six "side" inputs)
+        bufs = eouts = douts = None
+        if _CAT_IN_PLACE and not self.encoder.down_b.pool_by_max:
+            H, W = emb.shape[-2:]
+            half = lambda n: (n - 1) // 2 + 1  # 3x3, stride 2, padding 1
+            sizes = {"a": (H, W), "b": (half(H), half(W)), "c": (half(half(H)), half(half(W)))}
+            bufs, eouts, douts = self.tower_fusion.make_buffers(emb.shape[0], sizes, emb.t)
+        enc = self.encoder(emb, outs=eouts)
+        dec = self.decoder(enc, outs=douts)
+        tow = self.tower_fusion(encoded=enc, decoded=dec, bufs=bufs)
         size = tow["x_tower_a"].shape[-2:]
         out_a = self.final_a(tow["x_tower_a"], suffix="_a")
         out_b = self.final_b(tow["x_tower_b"], size=size, suffix="_b")

@@ -156,9 +156,11 @@ class UNetUpBlock(nn.Module):
                                           natten_kernel_size=natten_kernel_size, natten_dilation=natten_dilation,
                                           natten_attn_drop=natten_attn_drop, natten_proj_drop=natten_proj_drop)
 
-    def forward(self, x: E.Var, size) -> E.Var:
+    def forward(self, x: E.Var, size, out: T.Optional[torch.Tensor] = None) -> E.Var:
         if tuple(x.shape[-2:]) != tuple(size):
             x = self.up_conv(x, size=size)
+        if out is not None and isinstance(self.res_conv, ResidualAConv):
+            return self.res_conv(x, out=out)
         return self.res_conv(x)
 
 
@@ -182,10 +184,12 @@ class TowerUNetEncoder(nn.Module):
         self.down_d = PoolResidualConv(channels[2], channels[3], kernel_size=1, num_blocks=1, dilations=[1],
                                        attention_weights=None, **kw)
 
-    def forward(self, x: E.Var) -> T.Dict[str, E.Var]:
-        x_a = self.down_a(x)
-        x_b = self.down_b(x_a)
-        x_c = self.down_c(x_b)
+    def forward(self, x: E.Var, outs: T.Optional[T.Dict[str, torch.Tensor]] = None) -> T.Dict[str, E.Var]:
+        """``outs``: channel slices of the towers' concat buffers for x_a / x_b / x_c (TowerUNet.forward_vars)."""
+        o = outs or {}
+        x_a = self.down_a(x, out=o.get("x_a"))
+        x_b = self.down_b(x_a, out=o.get("x_b"))
+        x_c = self.down_c(x_b, out=o.get("x_c"))
         x_d = self.down_d(x_c)
         return {"x_a": x_a, "x_b": x_b, "x_c": x_c, "x_d": x_d}
 
@@ -208,11 +212,12 @@ class TowerUNetDecoder(nn.Module):
         self.up_au = UNetUpBlock(up_channels, up_channels, dilations=dilations,
                                  attention_weights=attention_weights, **{**kw, **NATTEN_PARAMS["a"]})
 
-    def forward(self, x: T.Dict[str, E.Var]) -> T.Dict[str, E.Var]:
+    def forward(self, x: T.Dict[str, E.Var], outs: T.Optional[T.Dict[str, torch.Tensor]] = None) -> T.Dict[str, E.Var]:
+        o = outs or {}
         x_du = self.over_d(x["x_d"], size=x["x_d"].shape[-2:])
-        x_cu = self.up_cu(x_du, size=x["x_c"].shape[-2:])
-        x_bu = self.up_bu(x_cu, size=x["x_b"].shape[-2:])
-        x_au = self.up_au(x_bu, size=x["x_a"].shape[-2:])
+        x_cu = self.up_cu(x_du, size=x["x_c"].shape[-2:], out=o.get("x_cu"))
+        x_bu = self.up_bu(x_cu, size=x["x_b"].shape[-2:], out=o.get("x_bu"))
+        x_au = self.up_au(x_bu, size=x["x_a"].shape[-2:], out=o.get("x_au"))
         return {"x_au": x_au, "x_bu": x_bu, "x_cu": x_cu, "x_du": x_du}
 
 
@@ -231,6 +236,8 @@ class TowerUNetBlock(nn.Module):
         self.use_latlon = use_latlon
         assert res_block_type in (ResBlockTypes.RES, ResBlockTypes.RESA)
         in_channels = backbone_side_channels + backbone_down_channels + up_channels * 2
+        self.cat_channels = [backbone_side_channels, backbone_down_channels, up_channels, up_channels] \
+            + ([up_channels] if tower else [])
         self.backbone_down_conv = ConvTranspose2d(backbone_down_channels, backbone_down_channels, 3, 2, 1)
         self.decode_down_conv = ConvTranspose2d(up_channels, up_channels, 3, 2, 1)
         if tower:
@@ -248,15 +255,25 @@ class TowerUNetBlock(nn.Module):
                                           natten_dilation=natten_dilation, natten_attn_drop=natten_attn_drop,
                                           natten_proj_drop=natten_proj_drop)
 
+    def make_buffer(self, B: int, size, like: torch.Tensor) -> T.Tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+        """The concat buffer of this block for a [B, ., size] level, allocated BEFORE the encoder / decoder run, and its
+        channel slices for ``backbone_side`` and ``decode_side``: their producers (the last op of down_x / up_xu) write
+        there directly and torch.cat (unet_parts.py:700-720 of the reference) copies nothing."""
+        cs = self.cat_channels
+        buf = E.new_buffer((B, sum(cs), size[0], size[1]), like)
+        return buf, buf[:, :cs[0]], buf[:, cs[0] + cs[1]:cs[0] + cs[1] + cs[2]]
+
     def forward(self, backbone_side: E.Var, backbone_down: E.Var, decode_side: E.Var, decode_down: E.Var,
-                tower_down: T.Optional[E.Var] = None, latlon_coords=None) -> E.Var:
+                tower_down: T.Optional[E.Var] = None, latlon_coords=None, buf: T.Optional[torch.Tensor] = None) -> E.Var:
         size = decode_side.shape[-2:]
         # the resized up-convolutions write straight into their channel slices of the concat buffer
         cs = [backbone_side.shape[1], backbone_down.shape[1], decode_side.shape[1], decode_down.shape[1]]
         if tower_down is not None:
             cs.append(tower_down.shape[1])
         B = decode_side.shape[0]
-        buf = E.new_buffer((B, sum(cs), size[0], size[1]), decode_side.t)
+        want = (B, sum(cs), size[0], size[1])
+        if buf is None or tuple(buf.shape) != want or buf.dtype != decode_side.t.dtype:
+            buf = E.new_buffer(want, decode_side.t)
         offs = [sum(cs[:i]) for i in range(len(cs))]
         sl = lambda i: buf[:, offs[i]:offs[i] + cs[i]]
         parts = [backbone_side, self.backbone_down_conv(backbone_down, size=size, out=sl(1)), decode_side,
@@ -283,8 +300,17 @@ class TowerUNetFusion(nn.Module):
         self.tower_a = TowerUNetBlock(channels[0], channels[1], tower=True, dilations=dilations,
                                       **{**kw, **NATTEN_PARAMS["a"]})
 
-    def forward(self, encoded: T.Dict[str, E.Var], decoded: T.Dict[str, E.Var], latlon_coords=None):
-        c = self.tower_c(encoded["x_c"], encoded["x_d"], decoded["x_cu"], decoded["x_du"])
-        b = self.tower_b(encoded["x_b"], encoded["x_c"], decoded["x_bu"], decoded["x_cu"], tower_down=c)
-        a = self.tower_a(encoded["x_a"], encoded["x_b"], decoded["x_au"], decoded["x_bu"], tower_down=b)
+    def make_buffers(self, B: int, sizes: T.Dict[str, T.Tuple[int, int]], like: torch.Tensor):
+        """(bufs, encoder outs, decoder outs): the three concat buffers and the slices x_a/x_b/x_c, x_au/x_bu/x_cu go to."""
+        bufs, enc, dec = {}, {}, {}
+        for k, blk in (("a", self.tower_a), ("b", self.tower_b), ("c", self.tower_c)):
+            bufs[k], enc["x_" + k], dec["x_" + k + "u"] = blk.make_buffer(B, sizes[k], like)
+        return bufs, enc, dec
+
+    def forward(self, encoded: T.Dict[str, E.Var], decoded: T.Dict[str, E.Var], latlon_coords=None,
+                bufs: T.Optional[T.Dict[str, torch.Tensor]] = None):
+        bf = bufs or {}
+        c = self.tower_c(encoded["x_c"], encoded["x_d"], decoded["x_cu"], decoded["x_du"], buf=bf.get("c"))
+        b = self.tower_b(encoded["x_b"], encoded["x_c"], decoded["x_bu"], decoded["x_cu"], tower_down=c, buf=bf.get("b"))
+        a = self.tower_a(encoded["x_a"], encoded["x_b"], decoded["x_au"], decoded["x_bu"], tower_down=b, buf=bf.get("a"))
         return {"x_tower_a": a, "x_tower_b": b, "x_tower_c": c}
