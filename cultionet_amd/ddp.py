@@ -102,15 +102,21 @@ class GradientAllReduce:
         if on_gpu and self.comm_stream is None:
             self.comm_stream = torch.cuda.Stream(device=flat.device)
         nodes, tape.nodes = tape.nodes, []
-        for k in range(len(nodes) - 1, -1, -1):
-            nodes[k]()
-            nodes[k] = None
-            ready = by_node.get(k, ())
-            # weight gradients run on the engine's side stream: the bucket stream waits for them, the compute stream
-            # does not (joining it here five times per step would serialise the two streams at every bucket)
-            side_ev = _engine.side_stream_event() if (ready and on_gpu) else None
-            for lo, hi in ready:
-                works.append(self._launch(flat[lo:hi], on_gpu, side_ev))
+        hold = _engine.begin_branch_backward(tape)
+        try:
+            for k in range(len(nodes) - 1, -1, -1):
+                nodes[k]()
+                if hold is not None:
+                    hold.append(nodes[k])
+                nodes[k] = None
+                ready = by_node.get(k, ())
+                # weight gradients run on the engine's side stream: the bucket stream waits for them, the compute stream
+                # does not (joining it here five times per step would serialise the two streams at every bucket)
+                side_ev = _engine.side_stream_event() if (ready and on_gpu) else None
+                for lo, hi in ready:
+                    works.append(self._launch(flat[lo:hi], on_gpu, side_ev))
+        finally:
+            _engine.release_branches()
         if on_gpu:
             _engine.join_side_stream()
         for lo, hi, r in plan:  # buckets whose ready index lies outside the tape (no nodes recorded)
@@ -137,4 +143,6 @@ class GradientAllReduce:
             self.comm_stream.wait_event(ev)
             if side_ev is not None:
                 self.comm_stream.wait_event(side_ev)
+            for ev in _engine.aux_stream_events():  # head branches still running their backward on auxiliary streams
+                self.comm_stream.wait_event(ev)
             return dist.all_reduce(chunk, op=dist.ReduceOp.SUM, group=self.group, async_op=True)

@@ -149,6 +149,9 @@ class Tape:
 
     def add(self, fn: T.Callable[[], None], params: T.Sequence[T.Optional[torch.Tensor]] = ()) -> None:
         if self.enabled:
+            br = getattr(_state, "branch", None)
+            if br is not None:  # recorded inside spawn(): its backward runs on the branch's stream
+                fn = br.wrap(fn)
             self.nodes.append(fn)
             if params:
                 base = current_store()._base
@@ -160,8 +163,15 @@ class Tape:
 
     def backward(self) -> None:
         nodes, self.nodes = self.nodes, []
-        while nodes:
-            nodes.pop()()
+        hold = begin_branch_backward(self)
+        try:
+            while nodes:
+                fn = nodes.pop()
+                fn()
+                if hold is not None:
+                    hold.append(fn)
+        finally:
+            release_branches()
         join_side_stream()
 
 
@@ -239,21 +249,29 @@ class side_stream:
             return self
         main = _main_stream()
         st = _side_state(main.device)
-        _py_op(st["event"].record, main)
-        _py_op(st["stream"].wait_event, st["event"])
+        cur = getattr(_state, "stream_obj_override", None) or main  # (inside spawn(): the branch's stream)
+        if cur is main:
+            _py_op(st["event"].record, main)
+            _py_op(st["stream"].wait_event, st["event"])
+        else:  # a fresh event: st["event"] may still be pending on the compute stream's behalf
+            ev = torch.cuda.Event()
+            _py_op(ev.record, cur)
+            _py_op(st["stream"].wait_event, ev)
         st["dirty"] = True
         self.st = st
+        self.prev = (getattr(_state, "stream_override", None), getattr(_state, "stream_obj_override", None))
         # launches go through the C ABI with an explicit stream handle: redirect _stream() instead of switching torch's
         # current stream (a torch.cuda.stream() context costs ~15 us of host time per layer). torch allocations made
         # inside the block still belong to the main stream: nothing inside may rely on a torch op (fills go through
         # cn_fill_f32 on the side stream).
         self.ctx = True
         _state.stream_override = st["stream"].cuda_stream
+        _state.stream_obj_override = st["stream"]
         return self
 
     def __exit__(self, *exc):
         if self.ctx is not None:
-            _state.stream_override = None
+            _state.stream_override, _state.stream_obj_override = self.prev
             for t in self.tensors:
                 if t is not None:
                     t.record_stream(self.st["stream"])
@@ -269,6 +287,216 @@ def join_side_stream() -> None:
     if st is not None and st["dirty"]:
         _py_op(main.wait_stream, st["stream"])
         st["dirty"] = False
+
+
+# ---------------------------------------------------------------------------
+# small sub-graphs beside the big kernels: spawn() / join()
+# ---------------------------------------------------------------------------
+# final_c and final_b (TowerUNetFinal, nunet.py:197-202 of the reference) are chains of ~15 small launches forward and
+# ~25 backward on 9- / 3- / 1-channel tensors. They depend only on x_tower_c / x_tower_b, which exist long before the
+# forward reaches the heads, and in backward nothing needs their result until tower_b / tower_c run. spawn() puts such
+# a chain on an auxiliary stream the moment its input exists, so that it executes BESIDE the MFMA-bound tower
+# convolutions of the compute stream (the regime in which overlap pays on this chip: a bandwidth- / latency-bound kernel
+# next to a matrix-pipe-bound one); its tape nodes run on the same stream in backward. CN_HEAD_STREAMS=0: off.
+_HEAD_STREAMS = os.environ.get("CN_HEAD_STREAMS", "1") != "0"
+_aux_streams: T.Dict[T.Any, T.List["torch.cuda.Stream"]] = {}
+_KEEP_FNS = ("empty", "empty_like", "zeros", "zeros_like", "full")
+
+
+def _aux_stream(dev, k: int) -> "torch.cuda.Stream":
+    if _OVERLAP_WGRAD:
+        _side_state(dev)  # HIP deals streams to hardware queues in creation order: the weight-gradient stream first
+    lst = _aux_streams.setdefault(dev, [])
+    while len(lst) <= k:
+        lst.append(torch.cuda.Stream(device=dev))
+    return lst[k]
+
+
+class _KeepAlive:
+    """Frees are deferred while any branch is open. torch's caching allocator only knows the compute stream (launches
+    go through the C ABI with explicit stream handles): a block freed on the host while an auxiliary stream's kernel
+    still uses it could be handed to a compute-stream allocation at once. Reference-counted: tensors torch hands out
+    (allocation functions wrapped, as the launch-plan recorder does), finished backward closures and incoming gradients
+    are held until the last open branch has been joined."""
+
+    def __init__(self):
+        self.depth = 0
+        self.keep: T.List[T.Any] = []
+        self.saved: T.Dict[str, T.Any] = {}
+
+    def acquire(self) -> None:
+        self.depth += 1
+        if self.depth > 1:
+            return
+        tid = threading.get_ident()
+        for name in _KEEP_FNS:
+            real = getattr(torch, name)
+            self.saved[name] = real
+
+            def f(*a, _real=real, **k):
+                t = _real(*a, **k)
+                if threading.get_ident() == tid:
+                    self.keep.append(t)
+                return t
+
+            setattr(torch, name, f)
+
+    def release(self, force: bool = False) -> None:
+        if self.depth == 0:
+            return
+        self.depth = 0 if force else self.depth - 1
+        if self.depth == 0:
+            for name, real in self.saved.items():
+                setattr(torch, name, real)
+            self.saved = {}
+            self.keep = []
+
+
+def _keepalive() -> _KeepAlive:
+    ka = getattr(_state, "keepalive", None)
+    if ka is None:
+        ka = _state.keepalive = _KeepAlive()
+    return ka
+
+
+def begin_branch_backward(tape) -> T.Optional[T.List[T.Any]]:
+    """A tape with spawned branches: NOTHING is freed during its backward (returns the list that holds the finished
+    nodes' closures; allocations are held by the wrappers). Between a branch's start and its fork the compute stream
+    runs arbitrary nodes of its own; a block one of them frees on the host while its kernel is still queued must not be
+    handed to an allocation whose kernel runs on an auxiliary stream."""
+    if not getattr(tape, "has_branches", False):
+        return None
+    ka = _keepalive()
+    ka.acquire()
+    return ka.keep
+
+
+def release_branches() -> None:
+    """After a backward pass (also one that raised): nothing may be left holding tensors or torch wrappers."""
+    _keepalive().release(force=True)
+    _state.open_branches = []
+
+
+def aux_stream_events() -> T.List["torch.cuda.Event"]:
+    """Events recorded now on the auxiliary streams with backward work of open branches (for the RCCL bucket stream,
+    like side_stream_event())."""
+    out = []
+    for br in getattr(_state, "open_branches", ()):
+        ev = torch.cuda.Event()
+        ev.record(br.stream)
+        out.append(ev)
+    return out
+
+
+class _Branch:
+    def __init__(self, stream: "torch.cuda.Stream", main: "torch.cuda.Stream", inputs, aliases):
+        self.stream, self.main = stream, main
+        self.inputs, self.aliases = inputs, aliases
+        self.fork_ev, self.done_ev = torch.cuda.Event(), torch.cuda.Event()
+        self.left = 0
+        self.result = None
+
+    def enter(self):
+        prev = (getattr(_state, "stream_override", None), getattr(_state, "stream_obj_override", None))
+        _state.stream_override, _state.stream_obj_override = self.stream.cuda_stream, self.stream
+        _bind_conv_workspace(self.main.device)
+        return prev
+
+    @staticmethod
+    def leave(prev) -> None:
+        _state.stream_override, _state.stream_obj_override = prev
+
+    def wrap(self, fn: T.Callable[[], None]) -> T.Callable[[], None]:
+        self.left += 1
+
+        def node():
+            prev = self.enter()
+            try:
+                fn()
+            finally:
+                self.leave(prev)
+            _keepalive().keep.append(fn)  # its closure (saved activations) lives until the branches are joined
+            self.left -= 1
+            if self.left == 0:
+                _py_op(self.done_ev.record, self.stream)
+
+        return node
+
+    def bwd_fork(self) -> None:
+        """In backward this runs AFTER the branch's nodes (it was recorded before them): the compute stream waits for
+        the branch, takes over the gradients of its inputs, and the deferred frees of this branch are released."""
+        _py_op(self.main.wait_event, self.done_ev)
+        for x, xa in zip(self.inputs, self.aliases):
+            if xa.grad is not None:
+                give_grad(x, xa.grad)
+                xa.grad = None
+        ob = getattr(_state, "open_branches", None)
+        if ob and self in ob:
+            ob.remove(self)
+        _keepalive().release()
+
+
+def spawn(fn: T.Callable[..., T.Any], inputs: T.Sequence[Var], k: int) -> T.Tuple[T.Optional[_Branch], T.Any]:
+    """Run ``fn(*aliases of inputs)`` -- engine ops that read nothing but ``inputs`` and the parameters -- on auxiliary
+    stream k, concurrently with whatever the compute stream does next. Returns (branch, result); join([branch, ...])
+    must be called before the result is used. The branch sees ALIASES of its inputs (same tensors, own gradient slots):
+    two streams never accumulate into one gradient buffer; the compute stream adds the alias gradients in bwd_fork."""
+    tape = current_tape()
+    if (not _HEAD_STREAMS or not _OVERLAP_WGRAD or not torch.cuda.is_available()
+            or getattr(_state, "stream_override", None) is not None or getattr(_state, "branch", None) is not None):
+        return None, fn(*inputs)
+    main = _main_stream()
+    aliases = [Var(x.t, x.req) for x in inputs]
+    br = _Branch(_aux_stream(main.device, k), main, list(inputs), aliases)
+    if tape.enabled:
+        tape.has_branches = True
+        tape.add(br.bwd_fork)
+    _keepalive().acquire()
+    _py_op(br.fork_ev.record, main)
+    _py_op(br.stream.wait_event, br.fork_ev)
+    prev = br.enter()
+    _state.branch = br
+    try:
+        br.result = fn(*aliases)
+    finally:
+        _state.branch = None
+        br.leave(prev)
+    _py_op(br.done_ev.record, br.stream)
+    return br, br.result
+
+
+def join(branches: T.Sequence[T.Optional[_Branch]]) -> None:
+    """The compute stream waits for the spawned branches (forward); in backward this is where they may start."""
+    brs = [b for b in branches if b is not None]
+    if not brs:
+        return
+    tape = current_tape()
+    for br in brs:
+        _py_op(br.main.wait_event, br.done_ev)
+        _keepalive().release()
+    if not tape.enabled:
+        return
+
+    def bwd_join():
+        ka = _keepalive()
+        ob = getattr(_state, "open_branches", None)
+        if ob is None:
+            ob = _state.open_branches = []
+        ev = torch.cuda.Event()
+        for br in brs:
+            ka.acquire()
+            ob.append(br)
+            r = br.result
+            for v in (r if isinstance(r, (tuple, list)) else (r,)):
+                if isinstance(v, Var) and v.grad is not None:
+                    ka.keep.append(v.grad)  # allocated before the deferral began, freed inside the branch
+        _py_op(ev.record, brs[0].main)
+        for br in brs:
+            _py_op(br.stream.wait_event, ev)
+            if br.left == 0:  # no backward nodes: nothing to wait for at the fork
+                _py_op(br.done_ev.record, br.stream)
+
+    tape.add(bwd_join)
 
 
 def side_stream_event() -> T.Optional["torch.cuda.Event"]:
@@ -1837,7 +2065,8 @@ def _ws16(need: int, dev: torch.device, pool_name: str = "wgrad") -> T.Tuple[int
     pool = getattr(_state, "ws16_pool", None)
     if pool is None:
         pool = _state.ws16_pool = {}
-    key = (dev, pool_name)
+    # ("wgrad" / "side" live on the ONE weight-gradient stream; every other pool belongs to the stream that launches)
+    key = (dev, pool_name) if pool_name in ("wgrad", "side") else (dev, pool_name, getattr(_state, "stream_override", None))
     ws = pool.get(key)
     if ws is None or ws.numel() < need:
         if ws is not None:  # growing: the old buffer may still be in use by launches in flight on either stream

@@ -206,11 +206,21 @@ class TowerUNet(nn.Module):
             bufs, eouts, douts = self.tower_fusion.make_buffers(emb.shape[0], sizes, emb.t)
         enc = self.encoder(emb, outs=eouts)
         dec = self.decoder(enc, outs=douts)
-        tow = self.tower_fusion(encoded=enc, decoded=dec, bufs=bufs)
-        size = tow["x_tower_a"].shape[-2:]
+        # final_c / final_b start the moment their tower exists, on auxiliary streams beside the next tower's convolutions
+        # (engine.spawn); final_a follows tower_a on the compute stream
+        size = enc["x_a"].shape[-2:]
+        heads = {}
+
+        def start(key, final):
+            def go(xt):
+                heads[key] = E.spawn(lambda v: final(v, size=size, suffix="_" + key), [xt], 0 if key == "c" else 1)
+            return go
+
+        tow = self.tower_fusion(encoded=enc, decoded=dec, bufs=bufs,
+                                after={"c": start("c", self.final_c), "b": start("b", self.final_b)})
         out_a = self.final_a(tow["x_tower_a"], suffix="_a")
-        out_b = self.final_b(tow["x_tower_b"], size=size, suffix="_b")
-        out_c = self.final_c(tow["x_tower_c"], size=size, suffix="_c")
+        (br_c, out_c), (br_b, out_b) = heads["c"], heads["b"]
+        E.join([br_c, br_b])
         if self.training:
             E._py_op(torch._foreach_add_, self.__dict__["_cn_nbt"], 1)  # BatchNorm bookkeeping (not arithmetic on the path)
         return self.final_combine(out_a, out_b, out_c, suffixes=["_a", "_b", "_c"])

@@ -34,7 +34,7 @@ class ForwardPlan:
     __slots__ = ("calls", "pool", "x", "outputs", "key", "keep")
 
     def __init__(self):
-        self.calls: T.List[T.Tuple[T.Any, tuple]] = []
+        self.calls: T.List[T.Tuple[int, T.Any, tuple]] = []  # (0, C entry point, args) | (1, python stream op, args)
         self.pool = None
         self.x: T.Optional[torch.Tensor] = None
         self.outputs: T.Optional[T.Dict[str, torch.Tensor]] = None
@@ -78,7 +78,10 @@ def forward(model, x: torch.Tensor, bf16: bool, run: T.Callable[[torch.Tensor], 
             plans[slot] = plans.pop(slot)
         if x.data_ptr() != plan.x.data_ptr():
             plan.x.copy_(x)
-        for fn, args in plan.calls:
+        for kind, fn, args in plan.calls:
+            if kind:  # a stream operation of the recorded forward (event record / wait of engine.spawn / join)
+                fn(*args)
+                continue
             rc = fn(*args)
             if rc != 0:
                 raise _lib.HipKernelError(f"replayed launch failed: {_lib.ERRORS.get(rc, rc)}")
@@ -95,7 +98,7 @@ def forward(model, x: torch.Tensor, bf16: bool, run: T.Callable[[torch.Tensor], 
         rc = fn(*args)
         if rc != 0:
             raise _lib.HipKernelError(f"{name} failed: {_lib.ERRORS.get(rc, rc)}")
-        plan.calls.append((fn, args))
+        plan.calls.append((0, fn, args))
         return rc
 
     epoch0 = E.workspace_epoch()
@@ -103,10 +106,13 @@ def forward(model, x: torch.Tensor, bf16: bool, run: T.Callable[[torch.Tensor], 
         plan.x = torch.empty_like(x)
         plan.x.copy_(x)
         _lib.call = recording
+        prev_rec = E._recorder
+        E._recorder = plan.calls  # engine._py_op appends (1, fn, args): stream operations in program order
         try:
             outs = run(plan.x)
         finally:
             _lib.call = orig
+            E._recorder = prev_rec
         plan.outputs = dict(outs)
     if E.workspace_epoch() != epoch0:  # a scratch buffer moved while recording: stale pointers, do not keep the plan
         return plan.outputs

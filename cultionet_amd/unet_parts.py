@@ -308,9 +308,16 @@ class TowerUNetFusion(nn.Module):
         return bufs, enc, dec
 
     def forward(self, encoded: T.Dict[str, E.Var], decoded: T.Dict[str, E.Var], latlon_coords=None,
-                bufs: T.Optional[T.Dict[str, torch.Tensor]] = None):
-        bf = bufs or {}
+                bufs: T.Optional[T.Dict[str, torch.Tensor]] = None,
+                after: T.Optional[T.Dict[str, T.Callable[[E.Var], None]]] = None):
+        """``after["c"]`` / ``after["b"]``: called with x_tower_c / x_tower_b as soon as they exist (TowerUNet starts their
+        heads there, beside the next tower's convolutions)."""
+        bf, af = bufs or {}, after or {}
         c = self.tower_c(encoded["x_c"], encoded["x_d"], decoded["x_cu"], decoded["x_du"], buf=bf.get("c"))
+        if "c" in af:
+            af["c"](c)
         b = self.tower_b(encoded["x_b"], encoded["x_c"], decoded["x_bu"], decoded["x_cu"], tower_down=c, buf=bf.get("b"))
+        if "b" in af:
+            af["b"](b)
         a = self.tower_a(encoded["x_a"], encoded["x_b"], decoded["x_au"], decoded["x_bu"], tower_down=b, buf=bf.get("a"))
         return {"x_tower_a": a, "x_tower_b": b, "x_tower_c": c}
