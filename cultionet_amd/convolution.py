@@ -12,6 +12,7 @@ reference); every forward runs engine ops on ``Var`` buffers:
 """
 from __future__ import annotations
 
+import os
 import typing as T
 
 import torch
@@ -217,6 +218,9 @@ class ResidualConv(nn.Module):
         return self.seq(x, residual=out)
 
 
+_ATT_STREAM = os.environ.get("CN_ATT_STREAM", "1") != "0"  # A/B switch: the attention chain beside the conv branches
+
+
 class ResidualAConv(nn.Module):
     """convolution.py:250-395: out = skip(x) + sum_d ResConvBlock2d_d(x) [+ LN(NA(LN(skip(x))))]."""
 
@@ -259,6 +263,14 @@ class ResidualAConv(nn.Module):
         G = len(self.res_modules)
         blocks0 = [m.block[0] for m in self.res_modules]
         sum_out = out if self.attention_weights is None else None  # (with attention the branch sum is an intermediate)
+        natten = self.attention_weights == AttentionTypes.NATTEN
+        att_br = att = None
+        if natten and _ATT_STREAM and not isinstance(self.skip, nn.Conv2d) and E.is16(x.t):
+            # LayerNorm -> neighbourhood attention (qkv, windows, projection) reads nothing but x: on an auxiliary stream
+            # beside the MFMA-bound convolution branches (engine.spawn); joined before the closing LayerNorm + add.
+            # Mixed precision only: there the chain is bandwidth-bound (same box: bf16 step +1.0 %, reference-default
+            # point +1.0 %, predict +3 %); in fp32 its 1x1 convolutions are matrix-pipe-bound like the branches (-0.5 %)
+            att_br, att = E.spawn(lambda v: self.attention_conv[2](E.layer_norm_c(v, self.attention_conv[1])), [x], 0)
         fused_eval = (not blocks0[0].batchnorm_first
                       and all(E.can_fuse_eval(x, b.seq[1], self.training) for m in self.res_modules for b in m.block))
         if 2 <= G <= 4 and all(len(m.block) == 2 for m in self.res_modules) and not blocks0[0].batchnorm_first \
@@ -284,10 +296,11 @@ class ResidualAConv(nn.Module):
             res = skip
             for layer in self.res_modules:
                 res = layer(x, residual=res)  # out + SiLU(BN(conv(...))) fused in the last block
-        if self.attention_weights == AttentionTypes.NATTEN:
-            a = E.layer_norm_c(skip, self.attention_conv[1])
-            a = self.attention_conv[2](a)
-            res = E.layer_norm_c(a, self.attention_conv[3], residual=res, out=out)
+        if natten:
+            if att is None:
+                att = self.attention_conv[2](E.layer_norm_c(skip, self.attention_conv[1]))
+            E.join([att_br])
+            res = E.layer_norm_c(att, self.attention_conv[3], residual=res, out=out)
         elif self.attention_weights is not None:  # spatial_channel: out *= attention(skip)
             res = E.spatial_channel_attention(skip, res, self.attention_conv)
         return res
