@@ -75,6 +75,7 @@ class GradientAllReduce:
         self.measure = False
         self.exposed: T.List[T.Tuple[T.Any, T.Any]] = []
         self.buckets_last_step = 0
+        _engine.disable_branch_streams("communicator")  # (measured: see engine.disable_branch_streams)
 
     def sync_initial_state(self, store, module=None) -> None:
         """Replicas must start identical (init_conv_weights is random per process): broadcast rank 0's state."""

@@ -303,12 +303,36 @@ _aux_streams: T.Dict[T.Any, T.List["torch.cuda.Stream"]] = {}
 _KEEP_FNS = ("empty", "empty_like", "zeros", "zeros_like", "full")
 
 
+def disable_branch_streams(reason: str) -> None:
+    """spawn() runs its sub-graph inline from now on (process-wide). Called by GradientAllReduce: with a process group
+    alive the auxiliary streams cost 40 % of the step (one-rank RCCL group, round 4: bf16 2115 -> 1230 chips/s, fp32 377 ->
+    238, whatever their priority) -- the heads' backward ends up serialised with the bucket collectives. Data-parallel
+    runs keep the single compute stream + weight-gradient stream + bucket stream of round 3."""
+    global _HEAD_STREAMS
+    _HEAD_STREAMS = False
+
+
 def _aux_stream(dev, k: int) -> "torch.cuda.Stream":
     if _OVERLAP_WGRAD:
         _side_state(dev)  # HIP deals streams to hardware queues in creation order: the weight-gradient stream first
     lst = _aux_streams.setdefault(dev, [])
     while len(lst) <= k:
-        lst.append(torch.cuda.Stream(device=dev))
+        # HIGHEST priority, through the C ABI like the weight-gradient stream: a priority is a property of the hardware
+        # queue, so these streams can never be dealt the queue of the compute stream, of the (lowest-priority)
+        # weight-gradient stream or of RCCL's streams -- with torch.cuda.Stream() (normal priority) a live process group
+        # put an auxiliary stream on a queue shared with the compute stream: 2115 -> 1255 chips/s (bf16), 377 -> 241 (fp32).
+        # CN_AUX_STREAM=normal restores that for experiments.
+        if os.environ.get("CN_AUX_STREAM", "high") == "normal":
+            lst.append(torch.cuda.Stream(device=dev))
+            continue
+        import ctypes
+
+        handle = ctypes.c_void_p()
+        rng = (ctypes.c_int * 2)()
+        with torch.cuda.device(dev):
+            _lib.call("cn_stream_priority_range", rng)
+            _lib.call("cn_stream_create", int(rng[1]), None, 0, ctypes.byref(handle))
+        lst.append(torch.cuda.ExternalStream(handle.value, device=dev))
     return lst[k]
 
 
