@@ -47,7 +47,7 @@ PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # MI355X_MICROARCH.md: f32-input M
 PEAK_HBM_GBS = 8000.0
 FAMILY = {0: "cn_conv_igemm*/cn_conv1x1 <NT=128>", 1: "cn_conv_igemm* <NT<=64>", 2: "cn_wgrad* <3x3>",
           3: "cn_wgrad* <1x1>", 4: "cn_bconv_kernel (bf16)", 5: "cn_bwgrad_kernel (bf16)"}
-PMC_FILES = {"f32": "profiles/r04_v3_pmc_traffic_f32.json", "bf16": "profiles/r04_v3_pmc_traffic_bf16.json"}
+PMC_FILES = {"f32": "profiles/r04_v5_pmc_traffic_f32.json", "bf16": "profiles/r04_v5_pmc_traffic_bf16.json"}
 
 
 def parse():
