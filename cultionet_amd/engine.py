@@ -309,7 +309,8 @@ def disable_branch_streams(reason: str) -> None:
     238, whatever their priority) -- the heads' backward ends up serialised with the bucket collectives. Data-parallel
     runs keep the single compute stream + weight-gradient stream + bucket stream of round 3."""
     global _HEAD_STREAMS
-    _HEAD_STREAMS = False
+    if os.environ.get("CN_KEEP_BRANCH_STREAMS") != "1":  # (diagnostic: keep them to profile the interaction)
+        _HEAD_STREAMS = False
 
 
 def _aux_stream(dev, k: int) -> "torch.cuda.Stream":
