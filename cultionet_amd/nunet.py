@@ -192,6 +192,13 @@ class TowerUNet(nn.Module):
 
     def forward_vars(self, x: E.Var) -> T.Dict[str, E.Var]:
         """Engine-level forward: x is a Var over [B, C*T, H, W]; returns {distance, edge, crop} Vars."""
+        try:
+            return self._forward_vars(x)
+        except BaseException:
+            E.release_branches()  # a forward that died between spawn() and join() must not leave frees deferred
+            raise
+
+    def _forward_vars(self, x: E.Var) -> T.Dict[str, E.Var]:
         E.current_store().refresh()  # torch optimizers / checkpoint loads since the last pack (drop-in mode)
         if self.training and self.has_dropout():
             E.begin_rng_step(x.t.device)  # fresh dropout masks for this step (device step word; see engine.manual_seed)
