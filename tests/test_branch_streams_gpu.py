@@ -1,0 +1,67 @@
+"""engine.spawn / join (the tower heads and, in mixed precision, the decoder attention chains on auxiliary streams beside
+MFMA-bound convolutions) against the single-stream step: the same kernels on the same data, only
+their streams differ, so trajectories agree to the noise the step has against ITSELF (float-atomic parameter-gradient
+sums). The first version of the branch streams passed every single-fixture test and failed two of seventeen when the
+fixtures ran in sequence (a block freed by a compute-stream node went to an auxiliary-stream allocation): hence several
+models of different shapes in ONE process here, each stepped with the streams on and off."""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def _trajectory(precision, hidden, B, H, streams, steps=5, dropout=0.0, seed=1234):
+    from cultionet_amd import engine as E
+    from cultionet_amd import synthetic as S
+    from cultionet_amd.data import Data
+    from cultionet_amd.lightning import CultionetLitModel, HipTrainer
+
+    prev = E._HEAD_STREAMS
+    E._HEAD_STREAMS = streams
+    try:
+        lit = CultionetLitModel(in_channels=3, in_time=12, hidden_channels=hidden, dropout=dropout)
+        m = lit.cultionet_model.mask_model
+        m.load_state_dict(S.seeded_state_dict(m.state_dict()))
+        lit = lit.to("cuda:0").train()
+        tr = HipTrainer(lit, precision=precision)
+        E.manual_seed(seed)
+        losses = []
+        for k in range(steps):
+            x, y, bd = S.seeded_batch(B, height=H, width=H, seed=70 + k % 3, with_mask=True)
+            losses.append(float(tr.training_step(Data(x=x.cuda(), y=y.cuda(), bdist=bd.cuda())).item()))
+        torch.cuda.synchronize()
+        state = {n: p.detach().float().cpu().clone() for n, p in m.named_parameters()}
+        return np.array(losses), state
+    finally:
+        E._HEAD_STREAMS = prev
+
+
+@pytest.mark.parametrize("precision,tol", [("32-true", 5e-6), ("bf16-mixed", 2e-3)])
+def test_branch_streams_follow_the_single_stream_trajectory(precision, tol):
+    # models of different widths / plane sizes back to back in one process: allocator blocks of one are re-used by the next
+    for hidden, B, H in ((8, 2, 28), (16, 3, 52), (32, 2, 100), (8, 1, 36)):
+        l1, s1 = _trajectory(precision, hidden, B, H, True)
+        l0, s0 = _trajectory(precision, hidden, B, H, False)
+        assert np.isfinite(l1).all()
+        assert np.abs(l1 - l0).max() <= tol, (hidden, B, H, l1, l0)
+        worst = max(float((s1[n] - s0[n]).abs().max()) for n in s1)
+        assert worst <= (2e-4 if precision == "32-true" else 0.05), (hidden, B, H, worst)
+
+
+def test_branch_streams_with_dropout_draw_the_same_masks():
+    """Mask seeds are counters taken in program order: the order in which ops are ISSUED does not depend on the stream
+    they run on, so a step with the branch streams draws the masks of the single-stream step."""
+    l1, _ = _trajectory("32-true", 8, 2, 28, True, dropout=0.25)
+    l0, _ = _trajectory("32-true", 8, 2, 28, False, dropout=0.25)
+    assert np.abs(l1 - l0).max() <= 5e-6, (l1, l0)
+
+
+def test_no_deferred_frees_are_left_behind():
+    from cultionet_amd import engine as E
+
+    _trajectory("bf16-mixed", 8, 2, 28, True, steps=2)
+    ka = E._keepalive()
+    assert ka.depth == 0 and not ka.keep and not ka.saved  # torch.empty & co. are the originals again
+    assert torch.empty.__module__ == "torch" or not hasattr(torch.empty, "__wrapped__")
+    assert not getattr(E._state, "open_branches", [])
