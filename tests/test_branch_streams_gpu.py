@@ -39,8 +39,10 @@ def _trajectory(precision, hidden, B, H, streams, steps=5, dropout=0.0, seed=123
 
 @pytest.mark.parametrize("precision,tol", [("32-true", 5e-6), ("bf16-mixed", 2e-3)])
 def test_branch_streams_follow_the_single_stream_trajectory(precision, tol):
-    # models of different widths / plane sizes back to back in one process: allocator blocks of one are re-used by the next
-    for hidden, B, H in ((8, 2, 28), (16, 3, 52), (32, 2, 100), (8, 1, 36)):
+    # models of different widths / plane sizes back to back in one process: allocator blocks of one are re-used by the
+    # next. (Checked: with the "nothing is freed during a branched backward" rule switched off this sequence fails in fp32
+    # on the first run; a sequence of small models only does not.)
+    for hidden, B, H in ((8, 2, 28), (32, 1, 100), (32, 8, 100), (8, 2, 28), (64, 1, 100), (16, 3, 52)):
         l1, s1 = _trajectory(precision, hidden, B, H, True)
         l0, s0 = _trajectory(precision, hidden, B, H, False)
         assert np.isfinite(l1).all()
