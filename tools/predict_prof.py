@@ -28,6 +28,7 @@ for _ in range(reps):
 t1 = time.perf_counter()
 torch.cuda.synchronize()
 t2 = time.perf_counter()
+print(f"peak allocated {torch.cuda.max_memory_allocated() / 2**30:.2f} GiB, reserved {torch.cuda.memory_reserved() / 2**30:.2f} GiB")
 print(f"{prec} batch {bs} replay {rp}: {(t2 - t0) / reps * 1e3:.2f} ms per scene ({HS * HS / ((t2 - t0) / reps) / 1e6:.1f} Mpx/s), "
       f"host enqueue {(t1 - t0) / reps * 1e3:.2f} ms per scene")
 if os.environ.get("CN_PROF_DUMP"):  # per-launch table of the contraction kernels: python tools/layerprof.py $CN_PROF_DUMP 3 bf16
