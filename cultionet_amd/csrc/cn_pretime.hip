@@ -301,7 +301,9 @@ template <int PASS, int CMAX, int MT, int NE>
 #ifndef PT_MINB
 #define PT_MINB 1
 #endif
-__global__ __launch_bounds__(256, PT_MINB) void cn_pretime_kernel(const CnPtArgs a) {
+// (PASS 3 at C <= 4, Cout <= 32 fits 251 VGPRs without its 48 AGPR copies: two blocks per CU instead of one)
+// (the output pass at three blocks per CU -- 168 VGPRs, 128 bytes of scratch -- measured 1-4 % faster: not worth the spills)
+__global__ __launch_bounds__(256, (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_MINB) void cn_pretime_kernel(const CnPtArgs a) {
   float* const lds = pt_smem;  // (only for the block-cooperative copy at the top and the parked doubles at the end)
   __shared__ int s_flag;
   const int tid = threadIdx.x, lane = tid & 63;
