@@ -600,7 +600,8 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
   }
   for (int i = 0; i < g.G; ++i)
     if ((reinterpret_cast<uintptr_t>(g.gS[i]) & 15) || (reinterpret_cast<uintptr_t>(g.gB[i]) & 15)) return CN_ERR_ARG;
-  const int slots = (lds * 2 <= 160 * 1024) ? 512 : 256;  // resident blocks on the chip
+  int slots = (lds * 2 <= 160 * 1024) ? 512 : 256;  // resident blocks on the chip
+  slots = slots * cn_side_cus() / 256;  // (experiment knob CN_WGRAD_CUS: leave CUs to the compute stream)
   int splits = slots / (gx * gy * g.G);                   // never spill into a second, mostly idle round
   if (splits > g.total_chunks) splits = g.total_chunks;
   if (splits < 1) splits = 1;

@@ -1216,6 +1216,17 @@ _PRETIME_FUSED = os.environ.get("CN_PRETIME_FUSED", "1")
 _PRETIME_BWD = os.environ.get("CN_PRETIME_BWD", "main")
 
 
+def _zeroed_scratch(n: int, dev: torch.device) -> torch.Tensor:
+    """A scratch buffer whose ticket-counter head must be zero before its first launch, zeroed ON THE STREAM THAT WILL
+    USE IT. ``torch.zeros`` fills on torch's current (compute) stream, but these buffers are keyed to the
+    weight-gradient side stream or an auxiliary stream, which had only waited for an event recorded BEFORE the
+    allocation: the fill raced the first ticketed kernel. ``cn_fill_f32`` on ``_stream()`` is ordered by construction;
+    a recycled block is safe because that stream already waits for everything the compute stream enqueued earlier."""
+    ws = torch.empty(n, dtype=torch.float32, device=dev)
+    _lib.call("cn_fill_f32", ws.data_ptr(), n, 0.0, _stream())
+    return ws
+
+
 def _pretime_ws(need: int, dev: torch.device) -> torch.Tensor:
     """Scratch of the fused PreTimeReduction calls, one per (device, stream): zero-filled once (ticket counters at its
     head; every launch leaves them zero)."""
@@ -1224,7 +1235,7 @@ def _pretime_ws(need: int, dev: torch.device) -> torch.Tensor:
     if ws is None or ws.numel() < need:
         if ws is not None:
             torch.cuda.synchronize(dev)
-        ws = _pt_ws[key] = torch.zeros(need, dtype=torch.float32, device=dev)
+        ws = _pt_ws[key] = _zeroed_scratch(need, dev)
         _bump_ws_epoch()
     return ws
 
@@ -2098,7 +2109,7 @@ def _ws16(need: int, dev: torch.device, pool_name: str = "wgrad") -> T.Tuple[int
             torch.cuda.synchronize(dev)
         # zero-filled: the single-launch reductions keep their ticket counters in the first words of these buffers
         # (zero on entry, left zero on exit)
-        ws = pool[key] = torch.zeros(need, dtype=torch.float32, device=dev)
+        ws = pool[key] = _zeroed_scratch(need, dev)
         _bump_ws_epoch()
     return ws.data_ptr(), ws.numel()
 
@@ -2497,7 +2508,7 @@ def _bn_group_ws16(G: int, C: int, dev: torch.device) -> int:
     if ws is None or ws.numel() < need:
         if ws is not None:
             torch.cuda.synchronize(dev)
-        ws = _bng_ws[key] = torch.zeros(max(need, 1 << 20), dtype=torch.float32, device=dev)
+        ws = _bng_ws[key] = _zeroed_scratch(max(need, 1 << 20), dev)
         _bump_ws_epoch()
     return ws.data_ptr()
 

@@ -29,6 +29,9 @@ from .losses import CombinedLoss, TanimotoComplementLoss, TanimotoDistLoss
 
 try:  # the real LightningModule when lightning is installed (it is not in the build image)
     from lightning import LightningModule as _Base  # type: ignore
+
+    if not hasattr(_Base, "load_from_checkpoint"):  # a test double left in sys.modules is not Lightning
+        raise ImportError("lightning.LightningModule lacks load_from_checkpoint")
 except Exception:  # pragma: no cover - exercised in the build image
     class _Base(torch.nn.Module):
         """Minimal stand-in providing the LightningModule methods this file uses."""

@@ -83,12 +83,19 @@ def _train_case(ns, hidden, B, H, W, with_mask, seed=7, stages=False, loss_name=
     out["loss"] = np.float64(loss.item())
     for k, v in rep.items():
         out[k] = np.float64(v.item())
-    names, norms = [], []
+    names, norms, firsts, projs, numels = [], [], [], [], []
     for n, p in m.named_parameters():
         names.append(n.replace("cultionet_TowerUNet.mask_model.", ""))
         norms.append(float(p.grad.double().norm()))
+        first, proj = O.grad_probe(names[-1], p.grad)  # element-level probe (norms alone cannot see a swap)
+        firsts.append(first.numpy())
+        projs.append(proj)
+        numels.append(p.numel())
     out["grad_names"] = np.array(names)
     out["grad_norms"] = np.array(norms, dtype=np.float64)
+    out["grad_probe_first"] = np.stack(firsts).astype(np.float32)
+    out["grad_probe_proj"] = np.array(projs, dtype=np.float64)
+    out["grad_numel"] = np.array(numels, dtype=np.int64)
     out["margin"] = np.float64(min(float((pred[k].float() - 0.5).abs().min()) for k in ("distance", "edge", "crop")))
     # running statistics after one train-mode forward (BN momentum path)
     sd = m.state_dict()

@@ -59,6 +59,8 @@ def import_reference():
             pass
 
     lightning.LightningModule = LightningModule
+    lightning._oracle_stub = True
+    prev_lightning = sys.modules.get("lightning")
     sys.modules["lightning"] = lightning
 
     try:  # a real torchmetrics pins the validation metrics; absent here => the restatement in oracle/metrics_ref.py
@@ -106,7 +108,17 @@ def import_reference():
 
     data_mod.Data = Data
     sys.modules["cultionet.data"] = data_mod
-    return _namespace()
+    try:
+        return _namespace()
+    finally:
+        # The stub is only needed while the reference modules are being imported (they bind LightningModule at class
+        # creation). Leaving it in sys.modules made a later ``import cultionet_amd.lightning`` subclass the STUB
+        # (no load_from_checkpoint): the suite passed only in alphabetical order.
+        if sys.modules.get("lightning") is lightning:
+            if prev_lightning is not None:
+                sys.modules["lightning"] = prev_lightning
+            else:
+                del sys.modules["lightning"]
 
 
 def _namespace():

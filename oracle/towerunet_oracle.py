@@ -653,3 +653,26 @@ def seeded_batch(batch: int, channels: int = 3, time: int = 12, height: int = 10
     bdist = torch.rand(batch, height, width, generator=g)
     y = torch.randint(-1 if with_mask else 0, 3, (batch, height, width), generator=g)
     return x, y, bdist
+
+
+# ---------------------------------------------------------------------------
+# gradient probes (fixtures): element-level evidence without shipping 42 MB of gradients
+# ---------------------------------------------------------------------------
+GRAD_PROBE_FIRST = 64
+
+
+def grad_probe(name: str, grad: torch.Tensor) -> T.Tuple["torch.Tensor", float]:
+    """(first GRAD_PROBE_FIRST elements zero-padded, fixed random projection) of one parameter's gradient.
+
+    The projection is ``sum(g * r) / sqrt(numel)`` with ``r ~ N(0, 1)`` drawn from a CPU generator seeded by
+    ``crc32(name)``: any permutation / swap / sign error inside the tensor moves it by O(rms(g)), while its value for
+    the right gradient is reproducible on every box. Generator (oracle/make_golden.py, real reference) and tests use
+    THIS function, so both sides project onto the same vector."""
+    g = grad.detach().double().flatten().cpu()
+    first = torch.zeros(GRAD_PROBE_FIRST, dtype=torch.float64)
+    k = min(GRAD_PROBE_FIRST, g.numel())
+    first[:k] = g[:k]
+    gen = torch.Generator().manual_seed(zlib.crc32(name.encode()))
+    r = torch.randn(g.numel(), generator=gen, dtype=torch.float64)
+    return first, float((g * r).sum() / math.sqrt(g.numel()))
+

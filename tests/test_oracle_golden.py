@@ -64,6 +64,13 @@ def test_oracle_train_matches_reference_vectors(golden_dir, name, kw, loss_name)
     norms = {n: float(p.grad.double().norm()) for n, p in m.named_parameters()}
     for n, ref in zip(names, g["grad_norms"]):
         assert abs(norms[n] - ref) <= 1e-5 * max(1.0, abs(ref)), n
+    # element-level probes of the reference's gradients (first 64 elements + a fixed random projection per parameter)
+    params = dict(m.named_parameters())
+    for i, n in enumerate(names):
+        first, proj = O.grad_probe(str(n), params[str(n)].grad)
+        scale = max(1.0, float(np.abs(g["grad_probe_first"][i]).max()), float(g["grad_norms"][i]))
+        assert np.abs(first.numpy() - g["grad_probe_first"][i]).max() <= 1e-5 * scale, n
+        assert abs(proj - float(g["grad_probe_proj"][i])) <= 1e-5 * scale, n
     sd = m.state_dict()
     k0 = str(g["bn_key"]) if "bn_key" in g.files else "tower_fusion.tower_a.res_conv.res_modules.0.block.0.seq.1."
     assert np.abs(sd[k0 + "running_mean"].numpy() - g["bn_running_mean"]).max() <= TOL
