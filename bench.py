@@ -411,7 +411,7 @@ def launch_ranks(args) -> int:
     return proc.returncode if (proc.returncode != 0 or line is not None) else 1
 
 
-def run_child(kind: str, args, extra: typing.Sequence[str] = ()) -> dict:
+def run_child(kind: str, args, extra: typing.Sequence[str] = (), env_extra: typing.Optional[dict] = None) -> dict:
     """One block of the default line -- the bf16 configuration, the predict scene -- in a FRESH child process of rank 0
     (N = 1 only). Which HIP streams end up sharing a hardware queue depends on the creation history of a process
     (DESIGN.md section 7): the second configuration of a process measured 1611-1937 chips/s where a process of its own
@@ -424,11 +424,36 @@ def run_child(kind: str, args, extra: typing.Sequence[str] = ()) -> dict:
     if args.no_cpu_baseline:
         cmd.append("--no-cpu-baseline")
     env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")}
+    env.update(env_extra or {})
     proc = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
     for ln in proc.stdout.splitlines():
         if ln.startswith("{"):
             return json.loads(ln)
     raise RuntimeError(f"bench child {kind!r} failed (rc {proc.returncode})")
+
+
+def ddp1_block(args) -> dict:
+    """The step AS A DATA-PARALLEL RANK RUNS IT, on the one GPU the driver's N = 1 run has: a one-rank RCCL process group
+    (CN_FORCE_COMM=1) puts the bucket stream, the five bucketed all-reduces per step and the stream set of
+    cultionet_amd.ddp into the timed region -- no auxiliary branch streams (engine.branch_streams_allowed), weight-gradient
+    slice sums flushed once per ready bucket. fp32 batch 8 and bf16 batch 32 (BASELINE configs[1] / configs[3] per GPU),
+    each in a fresh child process. One rank exchanges nothing over xGMI: this prices the stream set and the exposed
+    launch / wait time of the collectives, NOT the scaling curve (reference: strategy="ddp",
+    /root/reference/src/cultionet/model.py:101,168-186)."""
+    out = {"workload": "train step with a live one-rank RCCL group (CN_FORCE_COMM=1): the data-parallel stream set",
+           "note": "one rank: no bytes cross xGMI; no scaling curve is implied"}
+    for dt in ("f32", "bf16"):
+        try:
+            c = run_child("train", args, ["--dtype", dt, "--no-extras", "--no-cpu-baseline"], {"CN_FORCE_COMM": "1"})
+            cfg = c.get("config", {})
+            out[dt] = {"value": c["value"], "unit": c["unit"], "ms_per_step": c["ms_per_step"],
+                       "global_batch": cfg.get("global_batch"), "rccl_ranks": cfg.get("rccl_ranks"),
+                       "buckets_per_step": cfg.get("buckets_per_step"), "comm_ms_exposed": cfg.get("comm_ms_exposed"),
+                       "end_barrier_ms": cfg.get("end_barrier_ms"),
+                       "kernel_launches_per_step": cfg.get("kernel_launches_per_step")}
+        except Exception as e:
+            out[dt] = {"error": repr(e)}
+    return out
 
 
 class TrainLeg:
@@ -821,6 +846,11 @@ def main():
                 out["predict"] = {"error": repr(e)}
         else:
             out["predict"] = predict_block(dev, args.hidden, not args.no_cpu_baseline, args.cpu_threads)
+        if not use_dist:  # the data-parallel stream set (one-rank RCCL group), both precisions, child processes
+            try:
+                out["ddp1"] = ddp1_block(args)
+            except Exception as e:
+                out["ddp1"] = {"error": repr(e)}
         try:  # the reference CLI's default operating point (hidden 64, batch 4, 16-mixed, dropout 0.1), replayed
             out["default_point"] = run_child("default_point", args) if not use_dist else \
                 default_point_block(dev, min(args.steps, 30), args.warmup)
@@ -841,6 +871,14 @@ def main():
             cfg["predict_tile_ms_bf16"] = pr.get("tile", {}).get("bf16_mixed", {}).get("ms_per_tile")
         if "feed" in out:
             cfg["feed_delta_ms"] = out["feed"]["delta_ms_vs_resident"]
+        d1 = out.get("ddp1") or {}
+        for dt in ("f32", "bf16"):
+            if "value" in (d1.get(dt) or {}):
+                cfg[f"ddp1_{dt}_chips_per_s"] = d1[dt]["value"]
+                cfg[f"ddp1_{dt}_ms_per_step"] = d1[dt]["ms_per_step"]
+                cfg[f"ddp1_{dt}_buckets_per_step"] = d1[dt]["buckets_per_step"]
+                cfg[f"ddp1_{dt}_comm_ms_exposed"] = d1[dt]["comm_ms_exposed"]
+                cfg["ddp1_rccl_ranks"] = d1[dt]["rccl_ranks"]
         dp = out.get("default_point") or {}
         if "value" in dp:
             cfg["default_point_chips_per_s"] = dp["value"]

@@ -121,6 +121,10 @@ SIGNATURES = {
     "cn_profile_top": [I, P, I, P],
     "cn_profile_set_filter": [P],
     "cn_launch_count": [I],
+    "cn_slice_sums_begin": [P, I, P, L],
+    "cn_slice_sums_count": [],
+    "cn_slice_sums_end": [],
+    "cn_slice_sums_run": [P, P, I, I, I, P],
     "cn_stream_priority_range": [P],
     "cn_stream_create": [I, P, I, P],
     "cn_stream_destroy": [P],

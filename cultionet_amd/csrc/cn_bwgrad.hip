@@ -24,6 +24,7 @@
 //   tools/bwgrad_stamps.py). Two P fragments x (2 taps x 2 Q fragments) + the centre's = 14 reads per k-step: 224.
 #include "cn_bf16.h"
 #include "cn_profile.h"
+#include "cn_slicesum.h"
 
 #define CNW_PITCH 192  // bytes per pixel row in LDS (64 channels = 128 B + 64 B pad): conflict-free transposed reads
 #define CNW_MAX_TAPS 9
@@ -620,6 +621,12 @@ static int cnw_run(CnBWgGeom& g, float* dw, float* ws, long ws_floats, hipStream
 #undef CNW_GO1
   cn_prof_after(stream, 5, flops);  // the contraction kernel alone
   const long n = (long)g.CP * g.CQ * g.T;
+  {  // deferred: a sink on this thread takes the sum and runs it later in one batched launch (cn_slicesum.h)
+    CnSliceSum j = {};
+    j.part = g.part; j.dw = dw; j.slice_stride = (long)g.T * g.nbp * 64 * g.nbq * 64; j.n = n; j.nslices = g.nsplit;
+    j.kind = 1; j.T = g.T; j.CP = g.CP; j.CQ = g.CQ; j.CPp = g.nbp * 64; j.CQp = g.nbq * 64;
+    if (cn_ss_push(&j, 1)) return cn_check_launch();
+  }
   const int rb = (int)((n + 63) / 64 < 8192 ? (n + 63) / 64 : 8192);
   CN_LAUNCH(cn_bwgrad_reduce_kernel, dim3(rb), dim3(256), 0, stream, g.part, dw, g.nsplit, g.T, g.CP, g.CQ,
                      (long)g.nbp * 64, (long)g.nbq * 64);

@@ -13,6 +13,7 @@
 // /root/reference/src/cultionet/nn/modules/convolution.py:45-120.
 #include "cn_common.h"
 #include "cn_profile.h"
+#include "cn_slicesum.h"
 
 #define WG_MAX_TAPS 9
 #define WG_BC 32   // b-channels per block
@@ -652,6 +653,13 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
     CN_LAUNCH((cn_wgrad_vec_kernel<T, 2>), grid, dim3(256), lds, stream, g.gS[0], g.gB[0], out, g);
   cn_prof_after(stream, T == 9 ? 2 : 3, g.flops * g.G);  // the contraction kernel alone
   if (g.slice_stride != 0) {
+    // deferred: a sink on this thread takes the G sums (one record per group) and runs them later in one batched launch
+    CnSliceSum js[4] = {};
+    for (int i = 0; i < g.G; ++i) {
+      js[i].part = ws + (long)i * nslices * g.slice_stride; js[i].dw = g.gdW[i]; js[i].slice_stride = g.slice_stride;
+      js[i].n = dw_floats; js[i].nslices = (int)nslices; js[i].kind = 0;
+    }
+    if (cn_ss_push(js, g.G)) return cn_check_launch();
     CnWgradReduceArgs ra = {ws, g.slice_stride, (int)nslices, dw_floats, {g.gdW[0], g.gdW[1], g.gdW[2], g.gdW[3]}};
     CN_LAUNCH(cn_wgrad_reduce_kernel,
                        dim3((unsigned)((dw_floats + 255) / 256), nslices > 128 ? 16 : 1, g.G), dim3(256), 0, stream,

@@ -75,7 +75,6 @@ class GradientAllReduce:
         self.measure = False
         self.exposed: T.List[T.Tuple[T.Any, T.Any]] = []
         self.buckets_last_step = 0
-        _engine.disable_branch_streams("communicator")  # (measured: see engine.disable_branch_streams)
 
     def sync_initial_state(self, store, module=None) -> None:
         """Replicas must start identical (init_conv_weights is random per process): broadcast rank 0's state."""
@@ -105,17 +104,21 @@ class GradientAllReduce:
         nodes, tape.nodes = tape.nodes, []
         hold = _engine.begin_branch_backward(tape)
         try:
-            for k in range(len(nodes) - 1, -1, -1):
-                nodes[k]()
-                if hold is not None:
-                    hold.append(nodes[k])
-                nodes[k] = None
-                ready = by_node.get(k, ())
-                # weight gradients run on the engine's side stream: the bucket stream waits for them, the compute stream
-                # does not (joining it here five times per step would serialise the two streams at every bucket)
-                side_ev = _engine.side_stream_event() if (ready and on_gpu) else None
-                for lo, hi in ready:
-                    works.append(self._launch(flat[lo:hi], on_gpu, side_ev))
+            with _engine.deferring_slice_sums(store):
+                for k in range(len(nodes) - 1, -1, -1):
+                    nodes[k]()
+                    if hold is not None:
+                        hold.append(nodes[k])
+                    nodes[k] = None
+                    ready = by_node.get(k, ())
+                    if ready and on_gpu:
+                        # the weight-gradient slice sums deferred so far: ONE launch, in front of the bucket's event
+                        _engine.flush_slice_sums()
+                    # weight gradients run on the engine's side stream: the bucket stream waits for them, the compute
+                    # stream does not (joining it here five times per step would serialise the two streams at every bucket)
+                    side_ev = _engine.side_stream_event() if (ready and on_gpu) else None
+                    for lo, hi in ready:
+                        works.append(self._launch(flat[lo:hi], on_gpu, side_ev))
         finally:
             _engine.release_branches()
         if on_gpu:

@@ -164,12 +164,14 @@ class Tape:
     def backward(self) -> None:
         nodes, self.nodes = self.nodes, []
         hold = begin_branch_backward(self)
+        store = getattr(_state, "store", None)
         try:
-            while nodes:
-                fn = nodes.pop()
-                fn()
-                if hold is not None:
-                    hold.append(fn)
+            with deferring_slice_sums(store) if store is not None else contextlib.nullcontext():
+                while nodes:
+                    fn = nodes.pop()
+                    fn()
+                    if hold is not None:
+                        hold.append(fn)
         finally:
             release_branches()
         join_side_stream()
@@ -303,14 +305,42 @@ _aux_streams: T.Dict[T.Any, T.List["torch.cuda.Stream"]] = {}
 _KEEP_FNS = ("empty", "empty_like", "zeros", "zeros_like", "full")
 
 
-def disable_branch_streams(reason: str) -> None:
-    """spawn() runs its sub-graph inline from now on (process-wide). Called by GradientAllReduce: with a process group
-    alive the auxiliary streams cost 40 % of the step (one-rank RCCL group, round 4: bf16 2115 -> 1230 chips/s, fp32 377 ->
-    238, whatever their priority) -- the heads' backward ends up serialised with the bucket collectives. Data-parallel
-    runs keep the single compute stream + weight-gradient stream + bucket stream of round 3."""
-    global _HEAD_STREAMS
-    if os.environ.get("CN_KEEP_BRANCH_STREAMS") != "1":  # (diagnostic: keep them to profile the interaction)
-        _HEAD_STREAMS = False
+def branch_streams_allowed() -> bool:
+    """spawn() runs its sub-graph on an auxiliary stream only while no torch.distributed process group is alive.
+
+    With a live group AND bucket collectives in flight the auxiliary streams cost 40 % of the step (one-rank RCCL group,
+    round 4: bf16 2115 -> 1230 chips/s, fp32 377 -> 238, whatever their priority; cause not found with one GPU -- DESIGN
+    section 7). Data-parallel ranks therefore keep the stream set of round 3: compute, weight gradients, buckets. The
+    check is LIVE (the round-4 switch flipped a process-global flag for good when a GradientAllReduce was
+    constructed): it follows the process group's lifetime, covers the drop-in mode under Lightning's own DDP as well, and
+    a trainer / predictor created after the group is destroyed gets its branches back. CN_KEEP_BRANCH_STREAMS=1
+    overrides it (to profile the interaction); ``engine.branch_streams(False)`` switches spawn() off for a scope."""
+    if not _HEAD_STREAMS or getattr(_state, "no_branches", False):
+        return False
+    if _KEEP_BRANCHES:
+        return True
+    import torch.distributed as dist
+
+    return not (dist.is_available() and dist.is_initialized())
+
+
+_KEEP_BRANCHES = os.environ.get("CN_KEEP_BRANCH_STREAMS") == "1"
+
+
+class branch_streams:
+    """Context manager: allow (default) / forbid spawn() to use auxiliary streams on this thread for a scope."""
+
+    def __init__(self, enabled: bool):
+        self.enabled = bool(enabled)
+
+    def __enter__(self):
+        self.prev = getattr(_state, "no_branches", False)
+        _state.no_branches = not self.enabled
+        return self
+
+    def __exit__(self, *exc):
+        _state.no_branches = self.prev
+        return False
 
 
 def _aux_stream(dev, k: int) -> "torch.cuda.Stream":
@@ -337,44 +367,67 @@ def _aux_stream(dev, k: int) -> "torch.cuda.Stream":
     return lst[k]
 
 
+_ka_lock = threading.Lock()
+_ka_users = 0
+_ka_saved: T.Dict[str, T.Any] = {}
+
+
+def _ka_install() -> None:
+    """Wrap torch's allocation functions ONCE per process while any thread defers frees (reference-counted under a
+    lock -- ADVICE r4: per-thread save / restore of the module attributes let one thread uninstall another's wrapper
+    or leave its own installed for good). The wrapper files each tensor under the CALLING thread's keep list."""
+    global _ka_users
+    with _ka_lock:
+        _ka_users += 1
+        if _ka_users > 1:
+            return
+        for name in _KEEP_FNS:
+            real = getattr(torch, name)
+            _ka_saved[name] = real
+
+            def f(*a, _real=real, **k):
+                t = _real(*a, **k)
+                ka = getattr(_state, "keepalive", None)
+                if ka is not None and ka.depth > 0:
+                    ka.keep.append(t)
+                return t
+
+            setattr(torch, name, f)
+
+
+def _ka_uninstall() -> None:
+    global _ka_users
+    with _ka_lock:
+        _ka_users -= 1
+        if _ka_users == 0:
+            for name, real in _ka_saved.items():
+                setattr(torch, name, real)
+            _ka_saved.clear()
+
+
 class _KeepAlive:
     """Frees are deferred while any branch is open. torch's caching allocator only knows the compute stream (launches
     go through the C ABI with explicit stream handles): a block freed on the host while an auxiliary stream's kernel
-    still uses it could be handed to a compute-stream allocation at once. Reference-counted: tensors torch hands out
-    (allocation functions wrapped, as the launch-plan recorder does), finished backward closures and incoming gradients
-    are held until the last open branch has been joined."""
+    still uses it could be handed to a compute-stream allocation at once. Reference-counted per thread: tensors torch
+    hands out (allocation functions wrapped process-wide, see _ka_install), finished backward closures and incoming
+    gradients are held until the thread's last open branch has been joined."""
 
     def __init__(self):
         self.depth = 0
         self.keep: T.List[T.Any] = []
-        self.saved: T.Dict[str, T.Any] = {}
 
     def acquire(self) -> None:
         self.depth += 1
-        if self.depth > 1:
-            return
-        tid = threading.get_ident()
-        for name in _KEEP_FNS:
-            real = getattr(torch, name)
-            self.saved[name] = real
-
-            def f(*a, _real=real, **k):
-                t = _real(*a, **k)
-                if threading.get_ident() == tid:
-                    self.keep.append(t)
-                return t
-
-            setattr(torch, name, f)
+        if self.depth == 1:
+            _ka_install()
 
     def release(self, force: bool = False) -> None:
         if self.depth == 0:
             return
         self.depth = 0 if force else self.depth - 1
         if self.depth == 0:
-            for name, real in self.saved.items():
-                setattr(torch, name, real)
-            self.saved = {}
             self.keep = []
+            _ka_uninstall()
 
 
 def _keepalive() -> _KeepAlive:
@@ -467,8 +520,8 @@ def spawn(fn: T.Callable[..., T.Any], inputs: T.Sequence[Var], k: int) -> T.Tupl
     must be called before the result is used. The branch sees ALIASES of its inputs (same tensors, own gradient slots):
     two streams never accumulate into one gradient buffer; the compute stream adds the alias gradients in bwd_fork."""
     tape = current_tape()
-    if (not _HEAD_STREAMS or not _OVERLAP_WGRAD or not torch.cuda.is_available()
-            or getattr(_state, "stream_override", None) is not None or getattr(_state, "branch", None) is not None):
+    if (not _OVERLAP_WGRAD or not torch.cuda.is_available() or getattr(_state, "stream_override", None) is not None
+            or getattr(_state, "branch", None) is not None or not branch_streams_allowed()):
         return None, fn(*inputs)
     main = _main_stream()
     aliases = [Var(x.t, x.req) for x in inputs]
@@ -613,6 +666,8 @@ class ParamStore:
     all-reduce operate directly (``attach_grads`` exposes them as ``param.grad`` views).
     """
 
+    _serial = __import__("itertools").count(1)
+
     def __init__(self, module: torch.nn.Module):
         params = [p for p in module.parameters()]
         if not params:
@@ -636,6 +691,9 @@ class ParamStore:
                 view.copy_(p.data)
                 p.data = view
         self.version = 0  # bumped whenever parameter values change (invalidates packed weights)
+        # process-unique serial: caches key their validity on it (CPython may hand a rebuilt store the id() of a dead one,
+        # and a cached VIEW of the old flat buffer would then be used silently -- ADVICE r4)
+        self.uid = next(ParamStore._serial)
         self._sig = self._signature()
         self._base = self.flat.data_ptr()
         self._packs: T.List[T.Tuple] = []      # (PackedWeight, attr, dst tensor, w ptr, T, K, N, sk, sn, st)
@@ -850,9 +908,9 @@ def _pack(pw: "PackedWeight", attr: str, w: torch.Tensor, T_: int, K: int, N: in
 def _sync_packs(pw: "PackedWeight") -> None:
     """Bring all registered packed weights up to date if the parameters changed since the last pack."""
     st = current_store()
-    if pw.store_id != id(st):  # parameters were re-flattened into a new store: drop copies of the old one
+    if pw.store_id != st.uid:  # parameters were re-flattened into a new store: drop copies of the old one
         pw.fwd = pw.bwd = pw.fwd16 = pw.bwd16 = None
-        pw.store_id = id(st)
+        pw.store_id = st.uid
     if pw.version != st.version:
         if pw.fwd is None and pw.bwd is None and pw.fwd16 is None and pw.bwd16 is None:
             pw.version = st.version
@@ -937,6 +995,150 @@ def _rows(t: torch.Tensor) -> int:
 _WS_FLOATS = 16 << 20  # persistent weight-gradient scratch (64 MB): aligned operand copies + partial dW slices
 
 
+# ---------------------------------------------------------------------------
+# deferred weight-gradient slice sums (csrc/cn_slicesum.h)
+# ---------------------------------------------------------------------------
+# A many-split weight gradient leaves partial dW slices in scratch; `dW += sum(slices)` is needed by the optimizer (or by
+# the gradient bucket's all-reduce), not by the next backward node. During a backward pass the library appends those
+# sums to a table instead of launching them (34 fp32 / 68 bf16 dependent launches per step), and ONE batched launch per
+# flush -- per ready bucket under data parallelism, else one per step -- adds them all. Since the slices must survive
+# until then, every weight-gradient call of the pass takes its scratch from an arena that only moves forward.
+# CN_DEFER_SUMS=0: the sums run right behind their contraction as in rounds 1-4.
+_DEFER_SUMS = os.environ.get("CN_DEFER_SUMS", "1") != "0"
+_SS_CAP = 512            # records per backward pass (64 bytes each)
+_SS_BLOCK = 64 << 20     # floats per arena block (256 MB)
+
+
+class _SliceSums:
+    """Per-device state of the deferred sums: pinned host table the library writes, its device copy, the arena."""
+
+    def __init__(self, dev: torch.device):
+        self.dev = dev
+        self.host = torch.zeros(_SS_CAP * 64, dtype=torch.uint8).pin_memory()
+        self.table = torch.zeros(_SS_CAP * 64, dtype=torch.uint8, device=dev)
+        self.uploaded: T.Dict[T.Tuple[int, int], bytes] = {}  # record range -> bytes the device copy holds for it
+        self.upload_ev: T.Optional["torch.cuda.Event"] = None   # recorded behind the last table upload
+        self.blocks: T.List[torch.Tensor] = []
+        self.active = False
+        self.reset()
+
+    def reset(self) -> None:
+        self.cur, self.off, self.seen, self.flushed = 0, 0, 0, 0
+
+    def _commit(self) -> None:
+        """Move the arena past the slices of the records appended since the last call (a call whose sum was not
+        deferred leaves nothing behind: its scratch is reused by the next call, as stream order allows)."""
+        n = _lib.query("cn_slice_sums_count")
+        if n <= self.seen or not self.blocks:
+            return
+        import struct
+
+        raw = bytes(self.host[self.seen * 64:n * 64].numpy())
+        base = self.blocks[self.cur].data_ptr()
+        for i in range(n - self.seen):
+            part, _dw, stride, _n, nslices = struct.unpack_from("<QQqqi", raw, i * 64)
+            end = (part - base) // 4 + stride * nslices
+            if 0 <= end <= self.blocks[self.cur].numel():
+                self.off = max(self.off, (end + 63) // 64 * 64)
+        self.seen = n
+
+    def take(self, need: int) -> T.Tuple[int, int]:
+        self._commit()
+        need = int(need)
+        while True:
+            if self.cur >= len(self.blocks):
+                self.blocks.append(torch.empty(max(_SS_BLOCK, need), dtype=torch.float32, device=self.dev))
+                _bump_ws_epoch()
+            blk = self.blocks[self.cur]
+            if blk.numel() - self.off >= need:
+                return blk.data_ptr() + 4 * self.off, need
+            if self.off == 0:  # an oversized request in front of a standard block
+                torch.cuda.synchronize(self.dev)
+                self.blocks[self.cur] = torch.empty(need, dtype=torch.float32, device=self.dev)
+                _bump_ws_epoch()
+                continue
+            self.cur, self.off = self.cur + 1, 0
+
+
+_slice_sums: T.Dict[T.Any, _SliceSums] = {}
+
+
+def _ss_state() -> T.Optional[_SliceSums]:
+    """The active deferral state of this thread (None: sums run immediately)."""
+    return getattr(_state, "slice_sums", None)
+
+
+def _sum_stream() -> int:
+    """Handle of the stream every weight gradient of the pass runs on (the side stream, or the compute stream when the
+    overlap is off): the batched sums are stream-ordered behind the contractions that wrote their slices."""
+    if _OVERLAP_WGRAD:
+        return _side_state(_main_stream().device)["stream"].cuda_stream
+    return _stream()
+
+
+class deferring_slice_sums:
+    """Context manager around one backward pass: weight-gradient slice sums into ``store.flat_grad`` are collected and
+    run by flush_slice_sums() (called on exit, and by the data-parallel bucket logic before a bucket is reduced)."""
+
+    def __init__(self, store: "ParamStore"):
+        self.store = store
+        self.on = False
+
+    def __enter__(self):
+        if (not _DEFER_SUMS or _SIDE_MAX_WORK > 0 or _ss_state() is not None or not self.store.flat_grad.is_cuda):
+            return self
+        dev = self.store.flat_grad.device
+        st = _slice_sums.get(dev)
+        if st is None:
+            st = _slice_sums[dev] = _SliceSums(dev)
+        if st.active:  # another thread's pass on the same device: that one keeps the arena
+            return self
+        st.reset()
+        st.active = True
+        if st.upload_ev is not None:  # the library is about to rewrite the host table a pending upload still reads
+            st.upload_ev.synchronize()
+            st.upload_ev = None
+        _state.slice_sums = st
+        _lib.call("cn_slice_sums_begin", st.host.data_ptr(), _SS_CAP, self.store.flat_grad.data_ptr(),
+                  self.store.numel)
+        self.on = True
+        return self
+
+    def __exit__(self, *exc):
+        if self.on:
+            try:
+                if exc[0] is None:
+                    flush_slice_sums()
+            finally:
+                _lib.call("cn_slice_sums_end")
+                _state.slice_sums.active = False
+                _state.slice_sums = None
+        return False
+
+
+def flush_slice_sums() -> None:
+    """ONE launch adding every pending slice sum into the flat gradient, on the weight gradients' stream."""
+    st = _ss_state()
+    if st is None:
+        return
+    n = _lib.query("cn_slice_sums_count")
+    first = st.flushed
+    if n <= first:
+        return
+    now = st.host.numpy().reshape(-1, 64)[first:n, :60].tobytes()  # (without the block dealing the run call writes)
+    upload = 0 if st.uploaded.get((first, n)) == now else 1
+    stream = _sum_stream()
+    _lib.call("cn_slice_sums_run", st.host.data_ptr(), st.table.data_ptr(), first, n - first, upload, stream)
+    if upload:  # the device copy of every overlapping range is no longer what `uploaded` says
+        for k in [k for k in st.uploaded if k[0] < n and first < k[1]]:
+            del st.uploaded[k]
+        st.uploaded[(first, n)] = now
+        ev = torch.cuda.Event()
+        ev.record(torch.cuda.ExternalStream(stream, device=st.dev))
+        st.upload_ev = ev
+    st.flushed = n
+
+
 def _pad_ws(*tensors: torch.Tensor) -> T.Tuple[T.Optional[int], int]:
     """(pointer, floats) of the weight-gradient scratch: room for aligned copies of odd-sized operands plus the
     partial-dW slices of many-split launches. One persistent buffer per device (launches are stream-ordered)."""
@@ -946,6 +1148,9 @@ def _pad_ws(*tensors: torch.Tensor) -> T.Tuple[T.Optional[int], int]:
         if (H * W) % 4 or (W & 1):
             need += t.shape[0] * t.shape[1] * (H * (W + 1) + 3)
     dev = tensors[0].device
+    ss = _ss_state()
+    if ss is not None:  # deferred slice sums: this call's slices must outlive the next call
+        return ss.take(need)
     pool = getattr(_state, "ws_pool", None)
     if pool is None:
         pool = _state.ws_pool = {}
@@ -1161,10 +1366,10 @@ def time_conv(x: Var, mod, tin: int) -> Var:
     tout = tin - k + 1
     ver = current_store().version
     pw = mod.__dict__.get("_cn_packed")
-    if pw is None or pw.version != ver or pw.store_id != id(current_store()):
+    if pw is None or pw.version != ver or pw.store_id != current_store().uid:
         pw = PackedWeight()
         pw.version = ver
-        pw.store_id = id(current_store())
+        pw.store_id = current_store().uid
         mod.__dict__["_cn_packed"] = pw
     if pw.fwd is None:
         n = _lib.query("cn_conv_kpad", Cin * tin) * _lib.query("cn_conv_npad", Cout * tout)
@@ -2098,6 +2303,10 @@ def _ws16(need: int, dev: torch.device, pool_name: str = "wgrad") -> T.Tuple[int
     """(pointer, floats) of a persistent fp32 scratch of the bf16 kernels. One buffer per (device, purpose): the
     weight-gradient slices live on the side stream, BatchNorm partial sums on the main stream."""
     need = int(min(max(need, 1 << 20), _WS16_MAX_FLOATS))
+    if pool_name == "wgrad":
+        ss = _ss_state()
+        if ss is not None:  # deferred slice sums: this call's slices must outlive the next call
+            return ss.take(need)
     pool = getattr(_state, "ws16_pool", None)
     if pool is None:
         pool = _state.ws16_pool = {}
@@ -2382,7 +2591,7 @@ def conv_bn_act_eval(x: Var, conv, bn, act: int, stride: int, padding: int, dila
     fd = conv.__dict__.get("_cn_fold16")
     if fd is None:
         fd = conv.__dict__["_cn_fold16"] = _Fold16()
-    key = (id(store), store.version, _bn_stats_epoch, bn.running_mean._version, bn.running_var._version)
+    key = (store.uid, store.version, _bn_stats_epoch, bn.running_mean._version, bn.running_var._version)
     s = _stream()
     if fd.key != key:
         if fd.wp is None or fd.key is None or fd.key[0] != key[0]:
@@ -2729,9 +2938,9 @@ def _thin_conv3x3_bf16(x: Var, mods: T.Sequence, grouped: bool, dilation: int, o
     store = current_store()
     store.refresh()
     tw = mods[0].__dict__.get("_cn_thin16")
-    if tw is None or tw.store_id != id(store):
+    if tw is None or tw.store_id != store.uid:
         tw = _ThinPack16()
-        tw.store_id = id(store)
+        tw.store_id = store.uid
         per = CP * Cin * 9
         w0 = mods[0].weight
         # the store keeps declared groups adjacent (ParamStore._with_contiguous_groups): the n weights ARE one

@@ -220,7 +220,9 @@ class TowerUNet(nn.Module):
 
         def start(key, final):
             def go(xt):
-                heads[key] = E.spawn(lambda v: final(v, size=size, suffix="_" + key), [xt], 0 if key == "c" else 1)
+                # both heads on auxiliary stream 1: stream 0 belongs to the attention chains of the ResidualAConv blocks
+                # (convolution.py), which would queue behind final_c's ~15 launches inside tower_b / tower_a
+                heads[key] = E.spawn(lambda v: final(v, size=size, suffix="_" + key), [xt], 1)
             return go
 
         tow = self.tower_fusion(encoded=enc, decoded=dec, bufs=bufs,

@@ -53,7 +53,7 @@ def _bn_signature(model) -> int:
 
 def _key(model, store, x: torch.Tensor, bf16: bool):
     store.refresh()
-    return (tuple(x.shape), x.dtype, bool(bf16), id(store), store.version, E._bn_stats_epoch, _bn_signature(model),
+    return (tuple(x.shape), x.dtype, bool(bf16), store.uid, store.version, E._bn_stats_epoch, _bn_signature(model),
             torch.cuda.current_stream(x.device).cuda_stream, E._EVAL_FUSION, E.workspace_epoch())
 
 

@@ -506,6 +506,24 @@ int cn_profile_set_filter(const char* name);
  * reset != 0 returns the count and zeroes it. bench.py reports it as kernel launches per step. */
 long cn_launch_count(int reset);
 
+/* ---- deferred weight-gradient slice sums (cn_slicesum.h) ------------------------------------------------
+ * A many-split weight gradient leaves one partial dW slice per pixel split in the caller's scratch and must add
+ * them into dW (plain autograd accumulation: /root/reference/src/cultionet/nn/modules/convolution.py:71-120)
+ * before the optimizer / the bucket all-reduce reads it -- not before the next backward node. Between
+ * cn_slice_sums_begin and cn_slice_sums_end the *_bwd_weight_* entry points called on THIS thread with a dw
+ * inside [dw_lo, dw_lo + dw_floats) (the flat gradient buffer; a temporary dw is summed at once) append a
+ * 64-byte record to host_table (caller-owned, `capacity` records; pinned if cn_slice_sums_run uploads it)
+ * instead of launching their own reduction -- the caller must then keep every such call's scratch intact until
+ * the sums have run. cn_slice_sums_count: records so far (-1: no sink).
+ * cn_slice_sums_run: ONE launch summing records [first, first+n) (its blocks are dealt to the records on the
+ * host; that is written into host_table); dev_table = device copy of the table, refreshed from host_table for
+ * that range when upload != 0 (async on `stream`; upload == 0 asserts it already holds this range, dealt alike). Deterministic summation order; a record whose
+ * dW already has a pending record is refused by the sink (that call reduces immediately, as without a sink). */
+int cn_slice_sums_begin(void* host_table, int capacity, const float* dw_lo, long dw_floats);
+int cn_slice_sums_count(void);
+int cn_slice_sums_end(void);
+int cn_slice_sums_run(void* host_table, void* dev_table, int first, int n, int upload, void* stream);
+
 /* ---- runtime plumbing: streams torch cannot create ---------------------------------------------------
  * The training step issues weight gradients on a second stream (engine.py side_stream; the reference has no
  * counterpart: torch.autograd runs one stream). That stream must not starve the data-gradient chain:

@@ -41,3 +41,10 @@ def test_default_bench_line_has_every_block():
     assert "error" not in pr and pr["unit"] == "pixels/s" and pr["value"] == pr["bf16_mixed"]["value"] > pr["fp32"]["value"]
     assert 0 < pr["bf16_mixed"]["roofline"]["frac"] < 1 and pr["bf16_mixed"]["batch4"]["value"] > 0
     assert d["feed"]["value"] > 0 and d["feed"]["host_bytes_per_step"] > 0
+    # the data-parallel stream set on one GPU (one-rank RCCL group): both precisions, really through RCCL, buckets launched
+    d1 = d["ddp1"]
+    for dt in ("f32", "bf16"):
+        assert "error" not in d1[dt], d1[dt]
+        assert d1[dt]["rccl_ranks"] == 1 and d1[dt]["buckets_per_step"] >= 1 and d1[dt]["value"] > 0
+        assert d1[dt]["comm_ms_exposed"] is not None
+        assert d["config"][f"ddp1_{dt}_chips_per_s"] == d1[dt]["value"]
