@@ -559,7 +559,7 @@ static int cnw_plan(CnBWgGeom& g, int KH, int KW, int pad, int dil) {
   const int nb = g.nbp * g.nbq;
   // T = 9 keeps 144 accumulator registers per wave: one block per CU => one full round of 256 blocks; the 1x1
   // kernel runs two blocks per CU
-  const int want = (T > 4 ? 256 : 512) * cn_side_cus() / 256;  // (experiment knob CN_WGRAD_CUS)
+  const int want = T > 4 ? 256 : 512;
   int nsplit = (want + nb - 1) / nb;
   if (nsplit > g.ntiles) nsplit = g.ntiles;
   if (nsplit < 1) nsplit = 1;

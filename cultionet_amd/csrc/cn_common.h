@@ -1,6 +1,5 @@
 // Shared helpers for the cultionet_amd HIP kernels (gfx950 / CDNA4 only).
 #pragma once
-#include <cstdlib>
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
@@ -33,19 +32,6 @@ __device__ __forceinline__ unsigned long long cn_step_seed(unsigned long long se
 }
 
 static inline int cn_cdiv(long a, long b) { return (int)((a + b - 1) / b); }
-
-// Experiment knob (environment CN_WGRAD_CUS, default 256): how many of the 256 CUs the one-block-per-CU weight-gradient
-// launches of the side stream size their grids for. Fewer leaves whole CUs to the compute stream's kernels, which cannot
-// share a SIMD with a weight-gradient wave (393 of 512 registers per lane).
-static inline int cn_side_cus() {
-  static int v = -1;
-  if (v < 0) {
-    const char* e = getenv("CN_WGRAD_CUS");
-    v = e ? atoi(e) : 256;
-    if (v < 32 || v > 256) v = 256;
-  }
-  return v;
-}
 
 // ---- XCD-aware block order -------------------------------------------------------------------------------
 // Workgroups are dealt round-robin to the 8 XCDs, each with its own 4 MiB L2. Kernels whose neighbouring blocks

@@ -601,8 +601,10 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
   }
   for (int i = 0; i < g.G; ++i)
     if ((reinterpret_cast<uintptr_t>(g.gS[i]) & 15) || (reinterpret_cast<uintptr_t>(g.gB[i]) & 15)) return CN_ERR_ARG;
-  int slots = (lds * 2 <= 160 * 1024) ? 512 : 256;  // resident blocks on the chip
-  slots = slots * cn_side_cus() / 256;  // (experiment knob CN_WGRAD_CUS: leave CUs to the compute stream)
+  // resident blocks on the chip. (Sizing the grids for 224 / 192 / 160 of the 256 CUs, to leave whole CUs to the compute
+  // stream's kernels -- which cannot share a SIMD with a weight-gradient wave: 393 of 512 registers per lane -- was
+  // measured in round 5: fp32 386.4 -> 382.2 / 373.2 / 354.9 chips/s. The side stream is as long as the compute stream.)
+  const int slots = (lds * 2 <= 160 * 1024) ? 512 : 256;
   int splits = slots / (gx * gy * g.G);                   // never spill into a second, mostly idle round
   if (splits > g.total_chunks) splits = g.total_chunks;
   if (splits < 1) splits = 1;

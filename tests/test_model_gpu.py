@@ -405,6 +405,7 @@ def test_batch32_bf16_matches_oracle():
     relerr = np.array([e / r for _, e, r in live])
     print("bf16 batch 32: elementwise rel. error median %.3e p90 %.3e max %.3e over %d of %d parameters"
           % (np.median(relerr), np.percentile(relerr, 90), relerr.max(), len(live), len(errs)))
-    assert np.median(relerr) <= 8e-2 and np.percentile(relerr, 90) <= 0.3, (np.median(relerr), np.percentile(relerr, 90))
+    # (measured on the round-5 build: median 1.6e-2, 90th percentile 3.2e-2, max 4.6e-2)
+    assert np.median(relerr) <= 4e-2 and np.percentile(relerr, 90) <= 8e-2, (np.median(relerr), np.percentile(relerr, 90))
     worst = sorted(live, key=lambda t: -t[1] / t[2])[:8]
-    assert relerr.max() <= 0.9, worst  # (uncorrelated gradients: ||a - b|| / ||b|| ~ 1.4)
+    assert relerr.max() <= 0.2, worst  # (uncorrelated gradients: ||a - b|| / ||b|| ~ 1.4)
