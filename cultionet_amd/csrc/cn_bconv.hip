@@ -21,7 +21,6 @@
 // (packed in fragment order: one 16-byte load per lane serves WN MFMAs, no cross-wave reuse exists to stage for),
 // the pixel image is staged once per 32-channel chunk and shared by the four waves and all taps.
 #include <cstdlib>
-#include <type_traits>
 #include "cn_bf16.h"
 #include "cn_profile.h"
 #include "cn_ticket.h"
@@ -138,17 +137,19 @@ struct CnbPitch { static constexpr int value = KSC * 32 + 16; };  // bytes per h
 // fragments and register-prefetched the staging (209-237 VGPRs), thread-level parallelism wins on every 3x3 shape
 // (128->128 @100^2: 767 -> 842 TFLOP/s, @50^2: 531 -> 647): while one block stages or stores, two others multiply.
 //
-// NPW = 32-cout tiles PER WAVE (round 5). With NPW = 1 a wave multiplies one weight fragment into MPW = 4 pixel fragments:
-// the four waves of a block read the SAME pixel fragments from LDS, 16 KB per k-step for 128 MFMA cycles -- exactly the
-// LDS's 128 bytes per cycle, so the loop tops out at about half the matrix pipe's rate (1.18 PFLOP/s in the loop, DESIGN
-// 4b item 20). NPW = 2 (block = 2 cout waves x 2 pixel waves, 256 pixels x 128 couts, 8 accumulator tiles per wave): a
-// pixel fragment read from LDS and a weight fragment fetched from L2 each feed TWICE the MFMAs -- 64 B per cycle of LDS
-// and 32 B per cycle of L1 at the full matrix rate. 128 accumulator registers: two blocks per CU instead of three.
-template <int WN, int NP, int KSC, int MPW_ = 4, int NPW = 1>
-__global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const CnBGeom g) {
+// Round 5, built, parity-green and REMOVED: a "wide wave" variant (two 32-cout tiles per wave: block = 2 cout waves x 2
+// pixel waves, 256 pixels x 128 couts, 128 accumulator registers, two blocks per CU) on the premise that the step loop
+// is LDS-bound (four waves reading the same pixel fragments: 128 B per cycle at the full matrix rate) -- a fragment read
+// once would feed twice the MFMAs. In-kernel stamps (tools/bconv_stamps.py, 32 x 128 -> 128 x 100^2) say otherwise: the
+// loop ran at 26.9 ticks per MFMA and SIMD against 24.2 for this kernel (halving the LDS bytes per MFMA bought
+// nothing: the loop is not LDS-bound), while the staging of a 256-pixel halo in register-bounded phases cost 32 % of
+// a block's life (13 % here) with only two blocks per CU to hide it: 119 us against 104-107 us per launch, bf16 step
+// 2089 against 2140 chips/s. (Its first build also kept all 128 accumulators in SCRATCH: an un-unrolled loop over the
+// wave's cout tiles in the epilogue left acc[u] dynamically indexed -- 349 us.) profiles/r05_bconv_wide_stamps.txt.
+template <int WN, int NP, int KSC, int MPW_ = 4>
+__global__ __launch_bounds__(256, 3) void cn_bconv_kernel(const CnBGeom g) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int WM = 4 / WN;   // waves along the pixel columns
-  constexpr bool RP = NP <= 6 || NPW > 1;  // halo rows padded against bank conflicts (see cnb_launch: rowpad)
   constexpr int MPW = MPW_;    // 32-pixel columns per wave: every weight fragment (one 16-byte global load per
                                // lane) feeds MPW MFMAs; the block tile is 32 * MPW * WM pixels x 32 * WN couts.
                                // MPW = 4 everywhere but on small planes: (WN, MPW) = (2, 2) keeps the 128-pixel tile
@@ -193,7 +194,7 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
   const int tl = tile - b * k.tiles_per_img;
   const int tyi = tl / k.tiles_x, txi = tl - tyi * k.tiles_x;
   const int gy0 = tyi * g.TH, gx0 = txi * g.TW;  // logical tile origin
-  const int ntile = (nb * WN + wn) * NPW;        // this wave's (first) 32-cout tile
+  const int ntile = nb * WN + wn;                // this wave's 32-cout tile
   const bool n_live = ntile < g.NT;
   const int IW = k.IW;
   const int npix = g.TH * g.TW;
@@ -220,16 +221,14 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
   for (int i = 0; i < MPW; ++i) {
     const int m = (wm + i * WM) * 32 + r;
     const int ty = cnb_div(m, g.mgTW), tx = m - ty * g.TW;
-    pbase[i] = m < npix ? ((ty * g.is) * IW + tx * g.is) * PITCH + (RP ? (ty * g.is) * k.rowpad : 0) + h * 16 : h * 16;
+    pbase[i] = m < npix ? ((ty * g.is) * IW + tx * g.is) * PITCH + (NP <= 6 ? (ty * g.is) * k.rowpad : 0) + h * 16 : h * 16;
   }
 
-  f32x16 acc[NPW][MPW];
+  f32x16 acc[MPW];
 #pragma unroll
-  for (int u = 0; u < NPW; ++u)
+  for (int i = 0; i < MPW; ++i)
 #pragma unroll
-    for (int i = 0; i < MPW; ++i)
-#pragma unroll
-      for (int j = 0; j < 16; ++j) acc[u][i][j] = 0.f;
+    for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
 
   const int KS = g.KS, NT = g.NT;
   const int nchunks = (KS + KSC - 1) / KSC;
@@ -254,16 +253,12 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
         reinterpret_cast<bf16_t*>(((unsigned long long)whi << 32) | wlo), 0, 0x7fffffff, 0x00020000);
     const int lane16 = lane * 16;
     const int nt_c = n_live ? ntile : NT - 1;
-    int du[NPW];  // byte offset of this wave's u-th cout tile relative to its first (clamped to a valid fragment)
-    du[0] = 0;
-#pragma unroll
-    for (int u = 1; u < NPW; ++u) du[u] = ((ntile + u < NT ? ntile + u : NT - 1) - nt_c) * 1024;
     // step (ch, t, kp): k-steps ch*KSC + 2*kp and + 1
-    auto wload = [&](int ch, int t, int kp, int half, int u) -> bf16x8 {
+    auto wload = [&](int ch, int t, int kp, int half) -> bf16x8 {
       int ks = ch * KSC + kp * 2 + half;
       ks = ks < KS ? ks : KS - 1;
       const int wt = __builtin_amdgcn_readlane(wt_v, t);
-      const int soff = ((wt * KS + ks) * NT + nt_c) * 1024 + du[u];
+      const int soff = ((wt * KS + ks) * NT + nt_c) * 1024;
       // Inline asm on purpose: hipcc waits vmcnt(0) for compiler-visible loads carried around a loop, i.e. for the
       // fragments issued a few instructions earlier (a full L2 round trip per 8 MFMAs). These loads are waited for by
       // hand with a COUNTED s_waitcnt (CNB_WAIT_A) that leaves the other register set's two loads in flight.
@@ -276,27 +271,7 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
     // pixel fragments of a step are read from LDS in one batch (8 distinct register quads, so the 8 MFMAs wait with
     // counted lgkmcnt instead of read, wait, MFMA, read, wait, ... through one quad as the compiler schedules it).
     bf16x8 X[2 * MPW];
-    bf16x8 ax0[NPW], ax1[NPW], ay0[NPW], ay1[NPW];
-    // the counted wait in front of a step's MFMAs leaves exactly the OTHER register set's 2 * NPW loads in flight
-#define CNB_WAIT_A()                                                        \
-  do {                                                                      \
-    if constexpr (NPW == 1) asm volatile("s_waitcnt vmcnt(2)" ::: "memory"); \
-    else asm volatile("s_waitcnt vmcnt(4)" ::: "memory");                   \
-  } while (0)
-#define CNB_WLOAD(A0, A1, FN, C_, T_, K_)                                   \
-  do {                                                                      \
-    _Pragma("unroll") for (int u = 0; u < NPW; ++u) {                       \
-      A0[u] = FN(C_, T_, K_, 0, u);                                         \
-      A1[u] = FN(C_, T_, K_, 1, u);                                         \
-    }                                                                       \
-  } while (0)
-#define CNB_MFMAS(A0, A1, BUF)                                                                                   \
-  do {                                                                                                           \
-    _Pragma("unroll") for (int u = 0; u < NPW; ++u)                                                              \
-      _Pragma("unroll") for (int i = 0; i < MPW; ++i) acc[u][i] = cnb_mfma(A0[u], BUF[i], acc[u][i]);            \
-    _Pragma("unroll") for (int u = 0; u < NPW; ++u)                                                              \
-      _Pragma("unroll") for (int i = 0; i < MPW; ++i) acc[u][i] = cnb_mfma(A1[u], BUF[MPW + i], acc[u][i]);      \
-  } while (0)
+    bf16x8 ax0, ax1, ay0, ay1;
     int ch = 0, t = 0, kp = 0;      // current step
     int ch2 = 0, t2 = 0, kp2 = 0;   // two steps ahead (weight prefetch)
     auto adv = [&](int& c_, int& t_, int& k_) {
@@ -306,11 +281,11 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
       }
       if (++t_ == ntaps) { t_ = 0; ++c_; }
     };
-    CNB_WLOAD(ax0, ax1, wload, 0, 0, 0);
+    ax0 = wload(0, 0, 0, 0); ax1 = wload(0, 0, 0, 1);
     adv(ch2, t2, kp2);
     {
       const int cq = ch2 < nchunks ? ch2 : nchunks - 1;
-      CNB_WLOAD(ay0, ay1, wload, cq, t2, kp2);
+      ay0 = wload(cq, t2, kp2, 0); ay1 = wload(cq, t2, kp2, 1);
     }
     adv(ch2, t2, kp2);
 
@@ -330,25 +305,18 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
       const int q = tid + i * 256;                                                                      \
       if (q < npieces) {                                                                                \
         const int p_ = q / PPP;                                                                         \
-        *reinterpret_cast<u32x4*>(lds + p_ * PITCH + (RP ? cnb_div(p_, k.mgIW) * k.rowpad : 0) + (q % PPP) * 16) = sv[i - (I0)]; \
+        *reinterpret_cast<u32x4*>(lds + p_ * PITCH + (NP <= 6 ? cnb_div(p_, k.mgIW) * k.rowpad : 0) + (q % PPP) * 16) = sv[i - (I0)]; \
       }                                                                                                 \
     }                                                                                                   \
   }
 #define CNB_STAGE()                                                                                     \
   {                                                                                                     \
     const int cc = ch * (KSC * 16);                                                                     \
-    constexpr int H1 = NPW > 1 ? 4 : (NP > 6 ? 5 : NP); /* NP <= 6: one phase (one exposed global latency per chunk instead of two) */ \
+    constexpr int H1 = NP > 6 ? 5 : NP; /* NP <= 6: one phase (one exposed global latency per chunk instead of two) */                                                                 \
     CNB_ST(100 + ch * 4);                                                                               \
     CNB_PHASE(0, H1);                                                                                   \
     CNB_ST(101 + ch * 4);                                                                               \
-    if constexpr (NPW > 1) {                                                                            \
-      /* 128 accumulator registers are live across the staging: four pieces (16 registers) in flight at a time -- with \
-         seven the compiler spilled ALL accumulators around every chunk and, worse, answered the pending reloads with \
-         s_waitcnt vmcnt(0) inside the tap loop, draining the hand-counted weight prefetch (270 TFLOP/s) */ \
-      if (NP > 4) CNB_PHASE(4, (NP < 8 ? NP : 8));                                                      \
-      if (NP > 8) CNB_PHASE(8, (NP < 12 ? NP : 12));                                                    \
-      if (NP > 12) CNB_PHASE(12, NP);                                                                   \
-    } else if (NP > H1) CNB_PHASE(H1, NP);                                                              \
+    if (NP > H1) CNB_PHASE(H1, NP);                                                                     \
     CNB_ST(102 + ch * 4);                                                                               \
     /* A piece past the halo image is loaded (masked) but never stored, so the compiler's scoreboard leaves the  \
        chunk with that load "pending" into a register the step loop re-uses for pixel fragments -- and answers \
@@ -371,13 +339,15 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
     if (t == 0 && kp == 0) CNB_STAGE();                                                            \
     CNB_READ(CUR, t, kp);                                                                          \
     /* weight fragments of this step: everything but the two newest loads (the other set's) has landed */ \
-    CNB_WAIT_A();                                                                                  \
+    asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                               \
     __builtin_amdgcn_sched_barrier(0);                                                             \
-    CNB_MFMAS(A0, A1, CUR);                                                                        \
+    _Pragma("unroll") for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(A0, CUR[i], acc[i]);         \
+    _Pragma("unroll") for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(A1, CUR[MPW + i], acc[i]);   \
     __builtin_amdgcn_sched_barrier(0);                                                             \
     {                                                                                              \
       const int cq = ch2 < nchunks ? ch2 : nchunks - 1;                                            \
-      CNB_WLOAD(A0, A1, wload, cq, t2, kp2);                                                       \
+      A0 = wload(cq, t2, kp2, 0);                                                                  \
+      A1 = wload(cq, t2, kp2, 1);                                                                  \
     }                                                                                              \
     adv(ch2, t2, kp2);                                                                             \
     adv(ch, t, kp);                                                                                \
@@ -399,10 +369,10 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
       // as busy as the matrix pipes.
       const int NTK = NT * 1024;  // bytes between consecutive k-steps of one tap
       const int wtb_v = lane < CNB_MAX_TAPS ? (k.wt[lane < CNB_MAX_TAPS ? lane : 0] * KS * NT + nt_c) * 1024 : 0;
-      auto wl = [&](int chq, int tq, int kpq, int half, int u) -> bf16x8 {
+      auto wl = [&](int chq, int tq, int kpq, int half) -> bf16x8 {
         int ks = chq * KSC + kpq * 2 + half;
         ks = ks < KS ? ks : KS - 1;
-        const int soff = __builtin_amdgcn_readlane(wtb_v, tq) + ks * NTK + du[u];
+        const int soff = __builtin_amdgcn_readlane(wtb_v, tq) + ks * NTK;
         u32x4 v;
         asm volatile("buffer_load_dwordx4 %0, %1, %2, %3 offen" : "=v"(v) : "v"(lane16), "s"(wrsrc), "s"(soff));
         return __builtin_bit_cast(bf16x8, v);
@@ -426,20 +396,28 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
               X[i] = *reinterpret_cast<const bf16x8*>(lds + pbase[i] + toff_t + kq * 64);
               X[MPW + i] = *reinterpret_cast<const bf16x8*>(lds + pbase[i] + toff_t + kq * 64 + 32);
             }
-            CNB_WAIT_A();
+            asm volatile("s_waitcnt vmcnt(2)" ::: "memory");
             __builtin_amdgcn_sched_barrier(0);
             if ((kq & 1) == 0) {
-              CNB_MFMAS(ax0, ax1, X);
+#pragma unroll
+              for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(ax0, X[i], acc[i]);
+#pragma unroll
+              for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(ax1, X[MPW + i], acc[i]);
             } else {
-              CNB_MFMAS(ay0, ay1, X);
+#pragma unroll
+              for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(ay0, X[i], acc[i]);
+#pragma unroll
+              for (int i = 0; i < MPW; ++i) acc[i] = cnb_mfma(ay1, X[MPW + i], acc[i]);
             }
             __builtin_amdgcn_sched_barrier(0);
             const bool same = kq + 2 < KPAIRS;
             const int cq = same ? ch : chn, tq = same ? t : tn, kpq = same ? kq + 2 : kq + 2 - KPAIRS;
             if ((kq & 1) == 0) {
-              CNB_WLOAD(ax0, ax1, wl, cq, tq, kpq);
+              ax0 = wl(cq, tq, kpq, 0);
+              ax1 = wl(cq, tq, kpq, 1);
             } else {
-              CNB_WLOAD(ay0, ay1, wl, cq, tq, kpq);
+              ay0 = wl(cq, tq, kpq, 0);
+              ay1 = wl(cq, tq, kpq, 1);
             }
             CNB_STEP_STAMP();
           }
@@ -461,34 +439,25 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
 #undef CNB_STAGE
 #undef CNB_READ
 #undef CNB_HALF
-#undef CNB_WAIT_A
-#undef CNB_WLOAD
-#undef CNB_MFMAS
   }
 
-  // ---- epilogue: lane = pixel, registers = 4 groups of 4 consecutive couts; once per cout tile of the wave ----
+  // ---- epilogue: lane = pixel, registers = 4 groups of 4 consecutive couts ----
   CNB_ST(3);
-  float* const stats_g = g.stats[grp];
-  // (a generic lambda called with compile-time tile indices, NOT a `#pragma unroll` loop over u: the loop was not
-  // unrolled -- its body is the whole epilogue -- which left acc[u] dynamically indexed, i.e. the 128 accumulator
-  // registers of the wide variant in SCRATCH memory, reloaded and spilled around every chunk's tap loop)
-  auto epilogue_tile = [&](auto uc) {
-  constexpr int u = decltype(uc)::value;
-  const bool nl = ntile + u < g.NT;  // (wave-uniform) this cout tile exists
   const float* __restrict__ bias = g.bias[grp];
-  const int n0 = (ntile + u) * 32;
+  const int n0 = ntile * 32;
   float bsum[16];
   if (bias != nullptr) {  // wave-uniform: ConvBlock2d is bias-free (BatchNorm follows), skip the 16 predicated loads
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * h;
-      bsum[j] = (nl && n < g.Cout) ? bias[n] : 0.f;
+      bsum[j] = (n_live && n < g.Cout) ? bias[n] : 0.f;
     }
   } else {
 #pragma unroll
     for (int j = 0; j < 16; ++j) bsum[j] = 0.f;
   }
   float s1[16], s2[16];
+  float* const stats_g = g.stats[grp];
   if (stats_g != nullptr) {
 #pragma unroll
     for (int j = 0; j < 16; ++j) s1[j] = s2[j] = 0.f;
@@ -501,11 +470,11 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
   const int m = (wm + (i) * WM) * 32 + r;                                                      \
   const int ty = cnb_div(m, g.mgTW), tx = m - ty * g.TW;                                       \
   const int gy = gy0 + ty, gx = gx0 + tx;                                                      \
-  const bool ok = nl && m < npix && gy < k.Hg && gx < k.Wg;                                    \
+  const bool ok = n_live && m < npix && gy < k.Hg && gx < k.Wg;                                \
   const int oy = gy * g.os + k.oy0, ox = gx * g.os + k.ox0;                                    \
   if (stats_g != nullptr) {                                                                    \
     _Pragma("unroll") for (int j = 0; j < 16; ++j) {                                           \
-      const float v = ok ? acc[u][i][j] + bsum[j] : 0.f;                                       \
+      const float v = ok ? acc[i][j] + bsum[j] : 0.f;                                          \
       s1[j] += v;                                                                              \
       s2[j] += v * v;                                                                          \
     }                                                                                          \
@@ -521,8 +490,8 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
       for (int i = 0; i < MPW; ++i)
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
-          const float v = acc[u][i][j] + bsum[j];
-          acc[u][i][j] = v / (1.0f + __expf(-v));
+          const float v = acc[i][j] + bsum[j];
+          acc[i][j] = v / (1.0f + __expf(-v));
         }
 #pragma unroll
       for (int j = 0; j < 16; ++j) bsum[j] = 0.f;  // the bias is inside the activation now
@@ -534,10 +503,10 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
       bf16_t* yp = reinterpret_cast<bf16_t*>(g.y[grp]) + opix * g.ldy + n0;
 #pragma unroll
       for (int q = 0; q < 4; q += 2) {
-        unsigned a0 = cn_pack_bf16(acc[u][i][4 * q] + bsum[4 * q], acc[u][i][4 * q + 1] + bsum[4 * q + 1]);
-        unsigned a1 = cn_pack_bf16(acc[u][i][4 * q + 2] + bsum[4 * q + 2], acc[u][i][4 * q + 3] + bsum[4 * q + 3]);
-        unsigned b0 = cn_pack_bf16(acc[u][i][4 * q + 4] + bsum[4 * q + 4], acc[u][i][4 * q + 5] + bsum[4 * q + 5]);
-        unsigned b1 = cn_pack_bf16(acc[u][i][4 * q + 6] + bsum[4 * q + 6], acc[u][i][4 * q + 7] + bsum[4 * q + 7]);
+        unsigned a0 = cn_pack_bf16(acc[i][4 * q] + bsum[4 * q], acc[i][4 * q + 1] + bsum[4 * q + 1]);
+        unsigned a1 = cn_pack_bf16(acc[i][4 * q + 2] + bsum[4 * q + 2], acc[i][4 * q + 3] + bsum[4 * q + 3]);
+        unsigned b0 = cn_pack_bf16(acc[i][4 * q + 4] + bsum[4 * q + 4], acc[i][4 * q + 5] + bsum[4 * q + 5]);
+        unsigned b1 = cn_pack_bf16(acc[i][4 * q + 6] + bsum[4 * q + 6], acc[i][4 * q + 7] + bsum[4 * q + 7]);
         const auto sw0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
         const auto sw1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
         const int n = n0 + 8 * (q + h);
@@ -568,7 +537,7 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           if (n + e >= g.Cout) continue;
-          float v = acc[u][i][4 * q + e] + bsum[4 * q + e];
+          float v = acc[i][4 * q + e] + bsum[4 * q + e];
           if (g.accumulate) v += cn_bf16_to_f32(yp[8 * q + e]);
           yp[8 * q + e] = cn_f32_to_bf16(v);
         }
@@ -585,7 +554,7 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
       for (int j = 0; j < 16; ++j) {
         const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * h;
         if (n >= g.Cout) continue;
-        const float v = acc[u][i][j] + bsum[j];
+        const float v = acc[i][j] + bsum[j];
         if (g.accumulate) yp[n * cs] += v; else yp[n * cs] = v;
       }
     }
@@ -596,7 +565,7 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
     // Per-cout sums over this wave's pixels = sums over the LANES of 32 values per lane: transposed through LDS
     // (each lane writes its 32 partials as one padded row, then sums ONE column over its half-wave's 32 rows): ~100
     // instructions per wave instead of 160 cross-lane shuffles + 160 adds.
-    __syncthreads();  // every wave is done with the pixel image (and with the previous cout tile's scratch)
+    __syncthreads();  // every wave is done with the pixel image
     float* red = reinterpret_cast<float*>(lds) + wid * (64 * 33);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
@@ -621,20 +590,13 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
     }
     const int j = jj & 15;
     const int n = n0 + (j & 3) + 8 * (j >> 2) + 4 * hh;
-    if (nl && n < g.Cout && wm == 0) {  // wid = wm * WN + wn: the wm == 0 wave of each cout tile stores the row
+    if (n_live && n < g.Cout && wm == 0) {  // wid = wm * WN + wn: the wm == 0 wave of each cout tile stores the row
       float* row = stats_g + (long)tile * 2 * g.Cout + (jj >= 16 ? g.Cout : 0) + n;
       if (g.fin_cnt != nullptr) __hip_atomic_store(row, tot, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       else *row = tot;
     }
-  }
-  };  // epilogue_tile
-  epilogue_tile(std::integral_constant<int, 0>{});
-  if constexpr (NPW > 1) epilogue_tile(std::integral_constant<int, 1>{});
-  static_assert(NPW <= 2, "epilogue_tile is called for two cout tiles per wave at most");
-  if (stats_g != nullptr) {
     if (g.fin_cnt != nullptr) {  // block-uniform
-      constexpr int CB = 32 * WN * NPW;  // couts of this block
-      constexpr int W = 2 * CB;          // this block's columns: {sum, sum of squares} x its couts (<= 256 threads)
+      constexpr int W = 64 * WN;  // this block's columns: {sum, sum of squares} x its 32 * WN couts
       const int dom = grp * g.nblk_n + nb;
       int* cnt = g.fin_cnt + dom * CN_T2_COUNTERS;
       double* grows = g.fin_grows + (long)dom * (CN_T2_COUNTERS - 1) * W;
@@ -643,8 +605,8 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
       const int gn = t0 + CN_T2_GROUP <= ntl ? CN_T2_GROUP : ntl - t0;
       int* s_flag = reinterpret_cast<int*>(lds);
       double* tot2 = reinterpret_cast<double*>(lds + 16);
-      const int stat = tid / CB, cc = tid - stat * CB;
-      const int nc = nb * CB + cc;
+      const int stat = tid / (32 * WN), cc = tid - stat * (32 * WN);
+      const int nc = nb * (32 * WN) + cc;
       const long coff = (long)stat * g.Cout + (nc < g.Cout ? nc : g.Cout - 1);  // dead columns re-read the last channel
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();  // the row is on its way to memory; the transposition scratch is dead
@@ -691,10 +653,10 @@ __global__ __launch_bounds__(256, NPW == 1 ? 3 : 2) void cn_bconv_kernel(const C
             tot2[tid] = sd;
           }
           __syncthreads();
-          if (tid < CB && nc < g.Cout) {  // (stat == 0 here: nc is this thread's channel)
+          if (tid < 32 * WN && nc < g.Cout) {  // (stat == 0 here: nc is this thread's channel)
             const double count = (double)g.B * g.Hout * g.Wout;
             const double md = tot2[tid] / count;
-            double var = tot2[CB + tid] / count - md * md;
+            double var = tot2[32 * WN + tid] / count - md * md;
             if (var < 0.0) var = 0.0;
             g.fin_mean[grp][nc] = (float)md;
             g.fin_rstd[grp][nc] = (float)(1.0 / sqrt(var + (double)g.fin_eps));
@@ -899,20 +861,6 @@ static void cnb_pick_tile(int Hg, int Wg, int is, int span, int max_pix, int& TH
   }
 }
 
-// The wide-wave variant (NPW = 2: 256 pixels x 128 couts per block, see the kernel's header): stride-1 3x3 launches with
-// >= 128 couts whose every class fills the chip at two blocks per CU. Decided PER CLASS (never from the number of
-// groups of a launch), so that cn_conv2d_stats_rows_bf16 -- which sizes the per-tile statistics rows -- agrees with the
-// launch whatever the grouping. CN_BCONV_WIDE=0: off (A/B).
-static bool cnb_wide(int NT, int B, int Hg, int Wg, int is, int os, int span, int ntaps) {
-  static const bool on = getenv("CN_BCONV_WIDE") == nullptr || atoi(getenv("CN_BCONV_WIDE")) != 0;
-  if (!on || NT < 4 || is != 1 || os != 1 || ntaps < 2) return false;
-  int th, tw;
-  cnb_pick_tile(Hg, Wg, is, span, 256, th, tw);
-  if (((long)(th - 1) * is + span + 1) * ((long)(tw - 1) * is + span + 1) * 8 > 14 * 256) return false;  // 64-ch chunks, <= 14 pieces
-  const long blocks = (long)((Hg + th - 1) / th) * ((Wg + tw - 1) / tw) * B * ((NT + 3) / 4);
-  return blocks >= 600;
-}
-
 // Host request for the in-launch statistics finalize (cn_conv2d_fwd_grouped_bnstats_bf16); `done` reports the decision.
 struct CnBFinReq {
   float* const* means; float* const* rstds; float* const* rmeans; float* const* rvars;
@@ -949,13 +897,7 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops, CnBFi
     if ((long)(wt_max + 1) * g.KS * g.NT * 1024 >= (1L << 31)) return CN_ERR_ARG;
   }
   int WN = g.NT >= 4 ? 4 : (g.NT >= 2 ? 2 : 1);
-  int MPWv = 4, NPWv = 1;
-  {
-    bool wide = g.out_kind == 0 && (g.Cout & 7) == 0;
-    for (int c = 0; c < g.ncls && wide; ++c)
-      wide = cnb_wide(g.NT, g.B, g.cls[c].Hg, g.cls[c].Wg, g.is, g.os, span, g.cls[c].ntaps);
-    if (wide) { WN = 2; NPWv = 2; }
-  }
+  int MPWv = 4;
   cnb_pick_tile(Hg, Wg, g.is, span, 128 * (4 / WN), g.TH, g.TW);
   if (WN == 4 && getenv("CN_BCONV_NO_HALF") == nullptr) {
     // small planes (25x25 at batch 32: 160 tiles x 1 cout block on 256 CUs): two 64-cout blocks per pixel tile instead
@@ -964,7 +906,7 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops, CnBFi
       blocks += (long)((g.cls[c].Wg + g.TW - 1) / g.TW) * ((g.cls[c].Hg + g.TH - 1) / g.TH) * g.B * ((g.NT + 3) / 4);
     if (blocks <= 224) { WN = 2; MPWv = 2; }
   }
-  g.nblk_n = (g.NT + WN * NPWv - 1) / (WN * NPWv);
+  g.nblk_n = (g.NT + WN - 1) / WN;
   // halo sizes, then the chunk depth: as many 16-channel k-steps per staged image as the staging budget allows
   // (10 pieces of 16 bytes per thread), 1x1 launches preferring the deepest (one tap per chunk to amortise the
   // barrier + staging phase over), 3x3 launches 64 channels
@@ -983,14 +925,14 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops, CnBFi
     for (int i = 0; i < 3; ++i) {
       const int c = pref[i];
       if (c > 2 && c / 2 >= g.KS) continue;  // deeper than the input is wide
-      if (((long)max_pix * c * 2 + 255) / 256 <= (NPWv == 2 ? 14 : 10)) { KSC = c; break; }
+      if (((long)max_pix * c * 2 + 255) / 256 <= 10) { KSC = c; break; }
     }
   }
   const int pitch = KSC * 32 + 16;
   g.mgTW = cnb_magic(g.TW);
   for (int c = 0; c < g.ncls; ++c) g.cls[c].mgIW = cnb_magic(g.cls[c].IW);
   const int np = (int)(((long)max_pix * KSC * 2 + 255) / 256);
-  if (np > (NPWv == 2 ? 14 : 10)) return CN_ERR_LDS;
+  if (np > 10) return CN_ERR_LDS;
   // A wave's ds_read_b128 covers 32 consecutive tile pixels m (lane groups of 16, one 256-byte bank row per group):
   // with a pixel pitch of s = pitch/16 (odd) sixteen-byte slots the slot of pixel m is s*m mod 16, all distinct within
   // a group -- as long as consecutive m are consecutive in LDS. A 32-pixel column wraps over tile rows (TW = 25), where
@@ -1003,8 +945,7 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops, CnBFi
   for (int c = 0; c < g.ncls; ++c) {
     CnBClass& k = g.cls[c];
     k.rowpad = 0;
-    if (g.is == 1 && k.IH > 1 && (np <= 6 || NPWv == 2)) {  // the big-halo (NP = 10) instantiations of the three-blocks-per-CU
-                                                              // kernel sit at the VGPR limit: no pad there
+    if (g.is == 1 && k.IH > 1 && np <= 6) {  // the big-halo (NP = 10) instantiations sit at the VGPR limit: no pad there
       const int s16 = (pitch / 16) & 15;
       const int slots = ((-(s16 * (k.IW - g.TW))) % 16 + 16) % 16;
       k.rowpad = slots * 16;
@@ -1036,7 +977,7 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops, CnBFi
     static const bool on = getenv("CN_CONV_BNFIN") == nullptr || atoi(getenv("CN_CONV_BNFIN")) != 0;  // A/B switch
     const long tiles = (long)g.cls[0].tiles_per_img * g.B;
     const long domains = (long)G * g.nblk_n;
-    const long grow_doubles = domains * (CN_T2_COUNTERS - 1) * 64 * WN * NPWv;
+    const long grow_doubles = domains * (CN_T2_COUNTERS - 1) * 64 * WN;
     if (on && g.stats[0] != nullptr && tiles <= CN_BNWS_CONV_MAX_TILES && domains <= CN_BNWS_CONV_DOMAINS &&
         fin->ws != nullptr && (reinterpret_cast<uintptr_t>(fin->ws) & 7) == 0 &&
         fin->ws_floats >= CN_BNWS_HEAD_INTS + 2 * grow_doubles) {
@@ -1053,26 +994,6 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops, CnBFi
     }
   }
   const int NPv = np <= 4 ? 4 : (np <= 6 ? 6 : 10);
-  if (NPWv == 2) {
-    const int npw = np <= 10 ? 10 : 14;
-    cn_prof_name("cn_bconv_kernel<2, %d, %d, 4, 2>", npw, KSC);
-    cn_prof_desc("bconv B%d %dx%d %d->%d cls%d taps%d s%d/%d wide", g.B, g.Hin, g.Win, g.Cin, g.Cout, g.ncls,
-                 g.cls[0].ntaps, g.is, g.os);
-    cn_prof_before(stream);
-#define CNB_GOW(NP_, KSC_)                                                                                       \
-  do {                                                                                                           \
-    if (shmem > 64 * 1024)                                                                                       \
-      (void)hipFuncSetAttribute((const void*)cn_bconv_kernel<2, NP_, KSC_, 4, 2>,                                \
-                                hipFuncAttributeMaxDynamicSharedMemorySize, (int)shmem);                         \
-    CN_LAUNCH((cn_bconv_kernel<2, NP_, KSC_, 4, 2>), grid, block, shmem, stream, g);                             \
-  } while (0)
-    if (KSC == 4) { if (npw == 10) CNB_GOW(10, 4); else CNB_GOW(14, 4); }
-    else if (KSC == 2) { if (npw == 10) CNB_GOW(10, 2); else CNB_GOW(14, 2); }
-    else return CN_ERR_ARG;
-#undef CNB_GOW
-    cn_prof_after(stream, 4, flops);
-    return cn_check_launch();
-  }
   if (MPWv == 2)
     cn_prof_name("cn_bconv_kernel<%d, %d, %d, 2>", WN, (KSC == 2 ? NPv : (KSC == 4 ? (NPv <= 6 ? 6 : 10) : 10)), KSC);
   else
@@ -1210,10 +1131,9 @@ extern "C" int cn_conv2d_stats_rows_bf16(int B, int Hin, int Win, int Cout, int 
   const int Wout = (Win + 2 * pad - dil * (KW - 1) - 1) / stride + 1;
   if (Hout <= 0 || Wout <= 0) return 0;
   const int NT = (Cout + 31) / 32;
-  int WN = NT >= 4 ? 4 : (NT >= 2 ? 2 : 1);
+  const int WN = NT >= 4 ? 4 : (NT >= 2 ? 2 : 1);
   int TH, TW;
   const int span = dil * ((KH > KW ? KH : KW) - 1);
-  if ((Cout & 7) == 0 && cnb_wide(NT, B, Hout, Wout, stride, 1, span, KH * KW)) WN = 2;  // as cnb_launch decides
   cnb_pick_tile(Hout, Wout, stride, span, 128 * (4 / WN), TH, TW);
   return B * ((Hout + TH - 1) / TH) * ((Wout + TW - 1) / TW);
 }

@@ -94,13 +94,6 @@ CONV_CASES = [
     (8, 480, 100, 100, 128, 3, 1, 1, 1, False),
     (8, 576, 50, 50, 128, 3, 1, 1, 1, False),
     (8, 640, 25, 25, 128, 3, 1, 1, 1, False),
-    # the wide-wave variant (NPW = 2: 256 pixels x 128 couts per block; >= 600 such blocks per class) -- forward, its
-    # statistics rows and the stride-1 backward-data: exact tiles, ragged pixel tiles, ragged couts (5 cout tiles),
-    # bias, dilation 2 (14-piece halo staging)
-    (16, 128, 100, 100, 128, 3, 1, 1, 1, False),
-    (16, 16, 96, 104, 128, 3, 1, 1, 1, True),
-    (16, 24, 100, 100, 136, 3, 1, 1, 1, False),
-    (16, 32, 100, 100, 128, 3, 1, 2, 2, False),
 ]
 
 
@@ -470,8 +463,6 @@ def test_conv_group_bf16_statistics_feed_the_grouped_batchnorm():
     (4, 64, 100, 100, 256, 2, 1),  # 313 tiles x 2 cout blocks x 2 groups: 20 ticket groups per domain
     (2, 8, 13, 13, 8, 4, 1),       # tiny planes, four groups
     (14, 16, 100, 100, 128, 1, 0),  # 1120 tiles of 128 pixels > 1008: rows only, the caller runs the finalize
-    (16, 16, 100, 100, 128, 2, 1),  # wide-wave variant: 640 tiles of 256 pixels per conv, 256 columns per block
-    (32, 8, 100, 100, 128, 1, 0),   # wide-wave variant, 1280 tiles > 1008: rows only
 ])
 def test_conv_bnstats_bf16_finishes_its_own_batchnorm_statistics(B, Cin, H, W, Cout, G, expect):
     """cn_conv2d_fwd_grouped_bnstats_bf16: the convolution launch finishes the BatchNorm batch statistics of its outputs
@@ -743,8 +734,7 @@ def test_converters_and_slices_bf16():
 @pytest.mark.parametrize("case", [(2, 32, 25, 25, 64, 3, 1, 1, 1, 1, True), (1, 72, 13, 13, 128, 3, 1, 1, 1, 0, False),
                                   (2, 16, 28, 28, 16, 3, 2, 1, 1, 0, False), (2, 40, 14, 14, 128, 1, 1, 0, 1, 1, True),
                                   (2, 128, 50, 50, 128, 3, 1, 1, 1, 1, True), (1, 64, 20, 20, 64, 3, 1, 2, 2, 1, False),
-                                  (3, 128, 110, 110, 128, 3, 1, 1, 1, 1, True),
-                                  (14, 64, 110, 110, 128, 3, 1, 1, 1, 1, True)])  # (wide-wave variant: 770 blocks)
+                                  (3, 128, 110, 110, 128, 3, 1, 1, 1, 1, True)])
 def test_conv_bn_act_fused_eval_bf16(case):
     """cn_conv2d_fwd_fused_bf16 + cn_bn_fold_f32 + cn_pack_weights_scaled_bf16: y = res + SiLU(BN_eval(conv(x))) in one
     launch against torch (conv2d -> batch_norm(training=False) -> silu -> + res) in fp32 on the bf16-rounded operands.
