@@ -5,7 +5,6 @@
 // (/root/reference/src/cultionet/nn/functional.py:72-81), torch.cat in TowerUNetBlock /
 // TowerUNetFinal (nn/modules/unet_parts.py:281-309,700-760), TowerUNetFinalCombine + SigmoidCrisp
 // (unet_parts.py:43-193).
-#include <cstdlib>
 #include "cn_common.h"
 
 // ---------------------------------------------------------------------------
@@ -151,7 +150,6 @@ __device__ __forceinline__ int bl_candidates(int i, int in_size, int out_size, f
   return n;
 }
 
-template <bool ROW>
 __global__ __launch_bounds__(256) void cn_bilinear_bwd_near_kernel(const float* __restrict__ dy, long dybs,
                                                                   float* __restrict__ dx, long dxbs, int C, int Hi,
                                                                   int Wi, int Ho, int Wo, float sh, float sw,
@@ -178,69 +176,35 @@ __global__ __launch_bounds__(256) void cn_bilinear_bwd_near_kernel(const float* 
       }
       return;
     }
-    // Separable form: 3 + 3 weights and offsets live in registers (+ the rare fourth candidates), the nine products are
-    // formed per channel. The first version kept w[4][4] and off[4][4] (60 VGPRs): beside a weight-gradient wave of the
-    // side stream (393 of a SIMD's 512 registers per lane) only ONE wave of this latency-bound gather fitted per SIMD
-    // instead of eight -- 20.9 us alone, 142.8 us inside the step (profiles/r04_v5_bench_f32_kernel_stats*.csv).
-    float wy3[3], wx3[3];
-    int oy3[3], ox3[3];
+    float w[4][4];
+    int off[4][4];
 #pragma unroll
-    for (int k = 0; k < 3; ++k) {
-      wy3[k] = k < ny ? wyv[k] : 0.f;
-      oy3[k] = (k < ny ? oyv[k] : oyv[0]) * Wo;
-      wx3[k] = k < nx ? wxv[k] : 0.f;
-      ox3[k] = k < nx ? oxv[k] : oxv[0];
-    }
-    const bool tail_y = ny == 4, tail_x = nx == 4;
-    const float wy4 = tail_y ? wyv[3] : 0.f, wx4 = tail_x ? wxv[3] : 0.f;
-    const int oy4 = (tail_y ? oyv[3] : oyv[0]) * Wo, ox4 = tail_x ? oxv[3] : oxv[0];
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const bool live = k < ny && j < nx;
+        w[k][j] = live ? wyv[k] * wxv[j] : 0.f;
+        off[k][j] = live ? oyv[k] * Wo + oxv[j] : oyv[0] * Wo + oxv[0];
+      }
+    const bool tail = ny == 4 || nx == 4;
     for (int c = c_begin; c < c_end; ++c) {
       const float* dp = dy + b * dybs + (long)c * Ho * Wo;
-      // one candidate ROW at a time (three loads in flight, not nine; the row loop is deliberately not unrolled): the
-      // nine offsets and nine weight products are then never live together, and the occupancy this buys -- next to a
-      // weight-gradient wave -- is worth more than the instruction-level parallelism it gives up
+      float v[3][3];
+#pragma unroll
+      for (int k = 0; k < 3; ++k)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) v[k][j] = dp[off[k][j]];
       float acc = 0.f;
-      if constexpr (ROW) {
-#pragma unroll 1
-        for (int k = 0; k < 3; ++k) {
-          const int oyk = k == 0 ? oy3[0] : (k == 1 ? oy3[1] : oy3[2]);
-          const float wyk = k == 0 ? wy3[0] : (k == 1 ? wy3[1] : wy3[2]);
-          const float* dr = dp + oyk;
-          const float v0 = dr[ox3[0]], v1 = dr[ox3[1]], v2 = dr[ox3[2]];
-          const float w0 = wyk * wx3[0], w1 = wyk * wx3[1], w2 = wyk * wx3[2];
-          acc += w0 * v0;
-          acc += w1 * v1;
-          acc += w2 * v2;
-        }
-      } else {  // (A/B: nine loads in flight, 61 VGPRs)
-        float v[3][3];
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+      for (int k = 0; k < 3; ++k)
 #pragma unroll
-          for (int j = 0; j < 3; ++j) v[k][j] = dp[oy3[k] + ox3[j]];
+        for (int j = 0; j < 3; ++j) acc += w[k][j] * v[k][j];
+      if (tail) {
 #pragma unroll
-        for (int k = 0; k < 3; ++k)
+        for (int k = 0; k < 4; ++k)
 #pragma unroll
-          for (int j = 0; j < 3; ++j) {
-            const float w = wy3[k] * wx3[j];
-            acc += w * v[k][j];
-          }
-      }
-      if (tail_x) {  // fourth column candidate of rows 0..2 (the order of the 4 x 4 walk: (0,3), (1,3), (2,3), ...)
-#pragma unroll
-        for (int k = 0; k < 3; ++k) {
-          const float w = wy3[k] * wx4;
-          if (w != 0.f) acc += w * dp[oy3[k] + ox4];
-        }
-      }
-      if (tail_y) {  // ... (3,0), (3,1), (3,2), (3,3)
-#pragma unroll
-        for (int j = 0; j < 3; ++j) {
-          const float w = wy4 * wx3[j];
-          if (w != 0.f) acc += w * dp[oy4 + ox3[j]];
-        }
-        const float w = wy4 * wx4;
-        if (w != 0.f) acc += w * dp[oy4 + ox4];
+          for (int j = 0; j < 4; ++j)
+            if ((k == 3 || j == 3) && w[k][j] != 0.f) acc += w[k][j] * dp[off[k][j]];
       }
       float* o = dx + b * dxbs + (long)c * Hi * Wi + p;
       *o = accumulate ? *o + acc : acc;
@@ -297,13 +261,8 @@ extern "C" int cn_bilinear_bwd_f32(const float* dy, long dybs, float* dx, long d
   const float sh = bl_scale(Hi, Ho), sw = bl_scale(Wi, Wo);
   if (2 * Hi > Ho && 2 * Wi > Wo && (long)B * C * Hi * Wi >= 1 << 16) {  // near-1:1 resize of a large tensor
     dim3 gridn((Hi * Wi + 255) / 256, (C + BL_CH - 1) / BL_CH, B);
-    static const bool row = getenv("CN_BILINEAR_ROW") == nullptr || atoi(getenv("CN_BILINEAR_ROW")) != 0;  // A/B switch
-    if (row)
-      CN_LAUNCH(cn_bilinear_bwd_near_kernel<true>, gridn, dim3(256), 0, (hipStream_t)stream, dy, dybs, dx, dxbs, C,
-                Hi, Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, accumulate);
-    else
-      CN_LAUNCH(cn_bilinear_bwd_near_kernel<false>, gridn, dim3(256), 0, (hipStream_t)stream, dy, dybs, dx, dxbs, C,
-                Hi, Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, accumulate);
+    CN_LAUNCH(cn_bilinear_bwd_near_kernel, gridn, dim3(256), 0, (hipStream_t)stream, dy, dybs, dx, dxbs, C,
+                       Hi, Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, accumulate);
     return cn_check_launch();
   }
   dim3 grid((Hi * Wi + 255) / 256, C, B);
