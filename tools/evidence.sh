@@ -15,9 +15,15 @@ python3 $R/bench.py --dtype bf16 > $O/${TAG}_bench_bf16_b32.json 2> $O/bench_bf1
 python3 $R/bench.py --hidden 64 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/${TAG}_bench_f32_b8_h64.json 2> $O/bench_h64.err
 python3 $R/bench.py --hidden 64 --dtype bf16 --batch 16 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/${TAG}_bench_bf16_b16_h64.json 2>> $O/bench_h64.err
 # one-rank RCCL group (the only RCCL path one GPU can exercise): buckets per step and exposed communication time
-CN_FORCE_COMM=1 python3 $R/bench.py --no-cpu-baseline --no-extras > $O/${TAG}_bench_forcecomm_f32_b8.json 2> $O/bench_fc.err
-CN_FORCE_COMM=1 python3 $R/bench.py --dtype bf16 --no-cpu-baseline --no-extras > $O/${TAG}_bench_forcecomm_bf16_b32.json 2>> $O/bench_fc.err
-CN_FORCE_COMM=1 python3 $R/bench.py --hidden 64 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/${TAG}_bench_forcecomm_f32_b8_h64.json 2>> $O/bench_fc.err
+# (fp32 batch 8 and bf16 batch 32 under a one-rank RCCL group are the `ddp1` block of the default line since round 5)
+CN_FORCE_COMM=1 python3 $R/bench.py --hidden 64 --steps 10 --warmup 3 --no-cpu-baseline --no-extras > $O/${TAG}_bench_forcecomm_f32_b8_h64.json 2> $O/bench_fc.err
+# ordered kernel traces of one step (hardware queue per kernel): fp32 batch 8 and bf16 batch 32
+for P in f32 bf16; do
+  A=""; [ $P = bf16 ] && A="--dtype bf16"
+  rocprofv3 --kernel-trace -d $O/trace_$P -o s -- python3 $R/bench.py $A --steps 6 --warmup 3 --no-cpu-baseline --no-extras > /dev/null 2>&1
+  python3 $R/tools/step_trace.py $O/trace_$P/s_results.db > $O/${TAG}_step_trace_$P.txt
+  rm -rf $O/trace_$P
+done
 # sliding-window predict (36 windows per batch, bf16-mixed): kernel stats + timeline
 python3 $R/tools/predict_prof.py bf16 20 36 > $O/${TAG}_predict_bf16_timing.txt 2>&1
 rocprofv3 --kernel-trace --stats -d $O/stats_pred -o p -- python3 $R/tools/predict_prof.py bf16 10 36 > /dev/null 2>&1
