@@ -11,6 +11,7 @@
 // wave-instruction covers 2 x 128 contiguous bytes of dW.
 // Reference op: autograd of torch.nn.Conv2d / ConvTranspose2d used by
 // /root/reference/src/cultionet/nn/modules/convolution.py:45-120.
+#include <cstdlib>
 #include "cn_common.h"
 #include "cn_profile.h"
 #include "cn_slicesum.h"
@@ -604,6 +605,11 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
   // resident blocks on the chip. (Sizing the grids for 224 / 192 / 160 of the 256 CUs, to leave whole CUs to the compute
   // stream's kernels -- which cannot share a SIMD with a weight-gradient wave: 393 of 512 registers per lane -- was
   // measured in round 5: fp32 386.4 -> 382.2 / 373.2 / 354.9 chips/s. The side stream is as long as the compute stream.)
+  // (More, shorter-lived blocks -- 512 / 1024 / 2048 per launch, so that the compute stream's workgroups get CUs at every
+  // block boundary instead of once per launch -- cut the slowdown of a bilinear adjoint next to this kernel from 9.5x to
+  // 5.5x / 3.6x / 2.8x (tools/corun.py) and made the fp32 step SLOWER: 387.0 -> 373.5 / 357.6 / 342.7 chips/s, as did
+  // single-buffered staging (half the LDS: 374.5). The slices and per-block epilogues cost more machine time than the
+  // compute stream wins back: the step is bound by the sum of the work, not by who waits for whom.)
   const int slots = (lds * 2 <= 160 * 1024) ? 512 : 256;
   int splits = slots / (gx * gy * g.G);                   // never spill into a second, mostly idle round
   if (splits > g.total_chunks) splits = g.total_chunks;
