@@ -96,9 +96,9 @@ def _native_entry(kind: int, fn, args) -> T.Optional[T.List[int]]:
     return None
 
 
-def compile_native(ops: T.Sequence[T.Tuple[int, T.Any, tuple]]) -> T.Optional[T.List[T.Any]]:
-    """Segments of ``ops``: ("n", uint64 array [k][29], k) for runs cn_plan_run executes, ("p", fn, args) for the rest,
-    ("keep", obj) for what the arrays point at besides the op list itself (events created for stream joins).
+def compile_native(ops: T.Sequence[T.Tuple[int, T.Any, tuple]], keep: T.List[T.Any]) -> T.Optional[T.List[T.Any]]:
+    """Segments of ``ops``: ("n", uint64 array [k][29], k) for runs cn_plan_run executes, ("p", fn, args) for the rest.
+    ``keep`` receives what the arrays point at besides the op list itself (events created for stream joins).
     None: native execution is switched off or the library cannot be asked (CPU)."""
     if not _NATIVE or not torch.cuda.is_available():
         return None
@@ -121,7 +121,7 @@ def compile_native(ops: T.Sequence[T.Tuple[int, T.Any, tuple]]) -> T.Optional[T.
                 and len(args) == 1 and isinstance(args[0], torch.cuda.Stream):
             ev = torch.cuda.Event()
             ev.record(args[0])  # (creates the HIP event; an extra record of "now" on that stream is harmless)
-            segs.append(("keep", ev))
+            keep.append(ev)
             run.append([1, ev.cuda_event, args[0].cuda_stream])
             run.append([2, owner.cuda_stream, ev.cuda_event])
             continue
@@ -144,7 +144,7 @@ def run_segments(segs: T.Sequence[T.Any]) -> None:
             if rc != 0:
                 raise _lib.HipKernelError(f"replayed launch {failed.value} of a native plan segment failed: "
                                           f"{_lib.ERRORS.get(rc, rc)}")
-        elif seg[0] == "p":
+        else:
             seg[1](*seg[2])
 
 
@@ -239,7 +239,7 @@ def forward(model, x: torch.Tensor, bf16: bool, run: T.Callable[[torch.Tensor], 
     if E.workspace_epoch() != epoch0:  # a scratch buffer moved while recording: stale pointers, do not keep the plan
         return plan.outputs
     plan.key = _key(model, store, x, bf16)  # (recording may have refreshed packed weights: the key after it)
-    plan.segs = compile_native(plan.calls)
+    plan.segs = compile_native(plan.calls, plan.keep)
     plans.pop(slot, None)
     plans[slot] = plan
     # a plan owns a private memory pool with the whole activation set of its batch (GBs for a packed window batch):
@@ -356,7 +356,7 @@ def record_step(trainer, batch, eager: T.Callable) -> StepPlan:
     plan.key = step_key(trainer, batch) if E.workspace_epoch() == epoch0 else None
     plan.n_calls = sum(1 for o in ops if o[0] == 0)
     if plan.key is not None:
-        plan.segs = compile_native(ops)
+        plan.segs = compile_native(ops, plan.keep)
     return plan
 
 
