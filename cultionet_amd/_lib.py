@@ -125,8 +125,6 @@ SIGNATURES = {
     "cn_slice_sums_count": [],
     "cn_slice_sums_end": [],
     "cn_slice_sums_run": [P, P, I, I, I, P],
-    "cn_plan_fn_index": [P, P],
-    "cn_plan_run": [P, I, P],
     "cn_stream_priority_range": [P],
     "cn_stream_create": [I, P, I, P],
     "cn_stream_destroy": [P],

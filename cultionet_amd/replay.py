@@ -30,129 +30,10 @@ from . import engine as E
 MAX_PLANS = 4  # per model: (input shape, precision) slots kept alive
 
 
-# ---------------------------------------------------------------------------------------------------------------------
-# Native execution of a recorded op list (csrc/cn_plan.hip).
-#
-# ``for fn, args in ops: fn(*args)`` costs ~12 us per entry on the host (ctypes marshals ~20 arguments per call, torch
-# wraps every event record / stream wait): 7.5 ms for the reference-default training step, whose GPU work is ~7 ms.
-# compile_native() turns the SAME list into arrays of 232-byte CnPlanOp records -- the C-ABI calls as (trampoline index,
-# argument slots), event records / stream waits as raw HIP handles -- which cn_plan_run walks in C. Entries it cannot
-# translate (the two host-side / torch calls of a training step) stay Python calls between native segments.
-# CN_NATIVE_PLAN=0: the Python loop (A/B).
-# ---------------------------------------------------------------------------------------------------------------------
-import ctypes as _ct
-import os as _os
-import struct as _struct
-
-_NATIVE = _os.environ.get("CN_NATIVE_PLAN", "1") != "0"
-_SLOTS = 28
-_fn_index: T.Dict[str, T.Tuple[int, int]] = {}
-
-
-def _slot(arg, typ) -> int:
-    """One ctypes argument as the 64-bit slot the trampoline reads."""
-    if typ is _lib.F:
-        return _struct.unpack("<I", _struct.pack("<f", float(arg)))[0]
-    if typ is _lib.P:
-        if arg is None:
-            return 0
-        if isinstance(arg, int):
-            return arg & 0xFFFFFFFFFFFFFFFF
-        if hasattr(arg, "_obj"):  # ctypes.byref(x): the callee writes into x, which the op list keeps alive
-            return _ct.addressof(arg._obj)
-        if isinstance(arg, (_ct.Array, _ct.Structure)):
-            return _ct.addressof(arg)
-        if isinstance(arg, bytes):
-            raise TypeError("bytes argument")  # (would need an owned copy: not used by any recorded call)
-        v = _ct.cast(arg, _ct.c_void_p).value
-        return v or 0
-    return int(arg) & 0xFFFFFFFFFFFFFFFF  # I / L / U64: two's complement, the trampoline narrows
-
-
-def _native_entry(kind: int, fn, args) -> T.Optional[T.List[int]]:
-    """[kind | fn << 32, slots...] for one recorded op, or None if it has to stay a Python call."""
-    if kind == 0:
-        name = getattr(fn, "__name__", None)
-        types = _lib.SIGNATURES.get(name)
-        if types is None or len(types) != len(args) or len(args) > _SLOTS:
-            return None
-        ent = _fn_index.get(name)
-        if ent is None:
-            n = _ct.c_int(0)
-            idx = _lib.query("cn_plan_fn_index", name.encode(), _ct.byref(n))
-            ent = _fn_index[name] = (idx, n.value)
-        if ent[0] < 0 or ent[1] != len(args):
-            return None
-        try:
-            return [ent[0] << 32] + [_slot(a, t) for a, t in zip(args, types)]
-        except Exception:
-            return None
-    owner = getattr(fn, "__self__", None)
-    name = getattr(fn, "__name__", "")
-    if isinstance(owner, torch.cuda.Event) and name == "record" and len(args) == 1 and isinstance(args[0], torch.cuda.Stream):
-        return [1, owner.cuda_event, args[0].cuda_stream]
-    if isinstance(owner, torch.cuda.Stream) and name == "wait_event" and len(args) == 1 and isinstance(args[0], torch.cuda.Event):
-        return [2, owner.cuda_stream, args[0].cuda_event]
-    return None
-
-
-def compile_native(ops: T.Sequence[T.Tuple[int, T.Any, tuple]], keep: T.List[T.Any]) -> T.Optional[T.List[T.Any]]:
-    """Segments of ``ops``: ("n", uint64 array [k][29], k) for runs cn_plan_run executes, ("p", fn, args) for the rest.
-    ``keep`` receives what the arrays point at besides the op list itself (events created for stream joins).
-    None: native execution is switched off or the library cannot be asked (CPU)."""
-    if not _NATIVE or not torch.cuda.is_available():
-        return None
-    import numpy as np
-
-    segs: T.List[T.Any] = []
-    run: T.List[T.List[int]] = []
-
-    def close():
-        if run:
-            arr = np.zeros((len(run), _SLOTS + 1), dtype=np.uint64)
-            for i, e in enumerate(run):
-                arr[i, :len(e)] = np.array(e, dtype=np.uint64)
-            segs.append(("n", arr, len(run)))
-            run.clear()
-
-    for kind, fn, args in ops:
-        owner = getattr(fn, "__self__", None)
-        if kind != 0 and isinstance(owner, torch.cuda.Stream) and getattr(fn, "__name__", "") == "wait_stream" \
-                and len(args) == 1 and isinstance(args[0], torch.cuda.Stream):
-            ev = torch.cuda.Event()
-            ev.record(args[0])  # (creates the HIP event; an extra record of "now" on that stream is harmless)
-            keep.append(ev)
-            run.append([1, ev.cuda_event, args[0].cuda_stream])
-            run.append([2, owner.cuda_stream, ev.cuda_event])
-            continue
-        ent = _native_entry(kind, fn, args)
-        if ent is None:
-            close()
-            segs.append(("p", fn, args))
-        else:
-            run.append(ent)
-    close()
-    return segs
-
-
-def run_segments(segs: T.Sequence[T.Any]) -> None:
-    lib = _lib.load()
-    failed = _ct.c_int(-1)
-    for seg in segs:
-        if seg[0] == "n":
-            rc = lib.cn_plan_run(seg[1].ctypes.data, seg[2], _ct.byref(failed))
-            if rc != 0:
-                raise _lib.HipKernelError(f"replayed launch {failed.value} of a native plan segment failed: "
-                                          f"{_lib.ERRORS.get(rc, rc)}")
-        else:
-            seg[1](*seg[2])
-
-
 class ForwardPlan:
-    __slots__ = ("calls", "pool", "x", "outputs", "key", "keep", "segs")
+    __slots__ = ("calls", "pool", "x", "outputs", "key", "keep")
 
     def __init__(self):
-        self.segs = None  # compile_native(calls): the same list as native segments (None: replay the list from Python)
         self.calls: T.List[T.Tuple[int, T.Any, tuple]] = []  # (0, C entry point, args) | (1, python stream op, args)
         self.pool = None
         self.x: T.Optional[torch.Tensor] = None
@@ -197,9 +78,6 @@ def forward(model, x: torch.Tensor, bf16: bool, run: T.Callable[[torch.Tensor], 
             plans[slot] = plans.pop(slot)
         if x.data_ptr() != plan.x.data_ptr():
             plan.x.copy_(x)
-        if plan.segs is not None:
-            run_segments(plan.segs)
-            return plan.outputs
         for kind, fn, args in plan.calls:
             if kind:  # a stream operation of the recorded forward (event record / wait of engine.spawn / join)
                 fn(*args)
@@ -239,7 +117,6 @@ def forward(model, x: torch.Tensor, bf16: bool, run: T.Callable[[torch.Tensor], 
     if E.workspace_epoch() != epoch0:  # a scratch buffer moved while recording: stale pointers, do not keep the plan
         return plan.outputs
     plan.key = _key(model, store, x, bf16)  # (recording may have refreshed packed weights: the key after it)
-    plan.segs = compile_native(plan.calls, plan.keep)
     plans.pop(slot, None)
     plans[slot] = plan
     # a plan owns a private memory pool with the whole activation set of its batch (GBs for a packed window batch):
@@ -269,10 +146,9 @@ def forward(model, x: torch.Tensor, bf16: bool, run: T.Callable[[torch.Tensor], 
 # is not (float-atomic parameter-gradient sums): tests/test_replay_train_gpu.py.
 # ---------------------------------------------------------------------------------------------------------------------
 class StepPlan:
-    __slots__ = ("ops", "pool", "keep", "inputs", "outputs", "key", "n_calls", "segs")
+    __slots__ = ("ops", "pool", "keep", "inputs", "outputs", "key", "n_calls")
 
     def __init__(self):
-        self.segs = None  # compile_native(ops)
         self.ops: T.List[T.Tuple[int, T.Any, tuple]] = []
         self.pool = None
         self.keep: T.List[torch.Tensor] = []
@@ -355,8 +231,6 @@ def record_step(trainer, batch, eager: T.Callable) -> StepPlan:
     # the caller drops this plan and records again once the buffers have settled
     plan.key = step_key(trainer, batch) if E.workspace_epoch() == epoch0 else None
     plan.n_calls = sum(1 for o in ops if o[0] == 0)
-    if plan.key is not None:
-        plan.segs = compile_native(ops, plan.keep)
     return plan
 
 
@@ -364,14 +238,11 @@ def replay_step(plan: StepPlan, batch) -> None:
     for dst, src in zip(plan.inputs, (batch.x, batch.y, batch.bdist)):
         if dst.data_ptr() != src.data_ptr():
             dst.copy_(src)
-    if plan.segs is not None:
-        run_segments(plan.segs)
-    else:
-        for kind, fn, args in plan.ops:
-            if kind == 0:
-                rc = fn(*args)
-                if rc != 0:
-                    raise _lib.HipKernelError(f"replayed launch failed: {_lib.ERRORS.get(rc, rc)}")
-            else:
-                fn(*args)
+    for kind, fn, args in plan.ops:
+        if kind == 0:
+            rc = fn(*args)
+            if rc != 0:
+                raise _lib.HipKernelError(f"replayed launch failed: {_lib.ERRORS.get(rc, rc)}")
+        else:
+            fn(*args)
     E._note_bn_update(True)  # the recorded BatchNorm launches updated running statistics: invalidate eval-mode folds

@@ -524,17 +524,6 @@ int cn_slice_sums_count(void);
 int cn_slice_sums_end(void);
 int cn_slice_sums_run(void* host_table, void* dev_table, int first, int n, int upload, void* stream);
 
-/* ---- native executor of recorded launch plans (cn_plan.hip) -------------------------------------------
- * A recorded forward / training step (cultionet_amd/replay.py) is a list of C-ABI calls with constant arguments
- * plus event records / stream waits. cn_plan_run walks `n` 232-byte entries {int kind; int fn; uint64 a[28]} in
- * order: kind 0 calls entry point `fn` (cn_plan_fn_index(name)) with argument i taken from slot a[i] (pointers and
- * integers as 64-bit values, floats as their 32 bits; host arrays passed by address must stay alive), kind 1 =
- * hipEventRecord(event a[0], stream a[1]), kind 2 = hipStreamWaitEvent(stream a[0], event a[1]). Stops at the first
- * failing entry (its index in *failed). The reference has no counterpart (torch eager under Lightning's loop,
- * /root/reference/src/cultionet/model.py:273-314). */
-int cn_plan_fn_index(const char* name, int* nargs_out);
-int cn_plan_run(const void* ops, int n, int* failed);
-
 /* ---- runtime plumbing: streams torch cannot create ---------------------------------------------------
  * The training step issues weight gradients on a second stream (engine.py side_stream; the reference has no
  * counterpart: torch.autograd runs one stream). That stream must not starve the data-gradient chain:

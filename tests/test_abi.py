@@ -70,52 +70,3 @@ def test_product_path_has_no_cpu_fallback():
 
     with pytest.raises(RuntimeError):
         engine._check(torch.zeros(1))
-
-
-def test_plan_trampolines_match_the_header():
-    """cn_plan_gen.inc (one trampoline per entry point, generated from the header) is what the generator would write now."""
-    import subprocess
-    import sys
-
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "gen_plan_trampolines.py"), "--check"])
-    assert r.returncode == 0, "run `python tools/gen_plan_trampolines.py` and rebuild"
-
-
-def test_native_plan_executor_on_host_entry_points():
-    """cn_plan_run with pure-host entry points (no GPU): pointer / int / long slots arrive, execution stops at the first
-    failing entry and reports its index, unknown names are refused."""
-    import ctypes
-
-    import numpy as np
-
-    from cultionet_amd import _lib
-
-    lib = _lib.load()
-    n = ctypes.c_int(-1)
-    i_begin = _lib.query("cn_plan_fn_index", b"cn_slice_sums_begin", ctypes.byref(n))
-    assert i_begin >= 0 and n.value == 4
-    i_end = _lib.query("cn_plan_fn_index", b"cn_slice_sums_end", None)
-    i_kpad = _lib.query("cn_plan_fn_index", b"cn_conv_kpad", None)
-    assert _lib.query("cn_plan_fn_index", b"cn_no_such_entry", None) == -1
-    for name in _lib.SIGNATURES:  # every status-returning entry point has a trampoline with the binding's arity
-        if name in ("cn_plan_run", "cn_plan_fn_index"):
-            continue
-        assert _lib.query("cn_plan_fn_index", name.encode(), ctypes.byref(n)) >= 0 and n.value == len(_lib.SIGNATURES[name]), name
-    host = np.zeros(64 * 4, dtype=np.uint8)
-    grad = np.zeros(16, dtype=np.float32)
-    ops = np.zeros((3, 29), dtype=np.uint64)
-    ops[0, 0] = i_begin << 32
-    ops[0, 1:5] = [host.ctypes.data, 4, grad.ctypes.data, 16]
-    ops[1, 0] = i_kpad << 32   # returns 8 for K = 3: a non-zero "status" -> the executor stops HERE
-    ops[1, 1] = 3
-    ops[2, 0] = i_end << 32
-    failed = ctypes.c_int(-1)
-    assert lib.cn_plan_run(ops.ctypes.data, 1, ctypes.byref(failed)) == 0
-    assert _lib.query("cn_slice_sums_count") == 0  # the sink was registered with the pointers / sizes of the slots
-    assert lib.cn_plan_run(ops.ctypes.data, 3, ctypes.byref(failed)) == 8 and failed.value == 1
-    assert _lib.query("cn_slice_sums_count") == 0  # entry 2 (end) never ran
-    _lib.call("cn_slice_sums_end")
-    assert _lib.query("cn_slice_sums_count") == -1
-    bad = np.zeros((1, 29), dtype=np.uint64)
-    bad[0, 0] = 7  # unknown kind
-    assert lib.cn_plan_run(bad.ctypes.data, 1, ctypes.byref(failed)) == -1 and failed.value == 0

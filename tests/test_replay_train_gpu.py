@@ -183,31 +183,3 @@ def test_plan_recorded_without_a_weight_update_still_repacks():
         lp.append(float(plan.training_step(batches[i % 3]).item()))
     assert np.abs(np.array(le) - np.array(lp)).max() <= 2e-6, (le, lp)
     assert le[-1] < le[0]
-
-
-@pytest.mark.parametrize("precision", ["32-true", "bf16-mixed"])
-def test_native_plan_executor_replays_what_the_python_loop_replays(precision, monkeypatch):
-    """cn_plan_run (csrc/cn_plan.hip) walks the recorded op list in C; the Python loop walks the same list. Same launches,
-    same arguments, same stream order: identical losses step by step (the eager step's own float-atomic noise aside),
-    and nearly every entry of the plan runs natively."""
-    from cultionet_amd import replay as R
-
-    losses = {}
-    for native in (True, False):
-        monkeypatch.setattr(R, "_NATIVE", native)
-        (eager, plan), batches = _pair(precision)
-        out = []
-        for i in range(6):
-            out.append(float(plan.training_step(batches[i % len(batches)]).item()))
-        assert plan._plan is not None
-        if native:
-            segs = plan._plan.segs
-            assert segs is not None
-            n_native = sum(s[2] for s in segs if s[0] == "n")
-            n_python = sum(1 for s in segs if s[0] == "p")
-            assert n_native > 100 and n_python <= 4, (n_native, n_python)
-        else:
-            assert plan._plan.segs is None
-        losses[native] = out
-    tol = 2e-6 if precision == "32-true" else 1e-3
-    assert np.abs(np.array(losses[True]) - np.array(losses[False])).max() <= tol, losses
