@@ -719,6 +719,9 @@ struct CnChoice { int cfg, splits, cps; double cost; };
 static double cn_launch_cost(long blocks, int cps, double mt_units, int splits, double out_elems) {
   // per-chunk cost: alone on the CU 36.7 + 0.614 MT', two co-resident blocks 30 + 1.19 MT' each (MT' = pixel tile
   // scaled by NT/128 and taps/9); fitted to the (tile, split) sweeps of tools/kcfg.py on 128->128 at 50^2
+  // (Round 5 re-checked R INSIDE the step, where a split conv also competes with the weight-gradient stream for the CUs it
+  // fills: R = 0 / 80 / 170 / 340 / 680 / 1400 -> 386.0 / 386.0 / 387.3 / 385.3 / 377.1 / 359.8 chips/s, no split at all
+  // 347.8: the isolated calibration holds.)
   const double F = 273.0, R = 170.0;
   const double c1 = 36.7 + 0.614 * mt_units, c2 = 30.0 + 1.19 * mt_units;
   const long full = blocks / 512, rem = blocks % 512;
