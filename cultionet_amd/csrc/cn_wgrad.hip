@@ -531,6 +531,261 @@ __global__ __launch_bounds__(256) void cn_wgrad_vec_kernel(const float* __restri
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------------------
+// 3 x 3 weight gradient, TWELVE waves per block (round 5): the same tile, LDS images and LDS-DMA staging as
+// cn_wgrad_vec_kernel<9, S_>, but a wave owns ONE KERNEL ROW of the taps -- 32 couts x (32 channels x 3 taps) = three
+// accumulator tiles, 48 registers instead of 144 -- so three waves share a SIMD (wave = cout tile x kernel row x k-part).
+// cn_wgrad_vec_kernel<9, *> runs one wave per SIMD (393 registers) and issues everything in order: while it issues a
+// chunk's ~17 LDS-DMA instructions (~126 cycles each at the CU's issue rate), waits at the chunk barrier or for the first
+// operands, the matrix pipe idles -- 14.4k of a chunk's ~20k cycles are MFMAs (0.58 of the f32 peak alone, four rounds
+// running). Here a wave's DMA issue, barrier skew and LDS latency run under the other two waves' MFMAs.
+// Columns of a wave's tile: n = j * 32 + lane % 32 (j < 3), channel n / 3, tap ky * 3 + n % 3 -- dW runs of three floats.
+#define WG3_WAVES 12
+#define WG3_KS 3   // DMA instructions per wave for the S image  (arows * npix <= 8192 floats = 32 KiB = 32 instructions)
+#define WG3_KB 6   // DMA instructions per wave for the Bg image (32 * plane_b <= 16384 floats = 64 instructions)
+template <int S_>
+__global__ __launch_bounds__(WG3_WAVES * 64) void cn_wgrad_vec3_kernel(const float* __restrict__ S0,
+                                                                       const float* __restrict__ Bg0,
+                                                                       float* __restrict__ dW0, const CnWgradGeom g) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int T = 3;  // taps per wave
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = lane >> 5, l31 = lane & 31;
+  // wave = (k-part, kernel row, cout tile): the waves of one (cout tile, kernel row) are a_tiles * 3 apart
+  const int at = wid % g.a_tiles;
+  const int ky = (wid / g.a_tiles) % 3;
+  const int kp = wid / (g.a_tiles * 3), kparts = WG3_WAVES / (g.a_tiles * 3);
+  int bx, by, bz;
+  if (!cn_xcd_block(g.grid_x, g.grid_y, g.grid_x * g.grid_y * g.grid_z, bx, by, bz)) return;
+  const int grp = g.G > 1 ? bz / g.spg : 0;
+  const int split = bz - grp * g.spg;
+  const float* __restrict__ S = g.G > 1 ? g.gS[grp] : S0;
+  const float* __restrict__ Bg = g.G > 1 ? g.gB[grp] : Bg0;
+  float* __restrict__ dW = (g.G > 1 && g.slice_stride == 0) ? g.gdW[grp] : dW0;
+  const int a0 = by * g.a_tiles * 32;
+  const int b0 = bx * WG_BC;
+  const int npix = g.PR * g.Ws;
+  const int n4s = npix >> 2;
+  const int n4b = g.plane_b >> 2;
+  const float* zero = cn_zero_line16 + 4 * lane;
+
+  int boff[T], ox[T];
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    const int n = j * 32 + l31;
+    const int bl = n / 3, t = ky * 3 + (n - bl * 3);
+    boff[j] = bl * g.plane_b + (g.offy[t] - g.min_oy) * g.Wb + (g.offx[t] - g.min_ox) + half * g.s;
+    ox[j] = g.offx[t] + half * g.s;
+  }
+  const int aoff = (at * 32 + l31) * g.pitch_s + half;
+
+  f32x16 acc[T];
+#pragma unroll
+  for (int j = 0; j < T; ++j)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[j][r] = 0.f;
+
+  const int arows = g.a_tiles * 32;
+  int chunk = split * g.chunks_per_split;
+  int chunk_end = chunk + g.chunks_per_split;
+  if (chunk_end > g.total_chunks) chunk_end = g.total_chunks;
+
+  constexpr unsigned WG_IDLE = 0xFFFFFFFFu;
+  unsigned so[WG3_KS], bo[WG3_KB];
+  {
+    const int nsp = arows * n4s, nbp = WG_BC * n4b;
+#pragma unroll
+    for (int k = 0; k < WG3_KS; ++k) {
+      const int p = (wid + WG3_WAVES * k) * 64 + lane;
+      const int a = p / n4s, pc = p - a * n4s;
+      so[k] = (p < nsp && (a0 + a) < g.A) ? (unsigned)(((long)(a0 + a) * g.scs + 4 * pc) * 4) : WG_IDLE;
+    }
+#pragma unroll
+    for (int k = 0; k < WG3_KB; ++k) {
+      const int p = (wid + WG3_WAVES * k) * 64 + lane;
+      const int bl = p / n4b, pi = p - bl * n4b;
+      bo[k] = (p < nbp && (b0 + bl) < g.Bc) ? (unsigned)(((long)(b0 + bl) * g.bcs + 4 * pi) * 4) : WG_IDLE;
+    }
+  }
+  auto stage = [&](int ck, int buf) {
+    float* s_lds = smem + buf * g.buf_stride;
+    float* b_lds = s_lds + g.b_lds_off;
+    const int n = ck / g.chunks_per_img;
+    const int gy0 = (ck - n * g.chunks_per_img) * g.PR;
+    const int nsp = arows * n4s, nbp = WG_BC * n4b;
+    {
+      const int fs0 = gy0 * g.Ws;
+      const char* sbase = reinterpret_cast<const char*>(S + (long)n * g.sbs + fs0);
+      const bool inside = fs0 + npix <= (int)g.scs;  // wave-uniform: the whole chunk lies inside the plane
+#pragma unroll
+      for (int k = 0; k < WG3_KS; ++k) {
+        if ((wid + WG3_WAVES * k) * 64 < nsp && so[k] != WG_IDLE) {
+          const float* src = reinterpret_cast<const float*>(sbase + so[k]);
+          if (!inside) {
+            const int p = (wid + WG3_WAVES * k) * 64 + lane;
+            if (!((fs0 + 4 * (p % n4s) + 3) < (int)g.scs)) src = zero;
+          }
+          cn_glds16(src, s_lds + (wid + WG3_WAVES * k) * 256);
+        }
+      }
+    }
+    {
+      const int start = (gy0 * g.s + g.min_oy) * g.Wb + g.min_ox;
+      const int f0 = (start >> 2) << 2;
+      const char* bbase = reinterpret_cast<const char*>(Bg + (long)n * g.bbs + f0);
+      const bool inside = f0 >= 0 && f0 + g.plane_b <= (int)g.bcs;  // wave-uniform: the halo lies inside the plane
+#pragma unroll
+      for (int k = 0; k < WG3_KB; ++k) {
+        if ((wid + WG3_WAVES * k) * 64 < nbp && bo[k] != WG_IDLE) {
+          const float* src = reinterpret_cast<const float*>(bbase + bo[k]);
+          if (!inside) {
+            const int p = (wid + WG3_WAVES * k) * 64 + lane;
+            const int fq = f0 + 4 * (p % n4b);
+            if (!(fq >= 0 && (fq + 3) < (int)g.bcs)) src = zero;
+          }
+          cn_glds16(src, b_lds + (wid + WG3_WAVES * k) * 256);
+        }
+      }
+    }
+  };
+
+  int cur = 0;
+  if (chunk < chunk_end && g.nbuf == 2) stage(chunk, 0);
+  for (; chunk < chunk_end; ++chunk) {
+    if (g.nbuf == 1) {
+      __syncthreads();
+      stage(chunk, 0);
+    }
+    __syncthreads();
+    // (The barrier puts the three waves of a SIMD in the same phase. Skewing them -- the waves of kernel row ky start
+    // ky * 512 / 1024 / 2048 / 4096 cycles late -- was measured: 239 -> 245 / 245 / 249 / 260 us at 128 -> 128, 8 x 100^2;
+    // moving a wave's DMA issue into its group pipeline costs registers the three-waves budget does not have.)
+    if (g.nbuf == 2 && chunk + 1 < chunk_end) stage(chunk + 1, cur ^ 1);
+    const float* s_lds = smem + cur * g.buf_stride;
+    const float* b_lds = s_lds + g.b_lds_off;
+    const int gy0c = (chunk % g.chunks_per_img) * g.PR;
+    const int start = (gy0c * g.s + g.min_oy) * g.Wb + g.min_ox;
+    const int sh = start - ((start >> 2) << 2);
+    const int nq_row = g.Ws >> 1;
+    const int q_lo = (nq_row * kp) / kparts, q_hi = (nq_row * (kp + 1)) / kparts;
+    const int seg0 = min(max(g.mq_lo, q_lo), q_hi), seg1 = max(min(g.mq_hi, q_hi), seg0);
+    for (int r = 0; r < g.PR; ++r) {
+      const float* ap = s_lds + aoff + r * g.Ws;
+      const float* bp[T];
+#pragma unroll
+      for (int j = 0; j < T; ++j) bp[j] = b_lds + boff[j] + sh + (r * S_) * g.Wb;
+      int q = q_lo;
+      for (; q < seg0; ++q) {  // leading masked pairs
+        const float av = ap[2 * q];
+        const int cs = 2 * q * S_;
+        float bv[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) bv[j] = bp[j][cs];
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+          const float b_ = ((unsigned)(cs + ox[j]) < (unsigned)g.Wb) ? bv[j] : 0.f;
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_, acc[j], 0, 0, 0);
+        }
+      }
+      {  // interior pairs: groups of GS k-steps with the operands double-buffered in registers
+        constexpr int GS = 3;
+        const int ng = (seg1 - q) / GS;
+        if (ng > 0) {
+          float a0[GS], a1[GS], b0[GS][T], b1[GS][T];
+#define WG3_LOADG(qq_, a_, b_)                                                   \
+  {                                                                              \
+    const float* apq_ = ap + 2 * (qq_);                                          \
+    _Pragma("unroll") for (int u = 0; u < GS; ++u) a_[u] = apq_[2 * u];          \
+    _Pragma("unroll") for (int j = 0; j < T; ++j) {                              \
+      const float* bq_ = bp[j] + 2 * (qq_) * S_;                                 \
+      _Pragma("unroll") for (int u = 0; u < GS; ++u) b_[u][j] = bq_[2 * u * S_]; \
+    }                                                                            \
+  }
+#define WG3_MFMAG(a_, b_)                                                                                  \
+  {                                                                                                        \
+    _Pragma("unroll") for (int u = 0; u < GS; ++u)                                                         \
+        _Pragma("unroll") for (int j = 0; j < T; ++j)                                                      \
+            acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(a_[u], b_[u][j], acc[j], 0, 0, 0);               \
+  }
+          WG3_LOADG(q, a0, b0);
+          int i = 0;
+          for (; i + 2 <= ng; i += 2) {
+            WG3_LOADG(q + GS * (i + 1), a1, b1);
+            WG3_MFMAG(a0, b0);
+            if (i + 2 < ng) WG3_LOADG(q + GS * (i + 2), a0, b0);
+            WG3_MFMAG(a1, b1);
+          }
+          if (i < ng) WG3_MFMAG(a0, b0);
+#undef WG3_LOADG
+#undef WG3_MFMAG
+          q += GS * ng;
+        }
+      }
+      for (; q < seg1; ++q) {
+        const float av = ap[2 * q];
+        float bv[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) bv[j] = bp[j][2 * q * S_];
+#pragma unroll
+        for (int j = 0; j < T; ++j) acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, bv[j], acc[j], 0, 0, 0);
+      }
+      for (; q < q_hi; ++q) {  // trailing masked pairs
+        const float av = ap[2 * q];
+        const int cs = 2 * q * S_;
+        float bv[T];
+#pragma unroll
+        for (int j = 0; j < T; ++j) bv[j] = bp[j][cs];
+#pragma unroll
+        for (int j = 0; j < T; ++j) {
+          const float b_ = ((unsigned)(cs + ox[j]) < (unsigned)g.Wb) ? bv[j] : 0.f;
+          acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_, acc[j], 0, 0, 0);
+        }
+      }
+    }
+    if (g.nbuf == 2) cur ^= 1;
+  }
+
+  // the k-part waves of a (cout tile, kernel row) hold partial sums of the SAME dW tile: add them up through LDS
+  if (kparts > 1) {
+    __syncthreads();
+    float* red = smem;
+    const int slot = ky * g.a_tiles + at;  // (cout tile, kernel row) within the block
+    if (kp > 0) {
+      float* rp = red + (long)((kp - 1) * g.a_tiles * 3 + slot) * (T * 16 * 64) + lane;
+#pragma unroll
+      for (int j = 0; j < T; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) rp[(j * 16 + r) * 64] = acc[j][r];
+    }
+    __syncthreads();
+    if (kp > 0) return;
+    for (int k = 1; k < kparts; ++k) {
+      const float* rp = red + (long)((k - 1) * g.a_tiles * 3 + slot) * (T * 16 * 64) + lane;
+#pragma unroll
+      for (int j = 0; j < T; ++j)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[j][r] += rp[(j * 16 + r) * 64];
+    }
+  }
+  float* dWs = dW + (long)bz * g.slice_stride;
+#pragma unroll
+  for (int j = 0; j < T; ++j) {
+    const int n = j * 32 + l31;
+    const int bl = n / 3, t = ky * 3 + (n - bl * 3);
+    const bool bok = (b0 + bl) < g.Bc;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      const int a = a0 + at * 32 + (r & 3) + 8 * (r >> 2) + 4 * half;
+      if (bok && a < g.A) {
+        float* d = (g.slice_stride != 0 ? dWs : dW) + (long)a * g.sa + (long)(b0 + bl) * 9 + t;
+        if (g.slice_stride != 0) *d = acc[j][r];
+        else atomicAdd(d, acc[j][r]);
+      }
+    }
+  }
+}
+
 // dW_g[i] += sum_s part[g * nslices + s][i]; grid = (ceil(n / 256), 1 or 16, groups): with 16 slice groups,
 // 16-way atomics per address
 struct CnWgradReduceArgs {
@@ -654,8 +909,21 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
     g.slice_stride = dw_floats;
     out = ws;
   }
+  static const bool twelve = getenv("CN_WGRAD3") == nullptr || atoi(getenv("CN_WGRAD3")) != 0;  // A/B switch
+  if (T == 9 && twelve) cn_prof_name("cn_wgrad_vec3_kernel<%d>", g.s == 1 ? 1 : 2);
   cn_prof_before(stream);
-  if (g.s == 1)
+  if (T == 9 && twelve) {  // 3 x 3: twelve waves per block, one kernel row of taps per wave (cn_wgrad_vec3_kernel)
+    static bool attr3 = false;
+    if (!attr3) {
+      (void)hipFuncSetAttribute((const void*)cn_wgrad_vec3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      (void)hipFuncSetAttribute((const void*)cn_wgrad_vec3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+      attr3 = true;
+    }
+    if (g.s == 1)
+      CN_LAUNCH((cn_wgrad_vec3_kernel<1>), grid, dim3(WG3_WAVES * 64), lds, stream, g.gS[0], g.gB[0], out, g);
+    else
+      CN_LAUNCH((cn_wgrad_vec3_kernel<2>), grid, dim3(WG3_WAVES * 64), lds, stream, g.gS[0], g.gB[0], out, g);
+  } else if (g.s == 1)
     CN_LAUNCH((cn_wgrad_vec_kernel<T, 1>), grid, dim3(256), lds, stream, g.gS[0], g.gB[0], out, g);
   else
     CN_LAUNCH((cn_wgrad_vec_kernel<T, 2>), grid, dim3(256), lds, stream, g.gS[0], g.gB[0], out, g);
