@@ -688,7 +688,12 @@ __global__ __launch_bounds__(WG3_WAVES * 64) void cn_wgrad_vec3_kernel(const flo
           acc[j] = __builtin_amdgcn_mfma_f32_32x32x2f32(av, b_, acc[j], 0, 0, 0);
         }
       }
-      {  // interior pairs: groups of GS k-steps with the operands double-buffered in registers
+      {  // interior pairs: groups of GS k-steps with the operands double-buffered in registers.
+         // (A conflict-free A operand -- one ds_read_b128 per lane for four k-steps + two v_permlane32_swap, instead of
+         // four dwords at a row pitch that puts 32 couts on 8 banks -- was built and measured: 239 -> 251 us at 128 -> 128,
+         // 855 -> 899 at 480 -> 128, step 388 -> 383 chips/s: the bank conflicts are not what idles the pipe. Note for the
+         // next attempt: __builtin_bit_cast(unsigned, v[i]) of an ext_vector ELEMENT expression yields element 0 / undef
+         // with this compiler; copy the element to a scalar first.)
         constexpr int GS = 3;
         const int ng = (seg1 - q) / GS;
         if (ng > 0) {
