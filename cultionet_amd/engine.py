@@ -1023,6 +1023,7 @@ class _SliceSums:
         self.table = torch.zeros(_SS_CAP * 64, dtype=torch.uint8, device=dev)
         self.uploaded: T.Dict[T.Tuple[int, int], bytes] = {}  # record range -> bytes the device copy holds for it
         self.upload_ev = torch.cuda.Event()                    # (re-)recorded behind every table upload
+        self.writer: T.Any = None    # the launch plan that rewrote the host table last (None: an eager pass)
         self.blocks: T.List[torch.Tensor] = []
         self.active = False
         self.reset()
@@ -1105,6 +1106,8 @@ class deferring_slice_sums:
         # or by a replayed plan, which re-records the event) must have read it first
         if not st.upload_ev.query():
             st.upload_ev.synchronize()
+        if _recorder is None:
+            st.writer = None
         _state.slice_sums = st
         _lib.call("cn_slice_sums_begin", st.host.data_ptr(), _SS_CAP, self.store.flat_grad.data_ptr(),
                   self.store.numel)

@@ -146,7 +146,7 @@ def forward(model, x: torch.Tensor, bf16: bool, run: T.Callable[[torch.Tensor], 
 # is not (float-atomic parameter-gradient sums): tests/test_replay_train_gpu.py.
 # ---------------------------------------------------------------------------------------------------------------------
 class StepPlan:
-    __slots__ = ("ops", "pool", "keep", "inputs", "outputs", "key", "n_calls")
+    __slots__ = ("ops", "pool", "keep", "inputs", "outputs", "key", "n_calls", "sums")
 
     def __init__(self):
         self.ops: T.List[T.Tuple[int, T.Any, tuple]] = []
@@ -156,6 +156,7 @@ class StepPlan:
         self.outputs: T.Optional[T.Dict[str, torch.Tensor]] = None
         self.key = None
         self.n_calls = 0
+        self.sums = None  # the store's deferred-slice-sum state (engine._SliceSums) whose host table this plan rewrites
 
 
 def step_key(trainer, batch) -> tuple:
@@ -227,6 +228,9 @@ def record_step(trainer, batch, eager: T.Callable) -> StepPlan:
             for fname, real in wrapped.items():
                 setattr(torch, fname, real)
     plan.outputs = dict(trainer.last_outputs)
+    plan.sums = getattr(trainer.store, "_slice_sums", None)
+    if plan.sums is not None:
+        plan.sums.writer = plan
     # a scratch buffer that was (re)allocated WHILE recording leaves stale pointers in the earlier entries: no key, so
     # the caller drops this plan and records again once the buffers have settled
     plan.key = step_key(trainer, batch) if E.workspace_epoch() == epoch0 else None
@@ -238,6 +242,14 @@ def replay_step(plan: StepPlan, batch) -> None:
     for dst, src in zip(plan.inputs, (batch.x, batch.y, batch.bdist)):
         if dst.data_ptr() != src.data_ptr():
             dst.copy_(src)
+    st = plan.sums
+    if st is not None and st.writer is not plan:
+        # ANOTHER plan (or an eager pass) wrote the slice-sum table last and its upload may still be in flight: this plan's
+        # weight gradients are about to rewrite the host table with different records. (The same plan replayed back to
+        # back rewrites identical bytes -- no wait, the host keeps running ahead.)
+        if not st.upload_ev.query():
+            st.upload_ev.synchronize()
+        st.writer = plan
     for kind, fn, args in plan.ops:
         if kind == 0:
             rc = fn(*args)
