@@ -29,7 +29,8 @@
 #include "cn_bf16.h"
 #include "cn_ticket.h"
 
-#define PT_MAX_BLOCKS 512
+#define PT_MAX_BLOCKS 512      // persistent blocks of the generic kernel (two per CU)
+#define PT_MAX_BLOCKS_REG 768  // ... of the register variant (three per CU where the pass fits 168 registers)
 #define PT_MAX_C 8
 #define PT_PXB 128  // pixels per block tile: 4 waves x 32
 #define PT_KP 5     // weight row pitch of the first convolutions in LDS (k <= 5)
@@ -103,7 +104,7 @@ __host__ __device__ static inline int pt_nvals(int PASS, int C, int Cout, int CM
 struct PtLds {
   int wa, c3, k3, wA, wB, c2, ln, k2, xs, as_, drs, lacc, total;
 };
-__host__ __device__ static inline PtLds pt_lds(int PASS, int C, int T, int Cout, int CMAX) {
+__host__ __device__ static inline PtLds pt_lds(int PASS, int C, int T, int Cout, int CMAX, bool reg = false) {
   const int E3 = C * (T - 2), E5 = C * (T - 4);
   const int CP = pt_ceil32(Cout);
   const int EP = pt_ceil32(E3) + pt_ceil32(E5);
@@ -120,7 +121,7 @@ __host__ __device__ static inline PtLds pt_lds(int PASS, int C, int T, int Cout,
   l.k2 = o; o += 2 * CP * 2;
   l.wB = o; if (PASS == 4) o += CP * EP;
   o = (o + 3) & ~3;
-  l.xs = o; o += C * (T + 6) * PT_PXB;  // (T + PT_TPAD rows per channel)
+  l.xs = o; if (!reg) o += C * (T + 6) * PT_PXB;  // (T + PT_TPAD rows per channel; the register variant has no x tile)
   l.as_ = o; if (PASS == 4) o += 4 * EP * PT_LP;       // per wave: a[entry][pixel], later da[entry][pixel]
   l.drs = o; if (PASS == 4) o += 4 * 2 * CP * PT_LP;   // per wave: dr[branch][cout][pixel]
   l.lacc = o; o += (4 * pt_nvals(PASS, C, Cout, CMAX) + 3) & ~3;
@@ -292,31 +293,80 @@ __device__ __forceinline__ void pt_rows(int wl, int xs, int C, int T, int pcol, 
   }
 }
 
+// The same stack for a COMPILE-TIME (C, T) (round 5): the pixel's whole C x T cube sits in registers, loaded straight
+// from global memory and pre-shifted by the lane's entry parity -- xh[c][j] = x[c][half + j] -- so that every window
+// index below is a constant and the loops over output channels and steps unroll completely: no x tile in LDS, no staging
+// barrier (the waves of a block never meet inside the tile loop), no window shifting (a third of the generic loop's
+// vector instructions were v_mov), no padded fourth channel at C = 3. Same callbacks as pt_rows; xw[c][dt] is a view of
+// xh, renamed away by the compiler.
+template <int K, int CC, int TT, int CMAX, class FB, class FE, class FR>
+__device__ __forceinline__ void pt_rows_reg(int wl, const float (&xh)[CC][TT], int half, FB&& row_begin, FE&& entry,
+                                            FR&& row_end) {
+  constexpr int Tp = TT - K + 1;
+  constexpr int NS = (Tp + 1) >> 1;
+  // (the loop over output channels stays ROLLED: fully unrolled, the scheduler hoisted every LDS operand of the C x NS
+  // steps to the top of one giant block -- 256 VGPRs and 776 bytes of scratch in the output pass)
+#pragma unroll 1
+  for (int cp = 0; cp < CC; ++cp) {
+    float w[CC][K];
+#pragma unroll
+    for (int c = 0; c < CC; ++c)
+#pragma unroll
+      for (int dt = 0; dt < K; ++dt) w[c][dt] = SM(wl + ((cp * CMAX + c) * PT_KP + dt));
+    row_begin(cp);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      float xw[CC][K];
+      float h0 = 0.f, h1 = 0.f;
+#pragma unroll
+      for (int c = 0; c < CC; ++c)
+#pragma unroll
+        for (int dt = 0; dt < K; ++dt) {
+          xw[c][dt] = xh[c][2 * s + dt];
+          if ((c + dt) & 1) h1 += w[c][dt] * xw[c][dt];
+          else h0 += w[c][dt] * xw[c][dt];
+        }
+      const bool live = (2 * s + 1 < Tp) ? true : half == 0;
+      entry(cp, 2 * s + half, live, h0 + h1, xw);
+    }
+    row_end(cp);
+  }
+}
+
 // PASS 0: BatchNorm3d statistics   1: BatchNorm2d statistics   2: output (training or inference)
 // PASS 3: backward sums of LayerNorm / BatchNorm2d   4: dW of the second convolutions + BatchNorm3d sums (+ dz scratch)
 // PASS 5: dW of the first convolutions
 // CMAX: compile-time bound of the input channels (4 or 8). MT: 32-channel tiles of Cout (1 or 2). NE: 32-entry tiles per
-// branch (PASS 4 only; 1..3).
-template <int PASS, int CMAX, int MT, int NE>
+// branch (PASS 4 only; 1..3). CC, TT: compile-time (C, T) of the register variant (pt_rows_reg), 0 = the generic kernel.
+template <int PASS, int CMAX, int MT, int NE, int CC = 0, int TT = 0>
 #ifndef PT_MINB
 #define PT_MINB 1
 #endif
+#ifndef PT_REG_MINB
+#define PT_REG_MINB 2
+#endif
+#ifndef PT_REG_MINB4
+#define PT_REG_MINB4 1
+#endif
 // (PASS 3 at C <= 4, Cout <= 32 fits 251 VGPRs without its 48 AGPR copies: two blocks per CU instead of one)
 // (the output pass at three blocks per CU -- 168 VGPRs, 128 bytes of scratch -- measured 1-4 % faster: not worth the spills)
-__global__ __launch_bounds__(256, (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_MINB) void cn_pretime_kernel(const CnPtArgs a) {
+__global__ __launch_bounds__(256, CC > 0 ? (PASS == 4 ? PT_REG_MINB4 : PT_REG_MINB) : (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_MINB)
+void cn_pretime_kernel(const CnPtArgs a) {
+  constexpr bool REG = CC > 0;
+  constexpr int NC = REG ? CC : CMAX;  // input channels the unrolled loops walk (the generic kernel pads to CMAX)
   float* const lds = pt_smem;  // (only for the block-cooperative copy at the top and the parked doubles at the end)
   __shared__ int s_flag;
   const int tid = threadIdx.x, lane = tid & 63;
   const int wid = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int l32 = lane & 31, half = lane >> 5;
-  const int C = a.C, T = a.T, Cout = a.Cout, HW = a.HW;
+  const int C = REG ? CC : a.C, T = REG ? TT : a.T, Cout = a.Cout, HW = a.HW;
   constexpr int CP = 32 * MT;
   const int pcol = wid * 32 + l32;  // pixel column inside the block tile
   const int T3 = T - 2, T5 = T - 4;
   const int E3 = C * T3, E5 = C * T5, E = E3 + E5;
   const int EP3 = pt_ceil32(E3), EP = EP3 + pt_ceil32(E5);
   const int NS3 = C * ((T3 + 1) >> 1);  // wave steps of branch 3
-  const PtLds L = pt_lds(PASS, C, T, Cout, CMAX);
+  const PtLds L = pt_lds(PASS, C, T, Cout, CMAX, REG);
   const int wa_l = L.wa;
   const int c3_l = L.c3;
   const int k3_l = L.k3;
@@ -348,10 +398,12 @@ __global__ __launch_bounds__(256, (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_M
     }
   }
   for (int i = tid; i < 4 * NV; i += 256) SM(lacc + (i)) = 0.f;
-  for (int i = tid; i < C * PT_TPAD * PT_PXB; i += 256) {  // the pad rows of the x tile (never written again)
-    const int c = i / (PT_TPAD * PT_PXB), r = i - c * (PT_TPAD * PT_PXB);
-    SM(xs + ((c * (T + PT_TPAD) + T) * PT_PXB + r)) = 0.f;
-  }
+  if (!REG)
+    for (int i = tid; i < C * PT_TPAD * PT_PXB; i += 256) {  // the pad rows of the x tile (never written again)
+      const int c = i / (PT_TPAD * PT_PXB), r = i - c * (PT_TPAD * PT_PXB);
+      SM(xs + ((c * (T + PT_TPAD) + T) * PT_PXB + r)) = 0.f;
+    }
+  if (REG) __syncthreads();  // the staged tables become visible; the waves do not meet again before the final reduction
 
   const int my = lacc + wid * NV;  // this wave's accumulators (LDS offset)
   auto wsum = [&](int v, float val) {  // full-wave sum (both halves belong to the same value)
@@ -387,6 +439,22 @@ __global__ __launch_bounds__(256, (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_M
     const float vm = valid ? 1.f : 0.f;
     const int b = valid ? (int)(p / HW) : 0;
     const int l = valid ? (int)(p - (long)b * HW) : 0;
+    float xh[REG ? CC : 1][REG ? TT : 1];
+    if constexpr (REG) {
+      // (nothing writes LDS inside this loop any more, so the compiler hoisted every table read of the tile body --
+      // ~300 loop-invariant registers, 400-800 bytes of scratch -- out of it: the clobber keeps them where they are used)
+      asm volatile("" ::: "memory");
+      // the pixel's cube -> registers, shifted by the lane's parity: xh[c][j] = x[c][half + j] (j = T - 1 of the odd
+      // parity would be row T: it re-reads row T - 1, a value only dead entries touch); C T loads in flight per lane
+      const float* xq = a.x + (long)b * a.xbs + l;
+#pragma unroll
+      for (int c = 0; c < CC; ++c)
+#pragma unroll
+        for (int j = 0; j < TT; ++j) {
+          const float v = xq[(long)(c * TT + j + (j < TT - 1 ? half : 0)) * HW];
+          xh[c][j] = valid ? v : 0.f;
+        }
+    } else {
     __syncthreads();  // previous tile's LDS reads are done (first time: the staged weights become visible)
     {
       // x tile: the two halves of a wave load alternate rows of the wave's 32 pixels; twelve loads in flight per lane
@@ -408,6 +476,13 @@ __global__ __launch_bounds__(256, (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_M
       }
     }
     __syncthreads();
+    }
+    // the first-convolution stack of this build: register variant or LDS-window variant
+    auto rows = [&](auto kc, int wl, auto&& rb, auto&& en, auto&& re) {
+      constexpr int K = decltype(kc)::value;
+      if constexpr (REG) pt_rows_reg<K, CC, TT, CMAX>(wl, xh, half, rb, en, re);
+      else pt_rows<K, CMAX>(wl, xs, C, T, pcol, half, rb, en, re);
+    };
     if (st_i < 26) { PT_ST(st_i); ++st_i; }
 
     if (PASS == 0) {
@@ -416,8 +491,8 @@ __global__ __launch_bounds__(256, (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_M
       auto rb = [&](int) { s = 0.f; q = 0.f; };
       auto en = [&](int, int, bool live, float h, auto&) { if (live) { s += h; q += h * h; } };
       auto re = [&](int) { wsum(slot, s); wsum(slot + 1, q); slot += 2; };
-      pt_rows<3, CMAX>(wa_l, xs, C, T, pcol, half, rb, en, re);
-      pt_rows<5, CMAX>(wa_l + C * CMAX * PT_KP, xs, C, T, pcol, half, rb, en, re);
+      rows(std::integral_constant<int, 3>{}, wa_l, rb, en, re);
+      rows(std::integral_constant<int, 5>{}, wa_l + C * CMAX * PT_KP, rb, en, re);
       continue;
     }
     if (PASS == 5) {
@@ -425,7 +500,7 @@ __global__ __launch_bounds__(256, (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_M
       int ebase = 0, vbase = 0;
       auto branch = [&](auto kc, int wl, int brn) {
         constexpr int K = decltype(kc)::value;
-        float g[CMAX][K];
+        float g[NC][K];
         float rho = 0.f, off = 0.f, g3 = 0.f, c0 = 0.f, c1 = 0.f;
         const int Tp = T - K + 1;
         auto rb = [&](int cp) {
@@ -433,7 +508,7 @@ __global__ __launch_bounds__(256, (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_M
           rho = cc[0]; off = cc[1]; g3 = cc[2];
           c0 = SM(k3_l + ((brn * C + cp) * 2)); c1 = SM(k3_l + ((brn * C + cp) * 2 + 1));
 #pragma unroll
-          for (int c = 0; c < CMAX; ++c)
+          for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int dt = 0; dt < K; ++dt) g[c][dt] = 0.f;
         };
@@ -443,17 +518,17 @@ __global__ __launch_bounds__(256, (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_M
           const float dzv = (valid && live) ? a.dz[(long)e * a.P + p] : 0.f;
           const float dh = (valid && live) ? g3 * rho * (dzv - c0 - hh * c1) : 0.f;
 #pragma unroll
-          for (int c = 0; c < CMAX; ++c)
+          for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int dt = 0; dt < K; ++dt) g[c][dt] += dh * xw[c][dt];
         };
         auto re = [&](int cp) {
 #pragma unroll
-          for (int c = 0; c < CMAX; ++c)
+          for (int c = 0; c < NC; ++c)
 #pragma unroll
             for (int dt = 0; dt < K; ++dt) wsum(vbase + (cp * CMAX + c) * PT_KP + dt, g[c][dt]);
         };
-        pt_rows<K, CMAX>(wl, xs, C, T, pcol, half, rb, en, re);
+        rows(kc, wl, rb, en, re);
         ebase += C * Tp;
         vbase += C * CMAX * PT_KP;
       };
@@ -490,7 +565,7 @@ __global__ __launch_bounds__(256, (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_M
           ++gs;
         };
         auto re = [&](int) {};
-        pt_rows<K, CMAX>(wl, xs, C, T, pcol, half, rb, en, re);
+        rows(kc, wl, rb, en, re);
       };
       branch(std::integral_constant<int, 3>{}, wa_l, std::integral_constant<int, 0>{}, 0);
       branch(std::integral_constant<int, 5>{}, wa_l + C * CMAX * PT_KP, std::integral_constant<int, 1>{}, EP3);
@@ -725,7 +800,7 @@ __global__ __launch_bounds__(256, (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_M
           }
         };
         auto re = [&](int) { wsum(slot, s); wsum(slot + 1, q); slot += 2; };
-        pt_rows<K, CMAX>(wl, xs, C, T, pcol, half, rb, en, re);
+        rows(kc, wl, rb, en, re);
         ebase += C * Tp;
       };
       branch(std::integral_constant<int, 3>{}, wa_l, 0, 0);
@@ -890,10 +965,17 @@ static inline bool pt_supported(int C, int T, int Cout) {
   return C >= 1 && C <= PT_MAX_C && T >= 5 && Cout >= 8 && Cout <= 64 && (Cout & 7) == 0;
 }
 static inline int pt_ne(int C, int T) { return (pt_ceil32(C * (T - 2)) >> 5); }  // entry tiles of the longer branch
+// (C, T) with a register-variant instantiation (pt_rows_reg): the reference's default cube; everything else runs the
+// generic kernel. CN_PRETIME_REG=0 forces the generic kernel (A/B).
+static inline bool pt_reg(int C, int T, int Cout) {
+  static const int on = [] { const char* e = getenv("CN_PRETIME_REG"); return e ? atoi(e) : 1; }();
+  return on && C == 3 && T == 12 && Cout <= 32;
+}
 static inline size_t pt_shmem(int PASS, int C, int T, int Cout) {
-  size_t sh = (size_t)pt_lds(PASS, C, T, Cout, pt_cmax(C)).total * 4;
+  const bool reg = pt_reg(C, T, Cout);
+  size_t sh = (size_t)pt_lds(PASS, C, T, Cout, pt_cmax(C), reg).total * 4;
   if (PASS == 4) {  // the end-of-kernel slab of the dWb tiles overlays the x / a / dr regions
-    const PtLds L = pt_lds(PASS, C, T, Cout, pt_cmax(C));
+    const PtLds L = pt_lds(PASS, C, T, Cout, pt_cmax(C), reg);
     const size_t slab = (size_t)(L.xs + Cout * (C * (T - 2) + C * (T - 4))) * 4;
     sh = sh < slab ? slab : sh;
   }
@@ -905,7 +987,7 @@ static inline long pt_off_body() { return CN_T2_COUNTERS; }
 static inline long pt_body_floats(int C, int T, int Cout) {
   int w = 0;
   for (int ps = 0; ps < 6; ++ps) { const int r = pt_row_width(ps, C, T, Cout); w = r > w ? r : w; }
-  return (cn_t2_body_floats(PT_MAX_BLOCKS, w) + 63) / 64 * 64;
+  return (cn_t2_body_floats(PT_MAX_BLOCKS_REG, w) + 63) / 64 * 64;
 }
 extern "C" long cn_pretime_workspace_floats(int B, int C, int T, int HW, int Cout, int with_backward) {
   if (!pt_supported(C, T, Cout)) return -1;
@@ -951,7 +1033,9 @@ static int pt_fill(CnPtArgs& a, const float* x, long xbs, const void* const* par
 template <int PASS>
 static int pt_launch(CnPtArgs a, float* ws, hipStream_t stream) {
   const int ntb = (int)((a.P + PT_PXB - 1) / PT_PXB);
-  const int nblk = ntb < PT_MAX_BLOCKS ? ntb : PT_MAX_BLOCKS;  // persistent blocks: weights are staged once per block
+  const bool reg = pt_reg(a.C, a.T, a.Cout);
+  const int maxb = reg ? PT_MAX_BLOCKS_REG : PT_MAX_BLOCKS;
+  const int nblk = ntb < maxb ? ntb : maxb;  // persistent blocks: weights are staged once per block
   const size_t shmem = pt_shmem(PASS, a.C, a.T, a.Cout);
   if (shmem > 160 * 1024) return CN_ERR_LDS;
   const int W = pt_row_width(PASS, a.C, a.T, a.Cout);
@@ -974,7 +1058,12 @@ static int pt_launch(CnPtArgs a, float* ws, hipStream_t stream) {
       if (MT == 2) PT_GO(CM, 2, 1); else PT_GO(CM, 1, 1);                                                      \
     }                                                                                                          \
   } while (0)
-  if (pt_cmax(a.C) == 4) PT_GO_MT(4); else PT_GO_MT(8);
+  if (reg) {  // Cout <= 32, C T = 36: one cout tile, one entry tile per branch
+    if (shmem > 64 * 1024)
+      (void)hipFuncSetAttribute((const void*)cn_pretime_kernel<PASS, 4, 1, 1, 3, 12>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                (int)shmem);
+    CN_LAUNCH((cn_pretime_kernel<PASS, 4, 1, 1, 3, 12>), dim3(nblk), dim3(256), shmem, stream, a);
+  } else if (pt_cmax(a.C) == 4) PT_GO_MT(4); else PT_GO_MT(8);
 #undef PT_GO_MT
 #undef PT_GO
   return CN_OK;
