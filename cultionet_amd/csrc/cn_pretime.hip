@@ -28,9 +28,10 @@
 #include <type_traits>
 #include "cn_bf16.h"
 #include "cn_ticket.h"
+#include "cn_profile.h"
 
 #define PT_MAX_BLOCKS 512      // persistent blocks of the generic kernel (two per CU)
-#define PT_MAX_BLOCKS_REG 768  // ... of the register variant (three per CU where the pass fits 168 registers)
+#define PT_MAX_BLOCKS_REG 1008 // ... of the register variant (up to four per CU; the ticket's limit)
 #define PT_MAX_C 8
 #define PT_PXB 128  // pixels per block tile: 4 waves x 32
 #define PT_KP 5     // weight row pitch of the first convolutions in LDS (k <= 5)
@@ -122,8 +123,11 @@ __host__ __device__ static inline PtLds pt_lds(int PASS, int C, int T, int Cout,
   l.wB = o; if (PASS == 4) o += CP * EP;
   o = (o + 3) & ~3;
   l.xs = o; if (!reg) o += C * (T + 6) * PT_PXB;  // (T + PT_TPAD rows per channel; the register variant has no x tile)
-  l.as_ = o; if (PASS == 4) o += 4 * EP * PT_LP;       // per wave: a[entry][pixel], later da[entry][pixel]
-  l.drs = o; if (PASS == 4) o += 4 * 2 * CP * PT_LP;   // per wave: dr[branch][cout][pixel]
+  // per wave: a[entry][pixel] (later da[entry][pixel]) and dr[branch][cout][pixel]. Register variant: ONE slab per wave,
+  // a-rows packed to EP3 + E5 with dr right behind, so the 32-row tile accesses of the shorter branch run over into the
+  // wave's own (dead or finite) dr rows instead of needing padded rows: 81 KB, two blocks per CU
+  l.as_ = o; if (PASS == 4) o += reg ? 4 * (pt_ceil32(E3) + E5 + 2 * CP) * PT_LP : 4 * EP * PT_LP;
+  l.drs = o; if (PASS == 4 && !reg) o += 4 * 2 * CP * PT_LP;
   l.lacc = o; o += (4 * pt_nvals(PASS, C, Cout, CMAX) + 3) & ~3;
   l.total = o;
   return l;
@@ -234,6 +238,15 @@ extern "C" int cn_pretime_read_stamps(unsigned long long* out) {
 #else
 #define PT_ST(i) do { } while (0)
 #endif
+
+// Phase fence of the register variant: the scheduler otherwise pulls the LDS table reads of LATER phases of the tile
+// body (per-channel constants, transposed operands) above the current one to cover their latency -- tens of registers
+// each -- and the pass no longer fits the register budget of two or three blocks per CU. Costs one exposed LDS round
+// trip per phase, which the other resident waves cover.
+#ifndef PT_FENCES
+#define PT_FENCES 1
+#endif
+#define PT_PHASE() do { if (REG && PT_FENCES) asm volatile("" ::: "memory"); } while (0)
 
 extern __shared__ __attribute__((aligned(16))) float pt_smem[];  // the one dynamic LDS array of the pass kernels
 #define SM(i) pt_smem[(i)]
@@ -346,7 +359,7 @@ template <int PASS, int CMAX, int MT, int NE, int CC = 0, int TT = 0>
 #define PT_REG_MINB 2
 #endif
 #ifndef PT_REG_MINB4
-#define PT_REG_MINB4 1
+#define PT_REG_MINB4 2  // (PASS 4 at two blocks per CU: 256 registers with 60 bytes of scratch, 81 KB of LDS; 193 -> 145 us at batch 32)
 #endif
 // (PASS 3 at C <= 4, Cout <= 32 fits 251 VGPRs without its 48 AGPR copies: two blocks per CU instead of one)
 // (the output pass at three blocks per CU -- 168 VGPRs, 128 bytes of scratch -- measured 1-4 % faster: not worth the spills)
@@ -376,8 +389,9 @@ void cn_pretime_kernel(const CnPtArgs a) {
   const int ln_l = L.ln;
   const int k2_l = L.k2;
   const int xs = L.xs;
-  const int as_w = L.as_ + wid * EP * PT_LP;
-  const int drs_w = L.drs + wid * 2 * CP * PT_LP;
+  const int AR = REG ? EP3 + E5 : EP;  // a-rows of a wave's slab
+  const int as_w = REG ? L.as_ + wid * (AR + 2 * CP) * PT_LP : L.as_ + wid * EP * PT_LP;
+  const int drs_w = REG ? as_w + AR * PT_LP : L.drs + wid * 2 * CP * PT_LP;
   const int lacc = L.lacc;
   const int NV = pt_nvals(PASS, C, Cout, CMAX);
   const float vN = 1.0f / (float)Cout;
@@ -439,21 +453,36 @@ void cn_pretime_kernel(const CnPtArgs a) {
     const float vm = valid ? 1.f : 0.f;
     const int b = valid ? (int)(p / HW) : 0;
     const int l = valid ? (int)(p - (long)b * HW) : 0;
+    // The lane's coordinates are made OPAQUE once per tile: every table address of the body is lane part + constant, all
+    // of them loop-invariant, and the compiler hoisted ~100 of them out of the tile loop as separate registers (PASS 4:
+    // 464 bytes of scratch at two blocks per CU). Recomputed per tile they fold into the instructions' offset fields.
+    int hv_ = half, lv_ = l32;
+    asm volatile("" : "+v"(hv_), "+v"(lv_));
+    {
+    const int half = hv_, l32 = lv_;
     float xh[REG ? CC : 1][REG ? TT : 1];
-    if constexpr (REG) {
+    auto load_x = [&]() {
       // (nothing writes LDS inside this loop any more, so the compiler hoisted every table read of the tile body --
       // ~300 loop-invariant registers, 400-800 bytes of scratch -- out of it: the clobber keeps them where they are used)
       asm volatile("" ::: "memory");
       // the pixel's cube -> registers, shifted by the lane's parity: xh[c][j] = x[c][half + j] (j = T - 1 of the odd
       // parity would be row T: it re-reads row T - 1, a value only dead entries touch); C T loads in flight per lane
-      const float* xq = a.x + (long)b * a.xbs + l;
+      // (addresses: a UNIFORM row pointer per load -- scalar arithmetic -- plus one 32-bit per-lane byte offset, the
+      // global_load saddr form; with per-lane 64-bit pointers the compiler kept all 36 of them live: 72 registers)
+      const unsigned vo1 = (unsigned)(((long)b * a.xbs + l) * 4);
+      const unsigned vo = vo1 + (unsigned)half * (unsigned)HW * 4u;
+      const char* xb = reinterpret_cast<const char*>(a.x);
 #pragma unroll
       for (int c = 0; c < CC; ++c)
 #pragma unroll
         for (int j = 0; j < TT; ++j) {
-          const float v = xq[(long)(c * TT + j + (j < TT - 1 ? half : 0)) * HW];
+          const char* rowp = xb + (long)(c * TT + j) * HW * 4;
+          const float v = *reinterpret_cast<const float*>(rowp + (j < TT - 1 ? vo : vo1));
           xh[c][j] = valid ? v : 0.f;
         }
+    };
+    if constexpr (REG) {
+      load_x();
     } else {
     __syncthreads();  // previous tile's LDS reads are done (first time: the staged weights become visible)
     {
@@ -586,6 +615,7 @@ void cn_pretime_kernel(const CnPtArgs a) {
           }
       continue;
     }
+    PT_PHASE();
     // ---- BatchNorm2d + SiLU, branch sum, LayerNorm over Cout ----
     // acc <- rhat (normalised); vv = affine BatchNorm output; u = sum of the activations (0 for padded channels)
     f32x16 vv[2][MT], u[MT];
@@ -606,6 +636,7 @@ void cn_pretime_kernel(const CnPtArgs a) {
         uj = o < Cout ? uj : 0.f;
         u[mt][j] = uj;
         m += uj;
+        if ((j & 3) == 3) PT_PHASE();
       }
     m += __shfl_xor(m, 32, 64);
     m *= vN;
@@ -627,6 +658,7 @@ void cn_pretime_kernel(const CnPtArgs a) {
         const int o = mt * 32 + pt_row(j, half);
         u[mt][j] = o < Cout ? (u[mt][j] - m) * rL : 0.f;  // u <- uhat
       }
+    PT_PHASE();
     if (PASS == 2) {
       if (valid) {
         if (a.out_kind == 0) {
@@ -657,6 +689,7 @@ void cn_pretime_kernel(const CnPtArgs a) {
       }
       continue;
     }
+    PT_PHASE();
     // ---- backward: LayerNorm, SiLU, BatchNorm2d ----
     f32x16 dyv[MT];
     if (a.out_kind == 0) {
@@ -683,6 +716,7 @@ void cn_pretime_kernel(const CnPtArgs a) {
           dyv[mt][4 * q + 3] = cn_bf16_hi(pk[1]) * on;
         }
     }
+    PT_PHASE();
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt)
@@ -715,6 +749,7 @@ void cn_pretime_kernel(const CnPtArgs a) {
         }
       continue;
     }
+    PT_PHASE();
     // ---- PASS 4 ----
     // dr (kept in vv), and transposed into LDS [cout][pixel] for the dWb contraction
 #pragma unroll
@@ -733,6 +768,7 @@ void cn_pretime_kernel(const CnPtArgs a) {
           SM(drs_w + ((brn * CP + o) * PT_LP + l32)) = dr;
         }
       }
+    PT_PHASE();
     // dWb[cout][entry] += sum_px dr[cout][px] a[entry][px]: K = pixels, two per step; A = dr^T, B = a^T out of LDS
 #pragma unroll
     for (int brn = 0; brn < 2; ++brn) {
@@ -752,6 +788,7 @@ void cn_pretime_kernel(const CnPtArgs a) {
         }
       }
     }
+    PT_PHASE();
     // da[entry][px] = sum_cout wb[cout][entry] dr[cout][px]: K = couts, the accumulator registers of dr ARE the B
     // operands (k-step (mt, j): couts 32 mt + pt_row(j, 0) and + pt_row(j, 1)); result transposed through LDS into
     // the (pixel, entry parity) layout of the first convolutions (it replaces a[][] in as_w)
@@ -777,7 +814,10 @@ void cn_pretime_kernel(const CnPtArgs a) {
         }
       }
     }
+    PT_PHASE();
     // dz = da * silu'(z), BatchNorm3d sums, dz -> scratch
+    // (loading the cube AGAIN here instead of keeping its 36 registers live through the matrix-pipe phases made the
+    // allocation worse -- 192 bytes of scratch against 60 at two blocks per CU -- and was dropped)
     {
       float rho = 0.f, off = 0.f, g3 = 0.f, b3 = 0.f, s = 0.f, q = 0.f;
       int slot = 0, ebase = 0;
@@ -805,6 +845,7 @@ void cn_pretime_kernel(const CnPtArgs a) {
       };
       branch(std::integral_constant<int, 3>{}, wa_l, 0, 0);
       branch(std::integral_constant<int, 5>{}, wa_l + C * CMAX * PT_KP, 1, EP3);
+    }
     }
   }
 
@@ -971,8 +1012,7 @@ static inline bool pt_reg(int C, int T, int Cout) {
   static const int on = [] { const char* e = getenv("CN_PRETIME_REG"); return e ? atoi(e) : 1; }();
   return on && C == 3 && T == 12 && Cout <= 32;
 }
-static inline size_t pt_shmem(int PASS, int C, int T, int Cout) {
-  const bool reg = pt_reg(C, T, Cout);
+static inline size_t pt_shmem(int PASS, int C, int T, int Cout, bool reg = false) {
   size_t sh = (size_t)pt_lds(PASS, C, T, Cout, pt_cmax(C), reg).total * 4;
   if (PASS == 4) {  // the end-of-kernel slab of the dWb tiles overlays the x / a / dr regions
     const PtLds L = pt_lds(PASS, C, T, Cout, pt_cmax(C), reg);
@@ -1033,10 +1073,14 @@ static int pt_fill(CnPtArgs& a, const float* x, long xbs, const void* const* par
 template <int PASS>
 static int pt_launch(CnPtArgs a, float* ws, hipStream_t stream) {
   const int ntb = (int)((a.P + PT_PXB - 1) / PT_PXB);
-  const bool reg = pt_reg(a.C, a.T, a.Cout);
-  const int maxb = reg ? PT_MAX_BLOCKS_REG : PT_MAX_BLOCKS;
-  const int nblk = ntb < maxb ? ntb : maxb;  // persistent blocks: weights are staged once per block
-  const size_t shmem = pt_shmem(PASS, a.C, a.T, a.Cout);
+  // (the register variant addresses x with 32-bit per-lane byte offsets)
+  const bool reg = pt_reg(a.C, a.T, a.Cout) && (long)a.B * a.xbs * 4 < (1L << 32);
+  // (PASS 3 / 4 of the register variant hold two blocks per CU, the other passes four)
+  const int maxb = reg && PASS != 3 && PASS != 4 ? PT_MAX_BLOCKS_REG : PT_MAX_BLOCKS;
+  // persistent blocks: weights are staged once per block; the register variant takes equal shares (2500 tiles on 768
+  // blocks would be 4 rounds for 3.26 tiles of work: 834 blocks x 3)
+  const int nblk = ntb <= maxb ? ntb : reg ? (ntb + (ntb + maxb - 1) / maxb - 1) / ((ntb + maxb - 1) / maxb) : maxb;
+  const size_t shmem = pt_shmem(PASS, a.C, a.T, a.Cout, reg);
   if (shmem > 160 * 1024) return CN_ERR_LDS;
   const int W = pt_row_width(PASS, a.C, a.T, a.Cout);
   if (W > 0) a.tk = cn_t2_carve(reinterpret_cast<int*>(ws), ws + pt_off_body(), nblk, W);
@@ -1058,6 +1102,8 @@ static int pt_launch(CnPtArgs a, float* ws, hipStream_t stream) {
       if (MT == 2) PT_GO(CM, 2, 1); else PT_GO(CM, 1, 1);                                                      \
     }                                                                                                          \
   } while (0)
+  const bool prof = cn_prof_on();  // per-pass times for tools/pretime_bench.py (kind 6: not a contraction kernel)
+  if (prof) { cn_prof_name("cn_pretime_kernel<%d%s>", PASS, reg ? ", reg" : ""); cn_prof_before(stream); }
   if (reg) {  // Cout <= 32, C T = 36: one cout tile, one entry tile per branch
     if (shmem > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)cn_pretime_kernel<PASS, 4, 1, 1, 3, 12>, hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -1066,6 +1112,7 @@ static int pt_launch(CnPtArgs a, float* ws, hipStream_t stream) {
   } else if (pt_cmax(a.C) == 4) PT_GO_MT(4); else PT_GO_MT(8);
 #undef PT_GO_MT
 #undef PT_GO
+  if (prof) cn_prof_after(stream, 6, 0.0);
   return CN_OK;
 }
 

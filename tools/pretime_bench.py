@@ -70,3 +70,23 @@ for name, fn in (("train fwd", lambda: fwd(1)), ("eval fwd", lambda: fwd(0))) + 
         fn()
     torch.cuda.synchronize()
     print(f"{name}: {(time.perf_counter() - t0) / n * 1e6:.1f} us  (B={B} C={C} T={T} H={H} Cout={Cout} kind={kind})")
+
+# per-pass kernel times (HIP events inside the library, one window over 10 training forwards + 10 backwards)
+if not only_fwd:
+    prof = (ctypes.c_double * 24)()
+    _lib.call("cn_profile_set_filter", None)
+    _lib.call("cn_profile_begin")
+    for _ in range(10):
+        fwd(1)
+        bwd()
+    torch.cuda.synchronize()
+    _lib.call("cn_profile_end", prof)
+    rows = []
+    for r in range(16):
+        nb = ctypes.create_string_buffer(96)
+        o3 = (ctypes.c_double * 3)()
+        nk = _lib.query("cn_profile_top", r, nb, 96, o3)
+        if r >= nk:
+            break
+        rows.append((nb.value.decode(), o3[0] / max(o3[2], 1) * 1e3))
+    print("   passes: " + "  ".join(f"{n.replace('cn_pretime_kernel', 'k')} {t:.1f}" for n, t in sorted(rows)))

@@ -1,11 +1,11 @@
 """Register / LDS / occupancy table of every kernel of one csrc/*.hip file (hipcc -Rpass-analysis=kernel-resource-usage).
-Usage: python tools/resusage.py cn_pointwise [cn_norm ...]   (no GPU needed)"""
+Usage: [RESUSAGE_FLAGS="-DPT_REG_MINB=3"] python tools/resusage.py cn_pointwise [cn_norm ...]   (no GPU needed)"""
 import re, subprocess, sys, os, tempfile
 here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "cultionet_amd", "csrc")
 for stem in sys.argv[1:]:
     with tempfile.TemporaryDirectory() as d:
         r = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", "-Wno-unused-result",
-                            "-Rpass-analysis=kernel-resource-usage", "-c", os.path.join(here, stem + ".hip"), "-o", os.path.join(d, "x.o")],
+                            "-Rpass-analysis=kernel-resource-usage", *os.environ.get("RESUSAGE_FLAGS", "").split(), "-c", os.path.join(here, stem + ".hip"), "-o", os.path.join(d, "x.o")],
                            capture_output=True, text=True)
     pat = (r"Function Name: (\S+).*?VGPRs: (\d+).*?AGPRs: (\d+).*?ScratchSize \[bytes/lane\]: (\d+).*?"
            r"Occupancy \[waves/SIMD\]: (\d+).*?LDS Size \[bytes/block\]: (\d+)")
