@@ -86,6 +86,47 @@ __device__ __forceinline__ float pt_half_sum(float v) {
   v = cn_dpp_add<0x142, 0xa>(v);  // row_bcast:15 into rows 1 and 3
   return v;
 }
+// Sums EACH of the 16 values of v over the 32 lanes of a half-wave with a halving butterfly: at every step a lane keeps
+// one half of its values and hands the other half to the partner that keeps those (16 -> 8 -> 4 -> 2 -> 1 values, partner
+// distance 1, 2, 4, 8 inside the 16-lane row, then 16 across the rows). Returns, in lane l, the half-wave total of
+// value l % 16. ~55 vector instructions for the 16 sums; one DPP chain per value (5 dependent steps with their wait
+// states, a predicated LDS add each) was ~210.
+template <int CTRL, int BANKS>
+__device__ __forceinline__ float pt_dpp_into(float old, float src) {
+  return __int_as_float(__builtin_amdgcn_update_dpp(__float_as_int(old), __float_as_int(src), CTRL, 0xf, BANKS, false));
+}
+__device__ __forceinline__ float pt_hsum16(const f32x16& vin, int lane) {
+  const bool b0 = lane & 1, b1 = lane & 2, b2 = lane & 4, b3 = lane & 8;
+  float v[16], w[8], y[4], z[2];
+  // (the elements become opaque scalars first: `b ? vec[1] : vec[0]` is canonicalised into the DYNAMIC index vec[b],
+  // which the backend lowers to a chain of 16 compares and selects per access -- 2100 instructions a call)
+#pragma unroll
+  for (int j = 0; j < 16; ++j) {
+    v[j] = vin[j];
+    if (j & 1) asm volatile("" : "+v"(v[j]));  // (one opaque element per pair is enough to keep the select a select)
+  }
+#pragma unroll
+  for (int k = 0; k < 8; ++k) {  // partner lane ^ 1: quad_perm [1, 0, 3, 2]
+    const float keep = b0 ? v[2 * k + 1] : v[2 * k], give = b0 ? v[2 * k] : v[2 * k + 1];
+    w[k] = keep + pt_dpp_into<0xB1, 0xf>(0.f, give);
+  }
+#pragma unroll
+  for (int k = 0; k < 4; ++k) {  // lane ^ 2: quad_perm [2, 3, 0, 1]
+    const float keep = b1 ? w[2 * k + 1] : w[2 * k], give = b1 ? w[2 * k] : w[2 * k + 1];
+    y[k] = keep + pt_dpp_into<0x4E, 0xf>(0.f, give);
+  }
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {  // lane ^ 4: row_shl:4 into banks 0, 2 and row_shr:4 into banks 1, 3
+    const float keep = b2 ? y[2 * k + 1] : y[2 * k], give = b2 ? y[2 * k] : y[2 * k + 1];
+    z[k] = keep + pt_dpp_into<0x114, 0xa>(pt_dpp_into<0x104, 0x5>(0.f, give), give);
+  }
+  float r;
+  {  // lane ^ 8: row_shl:8 into banks 0, 1 and row_shr:8 into banks 2, 3
+    const float keep = b3 ? z[1] : z[0], give = b3 ? z[0] : z[1];
+    r = keep + pt_dpp_into<0x118, 0xc>(pt_dpp_into<0x108, 0x3>(0.f, give), give);
+  }
+  return r + __shfl_xor(r, 16, 64);  // the other row of the half-wave
+}
 // accumulator register j of lane (pixel, half) of a 32x32 tile holds output row 8 (j / 4) + 4 half + j % 4
 __device__ __forceinline__ int pt_row(int j, int half) { return 8 * (j >> 2) + 4 * half + (j & 3); }
 
@@ -128,7 +169,7 @@ __host__ __device__ static inline PtLds pt_lds(int PASS, int C, int T, int Cout,
   // wave's own (dead or finite) dr rows instead of needing padded rows: 81 KB, two blocks per CU
   l.as_ = o; if (PASS == 4) o += reg ? 4 * (pt_ceil32(E3) + E5 + 2 * CP) * PT_LP : 4 * EP * PT_LP;
   l.drs = o; if (PASS == 4 && !reg) o += 4 * 2 * CP * PT_LP;
-  l.lacc = o; o += (4 * pt_nvals(PASS, C, Cout, CMAX) + 3) & ~3;
+  l.lacc = o; o += (4 * pt_nvals(PASS, C, CP, CMAX) + 3) & ~3;  // (per-channel rows at pitch CP: see NVL in the kernel)
   l.total = o;
   return l;
 }
@@ -312,14 +353,15 @@ __device__ __forceinline__ void pt_rows(int wl, int xs, int C, int T, int pcol, 
 // barrier (the waves of a block never meet inside the tile loop), no window shifting (a third of the generic loop's
 // vector instructions were v_mov), no padded fourth channel at C = 3. Same callbacks as pt_rows; xw[c][dt] is a view of
 // xh, renamed away by the compiler.
-template <int K, int CC, int TT, int CMAX, class FB, class FE, class FR>
+template <int K, int CC, int TT, int CMAX, bool UCP, class FB, class FE, class FR>
 __device__ __forceinline__ void pt_rows_reg(int wl, const float (&xh)[CC][TT], int half, FB&& row_begin, FE&& entry,
                                             FR&& row_end) {
   constexpr int Tp = TT - K + 1;
   constexpr int NS = (Tp + 1) >> 1;
   // (the loop over output channels stays ROLLED: fully unrolled, the scheduler hoisted every LDS operand of the C x NS
-  // steps to the top of one giant block -- 256 VGPRs and 776 bytes of scratch in the output pass)
-#pragma unroll 1
+  // steps to the top of one giant block -- 256 VGPRs and 776 bytes of scratch in the output pass; UCP: PASS 5 unrolls it
+  // to keep its sums in registers across tiles)
+#pragma unroll(UCP ? CC : 1)
   for (int cp = 0; cp < CC; ++cp) {
     float w[CC][K];
 #pragma unroll
@@ -358,12 +400,15 @@ template <int PASS, int CMAX, int MT, int NE, int CC = 0, int TT = 0>
 #ifndef PT_REG_MINB
 #define PT_REG_MINB 2
 #endif
+#ifndef PT_REG_MINB5
+#define PT_REG_MINB5 3
+#endif
 #ifndef PT_REG_MINB4
 #define PT_REG_MINB4 2  // (PASS 4 at two blocks per CU: 256 registers with 60 bytes of scratch, 81 KB of LDS; 193 -> 145 us at batch 32)
 #endif
 // (PASS 3 at C <= 4, Cout <= 32 fits 251 VGPRs without its 48 AGPR copies: two blocks per CU instead of one)
 // (the output pass at three blocks per CU -- 168 VGPRs, 128 bytes of scratch -- measured 1-4 % faster: not worth the spills)
-__global__ __launch_bounds__(256, CC > 0 ? (PASS == 4 ? PT_REG_MINB4 : PT_REG_MINB) : (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_MINB)
+__global__ __launch_bounds__(256, CC > 0 ? (PASS == 4 ? PT_REG_MINB4 : PASS == 5 ? PT_REG_MINB5 : PT_REG_MINB) : (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_MINB)
 void cn_pretime_kernel(const CnPtArgs a) {
   constexpr bool REG = CC > 0;
   constexpr int NC = REG ? CC : CMAX;  // input channels the unrolled loops walk (the generic kernel pads to CMAX)
@@ -393,7 +438,10 @@ void cn_pretime_kernel(const CnPtArgs a) {
   const int as_w = REG ? L.as_ + wid * (AR + 2 * CP) * PT_LP : L.as_ + wid * EP * PT_LP;
   const int drs_w = REG ? as_w + AR * PT_LP : L.drs + wid * 2 * CP * PT_LP;
   const int lacc = L.lacc;
-  const int NV = pt_nvals(PASS, C, Cout, CMAX);
+  const int NV = pt_nvals(PASS, C, Cout, CMAX);  // values of the block's ticket row
+  // ... and of a wave's LDS accumulators: PASS 1 / 3 keep their per-channel rows at pitch CP there, so that the
+  // butterfly's one LDS add per lane needs no `channel < Cout` predicate (the padded slots are never copied out)
+  const int NVL = pt_nvals(PASS, C, CP, CMAX);
   const float vN = 1.0f / (float)Cout;
 
   PT_ST(0);
@@ -411,7 +459,7 @@ void cn_pretime_kernel(const CnPtArgs a) {
       for (int i = 0; i < 4; ++i) { const int k = i0 + i * 256; if (k < n4) dst[k] = v[i]; }
     }
   }
-  for (int i = tid; i < 4 * NV; i += 256) SM(lacc + (i)) = 0.f;
+  for (int i = tid; i < 4 * NVL; i += 256) SM(lacc + (i)) = 0.f;
   if (!REG)
     for (int i = tid; i < C * PT_TPAD * PT_PXB; i += 256) {  // the pad rows of the x tile (never written again)
       const int c = i / (PT_TPAD * PT_PXB), r = i - c * (PT_TPAD * PT_PXB);
@@ -419,16 +467,18 @@ void cn_pretime_kernel(const CnPtArgs a) {
     }
   if (REG) __syncthreads();  // the staged tables become visible; the waves do not meet again before the final reduction
 
-  const int my = lacc + wid * NV;  // this wave's accumulators (LDS offset)
+  const int my = lacc + wid * NVL;  // this wave's accumulators (LDS offset)
   auto wsum = [&](int v, float val) {  // full-wave sum (both halves belong to the same value)
     // (ds_add_f32, no return value: nothing waits for it -- a read-modify-write here exposed one LDS round trip per
     // VALUE, 100-200 of them per tile; the address belongs to this wave alone, so the order of the adds is the program's)
     const float t = cn_wave_sum_to_lane63(val);
     if (lane == 63) atomicAdd(&SM(my + (v)), t);
   };
-  auto hsum = [&](int v, float val, bool on) {  // per-half sum: lanes 31 / 63 own different values v
-    const float t = pt_half_sum(val);
-    if (l32 == 31 && on) atomicAdd(&SM(my + (v)), t);
+  // per-half sums of the 16 accumulator registers of a lane (channels 32 mt + pt_row(j, half)) into row `row` of the
+  // wave's accumulators: lane l < 16 of each half ends up with the total of register l
+  auto hsum16 = [&](int row, int mt, const f32x16& vals, int half_, int l32_) {
+    const float t = pt_hsum16(vals, l32_);
+    if (l32_ < 16) atomicAdd(&SM(my + (row * CP + mt * 32 + pt_row(l32_, half_))), t);
   };
 
   f32x16 accW[2][MT][NE];  // PASS 4: dWb accumulators (cout x entry tiles), summed over the wave's tiles
@@ -443,6 +493,21 @@ void cn_pretime_kernel(const CnPtArgs a) {
           for (int j = 0; j < 16; ++j) accW[brn][mt][et][j] = 0.f;
   }
 
+  // PASS 5, register variant: the first-convolution weight-gradient sums of ALL output channels stay in registers across
+  // the block's tiles (72 at C = 3) and are reduced over the wave once, after the loop: per tile that was 72 wave sums of
+  // 6 DPP steps + an LDS add each, as many vector instructions as the multiply-adds they finish
+  float gp3[REG && PASS == 5 ? CC : 1][NC][3], gp5[REG && PASS == 5 ? CC : 1][NC][5];
+  if (REG && PASS == 5) {
+#pragma unroll
+    for (int cp = 0; cp < CC; ++cp)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) gp3[cp][c][dt] = 0.f;
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) gp5[cp][c][dt] = 0.f;
+      }
+  }
   PT_ST(1);
   const int ntb = (int)((a.P + PT_PXB - 1) / PT_PXB);
   int st_i = 2;
@@ -509,7 +574,7 @@ void cn_pretime_kernel(const CnPtArgs a) {
     // the first-convolution stack of this build: register variant or LDS-window variant
     auto rows = [&](auto kc, int wl, auto&& rb, auto&& en, auto&& re) {
       constexpr int K = decltype(kc)::value;
-      if constexpr (REG) pt_rows_reg<K, CC, TT, CMAX>(wl, xh, half, rb, en, re);
+      if constexpr (REG) pt_rows_reg<K, CC, TT, CMAX, PASS == 5>(wl, xh, half, rb, en, re);
       else pt_rows<K, CMAX>(wl, xs, C, T, pcol, half, rb, en, re);
     };
     if (st_i < 26) { PT_ST(st_i); ++st_i; }
@@ -527,7 +592,7 @@ void cn_pretime_kernel(const CnPtArgs a) {
     if (PASS == 5) {
       // dh = g3 rho (dz - c0 - hh c1); dWa[cp][c][dt] += sum_px sum_tp dh * x[c][tp + dt] (the window IS x[c][tp + dt])
       int ebase = 0, vbase = 0;
-      auto branch = [&](auto kc, int wl, int brn) {
+      auto branch = [&](auto kc, int wl, int brn, auto& gp) {
         constexpr int K = decltype(kc)::value;
         float g[NC][K];
         float rho = 0.f, off = 0.f, g3 = 0.f, c0 = 0.f, c1 = 0.f;
@@ -549,20 +614,25 @@ void cn_pretime_kernel(const CnPtArgs a) {
 #pragma unroll
           for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int dt = 0; dt < K; ++dt) g[c][dt] += dh * xw[c][dt];
+            for (int dt = 0; dt < K; ++dt) {
+              if constexpr (REG) gp[cp][c][dt] += dh * xw[c][dt];  // (cp is a constant here: the stack is unrolled)
+              else g[c][dt] += dh * xw[c][dt];
+            }
         };
         auto re = [&](int cp) {
+          if constexpr (!REG) {
 #pragma unroll
-          for (int c = 0; c < NC; ++c)
+            for (int c = 0; c < NC; ++c)
 #pragma unroll
-            for (int dt = 0; dt < K; ++dt) wsum(vbase + (cp * CMAX + c) * PT_KP + dt, g[c][dt]);
+              for (int dt = 0; dt < K; ++dt) wsum(vbase + (cp * CMAX + c) * PT_KP + dt, g[c][dt]);
+          }
         };
         rows(kc, wl, rb, en, re);
         ebase += C * Tp;
         vbase += C * CMAX * PT_KP;
       };
-      branch(std::integral_constant<int, 3>{}, wa_l, 0);
-      branch(std::integral_constant<int, 5>{}, wa_l + C * CMAX * PT_KP, 1);
+      branch(std::integral_constant<int, 3>{}, wa_l, 0, gp3);
+      branch(std::integral_constant<int, 5>{}, wa_l + C * CMAX * PT_KP, 1, gp5);
       continue;
     }
 
@@ -606,13 +676,13 @@ void cn_pretime_kernel(const CnPtArgs a) {
       for (int brn = 0; brn < 2; ++brn)
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
+        {
+          f32x16 v1, v2;
 #pragma unroll
-          for (int j = 0; j < 16; ++j) {
-            const int o = mt * 32 + pt_row(j, half);
-            const float v = acc[brn][mt][j] * vm;
-            hsum((brn * 2) * Cout + o, v, o < Cout);
-            hsum((brn * 2 + 1) * Cout + o, v * v, o < Cout);
-          }
+          for (int j = 0; j < 16; ++j) { v1[j] = acc[brn][mt][j] * vm; v2[j] = v1[j] * v1[j]; }
+          hsum16(brn * 2, mt, v1, half, l32);
+          hsum16(brn * 2 + 1, mt, v2, half, l32);
+        }
       continue;
     }
     PT_PHASE();
@@ -732,21 +802,28 @@ void cn_pretime_kernel(const CnPtArgs a) {
     s1 *= vN; s2 *= vN;
     if (PASS == 3) {
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
+      for (int mt = 0; mt < MT; ++mt) {
+        f32x16 du, t1, t2;
 #pragma unroll
         for (int j = 0; j < 16; ++j) {
           const int o = mt * 32 + pt_row(j, half);
-          const bool on = o < Cout;
-          const float du = on ? rL * (dyv[mt][j] * SM(ln_l + (o)) - s1 - u[mt][j] * s2) : 0.f;
-#pragma unroll
-          for (int brn = 0; brn < 2; ++brn) {
-            const float dv = du * pt_silu_grad(vv[brn][mt][j]);
-            hsum((brn * 2) * Cout + o, dv, on);
-            hsum((brn * 2 + 1) * Cout + o, dv * acc[brn][mt][j], on);
-          }
-          hsum(4 * Cout + o, dyv[mt][j] * u[mt][j], on);
-          hsum(5 * Cout + o, dyv[mt][j], on);
+          du[j] = o < Cout ? rL * (dyv[mt][j] * SM(ln_l + (o)) - s1 - u[mt][j] * s2) : 0.f;
         }
+#pragma unroll
+        for (int brn = 0; brn < 2; ++brn) {
+#pragma unroll
+          for (int j = 0; j < 16; ++j) {
+            t1[j] = du[j] * pt_silu_grad(vv[brn][mt][j]);
+            t2[j] = t1[j] * acc[brn][mt][j];
+          }
+          hsum16(brn * 2, mt, t1, half, l32);
+          hsum16(brn * 2 + 1, mt, t2, half, l32);
+        }
+#pragma unroll
+        for (int j = 0; j < 16; ++j) t1[j] = dyv[mt][j] * u[mt][j];
+        hsum16(4, mt, t1, half, l32);
+        hsum16(5, mt, dyv[mt], half, l32);
+      }
       continue;
     }
     PT_PHASE();
@@ -849,6 +926,17 @@ void cn_pretime_kernel(const CnPtArgs a) {
     }
   }
 
+  if (REG && PASS == 5) {
+#pragma unroll
+    for (int cp = 0; cp < CC; ++cp)
+#pragma unroll
+      for (int c = 0; c < NC; ++c) {
+#pragma unroll
+        for (int dt = 0; dt < 3; ++dt) wsum((cp * CMAX + c) * PT_KP + dt, gp3[cp][c][dt]);
+#pragma unroll
+        for (int dt = 0; dt < 5; ++dt) wsum(C * CMAX * PT_KP + (cp * CMAX + c) * PT_KP + dt, gp5[cp][c][dt]);
+      }
+  }
   // ---- block row -> two-level last-block reduction -> finish ----
   PT_ST(30);
   if (PASS == 2) return;
@@ -856,8 +944,12 @@ void cn_pretime_kernel(const CnPtArgs a) {
   __syncthreads();
   {
     const int base = PASS == 4 ? Cout * E : 0;
-    for (int v = tid; v < NV; v += 256)
-      cn_t2_store(a.tk, blk, base + v, (SM(lacc + (v)) + SM(lacc + (NV + v))) + (SM(lacc + (2 * NV + v)) + SM(lacc + (3 * NV + v))));
+    for (int v = tid; v < NV; v += 256) {
+      int lv = v;
+      if (PASS == 1 || PASS == 3) { const int row = v / Cout; lv = row * CP + (v - row * Cout); }
+      cn_t2_store(a.tk, blk, base + v,
+                  (SM(lacc + (lv)) + SM(lacc + (NVL + lv))) + (SM(lacc + (2 * NVL + lv)) + SM(lacc + (3 * NVL + lv))));
+    }
   }
   if (PASS == 4) {
     // the four waves' dWb tiles -> LDS (wave-private slabs over the dead x / a / dr regions) -> summed in wave order
@@ -1075,8 +1167,8 @@ static int pt_launch(CnPtArgs a, float* ws, hipStream_t stream) {
   const int ntb = (int)((a.P + PT_PXB - 1) / PT_PXB);
   // (the register variant addresses x with 32-bit per-lane byte offsets)
   const bool reg = pt_reg(a.C, a.T, a.Cout) && (long)a.B * a.xbs * 4 < (1L << 32);
-  // (PASS 3 / 4 of the register variant hold two blocks per CU, the other passes four)
-  const int maxb = reg && PASS != 3 && PASS != 4 ? PT_MAX_BLOCKS_REG : PT_MAX_BLOCKS;
+  // (PASS 3 / 4 of the register variant hold two blocks per CU, PASS 5 three, the other passes four)
+  const int maxb = !reg || PASS == 3 || PASS == 4 ? PT_MAX_BLOCKS : PASS == 5 ? 256 * PT_REG_MINB5 : PT_MAX_BLOCKS_REG;
   // persistent blocks: weights are staged once per block; the register variant takes equal shares (2500 tiles on 768
   // blocks would be 4 rounds for 3.26 tiles of work: 834 blocks x 3)
   const int nblk = ntb <= maxb ? ntb : reg ? (ntb + (ntb + maxb - 1) / maxb - 1) / ((ntb + maxb - 1) / maxb) : maxb;
