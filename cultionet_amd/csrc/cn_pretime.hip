@@ -361,7 +361,7 @@ __device__ __forceinline__ void pt_rows_reg(int wl, const float (&xh)[CC][TT], i
   // (the loop over output channels stays ROLLED: fully unrolled, the scheduler hoisted every LDS operand of the C x NS
   // steps to the top of one giant block -- 256 VGPRs and 776 bytes of scratch in the output pass; UCP: PASS 5 unrolls it
   // to keep its sums in registers across tiles)
-#pragma unroll(UCP ? CC : 1)
+#pragma unroll UCP ? CC : 1
   for (int cp = 0; cp < CC; ++cp) {
     float w[CC][K];
 #pragma unroll
@@ -408,7 +408,9 @@ template <int PASS, int CMAX, int MT, int NE, int CC = 0, int TT = 0>
 #endif
 // (PASS 3 at C <= 4, Cout <= 32 fits 251 VGPRs without its 48 AGPR copies: two blocks per CU instead of one)
 // (the output pass at three blocks per CU -- 168 VGPRs, 128 bytes of scratch -- measured 1-4 % faster: not worth the spills)
-__global__ __launch_bounds__(256, CC > 0 ? (PASS == 4 ? PT_REG_MINB4 : PASS == 5 ? PT_REG_MINB5 : PT_REG_MINB) : (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_MINB)
+// (register variant, measured per pass at batch 32: PASS 3 at three blocks per CU spills 68 bytes and is slower, 67 -> 75 us;
+// the C = 4 inference cube at three spills 64 bytes and is faster, 239 -> 202 us)
+__global__ __launch_bounds__(256, CC > 0 ? (PASS == 4 ? PT_REG_MINB4 : PASS == 5 ? PT_REG_MINB5 : CC == 4 ? 3 : PT_REG_MINB) : (PASS == 3 && MT == 1 && CMAX == 4) ? 2 : PT_MINB)
 void cn_pretime_kernel(const CnPtArgs a) {
   constexpr bool REG = CC > 0;
   constexpr int NC = REG ? CC : CMAX;  // input channels the unrolled loops walk (the generic kernel pads to CMAX)
@@ -518,6 +520,7 @@ void cn_pretime_kernel(const CnPtArgs a) {
     const float vm = valid ? 1.f : 0.f;
     const int b = valid ? (int)(p / HW) : 0;
     const int l = valid ? (int)(p - (long)b * HW) : 0;
+    const unsigned pofs = (unsigned)(valid ? p : 0) * 4u;  // byte offset of the pixel inside a dz row (P < 2^30: host check)
     // The lane's coordinates are made OPAQUE once per tile: every table address of the body is lane part + constant, all
     // of them loop-invariant, and the compiler hoisted ~100 of them out of the tile loop as separate registers (PASS 4:
     // 464 bytes of scratch at two blocks per CU). Recomputed per tile they fold into the instructions' offset fields.
@@ -609,7 +612,9 @@ void cn_pretime_kernel(const CnPtArgs a) {
         auto en = [&](int cp, int tp, bool live, float h, auto& xw) {
           const float hh = h * rho + off;
           const int e = ebase + cp * Tp + (live ? tp : 0);
-          const float dzv = (valid && live) ? a.dz[(long)e * a.P + p] : 0.f;
+          // (uniform row pointer + 32-bit lane offset: the saddr form, as for x)
+          const float* dzp = reinterpret_cast<const float*>(reinterpret_cast<const char*>(a.dz) + (long)e * a.P * 4 + pofs);
+          const float dzv = (valid && live) ? *dzp : 0.f;
           const float dh = (valid && live) ? g3 * rho * (dzv - c0 - hh * c1) : 0.f;
 #pragma unroll
           for (int c = 0; c < NC; ++c)
@@ -913,7 +918,7 @@ void cn_pretime_kernel(const CnPtArgs a) {
             const float dzv = SM(as_w + ((slot0 + loc) * PT_LP + l32)) * pt_silu_grad(g3 * hh + b3);
             s += dzv;
             q += dzv * hh;
-            if (valid) a.dz[(long)(ebase + loc) * a.P + p] = dzv;
+            if (valid) *reinterpret_cast<float*>(reinterpret_cast<char*>(a.dz) + (long)(ebase + loc) * a.P * 4 + pofs) = dzv;
           }
         };
         auto re = [&](int) { wsum(slot, s); wsum(slot + 1, q); slot += 2; };
@@ -1100,9 +1105,11 @@ static inline bool pt_supported(int C, int T, int Cout) {
 static inline int pt_ne(int C, int T) { return (pt_ceil32(C * (T - 2)) >> 5); }  // entry tiles of the longer branch
 // (C, T) with a register-variant instantiation (pt_rows_reg): the reference's default cube; everything else runs the
 // generic kernel. CN_PRETIME_REG=0 forces the generic kernel (A/B).
-static inline bool pt_reg(int C, int T, int Cout) {
+// The inference cube of the scene predictor (C = 4, T = 25: 100 registers of x) has the output pass only.
+static inline bool pt_reg(int PASS, int C, int T, int Cout) {
   static const int on = [] { const char* e = getenv("CN_PRETIME_REG"); return e ? atoi(e) : 1; }();
-  return on && C == 3 && T == 12 && Cout <= 32;
+  if (!on || Cout > 32) return false;
+  return (C == 3 && T == 12) || (PASS == 2 && C == 4 && T == 25);
 }
 static inline size_t pt_shmem(int PASS, int C, int T, int Cout, bool reg = false) {
   size_t sh = (size_t)pt_lds(PASS, C, T, Cout, pt_cmax(C), reg).total * 4;
@@ -1139,7 +1146,7 @@ static int pt_fill(CnPtArgs& a, const float* x, long xbs, const void* const* par
                    int T, int HW, int Cout, int training, const float* bn, float eps_ln, float* ws, long ws_floats,
                    int with_backward) {
   if (!pt_supported(C, T, Cout) || B <= 0 || HW <= 0) return CN_ERR_ARG;
-  if ((long)B * HW >= (1L << 31) - 64) return CN_ERR_ARG;
+  if ((long)B * HW >= (1L << 30)) return CN_ERR_ARG;  // (32-bit byte offsets of a pixel inside a row of the dz scratch)
   if (ws == nullptr || ws_floats < cn_pretime_workspace_floats(B, C, T, HW, Cout, with_backward)) return CN_ERR_ARG;
   a.x = x; a.xbs = xbs; a.B = B; a.C = C; a.T = T; a.HW = HW; a.Cout = Cout; a.P = (long)B * HW;
   a.training = training; a.eps3 = bn[0]; a.mom3 = bn[1]; a.eps2 = bn[2]; a.mom2 = bn[3]; a.epsL = eps_ln;
@@ -1166,9 +1173,10 @@ template <int PASS>
 static int pt_launch(CnPtArgs a, float* ws, hipStream_t stream) {
   const int ntb = (int)((a.P + PT_PXB - 1) / PT_PXB);
   // (the register variant addresses x with 32-bit per-lane byte offsets)
-  const bool reg = pt_reg(a.C, a.T, a.Cout) && (long)a.B * a.xbs * 4 < (1L << 32);
-  // (PASS 3 / 4 of the register variant hold two blocks per CU, PASS 5 three, the other passes four)
-  const int maxb = !reg || PASS == 3 || PASS == 4 ? PT_MAX_BLOCKS : PASS == 5 ? 256 * PT_REG_MINB5 : PT_MAX_BLOCKS_REG;
+  const bool reg = pt_reg(PASS, a.C, a.T, a.Cout) && (long)a.B * a.xbs * 4 < (1L << 32);
+  // (PASS 3 / 4 of the register variant and the C = 4 output pass hold two blocks per CU, PASS 5 three, the others four)
+  const int maxb = !reg ? PT_MAX_BLOCKS : PASS == 4 ? 256 * PT_REG_MINB4 : PASS == 5 ? 256 * PT_REG_MINB5
+                   : PASS == 3 ? 256 * PT_REG_MINB : a.C == 4 ? 768 : PT_MAX_BLOCKS_REG;
   // persistent blocks: weights are staged once per block; the register variant takes equal shares (2500 tiles on 768
   // blocks would be 4 rounds for 3.26 tiles of work: 834 blocks x 3)
   const int nblk = ntb <= maxb ? ntb : reg ? (ntb + (ntb + maxb - 1) / maxb - 1) / ((ntb + maxb - 1) / maxb) : maxb;
@@ -1196,11 +1204,13 @@ static int pt_launch(CnPtArgs a, float* ws, hipStream_t stream) {
   } while (0)
   const bool prof = cn_prof_on();  // per-pass times for tools/pretime_bench.py (kind 6: not a contraction kernel)
   if (prof) { cn_prof_name("cn_pretime_kernel<%d%s>", PASS, reg ? ", reg" : ""); cn_prof_before(stream); }
-  if (reg) {  // Cout <= 32, C T = 36: one cout tile, one entry tile per branch
+  if (reg && a.C == 3) {  // Cout <= 32, C T = 36: one cout tile, one entry tile per branch
     if (shmem > 64 * 1024)
       (void)hipFuncSetAttribute((const void*)cn_pretime_kernel<PASS, 4, 1, 1, 3, 12>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 (int)shmem);
     CN_LAUNCH((cn_pretime_kernel<PASS, 4, 1, 1, 3, 12>), dim3(nblk), dim3(256), shmem, stream, a);
+  } else if (reg) {
+    if constexpr (PASS == 2) CN_LAUNCH((cn_pretime_kernel<2, 4, 1, 1, 4, 25>), dim3(nblk), dim3(256), shmem, stream, a);
   } else if (pt_cmax(a.C) == 4) PT_GO_MT(4); else PT_GO_MT(8);
 #undef PT_GO_MT
 #undef PT_GO
