@@ -322,6 +322,10 @@ __global__ __launch_bounds__(256) void cn_thin_fwd_ks_kernel(const float* __rest
         const int cw = wid * Cq + c0 + u;
         const float* wrow = wpk ? wpk + (long)(cw < Cin ? cw : 0) * RS : wl + cw * RS;
         const bool wok = !wpk || cw < Cin;  // packed rows exist for real channels only
+        // (round 5: scalar loads of the packed row instead -- s_load_dwordx16 into SGPRs, no v_readlane, v_pk_fma_f32 --
+        // cut the vector instructions per channel from ~165 to ~45 and made THIS kernel slower, 64 -> 89 us: the
+        // compiler waits for every 16-weight batch right where it is used (lgkmcnt(0)), five exposed scalar-cache
+        // misses per channel; the same change pays in cn_thin_bwd_data_ks_kernel, whose operands are all registers)
         const int wa = wok ? __float_as_int(wrow[lane]) : 0;
         const int wb = wok ? __float_as_int(wrow[64 + (lane < RS - 64 ? lane : 0)]) : 0;
 #pragma unroll
@@ -387,16 +391,27 @@ __global__ __launch_bounds__(256) void cn_thin_bwd_data_ks_kernel(const float* _
     // The RS weights of this channel are wave-uniform. Broadcasting them out of LDS (ds_read_b128, same address in
     // every lane) costs the full 64-lane LDS bandwidth and made the kernel LDS-bound; instead every lane reads ONE
     // weight (two conflict-free dword reads per channel) and v_readlane moves them to scalar registers.
-    const float* wrow = wpk ? wpk + (long)ci * RS : wl + (wid * Cq + cil) * RS;
+    f32x2 s2[2] = {{0.f, 0.f}, {0.f, 0.f}};  // packed fma (v_pk_fma_f32), two independent chains
+    if (wpk) {
+      // (round 5) packed weights: the row is wave-uniform -> scalar loads (s_load_dwordx16), and the packed FMA reads
+      // the SGPR pair directly: no v_readlane per weight (two of the three vector instructions per pair went into them)
+      const float* wr = wpk + (long)__builtin_amdgcn_readfirstlane(ci) * RS;
+#pragma unroll
+      for (int j = 0; j < RS / 2; ++j) {
+        const f32x2 w2 = {wr[2 * j], wr[2 * j + 1]};
+        s2[j & 1] = __builtin_elementwise_fma(dv[j], w2, s2[j & 1]);
+      }
+    } else {
+    const float* wrow = wl + (wid * Cq + cil) * RS;
     const int wa = __float_as_int(wrow[lane]);
     const int wb = __float_as_int(wrow[64 + (lane < RS - 64 ? lane : 0)]);
-    f32x2 s2[2] = {{0.f, 0.f}, {0.f, 0.f}};  // packed fma (v_pk_fma_f32), two independent chains
 #pragma unroll
     for (int j = 0; j < RS / 2; ++j) {
       const int i0 = 2 * j, i1 = 2 * j + 1;
       const f32x2 w2 = {__int_as_float(__builtin_amdgcn_readlane(i0 < 64 ? wa : wb, i0 & 63)),
                         __int_as_float(__builtin_amdgcn_readlane(i1 < 64 ? wa : wb, i1 & 63))};
       s2[j & 1] = __builtin_elementwise_fma(dv[j], w2, s2[j & 1]);
+    }
     }
     const float r = (s2[0][0] + s2[0][1]) + (s2[1][0] + s2[1][1]);
     if (live) {
