@@ -155,3 +155,20 @@ def test_pretime_unsupported_shapes_keep_the_generic_path():
     assert _lib.query("cn_pretime_workspace_floats", 1, 3, 4, 100, 32, 1) == -1    # T < 5
     assert _lib.query("cn_pretime_workspace_floats", 1, 9, 12, 100, 32, 1) == -1   # C > 8
     assert _lib.query("cn_pretime_workspace_floats", 1, 8, 60, 100, 64, 1) == -1   # LDS image beyond 160 KiB
+
+
+def test_generic_kernel_still_serves_the_default_cubes():
+    """The register variant takes (C, T) = (3, 12) and the (4, 25) inference pass by default; CN_PRETIME_REG=0 (read once
+    per process, hence the child) sends the same shapes through the generic kernel, which every other cube still uses."""
+    import os
+    import subprocess
+    import sys
+
+    if os.environ.get("CN_PRETIME_REG") == "0":
+        pytest.skip("already the generic-kernel child")
+    env = dict(os.environ, CN_PRETIME_REG="0")
+    r = subprocess.run([sys.executable, "-m", "pytest", __file__, "-q", "-x", "-k",
+                        "3-12-28-28-8 or 3-12-50-50-32 or 8-3-12-100-100-32 or 4-25-110-110-32"],
+                       env=env, capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "passed" in r.stdout
