@@ -661,6 +661,14 @@ __global__ __launch_bounds__(WG3_WAVES * 64) void cn_wgrad_vec3_kernel(const flo
     // (The barrier puts the three waves of a SIMD in the same phase. Skewing them -- the waves of kernel row ky start
     // ky * 512 / 1024 / 2048 / 4096 cycles late -- was measured: 239 -> 245 / 245 / 249 / 260 us at 128 -> 128, 8 x 100^2;
     // moving a wave's DMA issue into its group pipeline costs registers the three-waves budget does not have.)
+    // (Round 5, measured with tools/wgrad_bench.py at 8 x 100^2, same box: (a) the next chunk's nine DMA instructions
+    // spread through this chunk's MFMA loop, three per iteration, 168 registers without scratch once the source pointers
+    // were kept from being hoisted: 128 -> 128 240 -> 280 us, 160 -> 128 270-292 -> 346 us -- a DMA issue inside the
+    // loop stalls the wave's in-order MFMA stream; (b) progress-based issue priority, s_setprio 3..0 by quarter of the
+    // row so that the wave that is behind is served first: the three waves of a SIMD then finish their row together and
+    // the chunk takes exactly as long: 243.0 -> 242.2 us, 160 -> 128 268.5 -> 297.4 us. Neither kept. Under this kernel the
+    // shader clock reads ~1.97 GHz (s_memtime against the event time of the launch), not 2.4: its 0.62 of the nominal
+    // f32 peak is ~0.75 of what the matrix pipes can deliver at that clock.)
     if (g.nbuf == 2 && chunk + 1 < chunk_end) stage(chunk + 1, cur ^ 1);
     const float* s_lds = smem + cur * g.buf_stride;
     const float* b_lds = s_lds + g.b_lds_off;
