@@ -401,7 +401,8 @@ template <int PASS, int CMAX, int MT, int NE, int CC = 0, int TT = 0>
 #define PT_REG_MINB 2
 #endif
 #ifndef PT_REG_MINB5
-#define PT_REG_MINB5 3
+#define PT_REG_MINB5 2  // (three blocks per CU: 168 registers + 84 bytes of scratch -- 49 MB of scratch writes per launch in the
+                        // FETCH / WRITE counters -- and 72.2 us against 69.5 at two: 190 registers, no scratch)
 #endif
 #ifndef PT_REG_MINB4
 #define PT_REG_MINB4 2  // (PASS 4 at two blocks per CU: 256 registers with 60 bytes of scratch, 81 KB of LDS; 193 -> 145 us at batch 32)
