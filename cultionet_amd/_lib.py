@@ -16,7 +16,7 @@ LIB_PATH = os.environ.get("CN_LIB_PATH") or os.path.join(_HERE, "csrc", "libcult
 P = c_void_p  # device pointers are passed as integers (tensor.data_ptr())
 I, L, F, U64 = c_int, c_long, c_float, c_ulonglong
 
-# name -> argtypes (restype is always int); mirrors include/cultionet_hip.h one to one
+# name -> argtypes (restype int unless named in LONG_RESULT / DOUBLE_RESULT below); mirrors include/cultionet_hip.h one to one
 SIGNATURES = {
     "cn_version": [],
     "cn_conv_kpad": [I],
@@ -119,6 +119,7 @@ SIGNATURES = {
     "cn_profile_begin": [],
     "cn_profile_end": [P],
     "cn_profile_top": [I, P, I, P],
+    "cn_profile_top_bytes": [I],
     "cn_profile_set_filter": [P],
     "cn_launch_count": [I],
     "cn_slice_sums_begin": [P, I, P, L],
@@ -162,7 +163,7 @@ def load() -> ctypes.CDLL:
         except AttributeError as e:  # pragma: no cover
             raise HipLibraryMissing(f"symbol {name} missing from {LIB_PATH}; rebuild the extension") from e
         fn.argtypes = argtypes
-        fn.restype = c_long if name in LONG_RESULT else c_int
+        fn.restype = c_long if name in LONG_RESULT else (c_double if name in DOUBLE_RESULT else c_int)
     _lib = lib
     return lib
 
@@ -177,6 +178,8 @@ def call(name: str, *args) -> int:
 
 LONG_RESULT = {"cn_launch_count", "cn_bconv_packed_elems", "cn_bwgrad_workspace_floats", "cn_bn_workspace_floats_bf16",
                "cn_bn_group_workspace_floats_bf16", "cn_pretime_workspace_floats"}
+
+DOUBLE_RESULT = {"cn_profile_top_bytes"}
 
 
 def query(name: str, *args) -> int:

@@ -1000,6 +1000,12 @@ static int cnb_launch(CnBGeom& g, int G, hipStream_t stream, double flops, CnBFi
     cn_prof_name("cn_bconv_kernel<%d, %d, %d, 4>", WN, (KSC == 2 ? NPv : (KSC == 4 ? (NPv <= 6 ? 6 : 10) : 10)), KSC);
   cn_prof_desc("bconv B%d %dx%d %d->%d cls%d taps%d s%d/%d", g.B, g.Hin, g.Win, g.Cin, g.Cout, g.ncls, g.cls[0].ntaps,
                g.is, g.os);
+  {  // bf16 operands / results, every group its own tensors; the packed weights of all classes once
+    int taps_all = 0;
+    for (int c = 0; c < g.ncls; ++c) taps_all += g.cls[c].ntaps;
+    cn_prof_bytes(2.0 * G * ((double)g.B * g.Hin * g.Win * g.Cin + (double)g.B * g.Hout * g.Wout * g.Cout * (g.out_kind ? 2 : 1)) +
+                  2.0 * (double)taps_all * g.Cin * g.Cout);
+  }
   cn_prof_before(stream);
 #define CNB_GO3(WN_, NP_, KSC_)                                                                                  \
   do {                                                                                                           \

@@ -597,6 +597,7 @@ static int cnw_run(CnBWgGeom& g, float* dw, float* ws, long ws_floats, hipStream
                  g.TH * g.TW > 112 ? "true" : "false");
   }
   cn_prof_desc("bwgrad B%d %dx%d %dx%d T%d s%d split%d", g.B, g.Hg, g.Wg, g.CP, g.CQ, g.T, g.s, g.nsplit);
+  cn_prof_bytes(2.0 * g.B * ((double)g.Hg * g.Wg * g.CP + (double)g.Hq * g.Wq * g.CQ) + 4.0 * g.T * g.CP * g.CQ);
   cn_prof_before(stream);
 #define CNW_GO1(T_, NQ_, F_)                                                                                   \
   do {                                                                                                         \

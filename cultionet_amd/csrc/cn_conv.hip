@@ -622,6 +622,8 @@ static int cn_launch_igemm_v(const float* x, const float* wp, const float* bias,
   cn_prof_desc("igemm_vec<%d,%d,%d,%d,%d> G%d B%d %d->%d %dx%d->%dx%d taps%d cls%d is%d os%d grid%dx%dx%d", WAVES_N, TN,
                TM, NV, RP, g.G, g.B, g.Cin, g.Cout, g.Hin, g.Win, g.Hout, g.Wout, max_taps, g.ncls, g.is, g.os,
                total_tiles, (g.Cout + NT - 1) / NT, splits);
+  cn_prof_bytes(4.0 * g.G * ((double)g.B * g.Cin * g.Hin * g.Win + (double)g.B * g.Cout * g.Hout * g.Wout / (g.shared_y ? g.G : 1) +
+                             (double)(max_taps > 0 ? max_taps : 1) * g.Cin * g.Cout));
   cn_prof_before(stream);
   CN_LAUNCH((cn_conv_igemm_vec_kernel<WAVES_N, TN, TM, NV, RP>), grid, dim3(256), lds, stream, g);
   cn_prof_after(stream, NT == 128 ? 0 : 1, flops);  // the contraction kernel alone (matches rocprof's per-kernel rows)
@@ -654,6 +656,8 @@ static int cn_launch_igemm_t(const float* x, const float* wp, const float* bias,
   cn_prof_desc("igemm_dw<%d,%d,%d> G%d B%d %d->%d %dx%d->%dx%d taps%d cls%d is%d os%d grid%dx%dx%d", WAVES_N, TN, NI_T,
                g.G, g.B, g.Cin, g.Cout, g.Hin, g.Win, g.Hout, g.Wout, max_taps, g.ncls, g.is, g.os, total_tiles,
                (g.Cout + NT - 1) / NT, splits);
+  cn_prof_bytes(4.0 * g.G * ((double)g.B * g.Cin * g.Hin * g.Win + (double)g.B * g.Cout * g.Hout * g.Wout / (g.shared_y ? g.G : 1) +
+                             (double)(max_taps > 0 ? max_taps : 1) * g.Cin * g.Cout));
   cn_prof_before(stream);
   CN_LAUNCH((cn_conv_igemm_kernel<WAVES_N, TN, NI_T>), grid, dim3(256), lds, stream, g);
   cn_prof_after(stream, NT == 128 ? 0 : 1, flops);  // the contraction kernel alone (matches rocprof's per-kernel rows)

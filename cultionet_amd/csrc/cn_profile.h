@@ -10,3 +10,4 @@ void cn_prof_before(hipStream_t stream);
 void cn_prof_after(hipStream_t stream, int kind, double flops);
 void cn_prof_desc(const char* fmt, ...);
 void cn_prof_name(const char* fmt, ...);  // rocprof-style kernel name of the next recorded launch
+void cn_prof_bytes(double bytes);      // algorithmic HBM bytes of the next recorded launch

@@ -10,10 +10,11 @@
 #include "cn_common.h"
 
 namespace {
-struct Rec { hipEvent_t a, b; int kind; double flops; char desc[96]; char name[64]; };
-struct Agg { char name[64]; double ms, flops, launches; };
+struct Rec { hipEvent_t a, b; int kind; double flops, bytes; char desc[96]; char name[64]; };
+struct Agg { char name[64]; double ms, flops, launches, bytes; };
 char g_desc[96] = {0};
 char g_name[64] = {0};
+double g_bytes = 0.0;   // algorithmic bytes of the next recorded launch (cn_prof_bytes)
 char g_filter[64] = {0};  // non-empty: record only launches whose cn_prof_name equals it
 std::vector<Agg> g_aggs;  // per kernel name, filled by cn_profile_end, sorted by time
 bool g_on = false;
@@ -55,11 +56,17 @@ void cn_prof_name(const char* fmt, ...) {
   va_end(ap);
 }
 
+// Algorithmic HBM bytes of the next recorded launch: every operand read once, every result written once (true,
+// unpadded dims) -- what roofline.traffic (PMC counters) is held against.
+void cn_prof_bytes(double bytes) {
+  if (g_on) g_bytes = bytes;
+}
+
 void cn_prof_before(hipStream_t stream) {
   if (!g_on) return;
   // filtered window: bracket only launches of the named kernel (a few per step) so that the events themselves --
   // two markers on the launch stream per recorded kernel -- do not perturb the region being timed
-  if (g_filter[0] != 0 && strncmp(g_filter, g_name, sizeof(g_name)) != 0) { g_desc[0] = 0; g_name[0] = 0; return; }
+  if (g_filter[0] != 0 && strncmp(g_filter, g_name, sizeof(g_name)) != 0) { g_desc[0] = 0; g_name[0] = 0; g_bytes = 0.0; return; }
   g_pending = get_event();
   (void)hipEventRecord(g_pending, stream);
 }
@@ -68,7 +75,8 @@ void cn_prof_after(hipStream_t stream, int kind, double flops) {
   if (!g_on || g_pending == nullptr) return;
   hipEvent_t b = get_event();
   (void)hipEventRecord(b, stream);
-  Rec r = {g_pending, b, kind, flops, {0}, {0}};
+  Rec r = {g_pending, b, kind, flops, g_bytes, {0}, {0}};
+  g_bytes = 0.0;
   snprintf(r.desc, sizeof(r.desc), "%s", g_desc);
   snprintf(r.name, sizeof(r.name), "%s", g_name);
   g_desc[0] = 0;
@@ -108,11 +116,11 @@ extern "C" int cn_profile_end(double* out) {
       for (; i < g_aggs.size(); ++i)
         if (strncmp(g_aggs[i].name, r.name, sizeof(r.name)) == 0) break;
       if (i == g_aggs.size()) {
-        Agg a = {{0}, 0.0, 0.0, 0.0};
+        Agg a = {{0}, 0.0, 0.0, 0.0, 0.0};
         snprintf(a.name, sizeof(a.name), "%s", r.name);
         g_aggs.push_back(a);
       }
-      g_aggs[i].ms += ms; g_aggs[i].flops += r.flops; g_aggs[i].launches += 1.0;
+      g_aggs[i].ms += ms; g_aggs[i].flops += r.flops; g_aggs[i].launches += 1.0; g_aggs[i].bytes += r.bytes;
     }
     if (df) fprintf(df, "%d\t%s\t%.3f\t%.0f\n", r.kind, r.desc, ms * 1e3, r.flops);
     g_pool.push_back(r.a);
@@ -132,4 +140,10 @@ extern "C" int cn_profile_top(int rank, char* name_out, int cap, double* out) {
     out[0] = g_aggs[rank].ms; out[1] = g_aggs[rank].flops; out[2] = g_aggs[rank].launches;
   }
   return (int)g_aggs.size();
+}
+
+// After cn_profile_end: algorithmic HBM bytes (cn_prof_bytes at the launch sites: operands read once + results written
+// once, true dims) summed over the recorded launches of the rank-th kernel; 0 where a launch site states none.
+extern "C" double cn_profile_top_bytes(int rank) {
+  return (rank >= 0 && rank < (int)g_aggs.size()) ? g_aggs[rank].bytes : 0.0;
 }

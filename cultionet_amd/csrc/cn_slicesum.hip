@@ -1,6 +1,9 @@
 // One launch for all pending weight-gradient slice sums (see cn_slicesum.h).
 #include "cn_slicesum.h"
 
+#include <cstddef>
+#include <cstring>
+
 static thread_local CnSliceSum* cn_ss_sink = nullptr;
 static thread_local int cn_ss_cap = 0, cn_ss_count = 0;
 static thread_local const float* cn_ss_lo = nullptr;  // only sums into [lo, hi) are deferred (the flat gradient buffer)
@@ -16,11 +19,14 @@ bool cn_ss_push(const CnSliceSum* js, int n) {
       if (cn_ss_sink[i].dw == js[k].dw) return false;
   }
   for (int k = 0; k < n; ++k) {
-    // chunk0 belongs to cn_slice_sums_run: an identical record re-appended step after step leaves the table's bytes
-    // untouched, so a table upload still in flight never sees a torn record
-    const int keep = cn_ss_sink[cn_ss_count].chunk0;
-    cn_ss_sink[cn_ss_count] = js[k];
-    cn_ss_sink[cn_ss_count++].chunk0 = keep;
+    // chunk0 (the record's last word) belongs to cn_slice_sums_run. A table upload of the previous step may still be
+    // in flight when a plan is replayed back to back: an identical record writes NOTHING, a different one is stored by
+    // one assignment of a complete record -- an upload never sees a record with a zeroed chunk0.
+    CnSliceSum* slot = cn_ss_sink + cn_ss_count++;
+    if (memcmp(slot, &js[k], offsetof(CnSliceSum, chunk0)) == 0) continue;
+    CnSliceSum r = js[k];
+    r.chunk0 = slot->chunk0;
+    *slot = r;
   }
   return true;
 }

@@ -924,6 +924,7 @@ static int cn_wgrad_launch_vec(const float* S, const float* Bg, float* dW, CnWgr
   }
   static const bool twelve = getenv("CN_WGRAD3") == nullptr || atoi(getenv("CN_WGRAD3")) != 0;  // A/B switch
   if (T == 9 && twelve) cn_prof_name("cn_wgrad_vec3_kernel<%d>", g.s == 1 ? 1 : 2);
+  cn_prof_bytes(4.0 * g.G * ((double)g.N * g.A * g.Hs * g.Ws + (double)g.N * g.Bc * g.Hb * g.Wb + (double)dw_floats));
   cn_prof_before(stream);
   if (T == 9 && twelve) {  // 3 x 3: twelve waves per block, one kernel row of taps per wave (cn_wgrad_vec3_kernel)
     static bool attr3 = false;

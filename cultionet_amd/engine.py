@@ -302,7 +302,6 @@ def join_side_stream() -> None:
 # next to a matrix-pipe-bound one); its tape nodes run on the same stream in backward. CN_HEAD_STREAMS=0: off.
 _HEAD_STREAMS = os.environ.get("CN_HEAD_STREAMS", "1") != "0"
 _aux_streams: T.Dict[T.Any, T.List["torch.cuda.Stream"]] = {}
-_KEEP_FNS = ("empty", "empty_like", "zeros", "zeros_like", "full")
 
 
 def branch_streams_allowed() -> bool:
@@ -367,67 +366,81 @@ def _aux_stream(dev, k: int) -> "torch.cuda.Stream":
     return lst[k]
 
 
-_ka_lock = threading.Lock()
-_ka_users = 0
-_ka_saved: T.Dict[str, T.Any] = {}
+# ---- the engine's allocator -----------------------------------------------------------------------------------------
+# Every per-step buffer of the engine (activations, gradients, statistics rows, masks, scratch) comes from _alloc().
+# torch's caching allocator only knows the compute stream, while launches carry explicit stream handles: whoever needs
+# buffers to outlive a host-side free -- the branches of spawn() until they are joined, a launch plan while it is being
+# recorded -- registers a list as an allocation SINK of the calling thread (``holding_allocations``), and _alloc() files
+# every tensor it hands out there. Nothing in ``torch``'s namespace is touched (rounds 3-5 wrapped
+# torch.empty / zeros / full process-wide instead).
+def _alloc(shape, dtype: torch.dtype, device) -> torch.Tensor:
+    t = torch.empty(shape, dtype=dtype, device=device)
+    sinks = getattr(_state, "alloc_sinks", None)
+    if sinks:
+        for sink in sinks:
+            sink.append(t)
+    return t
 
 
-def _ka_install() -> None:
-    """Wrap torch's allocation functions ONCE per process while any thread defers frees (reference-counted under a
-    lock -- ADVICE r4: per-thread save / restore of the module attributes let one thread uninstall another's wrapper
-    or leave its own installed for good). The wrapper files each tensor under the CALLING thread's keep list."""
-    global _ka_users
-    with _ka_lock:
-        _ka_users += 1
-        if _ka_users > 1:
-            return
-        for name in _KEEP_FNS:
-            real = getattr(torch, name)
-            _ka_saved[name] = real
-
-            def f(*a, _real=real, **k):
-                t = _real(*a, **k)
-                ka = getattr(_state, "keepalive", None)
-                if ka is not None and ka.depth > 0:
-                    ka.keep.append(t)
-                return t
-
-            setattr(torch, name, f)
+def _alloc_like(t: torch.Tensor) -> torch.Tensor:
+    return _alloc(tuple(t.shape), t.dtype, t.device)
 
 
-def _ka_uninstall() -> None:
-    global _ka_users
-    with _ka_lock:
-        _ka_users -= 1
-        if _ka_users == 0:
-            for name, real in _ka_saved.items():
-                setattr(torch, name, real)
-            _ka_saved.clear()
+def alloc(shape, dtype: torch.dtype, device) -> torch.Tensor:
+    """Public form of the engine allocator for the host mirror (unet_parts / lightning): a buffer whose lifetime follows
+    the calling thread's open branches / plan recording."""
+    return _alloc(shape, dtype, device)
+
+
+class holding_allocations:
+    """Context manager: every buffer _alloc() hands out on this thread is also appended to ``sink`` (kept alive by it)."""
+
+    def __init__(self, sink: T.List[T.Any]):
+        self.sink = sink
+
+    def __enter__(self):
+        sinks = getattr(_state, "alloc_sinks", None)
+        if sinks is None:
+            sinks = _state.alloc_sinks = []
+        sinks.append(self.sink)
+        return self.sink
+
+    def __exit__(self, *exc):
+        sinks = _state.alloc_sinks
+        for i in range(len(sinks) - 1, -1, -1):
+            if sinks[i] is self.sink:
+                del sinks[i]
+                break
+        return False
 
 
 class _KeepAlive:
     """Frees are deferred while any branch is open. torch's caching allocator only knows the compute stream (launches
     go through the C ABI with explicit stream handles): a block freed on the host while an auxiliary stream's kernel
-    still uses it could be handed to a compute-stream allocation at once. Reference-counted per thread: tensors torch
-    hands out (allocation functions wrapped process-wide, see _ka_install), finished backward closures and incoming
+    still uses it could be handed to a compute-stream allocation at once. Reference-counted per thread: buffers the
+    engine allocates (``keep`` is an allocation sink of _alloc while depth > 0), finished backward closures and incoming
     gradients are held until the thread's last open branch has been joined."""
 
     def __init__(self):
         self.depth = 0
         self.keep: T.List[T.Any] = []
+        self._hold: T.Optional[holding_allocations] = None
 
     def acquire(self) -> None:
         self.depth += 1
         if self.depth == 1:
-            _ka_install()
+            self._hold = holding_allocations(self.keep)
+            self._hold.__enter__()
 
     def release(self, force: bool = False) -> None:
         if self.depth == 0:
             return
         self.depth = 0 if force else self.depth - 1
         if self.depth == 0:
+            if self._hold is not None:
+                self._hold.__exit__(None, None, None)
+                self._hold = None
             self.keep = []
-            _ka_uninstall()
 
 
 def _keepalive() -> _KeepAlive:
@@ -439,7 +452,7 @@ def _keepalive() -> _KeepAlive:
 
 def begin_branch_backward(tape) -> T.Optional[T.List[T.Any]]:
     """A tape with spawned branches: NOTHING is freed during its backward (returns the list that holds the finished
-    nodes' closures; allocations are held by the wrappers). Between a branch's start and its fork the compute stream
+    nodes' closures; the engine's allocations are filed there by _alloc). Between a branch's start and its fork the compute stream
     runs arbitrary nodes of its own; a block one of them frees on the host while its kernel is still queued must not be
     handed to an allocation whose kernel runs on an auxiliary stream."""
     if not getattr(tape, "has_branches", False):
@@ -899,7 +912,7 @@ def _pack(pw: "PackedWeight", attr: str, w: torch.Tensor, T_: int, K: int, N: in
     """Pack now (first use) into a persistent buffer and register it for the batched per-step repack."""
     kp = _lib.query("cn_conv_kpad", K)
     np_ = _lib.query("cn_conv_npad", N)
-    out = torch.empty(T_ * kp * np_, dtype=torch.float32, device=w.device)
+    out = _alloc(T_ * kp * np_, torch.float32, w.device)
     _lib.call("cn_pack_weights_f32", w.data_ptr(), out.data_ptr(), T_, K, N, sk, sn, st, _stream())
     current_store().register_pack(pw, attr, out, w, T_, K, N, sk, sn, st)
     return out
@@ -920,7 +933,7 @@ def _sync_packs(pw: "PackedWeight") -> None:
 
 def _pack16(pw: "PackedWeight", attr: str, w: torch.Tensor, T_: int, K: int, N: int, sk: int, sn: int,
             st: int) -> torch.Tensor:
-    out = torch.empty(_lib.query("cn_bconv_packed_elems", T_, K, N), dtype=torch.bfloat16, device=w.device)
+    out = _alloc(_lib.query("cn_bconv_packed_elems", T_, K, N), torch.bfloat16, w.device)
     _lib.call("cn_pack_weights_bf16", w.data_ptr(), out.data_ptr(), T_, K, N, sk, sn, st, _stream())
     current_store().register_pack16(pw, attr, out, w, T_, K, N, sk, sn, st)
     return out
@@ -979,8 +992,8 @@ def packed_convT(mod, need_bwd: bool, bf16: bool = False) -> PackedWeight:
 def _new(shape, like: torch.Tensor) -> torch.Tensor:
     if like.dtype == torch.bfloat16 and len(shape) == 4:
         B, C, H, W = shape
-        return torch.empty((B, H, W, C), dtype=torch.bfloat16, device=like.device).permute(0, 3, 1, 2)
-    return torch.empty(shape, dtype=torch.float32, device=like.device)
+        return _alloc((B, H, W, C), torch.bfloat16, like.device).permute(0, 3, 1, 2)
+    return _alloc(shape, torch.float32, like.device)
 
 
 def new_buffer(shape, like: torch.Tensor) -> torch.Tensor:
@@ -1131,6 +1144,7 @@ def flush_slice_sums() -> None:
     st = _ss_state()
     if st is None:
         return
+    st._commit()
     n = _lib.query("cn_slice_sums_count")
     first = st.flushed
     if n <= first:
@@ -1148,6 +1162,10 @@ def flush_slice_sums() -> None:
         _py_op(st.upload_ev.record, sobj)  # (a plan entry too: the next eager pass waits for a replay's upload)
     st.pending = 0
     st.flushed = n
+    # every slice handed out so far has been consumed by a launch that is now enqueued on the weight gradients' stream,
+    # and whatever takes scratch next runs behind it on the same stream: the arena starts over (it used to
+    # grow to the whole pass's slices, ~0.6 GB per fp32 step, and never shrank)
+    st.cur, st.off = 0, 0
 
 
 def _pad_ws(*tensors: torch.Tensor) -> T.Tuple[T.Optional[int], int]:
@@ -1403,7 +1421,7 @@ def time_conv(x: Var, mod, tin: int) -> Var:
                 return
             with side_stream(xt, dy):
                 s = _stream()
-                dwexp = torch.empty(Cout * tout * CT, dtype=torch.float32, device=xt.device)
+                dwexp = _alloc(Cout * tout * CT, torch.float32, xt.device)
                 _lib.call("cn_fill_f32", dwexp.data_ptr(), dwexp.numel(), 0.0, s)
                 _lib.call("cn_conv2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
                           dwexp.data_ptr(), B, CT, H, W, Cout * tout, 1, 1, 1, 0, 1, None, 0, s)
@@ -1491,10 +1509,10 @@ def pretime_reduction(x: Var, pre, in_channels: int, in_time: int) -> T.Optional
     dev = xt.device
     bf16 = bf16_enabled()
     if bf16:
-        y = torch.empty((B, H, W, Cout), dtype=torch.bfloat16, device=dev).permute(0, 3, 1, 2)
+        y = _alloc((B, H, W, Cout), torch.bfloat16, dev).permute(0, 3, 1, 2)
         ystride, kind = Cout, 1
     else:
-        y = torch.empty((B, Cout, H, W), dtype=torch.float32, device=dev)
+        y = _alloc((B, Cout, H, W), torch.float32, dev)
         ystride, kind = Cout * HW, 0
     plist = []
     for b, b3, b2 in zip(br, bn3, bn2):
@@ -1502,7 +1520,7 @@ def pretime_reduction(x: Var, pre, in_channels: int, in_time: int) -> T.Optional
                   b2.bias, b2.running_mean, b2.running_var]
     plist += [ln.weight, ln.bias]
     params = (ctypes.c_void_p * 22)(*[t.data_ptr() for t in plist])
-    stats_t = torch.empty(2 * (2 * C + 2 * Cout), dtype=torch.float32, device=dev)
+    stats_t = _alloc(2 * (2 * C + 2 * Cout), torch.float32, dev)
     offs, o = [], 0
     for _ in range(2):
         for n in (C, C, Cout, Cout):
@@ -1588,7 +1606,7 @@ def bn_act(x: Var, bn, act: int, residual: T.Optional[Var] = None, channels: T.O
     y = out if out is not None else _new(xt.shape, xt)
     mean = _new((C,), xt)
     rstd = _new((C,), xt)
-    ws = torch.empty(_lib.query("cn_bn_workspace_doubles", C), dtype=torch.float64, device=dev)
+    ws = _alloc(_lib.query("cn_bn_workspace_doubles", C), torch.float64, dev)
     rt = residual.t if residual is not None else None
     mom = _bn_momentum(bn)
     use_batch = training or (bn.running_mean is None)
@@ -1660,7 +1678,7 @@ def bn_act_group(xs: T.Sequence[Var], bns: T.Sequence, act: int, residual: T.Opt
         ys = [_new(xts[0].shape, xts[0])] if sum_outputs else [_new(xts[0].shape, xts[0]) for _ in range(G)]
     means = [_new((C,), xts[0]) for _ in range(G)]
     rstds = [_new((C,), xts[0]) for _ in range(G)]
-    ws = torch.empty(G * _lib.query("cn_bn_workspace_doubles", C), dtype=torch.float64, device=dev)
+    ws = _alloc(G * _lib.query("cn_bn_workspace_doubles", C), torch.float64, dev)
     rt = residual.t if residual is not None else None
     mom = _bn_momentum(bns[0])
     has_running = all(bn.running_mean is not None for bn in bns)
@@ -1743,7 +1761,7 @@ def layer_norm_c(x: Var, ln, residual: T.Optional[Var] = None, out: T.Optional[t
                 give_grad(residual, dy)
             dx, acc = grad_buffer(x)
             nws = _lib.query("cn_layernorm_c_workspace_floats", B, C, L)
-            ws = torch.empty(max(nws, 1), dtype=torch.float32, device=xt.device)
+            ws = _alloc(max(nws, 1), torch.float32, xt.device)
             _lib.call("cn_layernorm_c_bwd_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
                       ln.weight.data_ptr(), mu.data_ptr(), rstd.data_ptr(), dx.data_ptr(), bstride(dx),
                       store.grad_of(ln.weight).data_ptr(), store.grad_of(ln.bias).data_ptr(), B, C, L, acc,
@@ -1776,7 +1794,7 @@ def na2d(qkv: Var, heads: int, kernel_size: int, dilation: int, attn_drop: float
             do = ov.grad
             if do is None:
                 return
-            dattn = torch.empty_like(attn)
+            dattn = _alloc_like(attn)
             if qkv.grad is None:
                 dq = _new(qt.shape, qt)
                 _lib.call("cn_na2d_bwd_f32", qt.data_ptr(), bstride(qt), do.data_ptr(), bstride(do), attn.data_ptr(),
@@ -1810,11 +1828,11 @@ def spatial_channel_attention(skip: Var, out: Var, mod) -> Var:
     fc1, fc2 = mod.channel_attention.fc1, mod.channel_attention.fc2
     w1a, w2a, w1m, w2m = fc1[0].weight, fc1[2].weight, fc2[0].weight, fc2[2].weight
     gamma = mod.gamma
-    f = lambda *shape: torch.empty(shape, dtype=torch.float32, device=dev)
+    f = lambda *shape: _alloc(shape, torch.float32, dev)
     avg, mx, ca = f(B, C), f(B, C), f(B, C)
     hpre_a, hpre_m = f(B, Ch), f(B, Ch)
-    idx = torch.empty((B, C), dtype=torch.int32, device=dev)
-    cidx = torch.empty((B, L), dtype=torch.int32, device=dev)
+    idx = _alloc((B, C), torch.int32, dev)
+    cidx = _alloc((B, L), torch.int32, dev)
     pooled = f(B, 2, H, W)
     s = _stream()
     _lib.call("cn_sca_pool_fwd_f32", st.data_ptr(), bstride(st), B, C, L, avg.data_ptr(), mx.data_ptr(), idx.data_ptr(),
@@ -1840,7 +1858,7 @@ def spatial_channel_attention(skip: Var, out: Var, mod) -> Var:
             if skip.req:
                 dpool = pv.grad
                 if dpool is None:
-                    dpool = torch.empty_like(pooled)
+                    dpool = _alloc_like(pooled)
                     _lib.call("cn_fill_f32", dpool.data_ptr(), dpool.numel(), 0.0, s2)
                 dx, acc = grad_buffer(skip)
                 _lib.call("cn_sca_pool_bwd_f32", davg.data_ptr(), dmx.data_ptr(), idx.data_ptr(), dpool.data_ptr(),
@@ -2162,9 +2180,9 @@ def tanimoto_loss(pred: Var, *, target_f: T.Optional[torch.Tensor] = None, label
         _check(target_f)
         if not target_f.is_contiguous():
             raise RuntimeError("float target must be contiguous")
-    sums = torch.empty(5 * B, dtype=torch.float64, device=dev)
-    coef = torch.empty(4 * B, dtype=torch.float32, device=dev)
-    loss = torch.empty(1, dtype=torch.float32, device=dev)
+    sums = _alloc(5 * B, torch.float64, dev)
+    coef = _alloc(4 * B, torch.float32, dev)
+    loss = _alloc(1, torch.float32, dev)
     tf = target_f.data_ptr() if target_f is not None else None
     lb = labels.data_ptr() if labels is not None else None
     mk = mask.data_ptr() if mask is not None else None
@@ -2285,7 +2303,7 @@ def adaptive_max_pool2d(x: Var, size: T.Tuple[int, int]) -> Var:
     B, C, Hi, Wi = xt.shape
     Ho, Wo = int(size[0]), int(size[1])
     y = _new((B, C, Ho, Wo), xt)
-    idx = torch.empty((B, C, Ho, Wo), dtype=torch.int32, device=xt.device)
+    idx = _alloc((B, C, Ho, Wo), torch.int32, xt.device)
     _lib.call("cn_adaptive_maxpool_fwd_f32", xt.data_ptr(), bstride(xt), y.data_ptr(), bstride(y), idx.data_ptr(), B, C,
               Hi, Wi, Ho, Wo, _stream())
     yv = Var(y, tape.enabled and x.req)
@@ -2345,7 +2363,7 @@ def to_bf16(x: Var) -> Var:
     if is16(xt):
         return x
     B, C, H, W = xt.shape
-    y = torch.empty((B, H, W, C), dtype=torch.bfloat16, device=xt.device).permute(0, 3, 1, 2)
+    y = _alloc((B, H, W, C), torch.bfloat16, xt.device).permute(0, 3, 1, 2)
     if C % 8:
         raise RuntimeError("the bf16 region needs channel counts that are multiples of 8")
     _lib.call("cn_convert_f32nchw_to_bf16nhwc", xt.data_ptr(), bstride(xt), y.data_ptr(), ld(y), B, C, C, H * W,
@@ -2380,8 +2398,8 @@ def _bnstats_launch(xts, pws, ys, B, Cin, H, W, Cout, KH, KW, stride, paddings, 
     G = len(xts)
     dev = xts[0].device
     tab = lambda ptrs: (ctypes.c_void_p * G)(*ptrs)
-    means = torch.empty((G, Cout), dtype=torch.float32, device=dev)
-    rstds = torch.empty((G, Cout), dtype=torch.float32, device=dev)
+    means = _alloc((G, Cout), torch.float32, dev)
+    rstds = _alloc((G, Cout), torch.float32, dev)
     has_running = bns[0].running_mean is not None
     need = int(_lib.query("cn_bn_group_workspace_floats_bf16", G, Cout))
     ws = _bn_group_ws16(G, Cout, dev)
@@ -2423,7 +2441,7 @@ def _conv2d_bf16(x: Var, mod, stride: int, padding: int, dilation: int, out: T.O
     stats = None
     if want_stats:  # one row of {sum, sumsq}[Cout] per pixel tile, written by the conv epilogue (no zero-fill)
         rows = _lib.query("cn_conv2d_stats_rows_bf16", B, H, W, Cout, KH, KW, stride, padding, dilation)
-        stats = torch.empty((rows, 2, Cout), dtype=torch.float32, device=xt.device)
+        stats = _alloc((rows, 2, Cout), torch.float32, xt.device)
     bnfin = None
     if stats is not None and w.dim() == 4 and _bnfin_ok([bn] if bn is not None else None, [mod]):
         bnfin = _bnstats_launch([xt], [pw], [y], B, Cin, H, W, Cout, KH, KW, stride, [padding], [dilation], [stats], [bn])
@@ -2498,7 +2516,7 @@ def _conv2d_group_bf16(xs: T.Sequence[Var], mods: T.Sequence, paddings: T.Sequen
     stats = None
     if tape.enabled:  # (training forward: the tape is on; rows of {sum, sumsq}[Cout] per pixel tile and conv)
         rows = _lib.query("cn_conv2d_stats_rows_bf16", B, H, W, Cout, KH, KW, stride, max(paddings), max(dilations))
-        stats = [torch.empty((rows, 2, Cout), dtype=torch.float32, device=xts[0].device) for _ in range(G)]
+        stats = [_alloc((rows, 2, Cout), torch.float32, xts[0].device) for _ in range(G)]
     bnfin = None
     if stats is not None and _bnfin_ok(bns, mods):
         bnfin = _bnstats_launch(xts, pws, ys, B, Cin, H, W, Cout, KH, KW, stride, list(paddings), list(dilations), stats,
@@ -2606,9 +2624,9 @@ def conv_bn_act_eval(x: Var, conv, bn, act: int, stride: int, padding: int, dila
     s = _stream()
     if fd.key != key:
         if fd.wp is None or fd.key is None or fd.key[0] != key[0]:
-            fd.wp = torch.empty(_lib.query("cn_bconv_packed_elems", taps, Cin, Cout), dtype=torch.bfloat16, device=xt.device)
-            fd.scale = torch.empty(Cout, dtype=torch.float32, device=xt.device)
-            fd.shift = torch.empty(Cout, dtype=torch.float32, device=xt.device)
+            fd.wp = _alloc(_lib.query("cn_bconv_packed_elems", taps, Cin, Cout), torch.bfloat16, xt.device)
+            fd.scale = _alloc(Cout, torch.float32, xt.device)
+            fd.shift = _alloc(Cout, torch.float32, xt.device)
         cb = conv.bias
         _lib.call("cn_bn_fold_f32", bn.weight.data_ptr(), bn.bias.data_ptr(), bn.running_mean.data_ptr(),
                   bn.running_var.data_ptr(), cb.data_ptr() if cb is not None else None, float(bn.eps), Cout,
@@ -2678,8 +2696,8 @@ def _bn_act_bf16(x: Var, bn, act: int, residual: T.Optional[Var], training: bool
     P = B * H * W
     dev = xt.device
     y = _check(out) if out is not None else _new(xt.shape, xt)
-    mean = torch.empty(C, dtype=torch.float32, device=dev)
-    rstd = torch.empty(C, dtype=torch.float32, device=dev)
+    mean = _alloc(C, torch.float32, dev)
+    rstd = _alloc(C, torch.float32, dev)
     rt = _check(residual.t) if residual is not None else None
     use_batch = training or (bn.running_mean is None)
     _note_bn_update(training)
@@ -2770,8 +2788,8 @@ def _bn_act_group_bf16(xs: T.Sequence[Var], bns: T.Sequence, act: int, residual:
         means = [x.bnfin[1] for x in xs]
         rstds = [x.bnfin[2] for x in xs]
     else:
-        means = torch.empty((G, C), dtype=torch.float32, device=dev)
-        rstds = torch.empty((G, C), dtype=torch.float32, device=dev)
+        means = _alloc((G, C), torch.float32, dev)
+        rstds = _alloc((G, C), torch.float32, dev)
     rt = _check(residual.t) if residual is not None else None
     has_running = bns[0].running_mean is not None
     sums = [x.stats for x in xs] if (use_batch and has_sums and not prefin) else None
@@ -2861,7 +2879,7 @@ def _na2d_bf16(qkv: Var, heads: int, kernel_size: int, dilation: int, attn_drop:
     B, C3, H, W = qt.shape
     C = C3 // 3
     out = _new((B, C, H, W), qt)
-    attn = torch.empty((B, heads, kernel_size * kernel_size, H, W), dtype=torch.float32, device=qt.device)
+    attn = _alloc((B, heads, kernel_size * kernel_size, H, W), torch.float32, qt.device)
     _lib.call("cn_na2d_fwd_bf16", qt.data_ptr(), ld(qt), out.data_ptr(), ld(out), attn.data_ptr(), B, C, heads, H, W,
               kernel_size, dilation, float(attn_drop), seed, stepw, _stream())
     ov = Var(out, tape.enabled)
@@ -2871,7 +2889,7 @@ def _na2d_bf16(qkv: Var, heads: int, kernel_size: int, dilation: int, attn_drop:
             do = ov.grad
             if do is None:
                 return
-            dattn = torch.empty_like(attn)
+            dattn = _alloc_like(attn)
             dq = _new(qt.shape, qt)
             _lib.call("cn_na2d_bwd_bf16", qt.data_ptr(), ld(qt), do.data_ptr(), ld(do), attn.data_ptr(),
                       dattn.data_ptr(), dq.data_ptr(), ld(dq), B, C, heads, H, W, kernel_size, dilation,
@@ -2942,7 +2960,7 @@ def _thin_conv3x3_bf16(x: Var, mods: T.Sequence, grouped: bool, dilation: int, o
     n = len(mods)
     CP = mods[0].weight.shape[0]
     CPt = n * CP
-    y = out if out is not None else torch.empty((B, CPt, H, W), dtype=torch.float32, device=xt.device)
+    y = out if out is not None else _alloc((B, CPt, H, W), torch.float32, xt.device)
     if y.dtype != torch.float32 or not y.is_contiguous():
         raise RuntimeError("thin_conv3x3 (bf16 input) writes a dense fp32 NCHW tensor")
     HW = H * W
@@ -2959,8 +2977,8 @@ def _thin_conv3x3_bf16(x: Var, mods: T.Sequence, grouped: bool, dilation: int, o
         # copy-back launches (27 per step for the three towers)
         tw.view = all(m.weight.is_contiguous() and m.weight.data_ptr() == w0.data_ptr() + 4 * per * i
                       for i, m in enumerate(mods))
-        tw.fwd16 = torch.empty(_lib.query("cn_bconv_packed_elems", 9, Cin, CPt), dtype=torch.bfloat16, device=xt.device)
-        tw.bwd16 = torch.empty(_lib.query("cn_bconv_packed_elems", 9, CPt, Cin), dtype=torch.bfloat16, device=xt.device)
+        tw.fwd16 = _alloc(_lib.query("cn_bconv_packed_elems", 9, Cin, CPt), torch.bfloat16, xt.device)
+        tw.bwd16 = _alloc(_lib.query("cn_bconv_packed_elems", 9, CPt, Cin), torch.bfloat16, xt.device)
         if tw.view:
             o = (w0.data_ptr() - store._base) // 4
             tw.wcat = store.flat[o:o + n * per].view(CPt, Cin, 3, 3)
@@ -2972,8 +2990,8 @@ def _thin_conv3x3_bf16(x: Var, mods: T.Sequence, grouped: bool, dilation: int, o
             store.register_pack16(tw, "bwd16", tw.bwd16, tw.wcat, 9, CPt, Cin, Cin * 9, 9, 1)
             tw.version = store.version
         else:
-            tw.wcat = torch.empty((CPt, Cin, 3, 3), dtype=torch.float32, device=xt.device)
-            tw.dwcat = torch.empty_like(tw.wcat)
+            tw.wcat = _alloc((CPt, Cin, 3, 3), torch.float32, xt.device)
+            tw.dwcat = _alloc_like(tw.wcat)
         mods[0].__dict__["_cn_thin16"] = tw
     if tw.version != store.version:
         if tw.view:  # registered with the batched per-step repack: one launch for every layer of the model
@@ -2997,7 +3015,7 @@ def _thin_conv3x3_bf16(x: Var, mods: T.Sequence, grouped: bool, dilation: int, o
                 return
             s = _stream()
             cp8 = (CPt + 7) // 8 * 8
-            d16 = torch.empty((B, H, W, cp8), dtype=torch.bfloat16, device=xt.device)
+            d16 = _alloc((B, H, W, cp8), torch.bfloat16, xt.device)
             _lib.call("cn_convert_f32nchw_to_bf16nhwc", dy.data_ptr(), bstride(dy), d16.data_ptr(), cp8, B, CPt, cp8, HW, s)
             with side_stream(xt, d16):
                 ss = _stream()

@@ -211,8 +211,8 @@ class LightningModuleMixin(_Base):
             y = y.contiguous()
             bdist = batch.bdist.float().contiguous()
             dev = dist.device
-            counts = torch.empty(11, dtype=torch.float64, device=dev)
-            out = torch.empty(7, dtype=torch.float32, device=dev)
+            counts = E.alloc(11, torch.float64, dev)
+            out = E.alloc(7, torch.float32, dev)
             lossd = loss.detach().float().reshape(1).contiguous()
             _lib.call("cn_eval_metrics_f32", dist.data_ptr(), edge.data_ptr(), crop.data_ptr(), bdist.data_ptr(),
                       y.data_ptr(), int(self.edge_class), 0.5, y.numel(), lossd.data_ptr(), counts.data_ptr(),

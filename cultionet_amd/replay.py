@@ -54,7 +54,8 @@ def _bn_signature(model) -> int:
 def _key(model, store, x: torch.Tensor, bf16: bool):
     store.refresh()
     return (tuple(x.shape), x.dtype, bool(bf16), store.uid, store.version, E._bn_stats_epoch, _bn_signature(model),
-            torch.cuda.current_stream(x.device).cuda_stream, E._EVAL_FUSION, E.workspace_epoch())
+            torch.cuda.current_stream(x.device).cuda_stream, E._EVAL_FUSION, E.workspace_epoch(),
+            E.branch_streams_allowed())
 
 
 def plan_input(model, shape: T.Sequence[int], bf16: bool, device) -> T.Optional[torch.Tensor]:
@@ -137,7 +138,7 @@ def forward(model, x: torch.Tensor, bf16: bool, run: T.Callable[[torch.Tensor], 
 #   * NO buffer is reused inside a recorded step. The caching allocator makes cross-stream reuse safe EAGERLY by looking
 #     at events when a block is freed; a replay has no such check, so a block that held a weight gradient's operand and
 #     was later handed to the compute stream would be a race. While recording, every tensor torch hands out is kept alive
-#     (torch.empty / empty_like / zeros_like are wrapped), so each kernel of the step has buffers of its own; the price
+#     (the plan's ``keep`` list is an allocation sink of the engine allocator: engine.holding_allocations), so each kernel of the step has buffers of its own; the price
 #     is memory (the sum of a step's allocations instead of its peak), which is what 288 GB are for;
 #   * the optimizer (clip + AdamW: two launches with per-step scalars) stays outside the plan.
 # Valid for one (batch shapes, precision, stream, store, loss kind, scratch-buffer epoch); a communicator (per-bucket
@@ -161,9 +162,9 @@ class StepPlan:
 
 def step_key(trainer, batch) -> tuple:
     x, y, bd = batch.x, batch.y, batch.bdist
-    return (tuple(x.shape), x.dtype, tuple(y.shape), y.dtype, tuple(bd.shape), bd.dtype, trainer.bf16, id(trainer.store),
+    return (tuple(x.shape), x.dtype, tuple(y.shape), y.dtype, tuple(bd.shape), bd.dtype, trainer.bf16, trainer.store.uid,
             str(trainer.lit.loss_name), torch.cuda.current_stream(x.device).cuda_stream, E._OVERLAP_WGRAD,
-            E.workspace_epoch())
+            E.workspace_epoch(), E.branch_streams_allowed())
 
 
 def record_step(trainer, batch, eager: T.Callable) -> StepPlan:
@@ -186,23 +187,6 @@ def record_step(trainer, batch, eager: T.Callable) -> StepPlan:
         ops.append((0, fn, args))
         return rc
 
-    wrapped = {}
-    import threading
-
-    tid = threading.get_ident()
-
-    def keepalive(fname):
-        real = getattr(torch, fname)
-
-        def f(*a, **k):
-            t = real(*a, **k)
-            if threading.get_ident() == tid:  # (a loader / pin-memory thread allocating meanwhile is not the step's)
-                plan.keep.append(t)
-            return t
-
-        wrapped[fname] = real
-        setattr(torch, fname, f)
-
     with torch.cuda.use_mem_pool(plan.pool):
         # the plan's inputs in the CANONICAL form the loss / forward kernels consume (x fp32, labels int64, distances
         # fp32, all dense): `dst.copy_(src)` of every replayed step then does any cast / re-striding on the device, and no
@@ -215,18 +199,15 @@ def record_step(trainer, batch, eager: T.Callable) -> StepPlan:
         for dst, src in zip(plan.inputs, (batch.x, batch.y, batch.bdist)):
             dst.copy_(src)
         pb = Data(x=plan.inputs[0], y=plan.inputs[1], bdist=plan.inputs[2])
-        for fname in ("empty", "empty_like", "zeros_like"):
-            keepalive(fname)
         trainer.store.bump()  # the batched weight re-pack must be PART of the plan even if nothing changed since the last pack
         _lib.call = recording
         E._recorder = ops
         try:
-            eager(pb)
+            with E.holding_allocations(plan.keep):  # every buffer the engine hands out lives as long as the plan
+                eager(pb)
         finally:
             E._recorder = None
             _lib.call = orig_call
-            for fname, real in wrapped.items():
-                setattr(torch, fname, real)
     plan.outputs = dict(trainer.last_outputs)
     plan.sums = getattr(trainer.store, "_slice_sums", None)
     if plan.sums is not None:
@@ -250,6 +231,10 @@ def replay_step(plan: StepPlan, batch) -> None:
         if not st.upload_ev.query():
             st.upload_ev.synchronize()
         st.writer = plan
+    if st is not None:
+        # the plan's recorded cn_slice_sums_run calls upload their ranges themselves: whatever an eager pass believed the
+        # device table to hold is void from here on
+        st.uploaded.clear()
     for kind, fn, args in plan.ops:
         if kind == 0:
             rc = fn(*args)

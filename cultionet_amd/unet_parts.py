@@ -122,7 +122,7 @@ class TowerUNetFinal(nn.Module):
         heads = [s.conv[0] for s in streams]
         h9 = E.thin_conv3x3(x, [h.seq[0] for h in heads], grouped=False)
         B, _, H, W = h9.shape
-        buf = torch.empty((B, 9, H, W), dtype=torch.float32, device=h9.t.device)
+        buf = E.alloc((B, 9, H, W), torch.float32, h9.t.device)
         acts = E.bn_act_group(E.split_channels(h9, [3, 3, 3]), [h.seq[1] for h in heads], heads[0].act,
                               training=self.training, outs=[buf[:, 3 * i:3 * i + 3] for i in range(3)])
         a9 = E.join_channels(acts, buf)

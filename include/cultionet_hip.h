@@ -498,6 +498,11 @@ int cn_profile_end(double* out);
  * "cn_conv_igemm_vec_kernel<4, 1, 5, 1, 1>") with out[3] = {milliseconds, algorithmic flops, launches};
  * returns the number of distinct kernels recorded. */
 int cn_profile_top(int rank, char* name_out, int cap, double* out);
+/* after cn_profile_end: ALGORITHMIC HBM bytes of the rank-th recorded kernel, summed over its recorded launches --
+ * every operand read once and every result written once at the true (unpadded) dims, stated at the launch sites of the
+ * contraction kernels (the figure bench.py's roofline.traffic, taken from PMC counters, is held against).
+ * 0.0 for kernels whose launch site states none. */
+double cn_profile_top_bytes(int rank);
 /* record only launches of the kernel with exactly this name in the windows that follow ("" / NULL: every
  * contraction launch): bench.py brackets just the dominant kernel inside the timed region, so that the event
  * markers of the other ~250 launches per step do not perturb the time being measured. */

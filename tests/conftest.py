@@ -8,6 +8,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 os.environ.setdefault("TORCHDYNAMO_DISABLE", "1")
 
+import cultionet_amd  # noqa: E402
+
+cultionet_amd.configure_runtime()  # hardware queues for the step's streams: before anything initialises the HIP runtime
+
 GOLDEN = os.path.join(ROOT, "tests", "golden")
 
 

@@ -14,7 +14,7 @@ def _declarations():
     src = open(HEADER).read()
     src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
     decls = {}
-    for m in re.finditer(r"\b(?:int|long)\s+(cn_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
+    for m in re.finditer(r"\b(?:int|long|double)\s+(cn_\w+)\s*\(([^;]*?)\)\s*;", src, flags=re.S):
         name, params = m.group(1), m.group(2).strip()
         kinds = []
         if params and params != "void":

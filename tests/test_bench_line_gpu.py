@@ -30,6 +30,14 @@ def test_default_bench_line_has_every_block():
     r = d["roofline"]
     assert r["bound"] == "mfma" and r["unit"] == "TFLOP/s" and 0 < r["frac"] < 1 and abs(r["achieved"] / r["peak"] - r["frac"]) < 1e-9
     assert r["kernel"].startswith("cn_") and r["launches_per_step"] >= 1 and 0 < r["end_to_end_frac"] < 1
+    # provenance: the PMC traffic comes from the newest committed passes that contain THIS dominant
+    # kernel, next to the algorithmic bytes of its launches and the rocprof-average launch time frac can be recomputed from
+    for rr in (r, d["bf16"]["roofline"]):
+        assert rr["traffic"] is not None and rr["traffic_error"] is None, rr["traffic_error"]
+        assert rr["algorithmic_bytes"] > 0 and 0.5 < rr["traffic_vs_algorithmic"] < 4.0, rr["traffic_vs_algorithmic"]
+        assert rr["rocprof_avg_launch_us"] > 0 and 0 < rr["rocprof_frac"] < 1
+        assert os.path.exists(os.path.join(ROOT, rr["traffic_source"].split(" ")[0]))
+        assert os.path.exists(os.path.join(ROOT, rr["rocprof_source"].split(" ")[0]))
     c = d["cpu_baseline"]
     assert c["kind"] == "port" and c["cores"] >= 1 and c["value"] > 0 and c["unit"] == "chips/s"
     assert d["value"] > 10 * c["value"]  # north_star: >= 10x the host-CPU reference on one MI355X
