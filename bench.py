@@ -199,7 +199,7 @@ def streaming_pass(trainer, batch, steps: int = 2):
             return a[11] * a[12] * a[13], 4, 3
         if name == "cn_bilinear_fwd_f32":
             return a[4] * a[5] * (a[6] * a[7] + a[8] * a[9]), 4, 1
-        if name == "cn_bilinear_bwd_f32":
+        if name == "cn_bilinear_bwd_f32":  # (a[10], a[11]: the stored grid of dx; its image a[6] x a[7] is what moves)
             return a[4] * a[5] * (a[6] * a[7] + a[8] * a[9]), 4, 1
         if name == "cn_bn_act_fwd_bf16":
             return a[13] * a[14], 2, (2 if a[19] is not None else 3) if a[15] else 2  # a[19]: conv epilogue statistics

@@ -34,9 +34,9 @@ SIGNATURES = {
     "cn_thin_conv3x3_fwd_f32": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, P, P],
     "cn_thin_conv3x3_bwd_data_f32": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, P, P],
     "cn_thin_conv3x3_bwd_weight_f32": [P, L, P, L, P, I, I, I, I, I, I, I, I, P],
-    "cn_conv_transpose2d_fwd_f32": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, P],
-    "cn_conv_transpose2d_bwd_data_f32": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, I, P],
-    "cn_conv_transpose2d_bwd_weight_f32": [P, L, P, L, P, I, I, I, I, I, I, I, I, I, P, L, P],
+    "cn_conv_transpose2d_fwd_f32": [P, L, P, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
+    "cn_conv_transpose2d_bwd_data_f32": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, I, I, P],
+    "cn_conv_transpose2d_bwd_weight_f32": [P, L, P, L, P, I, I, I, I, I, I, I, I, I, I, P, L, P],
     "cn_channel_sum_f32": [P, L, I, I, I, P, I, P],
     "cn_bn_workspace_doubles": [I],
     "cn_bn_act_fwd_f32": [P, L, P, P, P, P, P, L, P, L, P, P, P, I, I, I, I, F, F, I, P],
@@ -54,8 +54,8 @@ SIGNATURES = {
     "cn_sca_apply_bwd_f32": [P, L, P, L, P, P, P, P, L, I, P, P, P, P, I, I, I, P],
     "cn_na2d_fwd_f32": [P, L, P, L, P, I, I, I, I, I, I, I, F, U64, P, P],
     "cn_na2d_bwd_f32": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, F, U64, P, P],
-    "cn_bilinear_fwd_f32": [P, L, P, L, I, I, I, I, I, I, P],
-    "cn_bilinear_bwd_f32": [P, L, P, L, I, I, I, I, I, I, I, P],
+    "cn_bilinear_fwd_f32": [P, L, P, L, I, I, I, I, I, I, I, I, P],
+    "cn_bilinear_bwd_f32": [P, L, P, L, I, I, I, I, I, I, I, I, I, P],
     "cn_copy_f32": [P, L, P, L, I, L, I, P],
     "cn_add_f32": [P, L, P, L, P, L, I, L, P],
     "cn_fill_f32": [P, L, F, P],

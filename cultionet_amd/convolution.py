@@ -45,8 +45,9 @@ class ConvTranspose2d(nn.Module):
         self.up_conv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding)
 
     def forward(self, x: E.Var, size, out: T.Optional[torch.Tensor] = None) -> E.Var:
-        y = E.conv_transpose2d(x, self.up_conv, self.stride, self.padding)
-        if out is not None and tuple(y.shape[-2:]) == tuple(size):
+        y = E.conv_transpose2d(x, self.up_conv, self.stride, self.padding, size=tuple(size))
+        natural = y.valid if y.valid is not None else tuple(y.shape[-2:])
+        if out is not None and tuple(natural) == tuple(size):
             out = None  # no resize to write through: the caller copies
         return E.resize_bilinear(y, tuple(size), out=out)
 

@@ -1203,12 +1203,23 @@ int cn_conv_igemm_launch(CnConvGeom& g, hipStream_t stream) {
       }
       return cn_launch_dword_cfg<2, 2>(x, wp, bias, y, gg, c.splits, c.cps, stream);
     }
+    // The narrow-cout configurations own 256-pixel tiles. A strided gather of few output channels from a large plane
+    // (ConvTranspose2d backward-data at stride 4 with 16-32 channels: 11 output rows = 44 input rows of 100) overflows
+    // the dword kernel's halo plane: such a launch falls back to the 128-pixel tile of the 128-cout configuration --
+    // wasteful on the cout side, but a non-default width must run, not fail with CN_ERR_LDS (found in round 6).
+    int rc;
     if (nt == 64) {
       if (vec) return cn_launch_vec_cfg<1, 2, 2>(x, wp, bias, y, gg, c.splits, c.cps, stream);
-      return cn_launch_dword_cfg<1, 2>(x, wp, bias, y, gg, c.splits, c.cps, stream);
+      rc = cn_launch_dword_cfg<1, 2>(x, wp, bias, y, gg, c.splits, c.cps, stream);
+    } else {
+      if (vec) return cn_launch_vec_cfg<1, 1, 2>(x, wp, bias, y, gg, c.splits, c.cps, stream);
+      rc = cn_launch_dword_cfg<1, 1>(x, wp, bias, y, gg, c.splits, c.cps, stream);
     }
-    if (vec) return cn_launch_vec_cfg<1, 1, 2>(x, wp, bias, y, gg, c.splits, c.cps, stream);
-    return cn_launch_dword_cfg<1, 1>(x, wp, bias, y, gg, c.splits, c.cps, stream);
+    if (rc == CN_ERR_LDS) {
+      CnConvGeom g2 = gg;
+      rc = cn_launch_dword_cfg<2, 2>(x, wp, bias, y, g2, c.splits, c.cps, stream);
+    }
+    return rc;
   };
   CnChoice c = cn_choose(g, mts, ncfg, nt, allow_split);
   if (g_autotune) {
@@ -1417,13 +1428,20 @@ extern "C" int cn_conv2d_bwd_data_grouped_f32(int G, const float* const* dys, lo
                            stride, pads, dils, accumulate, (hipStream_t)stream);
 }
 
-// ConvTranspose2d forward: y [B,Cout,Hout,Wout], Hout = (Hin-1)*s - 2*pad + K; wp packed with K=Cin, N=Cout.
+// ConvTranspose2d forward: y [B,Cout,Hout,Wout], Hout = (Hin-1)*s - 2*pad + K + out_pad; wp packed with K=Cin, N=Cout.
+// out_pad = nn.ConvTranspose2d's output_padding (0 <= out_pad < stride): the extra rows / columns at the bottom / right
+// are ordinary transposed-convolution outputs (taps that fall outside x read zeros). The engine uses it to put the
+// (2n-1)^2 result of the reference's ConvTranspose2d(3, 2, 1) on the 2n x 2n grid of the resize that follows
+// (convolution.py:45-68): rows / columns [0, 2n-1) are exactly the reference's tensor, the planes are 16-byte aligned
+// (99 x 99 is not), and nothing downstream needs an aligned copy or the dword-staging kernels.
 extern "C" int cn_conv_transpose2d_fwd_f32(const float* x, long xbs, const float* wp, const float* bias,
                                            float* y, long ybs, int B, int Cin, int Hin, int Win, int Cout,
-                                           int KH, int KW, int stride, int pad, int accumulate, void* stream) {
+                                           int KH, int KW, int stride, int pad, int out_pad, int accumulate,
+                                           void* stream) {
   cn_bind_ws(stream);
-  const int Hout = (Hin - 1) * stride - 2 * pad + KH;
-  const int Wout = (Win - 1) * stride - 2 * pad + KW;
+  if (out_pad < 0 || (out_pad > 0 && out_pad >= stride)) return CN_ERR_ARG;
+  const int Hout = (Hin - 1) * stride - 2 * pad + KH + out_pad;
+  const int Wout = (Win - 1) * stride - 2 * pad + KW + out_pad;
   return cn_scatter_conv(x, xbs, wp, bias, y, ybs, B, Cin, Hin, Win, Cout, Hout, Wout, KH, KW, stride, pad, 1,
                          accumulate, (hipStream_t)stream);
 }
@@ -1431,10 +1449,12 @@ extern "C" int cn_conv_transpose2d_fwd_f32(const float* x, long xbs, const float
 // ConvTranspose2d backward-data: dx [B,Cin,Hin,Win] (+)= conv_stride_s(dy); wp_t packed with K=Cout, N=Cin.
 extern "C" int cn_conv_transpose2d_bwd_data_f32(const float* dy, long dybs, const float* wp_t, float* dx,
                                                 long dxbs, int B, int Cin, int Hin, int Win, int Cout, int KH,
-                                                int KW, int stride, int pad, int accumulate, void* stream) {
+                                                int KW, int stride, int pad, int out_pad, int accumulate,
+                                                void* stream) {
   cn_bind_ws(stream);
-  const int Hout = (Hin - 1) * stride - 2 * pad + KH;
-  const int Wout = (Win - 1) * stride - 2 * pad + KW;
+  if (out_pad < 0 || (out_pad > 0 && out_pad >= stride)) return CN_ERR_ARG;
+  const int Hout = (Hin - 1) * stride - 2 * pad + KH + out_pad;
+  const int Wout = (Win - 1) * stride - 2 * pad + KW + out_pad;
   return cn_gather_conv(dy, dybs, wp_t, nullptr, dx, dxbs, B, Cout, Hout, Wout, Cin, Hin, Win, KH, KW, stride, pad,
                         1, accumulate, (hipStream_t)stream);
 }

@@ -20,9 +20,11 @@ __device__ __forceinline__ void bl_src(int o, float scale, int in_size, int& i0,
   l1 = src - i0;
 }
 
+// The source may live on a larger stored grid Hp x Wp (row pitch Wp, plane Hp*Wp) of which [0,Hi) x [0,Wi) is the image:
+// the output_padding grid the engine's ConvTranspose2d writes (cn_conv_transpose2d_fwd_f32).
 __global__ __launch_bounds__(256) void cn_bilinear_fwd_kernel(const float* __restrict__ x, long xbs,
                                                              float* __restrict__ y, long ybs, int C, int Hi, int Wi,
-                                                             int Ho, int Wo, float sh, float sw) {
+                                                             int Ho, int Wo, float sh, float sw, int Hp, int Wp) {
   const int p = blockIdx.x * 256 + threadIdx.x;
   if (p >= Ho * Wo) return;
   const int c = blockIdx.y, b = blockIdx.z;
@@ -31,10 +33,10 @@ __global__ __launch_bounds__(256) void cn_bilinear_fwd_kernel(const float* __res
   float ly, lx;
   bl_src(oy, sh, Hi, y0, y1, ly);
   bl_src(ox, sw, Wi, x0, x1, lx);
-  const float* xp = x + b * xbs + (long)c * Hi * Wi;
+  const float* xp = x + b * xbs + (long)c * Hp * Wp;
   const float hy = 1.f - ly, hx = 1.f - lx;
-  const float v = hy * (hx * xp[y0 * Wi + x0] + lx * xp[y0 * Wi + x1]) +
-                  ly * (hx * xp[y1 * Wi + x0] + lx * xp[y1 * Wi + x1]);
+  const float v = hy * (hx * xp[y0 * Wp + x0] + lx * xp[y0 * Wp + x1]) +
+                  ly * (hx * xp[y1 * Wp + x0] + lx * xp[y1 * Wp + x1]);
   y[b * ybs + (long)c * Ho * Wo + p] = v;
 }
 
@@ -42,11 +44,15 @@ __global__ __launch_bounds__(256) void cn_bilinear_fwd_kernel(const float* __res
 __global__ __launch_bounds__(256) void cn_bilinear_bwd_kernel(const float* __restrict__ dy, long dybs,
                                                              float* __restrict__ dx, long dxbs, int C, int Hi,
                                                              int Wi, int Ho, int Wo, float sh, float sw,
-                                                             float inv_sh, float inv_sw, int accumulate) {
+                                                             float inv_sh, float inv_sw, int accumulate, int Hp, int Wp) {
   const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= Hi * Wi) return;
+  if (p >= Hp * Wp) return;
   const int c = blockIdx.y, b = blockIdx.z;
-  const int iy = p / Wi, ix = p - iy * Wi;
+  const int iy = p / Wp, ix = p - iy * Wp;
+  if (iy >= Hi || ix >= Wi) {  // padding of the stored grid: no output reads it
+    if (!accumulate) dx[b * dxbs + (long)c * Hp * Wp + p] = 0.f;
+    return;
+  }
   // candidate outputs: src in (iy-1, iy+1)  ->  o in ((iy-1)/s, (iy+1)/s), widened by one for rounding
   int oy_lo = (int)floorf((iy - 1) * inv_sh) - 1, oy_hi = (int)ceilf((iy + 1) * inv_sh) + 1;
   int ox_lo = (int)floorf((ix - 1) * inv_sw) - 1, ox_hi = (int)ceilf((ix + 1) * inv_sw) + 1;
@@ -83,7 +89,7 @@ __global__ __launch_bounds__(256) void cn_bilinear_bwd_kernel(const float* __res
       for (int j = 0; j < 8; ++j)
         if (wxv[j] != 0.f) acc += wy * wxv[j] * row[j];
     }
-    float* o = dx + b * dxbs + (long)c * Hi * Wi + p;
+    float* o = dx + b * dxbs + (long)c * Hp * Wp + p;
     *o = accumulate ? *o + acc : acc;
     return;
   }
@@ -103,7 +109,7 @@ __global__ __launch_bounds__(256) void cn_bilinear_bwd_kernel(const float* __res
       if (wx != 0.f) acc += wy * wx * dp[oy * Wo + ox];
     }
   }
-  float* o = dx + b * dxbs + (long)c * Hi * Wi + p;
+  float* o = dx + b * dxbs + (long)c * Hp * Wp + p;
   *o = accumulate ? *o + acc : acc;
 }
 
@@ -153,15 +159,17 @@ __device__ __forceinline__ int bl_candidates(int i, int in_size, int out_size, f
 __global__ __launch_bounds__(256) void cn_bilinear_bwd_near_kernel(const float* __restrict__ dy, long dybs,
                                                                   float* __restrict__ dx, long dxbs, int C, int Hi,
                                                                   int Wi, int Ho, int Wo, float sh, float sw,
-                                                                  float inv_sh, float inv_sw, int accumulate) {
+                                                                  float inv_sh, float inv_sw, int accumulate, int Hp,
+                                                                  int Wp) {
   const int p = blockIdx.x * 256 + threadIdx.x;
-  if (p >= Hi * Wi) return;
+  if (p >= Hp * Wp) return;
   const int c_begin = blockIdx.y * BL_CH, b = blockIdx.z;
-  const int iy = p / Wi, ix = p - iy * Wi;
+  const int iy = p / Wp, ix = p - iy * Wp;
+  const bool padding = iy >= Hi || ix >= Wi;  // outside the image on the stored grid: written as zeros below (ny = 0)
   int oyv[4] = {0, 0, 0, 0}, oxv[4] = {0, 0, 0, 0};
   float wyv[4] = {0.f, 0.f, 0.f, 0.f}, wxv[4] = {0.f, 0.f, 0.f, 0.f};
-  const int ny = bl_candidates(iy, Hi, Ho, sh, inv_sh, oyv, wyv);
-  const int nx = bl_candidates(ix, Wi, Wo, sw, inv_sw, oxv, wxv);
+  const int ny = padding ? 0 : bl_candidates(iy, Hi, Ho, sh, inv_sh, oyv, wyv);
+  const int nx = padding ? 0 : bl_candidates(ix, Wi, Wo, sw, inv_sw, oxv, wxv);
   int c_end = c_begin + BL_CH;
   if (c_end > C) c_end = C;
   if (ny <= 4 && nx <= 4) {
@@ -171,7 +179,7 @@ __global__ __launch_bounds__(256) void cn_bilinear_bwd_near_kernel(const float* 
     // (resizes that shrink by almost 2x) goes through the predicated tail.
     if (ny == 0 || nx == 0) {  // no output reads this pixel
       for (int c = c_begin; c < c_end; ++c) {
-        float* o = dx + b * dxbs + (long)c * Hi * Wi + p;
+        float* o = dx + b * dxbs + (long)c * Hp * Wp + p;
         if (!accumulate) *o = 0.f;
       }
       return;
@@ -206,7 +214,7 @@ __global__ __launch_bounds__(256) void cn_bilinear_bwd_near_kernel(const float* 
           for (int j = 0; j < 4; ++j)
             if ((k == 3 || j == 3) && w[k][j] != 0.f) acc += w[k][j] * dp[off[k][j]];
       }
-      float* o = dx + b * dxbs + (long)c * Hi * Wi + p;
+      float* o = dx + b * dxbs + (long)c * Hp * Wp + p;
       *o = accumulate ? *o + acc : acc;
     }
     return;
@@ -237,7 +245,7 @@ __global__ __launch_bounds__(256) void cn_bilinear_bwd_near_kernel(const float* 
         if (wx != 0.f) acc += wy * wx * dp[oy * Wo + ox];
       }
     }
-    float* o = dx + b * dxbs + (long)c * Hi * Wi + p;
+    float* o = dx + b * dxbs + (long)c * Hp * Wp + p;
     *o = accumulate ? *o + acc : acc;
   }
 }
@@ -246,28 +254,36 @@ static inline float bl_scale(int in_size, int out_size) {
   return out_size > 1 ? (float)(in_size - 1) / (float)(out_size - 1) : 0.f;
 }
 
+// Hp x Wp: stored grid of the SOURCE (>= Hi x Wi; the image is its top-left Hi x Wi; 0 = dense, Hp = Hi, Wp = Wi).
 extern "C" int cn_bilinear_fwd_f32(const float* x, long xbs, float* y, long ybs, int B, int C, int Hi, int Wi, int Ho,
-                                   int Wo, void* stream) {
+                                   int Wo, int Hp, int Wp, void* stream) {
   if (B <= 0 || C <= 0) return CN_OK;
+  if (Hp <= 0) Hp = Hi;
+  if (Wp <= 0) Wp = Wi;
+  if (Hp < Hi || Wp < Wi) return CN_ERR_ARG;
   dim3 grid((Ho * Wo + 255) / 256, C, B);
   CN_LAUNCH(cn_bilinear_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, x, xbs, y, ybs, C, Hi, Wi, Ho,
-                     Wo, bl_scale(Hi, Ho), bl_scale(Wi, Wo));
+                     Wo, bl_scale(Hi, Ho), bl_scale(Wi, Wo), Hp, Wp);
   return cn_check_launch();
 }
 
+// Adjoint; dx lives on the stored grid Hp x Wp (see above): its padding is written as zeros (left alone when accumulating).
 extern "C" int cn_bilinear_bwd_f32(const float* dy, long dybs, float* dx, long dxbs, int B, int C, int Hi, int Wi,
-                                   int Ho, int Wo, int accumulate, void* stream) {
+                                   int Ho, int Wo, int Hp, int Wp, int accumulate, void* stream) {
   if (B <= 0 || C <= 0) return CN_OK;
+  if (Hp <= 0) Hp = Hi;
+  if (Wp <= 0) Wp = Wi;
+  if (Hp < Hi || Wp < Wi) return CN_ERR_ARG;
   const float sh = bl_scale(Hi, Ho), sw = bl_scale(Wi, Wo);
   if (2 * Hi > Ho && 2 * Wi > Wo && (long)B * C * Hi * Wi >= 1 << 16) {  // near-1:1 resize of a large tensor
-    dim3 gridn((Hi * Wi + 255) / 256, (C + BL_CH - 1) / BL_CH, B);
+    dim3 gridn((Hp * Wp + 255) / 256, (C + BL_CH - 1) / BL_CH, B);
     CN_LAUNCH(cn_bilinear_bwd_near_kernel, gridn, dim3(256), 0, (hipStream_t)stream, dy, dybs, dx, dxbs, C,
-                       Hi, Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, accumulate);
+                       Hi, Wi, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, accumulate, Hp, Wp);
     return cn_check_launch();
   }
-  dim3 grid((Hi * Wi + 255) / 256, C, B);
+  dim3 grid((Hp * Wp + 255) / 256, C, B);
   CN_LAUNCH(cn_bilinear_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dy, dybs, dx, dxbs, C, Hi, Wi,
-                     Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, accumulate);
+                     Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f, accumulate, Hp, Wp);
   return cn_check_launch();
 }
 

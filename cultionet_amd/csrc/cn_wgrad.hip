@@ -1179,9 +1179,11 @@ extern "C" int cn_conv2d_bwd_weight_f32(const float* x, long xbs, const float* d
 // ConvTranspose2d: dw [Cin][Cout][KH][KW] += x (small grid) (*) dy (gathered at stride s).
 extern "C" int cn_conv_transpose2d_bwd_weight_f32(const float* x, long xbs, const float* dy, long dybs, float* dw,
                                                   int B, int Cin, int Hin, int Win, int Cout, int KH, int KW,
-                                                  int stride, int pad, float* ws, long ws_floats, void* stream) {
-  const int Hout = (Hin - 1) * stride - 2 * pad + KH;
-  const int Wout = (Win - 1) * stride - 2 * pad + KW;
+                                                  int stride, int pad, int out_pad, float* ws, long ws_floats,
+                                                  void* stream) {
+  if (out_pad < 0 || (out_pad > 0 && out_pad >= stride)) return CN_ERR_ARG;
+  const int Hout = (Hin - 1) * stride - 2 * pad + KH + out_pad;  // dy lives on the output_padding grid (cn_conv.hip)
+  const int Wout = (Win - 1) * stride - 2 * pad + KW + out_pad;
   return cn_wgrad_generic(x, xbs, Cin, Hin, Win, dy, dybs, Cout, Hout, Wout, stride, KH, KW, 1, pad, dw, B, ws,
                           ws_floats, (hipStream_t)stream);
 }

@@ -126,7 +126,7 @@ def _dense_inner(t: torch.Tensor) -> bool:
 class Var:
     """A device buffer and (during training) its gradient buffer."""
 
-    __slots__ = ("t", "grad", "req", "parent", "stats", "bnfin")
+    __slots__ = ("t", "grad", "req", "parent", "stats", "bnfin", "valid")
 
     def __init__(self, t: torch.Tensor, req: bool = False):
         self.t = t
@@ -135,6 +135,7 @@ class Var:
         self.parent: T.Optional[T.Tuple["Var", int, int]] = None  # channel slice [c0, c1) of another Var
         self.stats: T.Optional[torch.Tensor] = None  # bf16 conv outputs: per-channel {sum, sumsq} from the epilogue
         self.bnfin = None  # (bn module, mean, rstd): BatchNorm statistics already finished by the producing conv launch
+        self.valid: T.Optional[T.Tuple[int, int]] = None  # (H, W) of the image inside a larger stored grid (conv_transpose2d)
 
     @property
     def shape(self):
@@ -1341,8 +1342,21 @@ def conv2d_group(xs: T.Sequence[Var], mods: T.Sequence, paddings: T.Sequence[int
     return yvs
 
 
-def conv_transpose2d(x: Var, mod, stride: int, padding: int) -> Var:
-    """nn.ConvTranspose2d forward (k x k, stride s, padding p, with bias)."""
+# CN_CONVT_OUTPAD=0: ConvTranspose2d writes the reference's (2n-1)^2 tensor (rounds 1-5) instead of the 2n x 2n
+# output_padding grid of the resize that follows (A/B switch).
+_CONVT_OUTPAD = os.environ.get("CN_CONVT_OUTPAD", "1") != "0"
+
+
+def conv_transpose2d(x: Var, mod, stride: int, padding: int, size: T.Optional[T.Tuple[int, int]] = None) -> Var:
+    """nn.ConvTranspose2d forward (k x k, stride s, padding p, with bias).
+
+    ``size``: the size check_upsample will resize the result to (convolution.py:45-68). When it exceeds the natural
+    (2n-1)-style output by less than the stride on both axes (every site of TowerUNet), the fp32 result is computed on
+    THAT grid -- the transposed convolution with output_padding = size - natural, whose top-left natural-size block is
+    exactly the reference's tensor -- and returned as a Var whose ``valid`` attribute names the image inside it:
+    planes of 100 x 100 / 50 x 50 are 16-byte aligned where 99 x 99 / 49 x 49 / 97 x 97 are not, so the weight gradient
+    needs no aligned copy of dy (cn_pad_planes), the data gradient stages 16 bytes per lane instead of 4, and
+    resize_bilinear reads / writes the stored grid in place."""
     tape = current_tape()
     xt = _check(x.t)
     if is16(xt):
@@ -1352,13 +1366,21 @@ def conv_transpose2d(x: Var, mod, stride: int, padding: int) -> Var:
     Cout, KH, KW = w.shape[1], w.shape[2], w.shape[3]
     Ho = (H - 1) * stride - 2 * padding + KH
     Wo = (W - 1) * stride - 2 * padding + KW
+    op = 0
+    if _CONVT_OUTPAD and size is not None and stride > 1:
+        dh, dw_ = int(size[0]) - Ho, int(size[1]) - Wo
+        if dh == dw_ and 0 < dh < stride:
+            op = dh
+    Hs, Ws = Ho + op, Wo + op  # the stored grid
     pw = packed_convT(mod, tape.enabled and x.req)
-    y = _new((B, Cout, Ho, Wo), xt)
+    y = _new((B, Cout, Hs, Ws), xt)
     bias = mod.bias
     _lib.call("cn_conv_transpose2d_fwd_f32", xt.data_ptr(), bstride(xt), pw.fwd.data_ptr(),
               bias.data_ptr() if bias is not None else None, y.data_ptr(), bstride(y), B, Cin, H, W, Cout, KH, KW,
-              stride, padding, 0, _stream())
+              stride, padding, op, 0, _stream())
     yv = Var(y, tape.enabled)
+    if op:
+        yv.valid = (Ho, Wo)
     if tape.enabled:
         store = current_store()
 
@@ -1370,14 +1392,14 @@ def conv_transpose2d(x: Var, mod, stride: int, padding: int) -> Var:
                 s = _stream()
                 wsp, wsn = _pad_ws(xt, dy)
                 _lib.call("cn_conv_transpose2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dy.data_ptr(), bstride(dy),
-                          store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, wsp, wsn, s)
-                if bias is not None:
-                    _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Ho * Wo,
+                          store.grad_of(w).data_ptr(), B, Cin, H, W, Cout, KH, KW, stride, padding, op, wsp, wsn, s)
+                if bias is not None:  # (the padding of dy is zero: the resize adjoint writes it)
+                    _lib.call("cn_channel_sum_f32", dy.data_ptr(), bstride(dy), B, Cout, Hs * Ws,
                               store.grad_of(bias).data_ptr(), 1, s)
             if x.req:
                 dx, acc = grad_buffer(x)
                 _lib.call("cn_conv_transpose2d_bwd_data_f32", dy.data_ptr(), bstride(dy), pw.bwd.data_ptr(),
-                          dx.data_ptr(), bstride(dx), B, Cin, H, W, Cout, KH, KW, stride, padding, acc, _stream())
+                          dx.data_ptr(), bstride(dx), B, Cin, H, W, Cout, KH, KW, stride, padding, op, acc, _stream())
             yv.grad = None
 
         tape.add(bwd, (w, bias))
@@ -1896,10 +1918,12 @@ def spatial_channel_attention(skip: Var, out: Var, mod) -> Var:
 
 
 def resize_bilinear(x: Var, size: T.Tuple[int, int], out: T.Optional[torch.Tensor] = None) -> Var:
-    """F.interpolate(mode='bilinear', align_corners=True); identity when the size already matches."""
+    """F.interpolate(mode='bilinear', align_corners=True); identity when the size already matches. A Var with a
+    ``valid`` attribute (conv_transpose2d on the output_padding grid) is resized from the image INSIDE its stored grid."""
     tape = current_tape()
     xt = _check(x.t)
-    B, C, Hi, Wi = xt.shape
+    B, C, Hp, Wp = xt.shape
+    Hi, Wi = x.valid if x.valid is not None else (Hp, Wp)
     Ho, Wo = int(size[0]), int(size[1])
     if (Hi, Wi) == (Ho, Wo) and out is None:
         return x
@@ -1907,7 +1931,7 @@ def resize_bilinear(x: Var, size: T.Tuple[int, int], out: T.Optional[torch.Tenso
         return _resize_bilinear_bf16(x, (Ho, Wo), out)
     y = out if out is not None else _new((B, C, Ho, Wo), xt)
     _lib.call("cn_bilinear_fwd_f32", xt.data_ptr(), bstride(xt), y.data_ptr(), bstride(y), B, C, Hi, Wi, Ho, Wo,
-              _stream())
+              Hp, Wp, _stream())
     yv = Var(y, tape.enabled and x.req)
     if tape.enabled and x.req:
 
@@ -1917,7 +1941,7 @@ def resize_bilinear(x: Var, size: T.Tuple[int, int], out: T.Optional[torch.Tenso
                 return
             dx, acc = grad_buffer(x)
             _lib.call("cn_bilinear_bwd_f32", dy.data_ptr(), bstride(dy), dx.data_ptr(), bstride(dx), B, C, Hi, Wi, Ho,
-                      Wo, acc, _stream())
+                      Wo, Hp, Wp, acc, _stream())
             yv.grad = None
 
         tape.add(bwd)

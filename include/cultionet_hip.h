@@ -71,17 +71,22 @@ int cn_conv2d_bwd_weight_f32(const float* x, long xbs, const float* dy, long dyb
 int cn_pack_timeconv_f32(const float* w, float* wp, int Cout, int Cin, int Tin, int k, int transposed, void* stream);
 int cn_fold_timeconv_grad_f32(const float* dwexp, float* dw, int Cout, int Cin, int Tin, int k, void* stream);
 
-/* ---- torch.nn.ConvTranspose2d(k=3, stride s, padding 1) (convolution.py:45-68) --------------- */
+/* ---- torch.nn.ConvTranspose2d(k=3, stride s, padding 1) (convolution.py:45-68) ---------------
+ * out_pad = nn.ConvTranspose2d's output_padding (0 <= out_pad < stride): y / dy are [B,Cout,Hout,Wout] with
+ * Hout = (Hin-1)*s - 2*pad + KH + out_pad. The reference never sets it; the engine does, to put the (2n-1)^2 result on
+ * the 2n x 2n grid of the check_upsample resize that follows (nn/functional.py:72-81): rows / columns [0, 2n-1) ARE the
+ * reference's tensor, the planes are 16-byte aligned (99 x 99 is not), and the resize reads them through the stored-grid
+ * arguments of cn_bilinear_*_f32. */
 int cn_conv_transpose2d_fwd_f32(const float* x, long xbs, const float* wp, const float* bias, float* y, long ybs,
                                 int B, int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride, int pad,
-                                int accumulate, void* stream);
+                                int out_pad, int accumulate, void* stream);
 int cn_conv_transpose2d_bwd_data_f32(const float* dy, long dybs, const float* wp_t, float* dx, long dxbs, int B,
                                      int Cin, int Hin, int Win, int Cout, int KH, int KW, int stride, int pad,
-                                     int accumulate, void* stream);
+                                     int out_pad, int accumulate, void* stream);
 /* dw [Cin][Cout][KH][KW] += ...  (zero first); ws as for cn_conv2d_bwd_weight_f32 */
 int cn_conv_transpose2d_bwd_weight_f32(const float* x, long xbs, const float* dy, long dybs, float* dw, int B, int Cin,
-                                       int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, float* ws,
-                                       long ws_floats, void* stream);
+                                       int Hin, int Win, int Cout, int KH, int KW, int stride, int pad, int out_pad,
+                                       float* ws, long ws_floats, void* stream);
 
 /* Optional scratch for the K-split launches of the cn_conv* entry points (small spatial sizes split the input
  * channels over blocks): with a workspace each split stores its partial output into a private slice and a reduce
@@ -215,11 +220,14 @@ int cn_na2d_bwd_f32(const float* qkv, long qbs, const float* dout, long dobs, co
                     float* dqkv, long dqbs, int B, int C, int heads, int H, int W, int kernel_size, int dilation,
                     float attn_drop, unsigned long long seed, const unsigned long long* step, void* stream);
 
-/* ---- F.interpolate(mode="bilinear", align_corners=True) (nn/functional.py:72-81) ------------ */
+/* ---- F.interpolate(mode="bilinear", align_corners=True) (nn/functional.py:72-81) ------------
+ * Hp x Wp (0, 0 = dense): the SOURCE of the forward / the input gradient of the adjoint is stored on a grid
+ * Hp x Wp >= Hi x Wi (row pitch Wp, plane Hp*Wp) whose top-left Hi x Wi is the image -- the output_padding grid of
+ * cn_conv_transpose2d_*_f32. The adjoint writes the padding as zeros (leaves it alone when accumulating). */
 int cn_bilinear_fwd_f32(const float* x, long xbs, float* y, long ybs, int B, int C, int Hi, int Wi, int Ho, int Wo,
-                        void* stream);
+                        int Hp, int Wp, void* stream);
 int cn_bilinear_bwd_f32(const float* dy, long dybs, float* dx, long dxbs, int B, int C, int Hi, int Wi, int Ho,
-                        int Wo, int accumulate, void* stream);
+                        int Wo, int Hp, int Wp, int accumulate, void* stream);
 
 /* ---- torch.cat / residual adds / fills on channel slices ------------------------------------ */
 int cn_copy_f32(const float* src, long sbs, float* dst, long dbs, int B, long n, int accumulate, void* stream);

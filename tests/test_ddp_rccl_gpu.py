@@ -101,11 +101,9 @@ def _check(got, world, hidden, B, H, W, bf16):
     print(f"[rccl x{world} {'bf16' if bf16 else 'fp32'} B={B} {H}x{W} hidden {hidden}] update |d| max {float(d.max()):.3e} "
           f"median {float(d.median()):.3e} frac>2e-4 {float((d > 2e-4).float().mean()):.3e} sign agreement {agree:.4f}")
     if not bf16:
-        # AdamW's first step moves an element by lr * g / (|g| + eps): where |g| is far below eps = 1e-4 a gradient
-        # difference is amplified 100x, so the bound on the MAX is the small-shape test's (2e-4) only for the bulk
-        assert float(d.max()) <= 2e-3, float(d.max())
-        assert float((d > 2e-4).float().mean()) <= 1e-3
-        assert float(d.median()) <= 2e-5
+        # the small-shape test's bound (tests/test_ddp_engine_gpu.py); measured with one rank on the GPU box: max 4.5e-7
+        assert float(d.max()) <= 2e-4, float(d.max())
+        assert float(d.median()) <= 1e-6
     else:  # AdamW turns every gradient into a +-lr move: compare directions and the median (test_ddp_engine_gpu.py)
         assert agree >= 0.97, agree
         assert float(d.median()) <= 2e-4

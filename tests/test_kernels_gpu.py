@@ -158,6 +158,48 @@ def test_conv_transpose2d(case):
     _close(pg["bias"], ref_b, 1e-4, "db")
 
 
+@pytest.mark.parametrize("case", [
+    # B, C, H, W, stride, size: the ConvTranspose2d + check_upsample sites of TowerUNet (convolution.py:45-68)
+    (2, 16, 25, 25, 2, 50),    # 49 -> 50
+    (2, 24, 50, 50, 2, 100),   # 99 -> 100 (the five 100 x 100 sites)
+    (1, 16, 25, 25, 4, 100),   # final_c: stride 4, 97 -> 100
+    (2, 16, 13, 13, 2, 25),    # 25 already: no resize, no output padding
+    (2, 8, 14, 14, 2, 30),     # 27 -> 30: a gap of 3 >= stride -- the unpadded path + a plain resize
+])
+def test_conv_transpose2d_then_resize(case):
+    """The reference's ConvTranspose2d module (up_conv, then check_upsample's align_corners bilinear resize) against
+    torch: the engine computes the transposed convolution on the resize's own grid (output_padding, 16-byte aligned
+    planes) and resizes from the image inside it; values and all gradients must not notice."""
+    from cultionet_amd import engine as E
+    from cultionet_amd.convolution import ConvTranspose2d
+
+    B, C, H, W, s, size = case
+    torch.manual_seed(11)
+    mod = ConvTranspose2d(C, C, 3, s, 1)
+    x = _rand(B, C, H, W, seed=31)
+    xr = x.clone().requires_grad_(True)
+    yr = mod.up_conv(xr)
+    natural = yr.shape[-1]
+    if natural != size:
+        yr = F.interpolate(yr, size=(size, size), mode="bilinear", align_corners=True)
+    dy = _rand(*yr.shape, seed=32)
+    yr.backward(dy)
+    ref_w, ref_b = mod.up_conv.weight.grad.clone(), mod.up_conv.bias.grad.clone()
+    seen = {}
+
+    def run(v):
+        out = mod(v, size=(size, size))
+        seen["stored"] = tuple(out.t.shape[-2:])
+        return out
+
+    y, (dx,), pg = _engine_run(mod, run, [x], dy)
+    assert tuple(y.shape[-2:]) == (size, size)
+    _close(y, yr, 2e-5, "y")
+    _close(dx, xr.grad, 1e-4, "dx")
+    _close(pg["up_conv.weight"], ref_w, 1e-4, "dw")
+    _close(pg["up_conv.bias"], ref_b, 1e-4, "db")
+
+
 @pytest.mark.parametrize("k", [3, 5])
 def test_time_conv(k):
     """nn.Conv3d(kernel (k,1,1)) of PreTimeReduction as a banded 1x1 contraction."""

@@ -47,9 +47,9 @@ small2 = torch.empty_like(small)
 ms = main.cuda_stream
 victims = {
     "bilinear_bwd 100->99 (x128 ch)": lambda: _lib.call("cn_bilinear_bwd_f32", dst.data_ptr(), C * 10000, src.data_ptr(), C * 9801,
-                                                        B, C, 99, 99, 100, 100, 0, ms),
+                                                        B, C, 99, 99, 100, 100, 0, 0, 0, ms),
     "bilinear_fwd 99->100": lambda: _lib.call("cn_bilinear_fwd_f32", src.data_ptr(), C * 9801, dst.data_ptr(), C * 10000, B, C,
-                                               99, 99, 100, 100, ms),
+                                               99, 99, 100, 100, 0, 0, ms),
     "copy 41 MB": lambda: _lib.call("cn_copy_f32", big.data_ptr(), C * H * W, big2.data_ptr(), C * H * W, B, C * H * W, 0, ms),
     "copy 2.6 MB": lambda: _lib.call("cn_copy_f32", small.data_ptr(), C * 625, small2.data_ptr(), C * 625, B, C * 625, 0, ms),
     "fill 41 MB": lambda: _lib.call("cn_fill_f32", big2.data_ptr(), big2.numel(), 0.0, ms),
