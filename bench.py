@@ -471,8 +471,8 @@ def run_child(kind: str, args, extra: typing.Sequence[str] = (), env_extra: typi
 def ddp1_block(args) -> dict:
     """The step AS A DATA-PARALLEL RANK RUNS IT, on the one GPU the driver's N = 1 run has: a one-rank RCCL process group
     (CN_FORCE_COMM=1) puts the bucket stream, the five bucketed all-reduces per step and the stream set of
-    cultionet_amd.ddp into the timed region -- no auxiliary branch streams (engine.branch_streams_allowed), weight-gradient
-    slice sums flushed once per ready bucket. fp32 batch 8 and bf16 batch 32 (BASELINE configs[1] / configs[3] per GPU),
+    cultionet_amd.ddp into the timed region -- with the auxiliary branch stream (round 6: allowed under a process group at
+    GPU_MAX_HW_QUEUES <= 5, engine.branch_streams_allowed), weight-gradient slice sums flushed once per ready bucket. fp32 batch 8 and bf16 batch 32 (BASELINE configs[1] / configs[3] per GPU),
     each in a fresh child process. One rank exchanges nothing over xGMI: this prices the stream set and the exposed
     launch / wait time of the collectives, NOT the scaling curve (reference: strategy="ddp",
     /root/reference/src/cultionet/model.py:101,168-186)."""

@@ -305,23 +305,41 @@ _HEAD_STREAMS = os.environ.get("CN_HEAD_STREAMS", "1") != "0"
 _aux_streams: T.Dict[T.Any, T.List["torch.cuda.Stream"]] = {}
 
 
-def branch_streams_allowed() -> bool:
-    """spawn() runs its sub-graph on an auxiliary stream only while no torch.distributed process group is alive.
+# Hardware queues of one process (round 6, tools/one_aux_try.sh + profiles/r06_hw_queues.txt). The HIP runtime keeps a
+# pool of up to GPU_MAX_HW_QUEUES hardware queues PER STREAM PRIORITY, and this chip runs a process's queues concurrently
+# only while there are at most SEVEN of them: with an eighth the queues are time-sliced and the whole step runs 1.5-1.9x
+# slower (that is the "auxiliary streams + bucket collectives" slowdown of rounds 4-5: a torch.distributed process group
+# brings six normal-priority streams with it -- 6 + the weight-gradient stream's lowest-priority queue + two
+# highest-priority auxiliary queues = 9). The engine therefore owns exactly one queue per extra priority -- the
+# weight-gradient stream (lowest) and ONE auxiliary stream for every spawn() (highest) -- and the process is expected to
+# cap the normal pool at 5 (cultionet_amd.configure_runtime): 5 + 1 + 1 = 7 whatever the process group creates.
+_HW_QUEUE_BUDGET = 7
 
-    With a live group AND bucket collectives in flight the auxiliary streams cost 40 % of the step (one-rank RCCL group,
-    round 4: bf16 2115 -> 1230 chips/s, fp32 377 -> 238, whatever their priority; cause not found with one GPU -- DESIGN
-    section 7). Data-parallel ranks therefore keep the stream set of round 3: compute, weight gradients, buckets. The
-    check is LIVE (the round-4 switch flipped a process-global flag for good when a GradientAllReduce was
-    constructed): it follows the process group's lifetime, covers the drop-in mode under Lightning's own DDP as well, and
-    a trainer / predictor created after the group is destroyed gets its branches back. CN_KEEP_BRANCH_STREAMS=1
-    overrides it (to profile the interaction); ``engine.branch_streams(False)`` switches spawn() off for a scope."""
+
+def _hw_queue_cap() -> int:
+    try:
+        return int(os.environ.get("GPU_MAX_HW_QUEUES", "4"))  # (unset: the runtime's default of 4)
+    except ValueError:
+        return 4
+
+
+def branch_streams_allowed() -> bool:
+    """spawn() runs its sub-graph on the auxiliary stream unless that could push the process over the hardware-queue
+    budget: with a torch.distributed process group alive (six normal-priority streams of its own) the auxiliary stream
+    needs GPU_MAX_HW_QUEUES <= 5 (cap + weight-gradient queue + auxiliary queue <= 7). Checked LIVE at every spawn()
+    (ADVICE r4), so it follows the group's lifetime and covers the drop-in mode under Lightning's own DDP;
+    CN_KEEP_BRANCH_STREAMS=1 overrides it (to profile the interaction); ``engine.branch_streams(False)`` switches
+    spawn() off for a scope. One-rank RCCL group, same box: bf16 2249 chips/s with the auxiliary stream at 5 queues
+    against 2162 without it at 8 (single process 2279-2285); at 6 queues 1396."""
     if not _HEAD_STREAMS or getattr(_state, "no_branches", False):
         return False
     if _KEEP_BRANCHES:
         return True
     import torch.distributed as dist
 
-    return not (dist.is_available() and dist.is_initialized())
+    if dist.is_available() and dist.is_initialized():
+        return _hw_queue_cap() + 2 <= _HW_QUEUE_BUDGET
+    return True
 
 
 _KEEP_BRANCHES = os.environ.get("CN_KEEP_BRANCH_STREAMS") == "1"
@@ -343,19 +361,18 @@ class branch_streams:
         return False
 
 
-def _aux_stream(dev, k: int) -> "torch.cuda.Stream":
+def _aux_stream(dev, k: int = 0) -> "torch.cuda.Stream":
+    """THE auxiliary stream of ``dev`` (``k`` names the sub-graph for the reader: every spawn() shares one stream since
+    round 6 -- a second highest-priority stream is a second hardware queue, see _HW_QUEUE_BUDGET; same box, single
+    process: bf16 2279 / fp32 387.5 chips/s with one stream against 2285 / 385.8 with two)."""
     if _OVERLAP_WGRAD:
         _side_state(dev)  # HIP deals streams to hardware queues in creation order: the weight-gradient stream first
     lst = _aux_streams.setdefault(dev, [])
-    while len(lst) <= k:
+    if not lst:
         # HIGHEST priority, through the C ABI like the weight-gradient stream: a priority is a property of the hardware
-        # queue, so these streams can never be dealt the queue of the compute stream, of the (lowest-priority)
+        # queue, so this stream can never be dealt the queue of the compute stream, of the (lowest-priority)
         # weight-gradient stream or of RCCL's streams -- with torch.cuda.Stream() (normal priority) a live process group
         # put an auxiliary stream on a queue shared with the compute stream: 2115 -> 1255 chips/s (bf16), 377 -> 241 (fp32).
-        # CN_AUX_STREAM=normal restores that for experiments.
-        if os.environ.get("CN_AUX_STREAM", "high") == "normal":
-            lst.append(torch.cuda.Stream(device=dev))
-            continue
         import ctypes
 
         handle = ctypes.c_void_p()
@@ -364,7 +381,7 @@ def _aux_stream(dev, k: int) -> "torch.cuda.Stream":
             _lib.call("cn_stream_priority_range", rng)
             _lib.call("cn_stream_create", int(rng[1]), None, 0, ctypes.byref(handle))
         lst.append(torch.cuda.ExternalStream(handle.value, device=dev))
-    return lst[k]
+    return lst[0]
 
 
 # ---- the engine's allocator -----------------------------------------------------------------------------------------
