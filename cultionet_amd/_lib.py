@@ -54,6 +54,8 @@ SIGNATURES = {
     "cn_sca_apply_bwd_f32": [P, L, P, L, P, P, P, P, L, I, P, P, P, P, I, I, I, P],
     "cn_na2d_fwd_f32": [P, L, P, L, P, I, I, I, I, I, I, I, F, U64, P, P],
     "cn_na2d_bwd_f32": [P, L, P, L, P, P, P, L, I, I, I, I, I, I, I, F, U64, P, P],
+    "cn_convt_taps_fwd_f32": [P, L, P, P, L, I, I, I, I, I, I, I, I, I, P],
+    "cn_convt_taps_bwd_f32": [P, L, P, L, I, I, I, I, I, I, I, I, I, P],
     "cn_bilinear_fwd_f32": [P, L, P, L, I, I, I, I, I, I, I, I, P],
     "cn_bilinear_bwd_f32": [P, L, P, L, I, I, I, I, I, I, I, I, I, P],
     "cn_copy_f32": [P, L, P, L, I, L, I, P],

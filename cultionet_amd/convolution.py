@@ -45,7 +45,9 @@ class ConvTranspose2d(nn.Module):
         self.up_conv = nn.ConvTranspose2d(in_channels, out_channels, kernel_size, stride=stride, padding=padding)
 
     def forward(self, x: E.Var, size, out: T.Optional[torch.Tensor] = None) -> E.Var:
-        y = E.conv_transpose2d(x, self.up_conv, self.stride, self.padding, size=tuple(size))
+        y = E.conv_transpose2d(x, self.up_conv, self.stride, self.padding, size=tuple(size), out=out)
+        if y.valid is None and tuple(y.shape[-2:]) == tuple(size) and (out is None or y.t.data_ptr() == out.data_ptr()):
+            return y  # already at ``size`` (the stride >= kernel path resizes in its own pointwise pass), or no resize needed
         natural = y.valid if y.valid is not None else tuple(y.shape[-2:])
         if out is not None and tuple(natural) == tuple(size):
             out = None  # no resize to write through: the caller copies

@@ -288,6 +288,131 @@ extern "C" int cn_bilinear_bwd_f32(const float* dy, long dybs, float* dx, long d
 }
 
 // ---------------------------------------------------------------------------
+// ConvTranspose2d with stride >= kernel size (TowerUNetFinal's up_conv of final_c: k 3, stride 4, padding 1;
+// /root/reference/src/cultionet/nn/modules/unet_parts.py:227-309 + convolution.py:45-68) as a DENSE 1x1 contraction plus a
+// pointwise pass. With s >= k no two taps of a cell meet: every input pixel (a, b) owns the k x k block of outputs at
+// (s*a - pad + ky, s*b - pad + kx) and every other output is bias only. The contraction
+//     P[b][co*k*k + ky*k + kx][a][b'] = sum_ci w[ci][co][ky][kx] * x[b][ci][a][b']
+// is a plain GEMM over the SMALL grid (cn_conv_transpose2d_*_f32 with a 1x1 kernel on the weight tensor viewed as
+// [Cin][Cout*k*k]: the 128 -> 128 layer at 8 x 25 x 25 is 1.5 GFLOP). The parity-class launches it replaces ran the same
+// arithmetic as 16 classes of one tap each (66 us), a 9-tap stride-4 gather (45 us) and a dword-staged weight gradient
+// at 10 TFLOP/s (142 us), plus the resize pair. The two kernels here do what is left:
+//   forward : z = resize(bias + scatter(P))      one pass, the (s*n - c)^2 intermediate never exists
+//   backward: dP = gather(resize^T(dz))          the adjoint of both, written in P's layout
+// (the bias gradient is the per-channel sum of dz: the resize weights of every output pixel sum to one).
+// ---------------------------------------------------------------------------
+#define CT_CH 16
+// y(p, q) of channel c = bias + P[c*KK + ky*K + kx][a][b'] when p = s*a - pad + ky, q = s*b' - pad + kx with ky, kx < K;
+// returns the offset of that element relative to channel c's block of P, or -1 (bias only).
+__device__ __forceinline__ int ct_src(int p, int q, int K, int s, int pad, int Hc, int Wc) {
+  const int pa = p + pad, qa = q + pad;
+  const int a = pa / s, b = qa / s;
+  const int ky = pa - a * s, kx = qa - b * s;
+  if (ky >= K || kx >= K || a >= Hc || b >= Wc) return -1;
+  return ((ky * K + kx) * Hc + a) * Wc + b;
+}
+
+// grid (pixels of z / 256, channel chunks, B)
+__global__ __launch_bounds__(256) void cn_convt_taps_fwd_kernel(const float* __restrict__ P, long pbs,
+                                                               const float* __restrict__ bias,
+                                                               float* __restrict__ z, long zbs, int C, int Hc, int Wc,
+                                                               int K, int s, int pad, int Hy, int Wy, int Ho, int Wo,
+                                                               float sh, float sw) {
+  const int px = blockIdx.x * 256 + threadIdx.x;
+  if (px >= Ho * Wo) return;
+  const int c0 = blockIdx.y * CT_CH, b = blockIdx.z;
+  const int oy = px / Wo, ox = px - oy * Wo;
+  int y0, y1, x0, x1;
+  float ly, lx;
+  if (Ho == Hy && Wo == Wy) {  // no resize behind the transposed convolution
+    y0 = y1 = oy; x0 = x1 = ox; ly = lx = 0.f;
+  } else {
+    bl_src(oy, sh, Hy, y0, y1, ly);
+    bl_src(ox, sw, Wy, x0, x1, lx);
+  }
+  const float hy = 1.f - ly, hx = 1.f - lx;
+  const int o00 = ct_src(y0, x0, K, s, pad, Hc, Wc), o01 = ct_src(y0, x1, K, s, pad, Hc, Wc);
+  const int o10 = ct_src(y1, x0, K, s, pad, Hc, Wc), o11 = ct_src(y1, x1, K, s, pad, Hc, Wc);
+  const long cstride = (long)K * K * Hc * Wc;
+  const int c1 = c0 + CT_CH < C ? c0 + CT_CH : C;
+  for (int c = c0; c < c1; ++c) {
+    const float* pc = P + b * pbs + c * cstride;
+    // (unused slots re-read element 0 with weight 0: four independent loads per channel, no branch per slot)
+    const float v00 = pc[o00 < 0 ? 0 : o00], v01 = pc[o01 < 0 ? 0 : o01];
+    const float v10 = pc[o10 < 0 ? 0 : o10], v11 = pc[o11 < 0 ? 0 : o11];
+    const float bv = bias != nullptr ? bias[c] : 0.f;
+    const float a00 = (o00 < 0 ? 0.f : v00) + bv, a01 = (o01 < 0 ? 0.f : v01) + bv;
+    const float a10 = (o10 < 0 ? 0.f : v10) + bv, a11 = (o11 < 0 ? 0.f : v11) + bv;
+    z[b * zbs + (long)c * Ho * Wo + px] = hy * (hx * a00 + lx * a01) + ly * (hx * a10 + lx * a11);
+  }
+}
+
+// grid (elements of one channel's block of dP / 256, channel chunks, B); a thread owns one (tap, cell) for CT_CH channels
+__global__ __launch_bounds__(256) void cn_convt_taps_bwd_kernel(const float* __restrict__ dz, long dzbs,
+                                                               float* __restrict__ dP, long dpbs, int C, int Hc, int Wc,
+                                                               int K, int s, int pad, int Hy, int Wy, int Ho, int Wo,
+                                                               float sh, float sw, float inv_sh, float inv_sw) {
+  const int e = blockIdx.x * 256 + threadIdx.x;
+  const int per = K * K * Hc * Wc;
+  if (e >= per) return;
+  const int c0 = blockIdx.y * CT_CH, b = blockIdx.z;
+  const int t = e / (Hc * Wc), cell = e - t * (Hc * Wc);
+  const int ky = t / K, kx = t - ky * K;
+  const int a = cell / Wc, bb = cell - a * Wc;
+  const int p = s * a - pad + ky, q = s * bb - pad + kx;
+  const int c1 = c0 + CT_CH < C ? c0 + CT_CH : C;
+  const bool inside = p >= 0 && p < Hy && q >= 0 && q < Wy;
+  int oyv[4] = {0, 0, 0, 0}, oxv[4] = {0, 0, 0, 0};
+  float wyv[4] = {0.f, 0.f, 0.f, 0.f}, wxv[4] = {0.f, 0.f, 0.f, 0.f};
+  int ny = 0, nx = 0;
+  if (inside) {
+    if (Ho == Hy && Wo == Wy) {
+      ny = nx = 1; oyv[0] = p; oxv[0] = q; wyv[0] = wxv[0] = 1.f;
+    } else {
+      ny = bl_candidates(p, Hy, Ho, sh, inv_sh, oyv, wyv);
+      nx = bl_candidates(q, Wy, Wo, sw, inv_sw, oxv, wxv);
+    }
+  }
+  if (ny > 4) ny = 4;  // (a resize that shrinks by 2x or more would need the general adjoint: refused by the launcher)
+  if (nx > 4) nx = 4;
+  for (int c = c0; c < c1; ++c) {
+    const float* dp = dz + b * dzbs + (long)c * Ho * Wo;
+    float acc = 0.f;
+    for (int k = 0; k < ny; ++k)
+      for (int j = 0; j < nx; ++j) acc += wyv[k] * wxv[j] * dp[oyv[k] * Wo + oxv[j]];
+    dP[b * dpbs + (long)c * per + e] = acc;
+  }
+}
+
+// P / dP: [B][C*K*K][Hc][Wc] (batch strides pbs / dpbs); z / dz: [B][C][Ho][Wo]; (Hy, Wy) = (Hc-1)*s - 2*pad + K, the
+// size of the transposed convolution's own output; (Ho, Wo) = the size check_upsample resizes it to (== (Hy, Wy): none).
+extern "C" int cn_convt_taps_fwd_f32(const float* P, long pbs, const float* bias, float* z, long zbs, int B, int C,
+                                     int Hc, int Wc, int K, int stride, int pad, int Ho, int Wo, void* stream) {
+  if (B <= 0 || C <= 0) return CN_OK;
+  if (K < 1 || stride < K || pad < 0 || pad >= stride) return CN_ERR_ARG;
+  const int Hy = (Hc - 1) * stride - 2 * pad + K, Wy = (Wc - 1) * stride - 2 * pad + K;
+  if (Hy < 1 || Wy < 1 || Ho < 1 || Wo < 1) return CN_ERR_ARG;
+  dim3 grid((Ho * Wo + 255) / 256, (C + CT_CH - 1) / CT_CH, B);
+  CN_LAUNCH(cn_convt_taps_fwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, P, pbs, bias, z, zbs, C, Hc, Wc, K, stride,
+            pad, Hy, Wy, Ho, Wo, bl_scale(Hy, Ho), bl_scale(Wy, Wo));
+  return cn_check_launch();
+}
+
+extern "C" int cn_convt_taps_bwd_f32(const float* dz, long dzbs, float* dP, long dpbs, int B, int C, int Hc, int Wc,
+                                     int K, int stride, int pad, int Ho, int Wo, void* stream) {
+  if (B <= 0 || C <= 0) return CN_OK;
+  if (K < 1 || stride < K || pad < 0 || pad >= stride) return CN_ERR_ARG;
+  const int Hy = (Hc - 1) * stride - 2 * pad + K, Wy = (Wc - 1) * stride - 2 * pad + K;
+  if (Hy < 1 || Wy < 1 || Ho < 1 || Wo < 1) return CN_ERR_ARG;
+  if (2 * Hy <= Ho || 2 * Wy <= Wo) return CN_ERR_ARG;  // <= 4 outputs read an input pixel only for resizes below 2x
+  const float sh = bl_scale(Hy, Ho), sw = bl_scale(Wy, Wo);
+  dim3 grid((K * K * Hc * Wc + 255) / 256, (C + CT_CH - 1) / CT_CH, B);
+  CN_LAUNCH(cn_convt_taps_bwd_kernel, grid, dim3(256), 0, (hipStream_t)stream, dz, dzbs, dP, dpbs, C, Hc, Wc, K, stride,
+            pad, Hy, Wy, Ho, Wo, sh, sw, sh > 0.f ? 1.f / sh : 0.f, sw > 0.f ? 1.f / sw : 0.f);
+  return cn_check_launch();
+}
+
+// ---------------------------------------------------------------------------
 // Strided-batch copy / add:  dst[b][i] (+)= src[b][i], i < n  (channel slices of NCHW tensors)
 // ---------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void cn_copy_kernel(const float* __restrict__ src, long sbs,

@@ -980,8 +980,9 @@ def packed_conv(mod, need_bwd: bool, bf16: bool = False) -> PackedWeight:
     return pw
 
 
-def packed_convT(mod, need_bwd: bool, bf16: bool = False) -> PackedWeight:
-    """Packed weights of an nn.ConvTranspose2d (weight [Cin][Cout][KH][KW])."""
+def packed_convT(mod, need_bwd: bool, bf16: bool = False, taps_as_channels: bool = False) -> PackedWeight:
+    """Packed weights of an nn.ConvTranspose2d (weight [Cin][Cout][KH][KW]). ``taps_as_channels`` (fp32, stride >=
+    kernel size, _conv_transpose2d_taps): the tensor as the [Cin][Cout*KH*KW] matrix of a 1x1 transposed convolution."""
     pw = mod.__dict__.get("_cn_packed")
     if pw is None:
         pw = PackedWeight()
@@ -990,6 +991,13 @@ def packed_convT(mod, need_bwd: bool, bf16: bool = False) -> PackedWeight:
     w = mod.weight
     cin, cout = w.shape[0], w.shape[1]
     taps = int(w[0, 0].numel())
+    if taps_as_channels and not bf16:
+        n = cout * taps
+        if pw.fwd is None:
+            pw.fwd = _pack(pw, "fwd", w, 1, cin, n, n, 1, 0)
+        if need_bwd and pw.bwd is None:
+            pw.bwd = _pack(pw, "bwd", w, 1, n, cin, 1, n, 0)
+        return pw
     if bf16:
         if pw.fwd16 is None:
             pw.fwd16 = _pack16(pw, "fwd16", w, taps, cin, cout, cout * taps, taps, 1)
@@ -1359,12 +1367,72 @@ def conv2d_group(xs: T.Sequence[Var], mods: T.Sequence, paddings: T.Sequence[int
     return yvs
 
 
+# CN_CONVT_TAPS=0: a ConvTranspose2d with stride >= kernel size (final_c's 3 x 3, stride 4) runs through the parity-class
+# launches like every other one instead of the dense 1x1 contraction + pointwise scatter / gather (A/B switch).
+_CONVT_TAPS = os.environ.get("CN_CONVT_TAPS", "1") != "0"
+
+
+def _conv_transpose2d_taps(x: Var, mod, stride: int, padding: int, size, out: T.Optional[torch.Tensor]) -> Var:
+    """nn.ConvTranspose2d(k, stride s >= k, padding) FOLLOWED BY check_upsample to ``size`` (None: no resize), fp32: no
+    two taps of an input pixel meet, so the contraction is a dense 1x1 GEMM on the small grid into
+    P [B, Cout*k*k, H, W] (the weight tensor viewed as [Cin][Cout*k*k]) and one pointwise pass writes
+    resize(bias + scatter(P)); backward: dP = gather(resize^T(dz)) in one pass, then the 1x1 data / weight gradients (the
+    weight gradient lands in the parameter's own [Cin][Cout][k][k] layout). Returns the RESIZED tensor (csrc/cn_pointwise.hip,
+    cn_convt_taps_*; convolution.py:45-68 + unet_parts.py:227-309 of the reference)."""
+    tape = current_tape()
+    xt = x.t
+    B, Cin, H, W = xt.shape
+    w = mod.weight
+    Cout, K = w.shape[1], w.shape[2]
+    KK = K * K
+    Hy = (H - 1) * stride - 2 * padding + K
+    Wy = (W - 1) * stride - 2 * padding + K
+    Ho, Wo = (int(size[0]), int(size[1])) if size is not None else (Hy, Wy)
+    pw = packed_convT(mod, tape.enabled and x.req, taps_as_channels=True)
+    P = _new((B, Cout * KK, H, W), xt)
+    _lib.call("cn_conv_transpose2d_fwd_f32", xt.data_ptr(), bstride(xt), pw.fwd.data_ptr(), None, P.data_ptr(),
+              bstride(P), B, Cin, H, W, Cout * KK, 1, 1, 1, 0, 0, 0, _stream())
+    z = out if (out is not None and tuple(out.shape) == (B, Cout, Ho, Wo)) else _new((B, Cout, Ho, Wo), xt)
+    bias = mod.bias
+    _lib.call("cn_convt_taps_fwd_f32", P.data_ptr(), bstride(P), bias.data_ptr() if bias is not None else None,
+              z.data_ptr(), bstride(z), B, Cout, H, W, K, stride, padding, Ho, Wo, _stream())
+    del P  # (not needed by the backward pass)
+    zv = Var(z, tape.enabled)
+    if tape.enabled:
+        store = current_store()
+
+        def bwd():
+            dz = zv.grad
+            if dz is None:
+                return
+            dP = _new((B, Cout * KK, H, W), xt)
+            _lib.call("cn_convt_taps_bwd_f32", dz.data_ptr(), bstride(dz), dP.data_ptr(), bstride(dP), B, Cout, H, W, K,
+                      stride, padding, Ho, Wo, _stream())
+            with side_stream(xt, dP, dz):
+                s = _stream()
+                wsp, wsn = _pad_ws(xt, dP)
+                _lib.call("cn_conv_transpose2d_bwd_weight_f32", xt.data_ptr(), bstride(xt), dP.data_ptr(), bstride(dP),
+                          store.grad_of(w).data_ptr(), B, Cin, H, W, Cout * KK, 1, 1, 1, 0, 0, wsp, wsn, s)
+                if bias is not None:  # the resize weights of every output pixel sum to one: sum of dz
+                    _lib.call("cn_channel_sum_f32", dz.data_ptr(), bstride(dz), B, Cout, Ho * Wo,
+                              store.grad_of(bias).data_ptr(), 1, s)
+            if x.req:
+                dx, acc = grad_buffer(x)
+                _lib.call("cn_conv_transpose2d_bwd_data_f32", dP.data_ptr(), bstride(dP), pw.bwd.data_ptr(),
+                          dx.data_ptr(), bstride(dx), B, Cin, H, W, Cout * KK, 1, 1, 1, 0, 0, acc, _stream())
+            zv.grad = None
+
+        tape.add(bwd, (w, bias))
+    return zv
+
+
 # CN_CONVT_OUTPAD=0: ConvTranspose2d writes the reference's (2n-1)^2 tensor (rounds 1-5) instead of the 2n x 2n
 # output_padding grid of the resize that follows (A/B switch).
 _CONVT_OUTPAD = os.environ.get("CN_CONVT_OUTPAD", "1") != "0"
 
 
-def conv_transpose2d(x: Var, mod, stride: int, padding: int, size: T.Optional[T.Tuple[int, int]] = None) -> Var:
+def conv_transpose2d(x: Var, mod, stride: int, padding: int, size: T.Optional[T.Tuple[int, int]] = None,
+                     out: T.Optional[torch.Tensor] = None) -> Var:
     """nn.ConvTranspose2d forward (k x k, stride s, padding p, with bias).
 
     ``size``: the size check_upsample will resize the result to (convolution.py:45-68). When it exceeds the natural
@@ -1383,6 +1451,9 @@ def conv_transpose2d(x: Var, mod, stride: int, padding: int, size: T.Optional[T.
     Cout, KH, KW = w.shape[1], w.shape[2], w.shape[3]
     Ho = (H - 1) * stride - 2 * padding + KH
     Wo = (W - 1) * stride - 2 * padding + KW
+    if _CONVT_TAPS and KH == KW and stride >= KH and 0 <= padding < stride and \
+            (size is None or (2 * Ho > int(size[0]) and 2 * Wo > int(size[1]))):
+        return _conv_transpose2d_taps(x, mod, stride, padding, size, out)
     op = 0
     if _CONVT_OUTPAD and size is not None and stride > 1:
         dh, dw_ = int(size[0]) - Ho, int(size[1]) - Wo

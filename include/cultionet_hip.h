@@ -220,6 +220,18 @@ int cn_na2d_bwd_f32(const float* qkv, long qbs, const float* dout, long dobs, co
                     float* dqkv, long dqbs, int B, int C, int heads, int H, int W, int kernel_size, int dilation,
                     float attn_drop, unsigned long long seed, const unsigned long long* step, void* stream);
 
+/* ---- ConvTranspose2d with stride >= kernel size + check_upsample in one pointwise pass (TowerUNetFinal.up_conv of
+ * final_c: k 3, stride 4, padding 1; unet_parts.py:227-309, convolution.py:45-68). With s >= k no two taps of an input
+ * pixel meet, so the contraction is a dense 1x1 GEMM on the SMALL grid -- cn_conv_transpose2d_{fwd,bwd_data,bwd_weight}_f32
+ * with KH = KW = 1 on the weight tensor viewed as [Cin][Cout*K*K] -- producing P [B][C*K*K][Hc][Wc], and
+ *   cn_convt_taps_fwd_f32: z [B][C][Ho][Wo] = resize_to(Ho, Wo)(bias + scatter(P))   (Ho, Wo) == natural size: no resize
+ *   cn_convt_taps_bwd_f32: dP = gather(resize^T(dz))                                  the adjoint, in P's layout
+ * The (s*n - c)^2 intermediate of the reference never exists; the bias gradient is the per-channel sum of dz. */
+int cn_convt_taps_fwd_f32(const float* P, long pbs, const float* bias /*nullable*/, float* z, long zbs, int B, int C,
+                          int Hc, int Wc, int K, int stride, int pad, int Ho, int Wo, void* stream);
+int cn_convt_taps_bwd_f32(const float* dz, long dzbs, float* dP, long dpbs, int B, int C, int Hc, int Wc, int K,
+                          int stride, int pad, int Ho, int Wo, void* stream);
+
 /* ---- F.interpolate(mode="bilinear", align_corners=True) (nn/functional.py:72-81) ------------
  * Hp x Wp (0, 0 = dense): the SOURCE of the forward / the input gradient of the adjoint is stored on a grid
  * Hp x Wp >= Hi x Wi (row pitch Wp, plane Hp*Wp) whose top-left Hi x Wi is the image -- the output_padding grid of
