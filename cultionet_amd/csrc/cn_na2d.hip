@@ -47,7 +47,8 @@ __global__ __launch_bounds__(256) void cn_na2d_fwd_kernel(const float* __restric
                                                          float* __restrict__ out, long obs,
                                                          float* __restrict__ attn, int B, int C, int heads, int H,
                                                          int W, int dil, float scale, unsigned long long dthresh,
-                                                         float dscale, unsigned long long dseed_, const unsigned long long* __restrict__ dstep) {
+                                                         float dscale, unsigned long long dseed_, const unsigned long long* __restrict__ dstep, int Dr) {
+  const int DD = D > 0 ? D : Dr;  // D == 0: head dimension known at run time only (any width)
   const unsigned long long dseed = cn_step_seed(dseed_, dstep);
   const int HW = H * W;
   int bx, h, b;
@@ -56,7 +57,7 @@ __global__ __launch_bounds__(256) void cn_na2d_fwd_kernel(const float* __restric
   if (p >= HW) return;
   const int y = p / W, x = p - y * W;
   const int sy = na_window_start(y, H, dil), sx = na_window_start(x, W, dil);
-  const float* qp = qkv + b * qbs + (long)(h * D) * HW;
+  const float* qp = qkv + b * qbs + (long)(h * DD) * HW;
   const float* kp = qp + (long)C * HW;
   const float* vp = kp + (long)C * HW;
   // Loop order: channel plane outermost, the 9 taps inside. A tap-outer order revisits each of the D planes once
@@ -71,7 +72,7 @@ __global__ __launch_bounds__(256) void cn_na2d_fwd_kernel(const float* __restric
 #pragma unroll
   for (int t = 0; t < NA_KK; ++t) lg[t] = 0.f;
 #pragma unroll 4
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < DD; ++d) {
     const float qd = qp[(long)d * HW + p] * scale;
     const float* kd = kp + (long)d * HW;
 #pragma unroll
@@ -94,9 +95,9 @@ __global__ __launch_bounds__(256) void cn_na2d_fwd_kernel(const float* __restric
     if (attn) ap[(long)t * HW] = lg[t];
     lg[t] *= na_keep(dthresh, dscale, dseed, (long)b * heads + h, t, HW, p);
   }
-  float* op = out + b * obs + (long)(h * D) * HW + p;
+  float* op = out + b * obs + (long)(h * DD) * HW + p;
 #pragma unroll 4
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < DD; ++d) {
     const float* vd = vp + (long)d * HW;
     float o = 0.f;
 #pragma unroll
@@ -113,7 +114,8 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_q_kernel(const float* __restr
                                                            float* __restrict__ dattn, float* __restrict__ dqkv,
                                                            long dqbs, int B, int C, int heads, int H, int W, int dil,
                                                            float scale, unsigned long long dthresh, float dscale,
-                                                           unsigned long long dseed_, const unsigned long long* __restrict__ dstep) {
+                                                           unsigned long long dseed_, const unsigned long long* __restrict__ dstep, int Dr) {
+  const int DD = D > 0 ? D : Dr;  // D == 0: head dimension known at run time only (any width)
   const unsigned long long dseed = cn_step_seed(dseed_, dstep);
   const int HW = H * W;
   int bx, h, b;
@@ -122,9 +124,9 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_q_kernel(const float* __restr
   if (p >= HW) return;
   const int y = p / W, x = p - y * W;
   const int sy = na_window_start(y, H, dil), sx = na_window_start(x, W, dil);
-  const float* kp = qkv + b * qbs + (long)(C + h * D) * HW;
+  const float* kp = qkv + b * qbs + (long)(C + h * DD) * HW;
   const float* vp = kp + (long)C * HW;
-  const float* dop = dout + b * dobs + (long)(h * D) * HW + p;
+  const float* dop = dout + b * dobs + (long)(h * DD) * HW + p;
   int kpix[NA_KK];
 #pragma unroll
   for (int i = 0; i < NA_K; ++i)
@@ -136,7 +138,7 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_q_kernel(const float* __restr
   for (int t = 0; t < NA_KK; ++t) dp[t] = 0.f;
   // plane-outer (see the forward kernel): dP[t] = sum_d dOut[d] * v[d][tap t]
 #pragma unroll 4
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < DD; ++d) {
     const float gd = dop[(long)d * HW];
     const float* vd = vp + (long)d * HW;
 #pragma unroll
@@ -155,9 +157,9 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_q_kernel(const float* __restr
     dp[t] = pr[t] * (dp[t] - dot);  // dS
     dap[(long)t * HW] = dp[t];
   }
-  float* dqp = dqkv + b * dqbs + (long)(h * D) * HW + p;
+  float* dqp = dqkv + b * dqbs + (long)(h * DD) * HW + p;
 #pragma unroll 4
-  for (int d = 0; d < D; ++d) {
+  for (int d = 0; d < DD; ++d) {
     const float* kd = kp + (long)d * HW;
     float dq = 0.f;
 #pragma unroll
@@ -176,7 +178,8 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_kv_kernel(const float* __rest
                                                             float* __restrict__ dqkv, long dqbs, int B, int C,
                                                             int heads, int H, int W, int dil, float scale,
                                                             unsigned long long dthresh, float dscale,
-                                                            unsigned long long dseed_, const unsigned long long* __restrict__ dstep) {
+                                                            unsigned long long dseed_, const unsigned long long* __restrict__ dstep, int Dr) {
+  const int DD = D > 0 ? D : Dr;  // D == 0: head dimension known at run time only (any width)
   const unsigned long long dseed = cn_step_seed(dseed_, dstep);
   const int HW = H * W;
   int bx, h, b;
@@ -184,56 +187,67 @@ __global__ __launch_bounds__(256) void cn_na2d_bwd_kv_kernel(const float* __rest
   const int p = bx * 256 + threadIdx.x;
   if (p >= HW) return;
   const int y = p / W, x = p - y * W;
-  const float* qp = qkv + b * qbs + (long)(h * D) * HW;
-  const float* dop = dout + b * dobs + (long)(h * D) * HW;
+  const float* qp = qkv + b * qbs + (long)(h * DD) * HW;
+  const float* dop = dout + b * dobs + (long)(h * DD) * HW;
   const float* ap = attn + ((long)(b * heads + h) * NA_KK) * HW;
   const float* dap = dattn + ((long)(b * heads + h) * NA_KK) * HW;
-  float dk[D], dv[D];
+  // CH channels of the head at a time: all D of them when D is a compile-time constant, eight per sweep of the window
+  // for a run-time head dimension (D == 0)
+  constexpr int CH = D > 0 ? D : 8;
+  float* dkp = dqkv + b * dqbs + (long)(C + h * DD) * HW + p;
+  float* dvp = dkp + (long)C * HW;
+  for (int d0 = 0; d0 < DD; d0 += CH) {
+    float dk[CH], dv[CH];
 #pragma unroll
-  for (int d = 0; d < D; ++d) {
-    dk[d] = 0.f;
-    dv[d] = 0.f;
-  }
-  for (int my = -2; my <= 2; ++my) {
-    const int qy = y + my * dil;
-    if (qy < 0 || qy >= H) continue;
-    const int offy = y - na_window_start(qy, H, dil);
-    if (offy < 0 || offy > 2 * dil) continue;  // same residue class => divisible by dil
-    const int i = offy / dil;
-    for (int mx = -2; mx <= 2; ++mx) {
-      const int qx = x + mx * dil;
-      if (qx < 0 || qx >= W) continue;
-      const int offx = x - na_window_start(qx, W, dil);
-      if (offx < 0 || offx > 2 * dil) continue;
-      const int t = i * NA_K + offx / dil;
-      const int qpix = qy * W + qx;
-      const float ds = dap[(long)t * HW + qpix];
-      const float pr = ap[(long)t * HW + qpix] * na_keep(dthresh, dscale, dseed, (long)b * heads + h, t, HW, qpix);
+    for (int d = 0; d < CH; ++d) {
+      dk[d] = 0.f;
+      dv[d] = 0.f;
+    }
+    for (int my = -2; my <= 2; ++my) {
+      const int qy = y + my * dil;
+      if (qy < 0 || qy >= H) continue;
+      const int offy = y - na_window_start(qy, H, dil);
+      if (offy < 0 || offy > 2 * dil) continue;  // same residue class => divisible by dil
+      const int i = offy / dil;
+      for (int mx = -2; mx <= 2; ++mx) {
+        const int qx = x + mx * dil;
+        if (qx < 0 || qx >= W) continue;
+        const int offx = x - na_window_start(qx, W, dil);
+        if (offx < 0 || offx > 2 * dil) continue;
+        const int t = i * NA_K + offx / dil;
+        const int qpix = qy * W + qx;
+        const float ds = dap[(long)t * HW + qpix];
+        const float pr = ap[(long)t * HW + qpix] * na_keep(dthresh, dscale, dseed, (long)b * heads + h, t, HW, qpix);
 #pragma unroll
-      for (int d = 0; d < D; ++d) {
-        dk[d] += ds * qp[(long)d * HW + qpix];
-        dv[d] += pr * dop[(long)d * HW + qpix];
+        for (int d = 0; d < CH; ++d) {
+          if (D > 0 || d0 + d < DD) {
+            dk[d] += ds * qp[(long)(d0 + d) * HW + qpix];
+            dv[d] += pr * dop[(long)(d0 + d) * HW + qpix];
+          }
+        }
+      }
+    }
+#pragma unroll
+    for (int d = 0; d < CH; ++d) {
+      if (D > 0 || d0 + d < DD) {
+        dkp[(long)(d0 + d) * HW] = dk[d] * scale;
+        dvp[(long)(d0 + d) * HW] = dv[d];
       }
     }
   }
-  float* dkp = dqkv + b * dqbs + (long)(C + h * D) * HW + p;
-  float* dvp = dkp + (long)C * HW;
-#pragma unroll
-  for (int d = 0; d < D; ++d) {
-    dkp[(long)d * HW] = dk[d] * scale;
-    dvp[(long)d * HW] = dv[d];
-  }
 }
 
+// Head dimensions of the reference's widths (hidden 8 .. 128: h/4, h/2, h for powers of two) are compiled in; any other
+// width (hidden 24, 40, 48, 96 ...) runs the same kernels with the head dimension as a run-time loop bound (D = 0).
 #define NA_DISPATCH(D_, KERNEL, ...)                                                                          \
   switch (D_) {                                                                                               \
-    case 2: CN_LAUNCH((KERNEL<2>), grid, dim3(256), 0, stream, __VA_ARGS__); break;                 \
-    case 4: CN_LAUNCH((KERNEL<4>), grid, dim3(256), 0, stream, __VA_ARGS__); break;                 \
-    case 8: CN_LAUNCH((KERNEL<8>), grid, dim3(256), 0, stream, __VA_ARGS__); break;                 \
-    case 16: CN_LAUNCH((KERNEL<16>), grid, dim3(256), 0, stream, __VA_ARGS__); break;               \
-    case 32: CN_LAUNCH((KERNEL<32>), grid, dim3(256), 0, stream, __VA_ARGS__); break;               \
-    case 64: CN_LAUNCH((KERNEL<64>), grid, dim3(256), 0, stream, __VA_ARGS__); break;               \
-    default: return CN_ERR_ARG;                                                                               \
+    case 2: CN_LAUNCH((KERNEL<2>), grid, dim3(256), 0, stream, __VA_ARGS__, D_); break;             \
+    case 4: CN_LAUNCH((KERNEL<4>), grid, dim3(256), 0, stream, __VA_ARGS__, D_); break;             \
+    case 8: CN_LAUNCH((KERNEL<8>), grid, dim3(256), 0, stream, __VA_ARGS__, D_); break;             \
+    case 16: CN_LAUNCH((KERNEL<16>), grid, dim3(256), 0, stream, __VA_ARGS__, D_); break;           \
+    case 32: CN_LAUNCH((KERNEL<32>), grid, dim3(256), 0, stream, __VA_ARGS__, D_); break;           \
+    case 64: CN_LAUNCH((KERNEL<64>), grid, dim3(256), 0, stream, __VA_ARGS__, D_); break;           \
+    default: CN_LAUNCH((KERNEL<0>), grid, dim3(256), 0, stream, __VA_ARGS__, D_); break;            \
   }
 
 // kernel_size must be 3 (every NATTEN_PARAMS entry used by TowerUNet: unet_parts.py:19-40).

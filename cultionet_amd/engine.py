@@ -2496,6 +2496,43 @@ def to_bf16(x: Var) -> Var:
     return yv
 
 
+def to_f32(x: Var) -> Var:
+    """bf16 NHWC -> fp32 NCHW inside the mixed-precision region: the way out for an op whose bf16 kernel does not cover a
+    shape (LayerNorm over a channel count that is not 8 x a power of two, attention head dimensions outside 4..64 --
+    widths like hidden 24 / 40 / 48 / 96): the op runs through its fp32 kernel and to_bf16() brings the result back."""
+    tape = current_tape()
+    xt = _check(x.t)
+    if not is16(xt):
+        return x
+    B, C, H, W = xt.shape
+    y = _alloc((B, C, H, W), torch.float32, xt.device)
+    _lib.call("cn_convert_bf16nhwc_to_f32nchw", xt.data_ptr(), ld(xt), y.data_ptr(), bstride(y), B, C, H * W, 0, _stream())
+    yv = Var(y, tape.enabled and x.req)
+    if tape.enabled and x.req:
+
+        def bwd():
+            dy = yv.grad
+            if dy is None:
+                return
+            dx, acc = grad_buffer(x)
+            if acc:
+                tmp = _new(tuple(xt.shape), xt)
+                _lib.call("cn_convert_f32nchw_to_bf16nhwc", dy.data_ptr(), bstride(dy), tmp.data_ptr(), ld(tmp), B, C, C,
+                          H * W, _stream())
+                _lib.call("cn_copy_bf16", tmp.data_ptr(), ld(tmp), dx.data_ptr(), ld(dx), _rows(tmp), C, 1, _stream())
+            else:
+                _lib.call("cn_convert_f32nchw_to_bf16nhwc", dy.data_ptr(), bstride(dy), dx.data_ptr(), ld(dx), B, C, C,
+                          H * W, _stream())
+            yv.grad = None
+
+        tape.add(bwd)
+    return yv
+
+
+def _pow2(n: int) -> bool:
+    return n >= 1 and (n & (n - 1)) == 0
+
+
 _CONV_BNFIN = os.environ.get("CN_CONV_BNFIN", "1") != "0"
 
 
@@ -2956,6 +2993,10 @@ def _layer_norm_c_bf16(x: Var, ln, residual: T.Optional[Var], out: T.Optional[to
     tape = current_tape()
     xt = x.t
     B, C, H, W = xt.shape
+    if C % 8 or not _pow2(C >> 3) or (C >> 3) > 64:
+        # the bf16 kernels reduce over C / 8 lanes with shuffles (8, 16, ... 512 channels): other widths through fp32
+        r32 = to_f32(residual) if residual is not None else None
+        return to_bf16(layer_norm_c(to_f32(x), ln, residual=r32))
     P = B * H * W
     y = out if _out_ok(out, xt) else _new(xt.shape, xt)
     rt = _check(residual.t) if residual is not None else None
@@ -2984,12 +3025,15 @@ def _layer_norm_c_bf16(x: Var, ln, residual: T.Optional[Var], out: T.Optional[to
 
 def _na2d_bf16(qkv: Var, heads: int, kernel_size: int, dilation: int, attn_drop: float = 0.0) -> Var:
     tape = current_tape()
-    seed = _next_seed() if attn_drop > 0.0 else 0
-    stepw = _step_word(qkv.t.device).data_ptr() if attn_drop > 0.0 else None
-    step_fwd = _rng["step"]
     qt = qkv.t
     B, C3, H, W = qt.shape
     C = C3 // 3
+    if C % heads or (C // heads) not in (4, 8, 16, 32, 64):
+        # head dimensions the bf16 kernels are not compiled for (hidden 24 / 40 / 48 / 96 ...): the fp32 kernels take any
+        return to_bf16(na2d(to_f32(qkv), heads, kernel_size, dilation, attn_drop))
+    seed = _next_seed() if attn_drop > 0.0 else 0
+    stepw = _step_word(qkv.t.device).data_ptr() if attn_drop > 0.0 else None
+    step_fwd = _rng["step"]
     out = _new((B, C, H, W), qt)
     attn = _alloc((B, heads, kernel_size * kernel_size, H, W), torch.float32, qt.device)
     _lib.call("cn_na2d_fwd_bf16", qt.data_ptr(), ld(qt), out.data_ptr(), ld(out), attn.data_ptr(), B, C, heads, H, W,
