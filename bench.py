@@ -673,6 +673,14 @@ class TrainLeg:
                 "loss": loss_val,
                 "abi_calls_per_step": calls[0],
                 "kernel_launches_per_step": launches,
+                # the stream set this step ran on (at most seven hardware queues run concurrently):
+                # normal-priority pool capped at GPU_MAX_HW_QUEUES, + the lowest-priority weight-gradient queue, + ONE
+                # highest-priority auxiliary queue when engine.spawn() is allowed to use it
+                "hw_queue_cap": int(os.environ.get("GPU_MAX_HW_QUEUES", "4")),
+                "streams": {"compute": "torch current stream (normal priority)",
+                            "weight_gradients": "lowest priority" if E._OVERLAP_WGRAD else None,
+                            "auxiliary": "highest priority, shared by every spawn()" if E.branch_streams_allowed() else None,
+                            "buckets": "normal priority (cultionet_amd.ddp)" if self.comm is not None else None},
             },
             "roofline": {
                 "bound": "mfma",
