@@ -1178,6 +1178,10 @@ int cn_conv_igemm_launch(CnConvGeom& g, hipStream_t stream) {
   // those stay on the dword kernel)
   g.odd_planes = (hw4 == 1 && odd_vec && !(g.is > 1 && (long)g.Hin * g.Win > 4096)) ? 1 : 0;
   bool vec = (hw4 == 0 || g.odd_planes) && (g.xbs % 4 == 0);
+  // ... and the same holds for ALIGNED large planes (round 6: with ConvTranspose2d on the 100 x 100 output_padding grid its
+  // backward-data gather became eligible for the 16-byte kernel: 83.7 vs 78.3 us alone, and 336 vs 177 us inside the step
+  // next to the weight-gradient stream -- one block per CU of a two-chunk image; step 390.0 -> 392.2 chips/s, same box)
+  if (g.is > 1 && (long)g.Hin * g.Win > 4096) vec = false;
   // the kernels' buffer loads carry 31-bit byte offsets inside one image / one packed weight tensor
   if ((long)g.Cin * g.Hin * g.Win * 4 >= (1L << 31) || (long)CN_MAX_TAPS * cn_conv_kpad(g.Cin) * g.Npad * 4 >= (1L << 31))
     return CN_ERR_ARG;
