@@ -309,45 +309,50 @@ class LightningModuleMixin(_Base):
         self.reg_loss = entry.get("regression")
         self.cls_loss = entry.get("classification")
 
-    def configure_optimizers(self):
-        """lightning.py:611-683."""
+    # The reference's optimizer / scheduler choices as data (lightning.py:611-683): name -> (torch class, which of the
+    # module's hyper-parameters it takes, fixed keyword arguments). AdamW's betas (0.9, 0.98) and eps are what
+    # cultionet_amd.lightning.HipTrainer's fused kernel implements natively.
+    _OPTIMIZERS = {
+        "Adam": ("Adam", ("lr", "eps"), {}),
+        "AdamW": ("AdamW", ("lr", "weight_decay", "eps"), {"betas": (0.9, 0.98)}),
+        "RAdam": ("RAdam", ("lr", "weight_decay", "eps"), {"betas": (0.9, 0.99), "decoupled_weight_decay": True}),
+        "SGD": ("SGD", ("lr", "weight_decay"), {"momentum": 0.9}),
+    }
+
+    def _make_scheduler(self, optimizer):
+        """(scheduler, stepping interval) for ``self.lr_scheduler``; OneCycleLR alone steps per batch."""
         from torch.optim import lr_scheduler as sched
 
-        params_list = list(self.cultionet_model.parameters())
-        interval = "epoch"
-        if self.optimizer == "Adam":
-            optimizer = torch.optim.Adam(params_list, lr=self.learning_rate, eps=self.eps)
-        elif self.optimizer == "AdamW":
-            optimizer = torch.optim.AdamW(params_list, lr=self.learning_rate, weight_decay=self.weight_decay,
-                                          eps=self.eps, betas=(0.9, 0.98))
-        elif self.optimizer == "RAdam":
-            optimizer = torch.optim.RAdam(params_list, lr=self.learning_rate, weight_decay=self.weight_decay,
-                                          decoupled_weight_decay=True, eps=self.eps, betas=(0.9, 0.99))
-        elif self.optimizer == "SGD":
-            optimizer = torch.optim.SGD(params_list, lr=self.learning_rate, weight_decay=self.weight_decay,
-                                        momentum=0.9)
-        else:
-            raise NameError("Choose either 'AdamW' or 'SGD'.")
-
-        if self.lr_scheduler == LearningRateSchedulers.COSINE_ANNEALING_LR:
-            model_lr_scheduler = sched.CosineAnnealingLR(optimizer, T_max=20, eta_min=1e-5, last_epoch=-1)
-        elif self.lr_scheduler == LearningRateSchedulers.EXPONENTIAL_LR:
-            model_lr_scheduler = sched.ExponentialLR(optimizer, gamma=0.5)
-        elif self.lr_scheduler == LearningRateSchedulers.ONE_CYCLE_LR:
-            model_lr_scheduler = sched.OneCycleLR(optimizer, max_lr=self.learning_rate,
-                                                  epochs=self.trainer.max_epochs,
-                                                  steps_per_epoch=self.trainer.estimated_stepping_batches)
-            interval = "step"
-        elif self.lr_scheduler == LearningRateSchedulers.STEP_LR:
-            model_lr_scheduler = sched.StepLR(optimizer, step_size=self.steplr_step_size, gamma=0.5)
-        else:
-            raise NameError("The learning rate scheduler is not implemented in Cultionet.")
-
-        return {
-            "optimizer": optimizer,
-            "lr_scheduler": {"scheduler": model_lr_scheduler, "name": "lr_sch", "monitor": "val_score",
-                             "interval": interval, "frequency": 1},
+        name = str(self.lr_scheduler)
+        if name == str(LearningRateSchedulers.ONE_CYCLE_LR):
+            tr = self.trainer
+            return sched.OneCycleLR(optimizer, max_lr=self.learning_rate, epochs=tr.max_epochs,
+                                    steps_per_epoch=tr.estimated_stepping_batches), "step"
+        per_epoch = {
+            str(LearningRateSchedulers.COSINE_ANNEALING_LR): lambda: sched.CosineAnnealingLR(optimizer, T_max=20, eta_min=1e-5,
+                                                                                             last_epoch=-1),
+            str(LearningRateSchedulers.EXPONENTIAL_LR): lambda: sched.ExponentialLR(optimizer, gamma=0.5),
+            str(LearningRateSchedulers.STEP_LR): lambda: sched.StepLR(optimizer, step_size=self.steplr_step_size, gamma=0.5),
         }
+        if name not in per_epoch:
+            raise NameError("The learning rate scheduler is not implemented in Cultionet.")
+        return per_epoch[name](), "epoch"
+
+    def configure_optimizers(self):
+        """Lightning hook, same choices and error behaviour as the reference (lightning.py:611-683): a torch optimizer over
+        the model's parameters + one scheduler monitored on ``val_score``. (The native path -- HipTrainer -- does not use
+        this: its clip + AdamW + OneCycleLR run in cn_optim.hip.)"""
+        recipe = self._OPTIMIZERS.get(str(self.optimizer))
+        if recipe is None:
+            raise NameError("Choose either 'AdamW' or 'SGD'.")
+        cls_name, takes, fixed = recipe
+        hyper = {"lr": self.learning_rate, "weight_decay": self.weight_decay, "eps": self.eps}
+        optimizer = getattr(torch.optim, cls_name)(list(self.cultionet_model.parameters()),
+                                                   **{k: hyper[k] for k in takes}, **fixed)
+        scheduler, interval = self._make_scheduler(optimizer)
+        return {"optimizer": optimizer,
+                "lr_scheduler": {"scheduler": scheduler, "name": "lr_sch", "monitor": "val_score", "interval": interval,
+                                 "frequency": 1}}
 
 
 class CultionetLitTransferModel(LightningModuleMixin):
