@@ -61,6 +61,15 @@ def test_bf16_train_step_matches_reference(golden_dir, name):
         assert d32.mean() <= 6e-3 and d32.max() <= 8e-2, (k, d32.mean(), d32.max())
         assert d32.mean() <= 1.5 * dref.mean() + 1e-4, (k, d32.mean(), dref.mean())
         assert np.abs(p - g[k]).max() <= 0.12, k  # against the reference's own bf16 run (two different roundings)
+        # > 0.5 masks (only asserted on the fp32 path). bf16 cannot promise identity at the
+        # threshold itself -- random-init maps hover around 0.5 -- so: identical wherever the fp32 probability is farther
+        # from 0.5 than the bf16 tolerance, and overall agreement no worse than the REFERENCE's own bf16 run minus 1 %
+        f32 = g["fp32_" + k]
+        clear = np.abs(f32 - 0.5) > 8e-2
+        assert np.array_equal((p > 0.5)[clear], (f32 > 0.5)[clear]), k
+        agree = float(((p > 0.5) == (f32 > 0.5)).mean())
+        agree_ref = float(((g[k] > 0.5) == (f32 > 0.5)).mean())
+        assert agree >= agree_ref - 0.01, (k, agree, agree_ref)
     loss = trainer.forward_backward(batch)
     torch.cuda.synchronize()
     assert abs(float(loss.item()) - float(g["fp32_loss"])) <= 5e-4, (float(loss.item()), float(g["fp32_loss"]))
