@@ -92,9 +92,13 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const CnConvGeom g) 
   int bx, by, split;
   if (!cn_xcd_block(g.grid_x, g.grid_y, g.grid_x * g.grid_y * g.splits, bx, by, split)) return;
   int ci_ = 0;
+  if (g.interleave) {
+    ci_ = bx % g.ncls;
+  } else {
 #pragma unroll 1
-  for (int c = 1; c < g.ncls; ++c)
-    if (bx >= g.cls[c].block_begin) ci_ = c;
+    for (int c = 1; c < g.ncls; ++c)
+      if (bx >= g.cls[c].block_begin) ci_ = c;
+  }
   const int grp = g.cls[ci_].grp;
   const float* __restrict__ x = g.gx[grp];
   const float* __restrict__ wp = g.gwp[grp];
@@ -105,7 +109,7 @@ __global__ __launch_bounds__(256) void cn_conv_igemm_kernel(const CnConvGeom g) 
   const int min_dy = g.cls[ci_].min_dy, min_dx = g.cls[ci_].min_dx;
   const int oy0 = g.cls[ci_].oy0, ox0 = g.cls[ci_].ox0;
   const int tiles_per_img = g.cls[ci_].tiles_per_img;
-  const int tile = bx - g.cls[ci_].block_begin;
+  const int tile = g.interleave ? bx / g.ncls : bx - g.cls[ci_].block_begin;
   const int b = tile / tiles_per_img;
   const int m0 = (tile - b * tiles_per_img) * MT;
   if (tid < ntaps) {
@@ -284,9 +288,13 @@ __global__ __launch_bounds__(256, (NV <= 1 ? 2 : 1)) void cn_conv_igemm_vec_kern
   int bx, by, split;
   if (!cn_xcd_block(g.grid_x, g.grid_y, g.grid_x * g.grid_y * g.splits, bx, by, split)) return;
   int ci_ = 0;
+  if (g.interleave) {
+    ci_ = bx % g.ncls;
+  } else {
 #pragma unroll 1
-  for (int c = 1; c < g.ncls; ++c)
-    if (bx >= g.cls[c].block_begin) ci_ = c;
+    for (int c = 1; c < g.ncls; ++c)
+      if (bx >= g.cls[c].block_begin) ci_ = c;
+  }
   const int grp = g.cls[ci_].grp;
   const float* __restrict__ x = g.gx[grp];
   const float* __restrict__ wp = g.gwp[grp];
@@ -297,7 +305,7 @@ __global__ __launch_bounds__(256, (NV <= 1 ? 2 : 1)) void cn_conv_igemm_vec_kern
   const int min_dy = g.cls[ci_].min_dy, min_dx = g.cls[ci_].min_dx;
   const int oy0 = g.cls[ci_].oy0, ox0 = g.cls[ci_].ox0;
   const int tiles_per_img = g.cls[ci_].tiles_per_img;
-  const int tile = bx - g.cls[ci_].block_begin;
+  const int tile = g.interleave ? bx / g.ncls : bx - g.cls[ci_].block_begin;
   const int b = tile / tiles_per_img;
   const int m0 = (tile - b * tiles_per_img) * MT;
   const int Win = g.Win;
@@ -705,6 +713,16 @@ static CnPlan cn_plan(CnConvGeom& g, int MT) {
     if (k.vplane > p.max_vplane) p.max_vplane = k.vplane;
     if (k.ntaps > p.max_taps) p.max_taps = k.ntaps;
     p.flops += 2.0 * g.B * Mimg * (double)g.Cout * g.Cin * k.ntaps;
+  }
+  // parity classes of a strided scatter: 1 / 2 / 2 / 4 taps per class at stride 2. Laid out class after class, the
+  // XCD-aware block order hands each XCD ONE class -- two XCDs run the 4-tap class for the whole launch while two others
+  // finish the 1-tap class in a quarter of the time (0.56 of the machine at best). With equal tile counts the classes are
+  // interleaved instead (CnConvGeom::interleave; cn_scatter_conv_g sorts them by descending taps).
+  g.interleave = 0;
+  if (g.ncls > 1 && g.want_interleave) {
+    bool same = true;
+    for (int c = 1; c < g.ncls; ++c) same = same && g.cls[c].tiles_per_img == g.cls[0].tiles_per_img;
+    g.interleave = same ? 1 : 0;
   }
   return p;
 }
@@ -1226,6 +1244,9 @@ int cn_conv_igemm_launch(CnConvGeom& g, hipStream_t stream) {
     return rc;
   };
   CnChoice c = cn_choose(g, mts, ncfg, nt, allow_split);
+  // (Round 6, measured for the interleaved parity-class launches at 8 x 50^2 -> 100^2, 128 -> 128: smaller pixel tiles so
+  // that the classes balance dynamically -- 864 blocks of 96 pixels, 640 of 128 -- run 141.9 / 168.1 us against 105.7 at
+  // 512 blocks of 160: these launches are bound by the per-chunk staging of few-tap classes, not by class imbalance.)
   if (g_autotune) {
     std::lock_guard<std::mutex> lk(g_tune_mu);  // tuning runs are serialised across threads
     const uint64_t key = cn_tune_key(g, vec, nt, allow_split);
@@ -1369,6 +1390,14 @@ static int cn_scatter_conv_g(int G, const float* const* srcs, long sbs, const fl
   }
   g.ncls = nc;
   if (nc == 0) return CN_OK;
+  // heavy classes first (stable: insertion sort over <= 16 classes), interleaved by cn_plan when their tile counts agree
+  for (int i = 1; i < nc; ++i) {
+    const CnConvClass key = g.cls[i];
+    int j = i - 1;
+    while (j >= 0 && g.cls[j].ntaps < key.ntaps) { g.cls[j + 1] = g.cls[j]; --j; }
+    g.cls[j + 1] = key;
+  }
+  g.want_interleave = stride > 1 ? 1 : 0;  // (8 x 50^2 -> 100^2, 128 -> 128: 114.1 -> 105.7 us alone; the step does not move)
   return cn_conv_igemm_launch(g, stream);
 }
 

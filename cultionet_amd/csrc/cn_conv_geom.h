@@ -36,6 +36,10 @@ struct CnConvGeom {
   // (CnConvClass::grp), so groups may differ in taps (dilation). shared_y: all groups sum into one output.
   int G, splits, shared_y;
   int odd_planes;      // H*W % 4 == 1: the 16-byte staging kernel runs its odd-plane variant (RP == 3)
+  int want_interleave; // the launch asks for it (strided scatter); cn_plan grants it when the classes' tile counts agree
+  int interleave;      // != 0: logical block l = tile * ncls + class (every class has the same number of tiles), classes in
+                       // order of DESCENDING taps: the blocks of one cell tile sit next to each other (shared halo in L2) and
+                       // every XCD / dispatch round gets the same mix of heavy and light parity classes
   float* part;         // split-K partial slices [(grp * splits + split)][B][Cout][Hout][Wout] (slice_stride != 0)
   long slice_stride;
   int grid_x, grid_y;  // logical grid (pixel tiles, N tiles); z = splits. Launched 1-D in XCD-aware order
