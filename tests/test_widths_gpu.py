@@ -1,50 +1,89 @@
-"""Widths the fixtures and the benchmark do not cover (round 6): hidden sizes whose attention head dimensions are not
-powers of two (24, 48 -> 6 / 12 / 24 / 48) and a narrow model whose stride-4 ConvTranspose2d gathers few channels from a
-100 x 100 plane. Before round 6 these failed INSIDE the library (CN_ERR_ARG in cn_na2d_*_f32 / cn_layernorm_c_*_bf16,
-CN_ERR_LDS in cn_conv_transpose2d_bwd_data_f32); now the fp32 kernels take any head dimension, the bf16 region routes the
-two ops through them, and the strided gather falls back to a smaller pixel tile. One native training step each: fp32 loss
-against the CPU oracle at 1e-4 (north_star), mixed precision at 5e-4 of the fp32 engine's loss, all maps finite.
-(tools/shape_sweep.py is the long form of this test.)"""
+"""Widths, chip shapes and cubes the fixtures and the benchmark do not cover (round 6): hidden sizes whose attention head
+dimensions are not powers of two (24, 48 -> 6 / 12 / 24 / 48), a narrow model whose stride-4 ConvTranspose2d gathers few
+channels from a 100 x 100 plane, non-square / odd chip sizes, other channel and time counts. Before round 6 three of these
+failed INSIDE the library (CN_ERR_ARG in cn_na2d_*_f32 / cn_layernorm_c_*_bf16, CN_ERR_LDS in
+cn_conv_transpose2d_bwd_data_f32); now the fp32 kernels take any head dimension, the bf16 region routes the two ops
+through them, and the strided gather falls back to a smaller pixel tile.
+
+Per case, against the CPU oracle on the same key-seeded weights and seeded batch (north_star tolerances): the three
+probability maps to 1e-4 with identical > 0.5 masks outside that band, the loss to 1e-4, EVERY parameter's gradient to
+||g - g_ref|| <= 2e-3 ||g_ref|| (element-level, not norms), then one optimizer step that lowers the loss; mixed precision:
+loss within 5e-4 of the fp32 engine's, maps finite. (tools/shape_sweep.py is the long form: 36 configurations.)"""
 import pytest
 import torch
 
 pytestmark = pytest.mark.gpu
 
+CASES = [
+    # hidden, batch, channels, time, height, width
+    (24, 2, 3, 12, 50, 50),     # head dimensions 6 / 12 / 24
+    (48, 1, 3, 12, 52, 48),     # 12 / 24 / 48, non-square
+    (8, 2, 3, 12, 100, 100),    # the narrow stride-4 gather from 100 x 100
+    (16, 2, 3, 12, 75, 110),    # odd, non-square chips: 75 x 110 -> 38 x 55 -> 19 x 28 -> 10 x 14
+    (8, 3, 5, 6, 36, 36),       # another cube: 5 channels, 6 time steps
+    (16, 1, 4, 25, 64, 64),     # the predictor's cube (4 channels, 25 steps)
+]
 
-def _step(hidden, B, H, W, precision):
+
+def _engine(hidden, B, C, Tn, H, W, precision):
     from cultionet_amd import synthetic as S
     from cultionet_amd.data import Data
     from cultionet_amd.lightning import CultionetLitModel, HipTrainer
 
     dev = torch.device("cuda:0")
-    lit = CultionetLitModel(in_channels=3, in_time=12, hidden_channels=hidden, dropout=0.0)
+    lit = CultionetLitModel(in_channels=C, in_time=Tn, hidden_channels=hidden, dropout=0.0)
     model = lit.cultionet_model.mask_model
     model.load_state_dict(S.seeded_state_dict(model.state_dict()))
     lit = lit.to(dev).train()
     tr = HipTrainer(lit, gradient_clip_val=1.0, precision=precision)
-    x, y, bd = S.seeded_batch(B, height=H, width=W, seed=5, with_mask=True)
+    x, y, bd = S.seeded_batch(B, channels=C, time=Tn, height=H, width=W, seed=5, with_mask=True)
     batch = Data(x=x.to(dev), y=y.to(dev), bdist=bd.to(dev))
-    l1 = float(tr.training_step(batch).item())
-    l2 = float(tr.training_step(batch).item())
-    lit.eval()
-    with torch.no_grad():
-        out = lit(batch)
-    torch.cuda.synchronize()
-    assert all(torch.isfinite(v.float()).all().item() for v in out.values() if torch.is_tensor(v))
-    return l1, l2, (x, y, bd)
+    return lit, model, tr, batch, (x, y, bd)
 
 
-@pytest.mark.parametrize("hidden,B,H,W", [(24, 2, 50, 50), (48, 1, 52, 48), (8, 2, 100, 100)])
-def test_unusual_widths_train_in_both_precisions(hidden, B, H, W):
+@pytest.mark.parametrize("hidden,B,C,Tn,H,W", CASES)
+def test_unusual_shapes_match_the_oracle(hidden, B, C, Tn, H, W):
     from oracle import towerunet_oracle as O
 
-    l32, l32b, (x, y, bd) = _step(hidden, B, H, W, "32-true")
-    m = O.TowerUNet(3, 12, hidden_channels=hidden)
-    m.load_state_dict(O.seeded_state_dict(m.state_dict()))
-    m.train()
-    lo, _ = O.calc_loss(m(x), y, bd)
-    assert abs(float(lo.detach()) - l32) <= 1e-4, (float(lo), l32)
-    assert l32b < l32  # the optimizer step moved the loss down
-    l16, l16b, _ = _step(hidden, B, H, W, "bf16-mixed")
+    lit, model, tr, batch, (x, y, bd) = _engine(hidden, B, C, Tn, H, W, "32-true")
+    l1 = float(tr.forward_backward(batch).item())  # (the trainer returns its running total buffer: read it now)
+    ref = O.TowerUNet(C, Tn, hidden_channels=hidden)
+    ref.load_state_dict(O.seeded_state_dict(ref.state_dict()))
+    ref.train()
+    out = ref(x)
+    lo, _ = O.calc_loss(out, y, bd)
+    lo.backward()
+    assert abs(float(lo.detach()) - l1) <= 1e-4, (float(lo), l1)
+    for k in ("distance", "edge", "crop"):
+        p = tr.last_outputs[k].float().cpu()
+        r = out[k].detach()
+        assert float((p - r).abs().max()) <= 1e-4, k
+        clear = (r - 0.5).abs() > 1e-4
+        assert torch.equal((p > 0.5)[clear], (r > 0.5)[clear]), k
+    bad = []
+    for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
+        g = tr.store.grad_of(p).double().cpu()
+        gr = pr.grad.double()
+        err, nrm = float((g - gr).norm()), float(gr.norm())
+        if err > 2e-3 * max(nrm, 1e-3) + 1e-6:
+            bad.append((n, err, nrm))
+    assert not bad, bad[:6]
+    tr.optimizer_step()
+    l2 = float(tr.training_step(batch).item())
+    assert l2 < l1
+
+
+@pytest.mark.parametrize("hidden,B,C,Tn,H,W", [c for c in CASES if c[0] % 8 == 0])
+def test_unusual_shapes_in_mixed_precision(hidden, B, C, Tn, H, W):
+    lit, _, tr, batch, _ = _engine(hidden, B, C, Tn, H, W, "32-true")
+    l32 = float(tr.training_step(batch).item())
+    lit16, _, tr16, batch16, _ = _engine(hidden, B, C, Tn, H, W, "bf16-mixed")
+    l16 = float(tr16.training_step(batch16).item())
+    l16b = float(tr16.training_step(batch16).item())
     assert abs(l16 - l32) <= 5e-4, (l16, l32)
     assert l16b < l16
+    lit16.eval()
+    with torch.no_grad():
+        out = lit16(batch16)
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(v.float()).all().item() for v in out.values() if torch.is_tensor(v))
