@@ -87,3 +87,29 @@ def test_unusual_shapes_in_mixed_precision(hidden, B, C, Tn, H, W):
         out = lit16(batch16)
     torch.cuda.synchronize()
     assert all(torch.isfinite(v.float()).all().item() for v in out.values() if torch.is_tensor(v))
+
+
+def test_dropin_surface_at_an_unusual_width():
+    """The LightningModule surface (forward(Data) -> calc_loss -> loss.backward() through torch.autograd, what Lightning
+    drives) at hidden 24 on a non-square chip: every parameter's .grad against the oracle, element-wise."""
+    from oracle import towerunet_oracle as O
+
+    hidden, B, C, Tn, H, W = 24, 2, 3, 12, 44, 60
+    lit, model, _, batch, (x, y, bd) = _engine(hidden, B, C, Tn, H, W, "32-true")
+    pred = lit(batch)
+    loss, rep = lit.calc_loss(batch, pred)
+    loss.backward()
+    torch.cuda.synchronize()
+    ref = O.TowerUNet(C, Tn, hidden_channels=hidden)
+    ref.load_state_dict(O.seeded_state_dict(ref.state_dict()))
+    ref.train()
+    lo, rrep = O.calc_loss(ref(x), y, bd)
+    lo.backward()
+    assert abs(float(lo.detach()) - float(loss.detach())) <= 1e-4
+    bad = []
+    for (n, p), (_, pr) in zip(model.named_parameters(), ref.named_parameters()):
+        assert p.grad is not None, n
+        err, nrm = float((p.grad.double().cpu() - pr.grad.double()).norm()), float(pr.grad.double().norm())
+        if err > 2e-3 * max(nrm, 1e-3) + 1e-6:
+            bad.append((n, err, nrm))
+    assert not bad, bad[:6]
