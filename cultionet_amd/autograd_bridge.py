@@ -79,6 +79,12 @@ def _autocast_bf16(model=None) -> bool:
        (model.py:168-186). fp16 autocast is served by the bf16 path (MI355X has no reason to prefer fp16, and the
        GradScaler of "16-mixed" is harmless on it); that substitution and the implicit selection are announced once.
     """
+    if model is not None and not getattr(model, "mixed_precision_ok", True):
+        explicit = getattr(model, "precision", None)
+        if explicit in ("bf16-mixed", "16-mixed") or (explicit is None and _ambient_autocast() is not None):
+            _warn_once("width", "cultionet_amd: the mixed-precision path needs channel counts that are multiples of 8 "
+                                "(hidden_channels % 8 == 0); this model runs in fp32")
+        return False
     explicit = getattr(model, "precision", None) if model is not None else None
     if explicit is not None:
         if explicit in ("32-true", "32"):

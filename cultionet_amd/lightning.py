@@ -565,6 +565,12 @@ class HipTrainer:
         if precision not in ("32-true", "32", "bf16-mixed", "16-mixed"):
             raise ValueError(f"unsupported precision {precision!r}")
         self.bf16 = precision in ("bf16-mixed", "16-mixed")
+        if self.bf16 and not getattr(self.model, "mixed_precision_ok", True):
+            import warnings
+
+            warnings.warn("cultionet_amd: the mixed-precision path needs channel counts that are multiples of 8 "
+                          "(hidden_channels % 8 == 0); this trainer runs in fp32", stacklevel=2)
+            self.bf16 = False
         if lit.optimizer != "AdamW":
             raise NotImplementedError("the fused HIP optimizer implements AdamW (the reference default)")
         if any(not p.requires_grad for p in self.store.params):

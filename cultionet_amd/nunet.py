@@ -114,6 +114,8 @@ class TowerUNet(nn.Module):
         channels = [hidden_channels, hidden_channels * 2, hidden_channels * 4, hidden_channels * 8]
         up_channels = int(hidden_channels * len(channels))
         self.in_channels, self.in_time = in_channels, in_time
+        # the bf16 NHWC kernels move channels in 16-byte groups: widths that are not multiples of 8 train / predict in fp32
+        self.mixed_precision_ok = hidden_channels % 8 == 0
         # the reference wraps pre_unet in torch.compile (nunet.py:141), which renames its checkpoint keys to
         # pre_unet._orig_mod.*; both spellings are accepted on load (see _load_from_state_dict).
         self.pre_unet = PreTimeReduction(in_channels, in_time, channels[0], activation_type)

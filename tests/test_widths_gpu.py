@@ -113,3 +113,14 @@ def test_dropin_surface_at_an_unusual_width():
         if err > 2e-3 * max(nrm, 1e-3) + 1e-6:
             bad.append((n, err, nrm))
     assert not bad, bad[:6]
+
+
+def test_mixed_precision_request_at_a_width_it_cannot_take_runs_fp32():
+    """hidden 12: channel counts that are not multiples of 8. The bf16 NHWC kernels move channels in 16-byte groups, so a
+    mixed-precision request trains in fp32 with one warning (it used to raise inside the first forward)."""
+    _, _, tr32, batch, _ = _engine(12, 2, 3, 12, 40, 40, "32-true")
+    l32 = float(tr32.training_step(batch).item())
+    with pytest.warns(UserWarning, match="multiples of 8"):
+        _, _, tr16, batch16, _ = _engine(12, 2, 3, 12, 40, 40, "bf16-mixed")
+    assert tr16.bf16 is False
+    assert float(tr16.training_step(batch16).item()) == l32

@@ -35,8 +35,7 @@ def main():
     bad = 0
     for prec in ("32-true", "bf16-mixed"):
         for (hid, B, C, Tn, H, W) in CASES:
-            if prec == "bf16-mixed" and hid % 8:
-                continue  # the bf16 region needs channel counts that are multiples of 8 (engine.to_bf16 says so)
+            # (hidden % 8 != 0 under "bf16-mixed": the trainer warns once and runs fp32)
             tag = f"{prec} hidden {hid} B {B} [{C},{Tn},{H},{W}]"
             try:
                 torch.manual_seed(0)
