@@ -69,6 +69,8 @@ SIGNATURES = {
     "cn_final_combine_bwd_f32": [P, P, P, P, P, P, P, P, P, P, P, P, P, P, I, I, F, P],
     "cn_tanimoto_fwd_f32": [P, L, P, P, P, I, I, I, I, I, L, I, F, I, P, P, P, F, P, P],
     "cn_tanimoto_bwd_f32": [P, L, P, P, P, I, I, I, I, I, L, P, F, P, L, I, P],
+    "cn_tanimoto_multi_fwd_f32": [I, P, I, L, I, F, I, P, P, P, P, P],
+    "cn_tanimoto_multi_bwd_f32": [I, P, I, L, P, P],
     "cn_eval_metrics_f32": [P, P, P, P, P, I, F, L, P, P, P, P],
     "cn_grad_sumsq_f32": [P, L, P, P],
     "cn_adamw_step_f32": [P, P, P, P, L, F, F, F, F, F, I, F, P, F, P],

@@ -192,6 +192,168 @@ extern "C" int cn_tanimoto_bwd_f32(const float* pred, long pbs, const float* tar
 }
 
 // ---------------------------------------------------------------------------------------------------------------
+// The three main losses of calc_loss (distance, edge, crop: lightning.py:307-339) in ONE launch per pass (round 6). The
+// native step ran them head by head -- memset, sums, finalize (x3), a fill of the running total, backward (x3): thirteen
+// dependent launches of 5-9 us on tensors of [B,1,100,100], in the one stretch of the step where nothing else runs (the
+// turn from forward to backward). Same kernels' arithmetic, head = blockIdx.z; the total is written (w0*l0 + w1*l1 + w2*l2,
+// added in head order as the per-head calls did), not accumulated: no fill in front.
+// ---------------------------------------------------------------------------------------------------------------
+#define CN_LOSS_MAX_HEADS 4
+struct CnLossHead {       // 80 bytes; the engine packs a host array of these
+  const float* pred;      // [B][C][HW], batch stride pbs
+  long pbs;
+  const float* tf;        // float target (TGT_FLOAT) or NULL
+  const long long* lab;   // labels or NULL
+  const void* mk;         // explicit mask or NULL
+  float* dpred;           // backward: gradient of pred (batch stride dbs), NULL in forward
+  long dbs;
+  int tmode, mmode, klass, C;
+  float weight;
+  int accumulate;         // backward: dpred += instead of =
+};
+static_assert(sizeof(CnLossHead) == 80, "CnLossHead is an 80-byte record");
+struct CnLossHeads { CnLossHead h[CN_LOSS_MAX_HEADS]; int n; };
+
+__global__ __launch_bounds__(256) void cn_tanimoto_multi_sums_kernel(const CnLossHeads hs, long HW,
+                                                                    double* __restrict__ sums, int B) {
+  __shared__ double scratch[4];
+  const CnLossHead& h = hs.h[blockIdx.z];
+  const long b = blockIdx.y;
+  const long n = (long)h.C * HW;
+  double a[5] = {0, 0, 0, 0, 0};
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i / HW);
+    const long p = i - c * HW;
+    const float m = ls_mask(h.mmode, h.lab, h.mk, b, HW, p);
+    const float yh = h.pred[b * h.pbs + i] * m;
+    const float y = ls_target(h.tmode, h.tf, h.lab, b, c, h.C, HW, p, h.klass) * m;
+    a[0] += y;
+    a[1] += yh;
+    a[2] += (double)y * yh;
+    a[3] += (double)y * y;
+    a[4] += (double)yh * yh;
+  }
+  double* out = sums + ((long)blockIdx.z * B + b) * 5;
+#pragma unroll
+  for (int k = 0; k < 5; ++k) {
+    const double r = cn_block_sum<double, 256>(a[k], scratch);
+    if (threadIdx.x == 0) atomicAdd(out + k, r);
+  }
+}
+
+__global__ void cn_tanimoto_multi_finalize_kernel(const CnLossHeads hs, const double* __restrict__ sums, int B, long HW,
+                                                  int kind, float smooth, int depth, float* __restrict__ loss_out,
+                                                  float* __restrict__ coef, float* __restrict__ total_out) {
+  __shared__ double scratch[4];
+  float total = 0.f;
+  for (int hd = 0; hd < hs.n; ++hd) {
+    const double N = (double)hs.h[hd].C * HW;
+    const double* sm = sums + (long)hd * B * 5;
+    float* cf = coef + (long)hd * B * 4;
+    double lsum = 0.0;
+    for (int b = threadIdx.x; b < B; b += 256) {
+      const double Sy = sm[b * 5 + 0], Syh = sm[b * 5 + 1], tpl = sm[b * 5 + 2];
+      const double sq = sm[b * 5 + 3] + sm[b * 5 + 4];
+      const double tplc = N - Sy - Syh + tpl;
+      const double sqc = 2.0 * N - 2.0 * Sy - 2.0 * Syh + sq;
+      double f1 = 0, a1 = 0, b1 = 0, f2 = 0, a2 = 0, b2 = 0, w = 1.0;
+      if (kind == LOSS_COMPLEMENT || kind == LOSS_COMBINED) {
+        double f, da, db;
+        tnm_complement(tpl, sq, smooth, depth, f, da, db); f1 += f; a1 += da; b1 += db;
+        tnm_complement(tplc, sqc, smooth, depth, f, da, db); f2 += f; a2 += da; b2 += db;
+      }
+      if (kind == LOSS_DIST || kind == LOSS_COMBINED) {
+        double f, da, db;
+        tnm_dist(tpl, sq, smooth, f, da, db); f1 += f; a1 += da; b1 += db;
+        tnm_dist(tplc, sqc, smooth, f, da, db); f2 += f; a2 += da; b2 += db;
+      }
+      if (kind == LOSS_COMBINED) w = 0.5;
+      lsum += 0.5 * (f1 + f2) * w;
+      const double sc = 0.5 * w / B;
+      cf[b * 4 + 0] = (float)(a1 * sc);
+      cf[b * 4 + 1] = (float)(b1 * sc);
+      cf[b * 4 + 2] = (float)(a2 * sc);
+      cf[b * 4 + 3] = (float)(b2 * sc);
+    }
+    lsum = cn_block_sum<double, 256>(lsum, scratch);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+      loss_out[hd] = (float)(lsum / B);
+      total += hs.h[hd].weight * (float)(lsum / B);
+    }
+  }
+  if (threadIdx.x == 0 && total_out != nullptr) total_out[0] = total;
+}
+
+__global__ __launch_bounds__(256) void cn_tanimoto_multi_bwd_kernel(const CnLossHeads hs, long HW,
+                                                                   const float* __restrict__ coef, int B) {
+  const CnLossHead& h = hs.h[blockIdx.z];
+  const long b = blockIdx.y;
+  const long n = (long)h.C * HW;
+  const float* cf = coef + ((long)blockIdx.z * B + b) * 4;
+  const float A = cf[0], Bq = cf[1], Ac = cf[2], Bc = cf[3];
+  const float upstream = h.weight;
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const int c = (int)(i / HW);
+    const long p = i - c * HW;
+    const float m = ls_mask(h.mmode, h.lab, h.mk, b, HW, p);
+    const float yh = h.pred[b * h.pbs + i] * m;
+    const float y = ls_target(h.tmode, h.tf, h.lab, b, c, h.C, HW, p, h.klass) * m;
+    float g = upstream * m * (A * y + 2.f * Bq * yh - Ac * (1.f - y) - 2.f * Bc * (1.f - yh));
+    if (h.accumulate) g += h.dpred[b * h.dbs + i];
+    h.dpred[b * h.dbs + i] = g;
+  }
+}
+
+static int loss_heads(int n, const void* heads, CnLossHeads& hs, int& Cmax) {
+  if (n < 1 || n > CN_LOSS_MAX_HEADS || heads == nullptr) return CN_ERR_ARG;
+  hs = CnLossHeads{};
+  hs.n = n;
+  Cmax = 1;
+  for (int i = 0; i < n; ++i) {
+    hs.h[i] = ((const CnLossHead*)heads)[i];
+    if (hs.h[i].pred == nullptr || hs.h[i].C < 1) return CN_ERR_ARG;
+    if (hs.h[i].C > Cmax) Cmax = hs.h[i].C;
+  }
+  return CN_OK;
+}
+
+// n (<= 4) losses over tensors of the same batch size and H*W. heads: HOST array of n CnLossHead records. sums:
+// n*B*5 doubles of scratch, coef: n*B*4 floats kept for backward, loss_out: n floats (per-head batch means),
+// total_out (nullable): = sum_h weight_h * loss_h.
+extern "C" int cn_tanimoto_multi_fwd_f32(int n, const void* heads, int B, long HW, int loss_kind, float smooth, int depth,
+                                         double* sums, float* coef, float* loss_out, float* total_out, void* stream_) {
+  hipStream_t stream = (hipStream_t)stream_;
+  if (B <= 0 || B > 65535) return CN_ERR_ARG;
+  CnLossHeads hs;
+  int Cmax;
+  const int rc = loss_heads(n, heads, hs, Cmax);
+  if (rc != CN_OK) return rc;
+  if (hipMemsetAsync(sums, 0, sizeof(double) * 5 * B * n, stream) != hipSuccess) return CN_ERR_LAUNCH;
+  dim3 g = loss_grid(B, (long)Cmax * HW);
+  g.z = n;
+  CN_LAUNCH(cn_tanimoto_multi_sums_kernel, g, dim3(256), 0, stream, hs, HW, sums, B);
+  CN_LAUNCH(cn_tanimoto_multi_finalize_kernel, dim3(1), dim3(256), 0, stream, hs, sums, B, HW, loss_kind, smooth, depth,
+            loss_out, coef, total_out);
+  return cn_check_launch();
+}
+
+// dpred_h (+)= weight_h * dL_h/dpred_h for the n heads (records as in the forward call, with dpred / dbs / accumulate set).
+extern "C" int cn_tanimoto_multi_bwd_f32(int n, const void* heads, int B, long HW, const float* coef, void* stream_) {
+  if (B <= 0 || B > 65535) return CN_ERR_ARG;
+  CnLossHeads hs;
+  int Cmax;
+  const int rc = loss_heads(n, heads, hs, Cmax);
+  if (rc != CN_OK) return rc;
+  for (int i = 0; i < n; ++i)
+    if (hs.h[i].dpred == nullptr) return CN_ERR_ARG;
+  dim3 g = loss_grid(B, (long)Cmax * HW);
+  g.z = n;
+  CN_LAUNCH(cn_tanimoto_multi_bwd_kernel, g, dim3(256), 0, (hipStream_t)stream_, hs, HW, coef, B);
+  return cn_check_launch();
+}
+
+// ---------------------------------------------------------------------------------------------------------------
 // Validation metrics of _shared_eval_step (/root/reference/src/cultionet/models/lightning.py:374-481): one pass over
 // the three probability maps builds the masked regression sums and the two 2x2 confusion matrices; a one-thread
 // finalize turns them into what the reference gets from torchmetrics:

@@ -2313,6 +2313,61 @@ def tanimoto_loss(pred: Var, *, target_f: T.Optional[torch.Tensor] = None, label
     return loss
 
 
+def tanimoto_loss_multi(preds: T.Sequence[Var], terms: T.Sequence[T.Dict[str, T.Any]], *, loss_kind: int = 0,
+                        weights: T.Optional[T.Sequence[float]] = None, smooth: float = 1e-5, depth: int = 5,
+                        total: T.Optional[torch.Tensor] = None) -> torch.Tensor:
+    """The n (<= 4) Tanimoto losses of calc_loss in ONE launch per pass (cn_tanimoto_multi_*_f32): ``terms[h]`` holds
+    tanimoto_loss()'s keyword arguments for head h (target_f / labels / mask / target_mode / mask_mode / klass). Returns
+    the n per-head batch means (device tensor); ``total`` (1 element) is WRITTEN with sum_h weights[h] * loss_h. The one
+    tape node writes weights[h] * dL_h/dpred_h into every head's gradient."""
+    import struct
+
+    tape = current_tape()
+    n = len(preds)
+    weights = [1.0] * n if weights is None else [float(w) for w in weights]
+    pts = [_check(p.t) for p in preds]
+    B = pts[0].shape[0]
+    HW = int(pts[0][0, 0].numel())
+    dev = pts[0].device
+    for pt in pts:
+        if pt.shape[0] != B or int(pt[0, 0].numel()) != HW:
+            raise ValueError("tanimoto_loss_multi: the heads must share batch size and H*W")
+    for kw in terms:
+        lab, tf = kw.get("labels"), kw.get("target_f")
+        if lab is not None and lab.dtype != torch.int64:
+            raise RuntimeError("labels must be int64")
+        if tf is not None and not _check(tf).is_contiguous():
+            raise RuntimeError("float target must be contiguous")
+    sums = _alloc(5 * B * n, torch.float64, dev)
+    coef = _alloc(4 * B * n, torch.float32, dev)
+    loss = _alloc(n, torch.float32, dev)
+
+    def records(grads):
+        buf = bytearray()
+        for h, (pt, kw) in enumerate(zip(pts, terms)):
+            ptr = lambda t: t.data_ptr() if t is not None else 0
+            dp, dbs, acc = grads[h] if grads is not None else (0, 0, 0)
+            buf += struct.pack("<QqQQQQqiiiifi", pt.data_ptr(), bstride(pt), ptr(kw.get("target_f")), ptr(kw.get("labels")),
+                               ptr(kw.get("mask")), dp, dbs, int(kw["target_mode"]), int(kw["mask_mode"]),
+                               int(kw.get("klass", 0)), pt.shape[1], weights[h], acc)
+        return bytes(buf)
+
+    _lib.call("cn_tanimoto_multi_fwd_f32", n, records(None), B, HW, loss_kind, smooth, depth, sums.data_ptr(),
+              coef.data_ptr(), loss.data_ptr(), total.data_ptr() if total is not None else None, _stream())
+    if tape.enabled and any(p.req for p in preds):
+
+        def bwd():
+            grads = []
+            for p in preds:
+                dp, acc = grad_buffer(p)
+                grads.append((dp.data_ptr(), bstride(dp), acc))
+            _lib.call("cn_tanimoto_multi_bwd_f32", n, records(grads), B, HW, coef.data_ptr(), _stream())
+            _keep = terms  # noqa: F841  keep targets / labels / masks alive until backward has run
+
+        tape.add(bwd)
+    return loss
+
+
 # ---------------------------------------------------------------------------
 # dropout / pooling
 # ---------------------------------------------------------------------------

@@ -606,13 +606,13 @@ class HipTrainer:
 
         lit, store = self.lit, self.store
         kind = E.LOSS_KINDS[str(lit.loss_name)]
-        s = E._stream()
-        _lib.call("cn_fill_f32", self.total.data_ptr(), 1, 0.0, s)
         with E.using_store(store), E.recording(True) as tape, E.mixed_precision(self.bf16):
             outs = self.model.forward_vars(self.model.input_var(batch.x))
             self.last_outputs = {k: v.t for k, v in outs.items()}  # distance / edge / crop of this step (no copies)
-            for key, kw in lit._loss_terms(batch):
-                E.tanimoto_loss(outs[key], loss_kind=kind, weight=1.0 / 3.0, total=self.total, **kw)
+            # the three losses in one launch per pass; self.total = (dist + edge + crop) / 3 is written by the kernel
+            terms = lit._loss_terms(batch)
+            self.last_losses = E.tanimoto_loss_multi([outs[key] for key, _ in terms], [kw for _, kw in terms],
+                                                     loss_kind=kind, weights=[1.0 / 3.0] * len(terms), total=self.total)
             store.zero_grad()
             if self.comm is not None:
                 self.comm.backward(tape, store)

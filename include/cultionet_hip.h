@@ -288,6 +288,14 @@ int cn_tanimoto_fwd_f32(const float* pred, long pbs, const float* target_f, cons
 int cn_tanimoto_bwd_f32(const float* pred, long pbs, const float* target_f, const long long* labels, const void* mask,
                         int target_mode, int mask_mode, int klass, int B, int C, long HW, const float* coef,
                         float upstream, float* dpred, long dbs, int accumulate, void* stream);
+/* The three main losses of calc_loss (lightning.py:307-339) in ONE launch per pass: n (<= 4) heads over tensors of the same
+ * batch size and H*W. heads: HOST array of n 80-byte records {const float* pred; long pbs; const float* target_f;
+ * const long long* labels; const void* mask; float* dpred; long dbs; int target_mode, mask_mode, klass, C; float weight;
+ * int accumulate}. Forward: sums n*B*5 doubles (scratch), coef n*B*4 floats (kept for backward), loss_out n floats,
+ * total_out (nullable) = sum_h weight_h * loss_h (WRITTEN, not accumulated). Backward: dpred_h (+)= weight_h * dL_h/dpred_h. */
+int cn_tanimoto_multi_fwd_f32(int n, const void* heads, int B, long HW, int loss_kind, float smooth, int depth,
+                              double* sums, float* coef, float* loss_out, float* total_out, void* stream);
+int cn_tanimoto_multi_bwd_f32(int n, const void* heads, int B, long HW, const float* coef, void* stream);
 
 /* ---- validation metrics of _shared_eval_step (models/lightning.py:374-481): masked MAE / MSE of the distance map,
  * micro F-beta (= accuracy, torchmetrics FBetaScore(task="multiclass", num_classes=2)) and MatthewsCorrCoef of the
